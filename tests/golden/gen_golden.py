@@ -1,0 +1,259 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by IMPORTING the reference (read-only, /root/reference).
+
+Run in the build container only:  python tests/golden/gen_golden.py
+The reference's Python never travels; only the small data files written here do.
+
+Stubs: `pointops_cuda` (CUDA extension, absent), `h5py` (not installed) and
+`evaluation.StructuralLosses.{match_cost,nn_distance}` (CUDA extension wrappers)
+are replaced by empty modules so that the pure-torch parts of the reference
+import.  Nothing in a fixture is computed by a stub: every stored value is the
+output of the reference's own torch code, except where a file says "composed"
+(reference torch modules + the C oracle standing in for the CUDA pointops).
+"""
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, REF)
+
+for name in ("pointops_cuda", "h5py"):
+    sys.modules[name] = types.ModuleType(name)
+sl = types.ModuleType("evaluation.StructuralLosses")
+mc = types.ModuleType("evaluation.StructuralLosses.match_cost")
+mc.match_cost = None
+nd = types.ModuleType("evaluation.StructuralLosses.nn_distance")
+nd.nn_distance = None
+sys.modules["evaluation.StructuralLosses"] = sl
+sys.modules["evaluation.StructuralLosses.match_cost"] = mc
+sys.modules["evaluation.StructuralLosses.nn_distance"] = nd
+
+import models.PDGNet_v2 as ref                                  # noqa: E402
+from lib.pointops.functions import pointops as ref_pointops       # noqa: E402
+from utils.chamfer_loss import ChamferLoss as RefChamferLoss      # noqa: E402
+from evaluation.evaluation_metrics import distChamfer as ref_distChamfer  # noqa: E402
+
+from hashweights import fill_module, hash_tensor, lattice_points  # noqa: E402
+from oracle import cref, pdgnet_ref                               # noqa: E402
+
+torch.set_num_threads(8)
+
+
+def save(name, **arrays):
+    out = {}
+    for k, v in arrays.items():
+        out[k] = v.detach().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **out)
+    print("wrote %-28s %7.1f KB" % (name, os.path.getsize(path) / 1024))
+
+
+# ------------------------------------------------------------------ 1. 3-D kNN (KNNQueryNaive)
+def gen_knn():
+    """lib/pointops/functions/pointops.py:368-405 on lattice inputs whose top-(k+1)
+    distances are pairwise distinct, so the expected idx is independent of sort
+    stability and of FMA contraction."""
+    cases = {}
+    for tag, (b, n, m, k) in {"a": (2, 64, 16, 8), "b": (2, 96, 96, 20), "c": (1, 300, 40, 20)}.items():
+        salt = 0
+        while True:
+            xyz = lattice_points("knn_xyz_" + tag, (b, n, 3), salt=salt)
+            new_xyz = xyz[:, :m].copy() if tag == "b" else lattice_points("knn_q_" + tag, (b, m, 3), salt=salt)
+            d = ((new_xyz[:, :, None, :].astype(np.float64) - xyz[:, None, :, :]) ** 2).sum(-1)
+            ds = np.sort(d, axis=2)[:, :, :k + 1]
+            if (np.diff(ds, axis=2) > 0).all():
+                break
+            salt += 1
+        idx = ref_pointops.KNNQueryNaive.forward(None, k, torch.from_numpy(xyz), torch.from_numpy(new_xyz))
+        cases.update({tag + "_xyz": xyz, tag + "_new_xyz": new_xyz, tag + "_idx": idx.numpy(),
+                      tag + "_k": k})
+    save("pointops_knn.npz", **cases)
+
+
+# ------------------------------------------------------------------ 2. edge features
+def gen_edges():
+    x = hash_tensor("edge_x", (2, 6, 24))
+    pc = hash_tensor("edge_pc", (2, 3, 24))
+    k = 5
+    idx, dist = pdgnet_ref.feature_knn(x, k)
+    e = ref.get_edge_features(x, k)
+    e2, exyz = ref.get_edge_features_xyz(x, pc, k)
+    assert torch.equal(e, pdgnet_ref.edge_features(x, idx)), "idx extraction disagrees with reference"
+    assert torch.equal(e, e2)
+    save("edge_features.npz", x=x, pc=pc, k=k, idx=idx, dist=dist, e_fea=e, e_xyz=exyz)
+
+
+# ------------------------------------------------------------------ 3. deconv blocks
+def run_block(mod, x, pc, gout):
+    x = x.clone().requires_grad_(True)
+    args = (x,)
+    if pc is not None:
+        pc = pc.clone().requires_grad_(True)
+        args = (x, pc)
+    y = mod(*args)
+    y.backward(gout)
+    return y.detach(), x.grad, (pc.grad if pc is not None else None)
+
+
+def gen_deconv():
+    for tag, (F, Fo, k, N, B) in {"k4": (8, 8, 4, 16, 2), "k10": (8, 12, 10, 32, 2)}.items():
+        for bilateral in (False, True):
+            name = ("bilateral_" if bilateral else "plain_") + tag
+            mod = (ref.bilateral_upsample_edgeConv(F, Fo, k, 1) if bilateral
+                   else ref.upsample_edgeConv(F, Fo, k, 1))
+            fill_module(mod, salt=3)
+            x = hash_tensor(name + "_x", (B, F, N))
+            pc = hash_tensor(name + "_pc", (B, 3, N)) if bilateral else None
+            gout = hash_tensor(name + "_gout", (B, Fo, 2 * N))
+            idx, dist = pdgnet_ref.feature_knn(x, k)
+            ds = dist.sort(dim=2)[0]
+            margin = (ds[:, :, 1:k + 2] - ds[:, :, 0:k + 1]).min().item()
+            mod.train()
+            y_tr, gx, gpc = run_block(mod, x, pc, gout)
+            grads = {"grad." + n: p.grad.clone() for n, p in mod.named_parameters()}
+            stats = {"stat." + n: b.clone() for n, b in mod.named_buffers() if "num_batches" not in n}
+            mod.eval()
+            with torch.no_grad():
+                y_ev = mod(x, pc) if bilateral else mod(x)
+            out = dict(x=x, gout=gout, idx=idx, knn_margin=margin, y_train=y_tr, grad_x=gx,
+                       y_eval=y_ev, F=F, Fout=Fo, k=k, **grads, **stats)
+            if bilateral:
+                out.update(pc=pc, grad_pc=gpc)
+            save("deconv_%s.npz" % name, **out)
+
+
+# ------------------------------------------------------------------ 4. generator + discriminators
+def gen_networks():
+    G = ref.PointGenerator(2048, 20)
+    fill_module(G, salt=1)
+    Ds = [ref.PointDiscriminator_1(), ref.PointDiscriminator_2(), ref.PointDiscriminator_3(),
+          ref.PointDiscriminator_4()]
+    for i, d in enumerate(Ds):
+        fill_module(d, salt=10 + i)
+    manifest = {"G": {k: list(v.shape) for k, v in G.state_dict().items()}}
+    for i, d in enumerate(Ds):
+        manifest["D%d" % (i + 1)] = {k: list(v.shape) for k, v in d.state_dict().items()}
+    with open(os.path.join(HERE, "state_dict_manifest.json"), "w") as f:
+        json.dump(manifest, f, indent=0, sort_keys=True)
+    z = hash_tensor("G_z", (2, 128), 0.2)
+    G.train()
+    with torch.no_grad():
+        outs = G(z)
+    # the kNN graphs the reference picked, stage by stage (oracle idx for margin-free parity)
+    idxs, margins = [], []
+    hooks = []
+
+    def grab(mod, inp):
+        i, d = pdgnet_ref.feature_knn(inp[0], mod.k)
+        ds = d.sort(dim=2)[0]
+        margins.append((ds[:, :, 1:mod.k + 2] - ds[:, :, 0:mod.k + 1]).min().item())
+        idxs.append(i)
+    fill_module(G, salt=1)                                   # reset BN running stats
+    for blk in (G.bilateral1.upsample_cov[0], G.bilateral2.upsample_cov, G.bilateral3.upsample_cov,
+                G.bilateral4.upsample_cov):
+        hooks.append(blk.register_forward_pre_hook(grab))
+    with torch.no_grad():
+        outs2 = G(z)
+    for h in hooks:
+        h.remove()
+    assert all(torch.equal(a, b) for a, b in zip(outs, outs2))
+    d_out = {}
+    for i, d in enumerate(Ds):
+        d.train()
+        with torch.no_grad():
+            d_out["d%d" % (i + 1)] = d(outs[i])
+    save("generator_b2.npz", z=z, p1=outs[0], p2=outs[1], p3=outs[2], p4=outs[3],
+         idx1=idxs[0].to(torch.int16), idx2=idxs[1].to(torch.int16), idx3=idxs[2].to(torch.int16),
+         idx4=idxs[3].to(torch.int16), knn_margins=np.array(margins), **d_out)
+    return G, Ds, z, outs
+
+
+# ------------------------------------------------------------------ 5. chamfer / local statistics
+def gen_losses():
+    a = hash_tensor("cd_a", (3, 40, 3))
+    b = hash_tensor("cd_b", (3, 40, 3), salt=1)
+    a9 = hash_tensor("cd_a9", (2, 24, 9))
+    b9 = hash_tensor("cd_b9", (2, 24, 9), salt=1)
+    loss3 = RefChamferLoss()(a, b)
+    loss9 = RefChamferLoss()(a9, b9)
+    dl, dr = ref_distChamfer(a, b)
+    pts = hash_tensor("meancov", (10, 3, 20))
+    mu, cov = ref.PDGNet_v2.compute_mean_covariance(None, pts)
+    save("chamfer.npz", a=a, b=b, a9=a9, b9=b9, chamfer_sum3=loss3, chamfer_sum9=loss9,
+         dist_l=dl, dist_r=dr, mc_points=pts, mc_mu=mu, mc_cov=cov)
+
+
+# ------------------------------------------------------------------ 6. one G+D iteration (composed)
+def gen_step(G, Ds):
+    """COMPOSED: reference torch modules / ChamferLoss / compute_mean_covariance / Adam with
+    the C oracle standing in for the CUDA knnquery+grouping (models/PDGNet_v2.py:171-256).
+    B=2 (BASELINE.json configs[0] uses 256->512; the full 4-stage net is used here because
+    the reference generator cannot stop at 512)."""
+    B = 2
+    fill_module(G, salt=1)
+    for i, d in enumerate(Ds):
+        fill_module(d, salt=10 + i)
+    G.train()
+    reals = [hash_tensor("real%d" % i, (B, 3, n), 0.8) for i, n in enumerate((256, 512, 1024, 2048))]
+    z1 = hash_tensor("step_z1", (B, 128), 0.2)
+    z2 = hash_tensor("step_z2", (B, 128), 0.2)
+    adam = lambda m: torch.optim.Adam(m.parameters(), lr=1e-4, betas=(0.5, 0.999))
+    optG, optD = adam(G), [adam(d) for d in Ds]
+    mse = torch.nn.MSELoss()
+    cham = RefChamferLoss()
+    ones, zeros = torch.ones(B, 1), torch.zeros(B, 1)
+    fakes = G(z1)
+    res = {}
+    for i in range(4):
+        optD[i].zero_grad()
+        lossD = (mse(Ds[i](reals[i]), ones) + mse(Ds[i](fakes[i].detach()), zeros)) / 2.0
+        lossD.backward()
+        optD[i].step()
+        res["d_loss%d" % (i + 1)] = lossD.item()
+    optG.zero_grad()
+    p = G(z2)
+
+    def local_pair(pt1, pt2):
+        M = pt1.shape[2]
+        new_xyz = pt1.transpose(1, 2).contiguous()
+        g1 = pdgnet_ref.query_and_group_xyz(new_xyz, new_xyz).transpose(1, 2).contiguous().view(-1, 3, 20)
+        g2 = pdgnet_ref.query_and_group_xyz(pt2.transpose(1, 2).contiguous(), new_xyz)
+        g2 = g2.transpose(1, 2).contiguous().view(-1, 3, 20)
+        mu1, var1 = ref.PDGNet_v2.compute_mean_covariance(None, g1)
+        mu2, var2 = ref.PDGNet_v2.compute_mean_covariance(None, g2)
+        return (cham(mu1.view(B, -1, 3), mu2.view(B, -1, 3)) / float(M),
+                cham(var1.view(B, -1, 9), var2.view(B, -1, 9)) / float(M))
+    mus, covs = [], []
+    for a, b in ((0, 1), (0, 2), (0, 3), (1, 2), (1, 3), (2, 3)):
+        mu, cov = local_pair(p[a], p[b])
+        mus.append(mu)
+        covs.append(cov)
+    sim = sum(mus[1:], mus[0]) + sum(covs[1:], covs[0])
+    g = [mse(Ds[i](p[i]), ones) for i in range(4)]
+    lossG = (1.2 * g[0] + 1.2 * g[1] + 1.2 * g[2] + g[3]) + 0.1 * sim
+    lossG.backward()
+    gnorm = torch.sqrt(sum((q.grad ** 2).sum() for q in G.parameters())).item()
+    optG.step()
+    res.update(g_loss=lossG.item(), similar_loss=sim.item(), g_grad_norm=gnorm,
+               g_fc1_w_after=G.fc1[0].weight.detach()[:4, :8].clone())
+    save("step_b2.npz", **res)
+
+
+if __name__ == "__main__":
+    cref.build()
+    gen_knn()
+    gen_edges()
+    gen_deconv()
+    gen_losses()
+    G, Ds, z, outs = gen_networks()
+    if "--no-step" not in sys.argv:
+        gen_step(G, Ds)
