@@ -1,0 +1,109 @@
+/*
+ * pdgn_hip.h -- C ABI of libpdgn_hip.so: the MI355X (gfx950) drop-in for the native
+ * side of PDGN's hot path.
+ *
+ * Every entry point takes plain device pointers + sizes + a hipStream_t (passed as
+ * void*), launches asynchronously on that stream, never allocates, never synchronises,
+ * and returns 0 on success, a hipError_t value (>0) on a launch failure, or
+ * PDGN_ERR_INVALID (-1) when an argument is out of the supported range.  The library
+ * keeps no global state and is safe to call from one process per GPU.
+ *
+ * All tensors are contiguous, batch-major; float = fp32, idx = int32 -- exactly the
+ * layouts of the reference launchers cited per function (paths relative to the
+ * reference repository root).
+ */
+#ifndef PDGN_HIP_H
+#define PDGN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PDGN_ERR_INVALID (-1)
+#define PDGN_KNN_MAX_NSAMPLE 200 /* lib/pointops/src/knnquery/knnquery_cuda_kernel.cu:21-22 */
+
+typedef void *pdgn_stream_t; /* hipStream_t */
+
+/* ABI version of this header (bumped on any signature change). */
+int pdgn_abi_version(void);
+
+/* ------------------------------------------------------------------ pointops
+ * Replaces knnquery_cuda_launcher (lib/pointops/src/knnquery/knnquery_cuda_kernel.h:14,
+ * kernel knnquery_cuda_kernel.cu:6-50).  xyz (b,n,3), new_xyz (b,m,3) ->
+ * idx (b,m,nsample) int32, dist2 (b,m,nsample) f32 (dist2 may be NULL).
+ * Ascending (squared distance, index); for n < nsample the tail is idx 0 / +inf.
+ * nsample <= PDGN_KNN_MAX_NSAMPLE. */
+int pdgn_knnquery(int b, int n, int m, int nsample, const float *xyz, const float *new_xyz,
+                  int32_t *idx, float *dist2, pdgn_stream_t stream);
+
+/* Replaces grouping_forward_cuda_launcher_fast (grouping/grouping_cuda_kernel.h:19,
+ * kernel grouping_cuda_kernel.cu:60-74).  points (b,c,n), idx (b,m,nsample) ->
+ * out (b,c,m,nsample). */
+int pdgn_grouping_forward(int b, int c, int n, int m, int nsample, const float *points,
+                          const int32_t *idx, float *out, pdgn_stream_t stream);
+
+/* Replaces grouping_backward_cuda_launcher (grouping/grouping_cuda_kernel.h:17,
+ * kernel :28-46).  grad_out (b,c,m,nsample), idx -> grad_points (b,c,n), ACCUMULATED
+ * into the caller's buffer (the caller zero-fills it, pointops.py:146). */
+int pdgn_grouping_backward(int b, int c, int n, int m, int nsample, const float *grad_out,
+                           const int32_t *idx, float *grad_points, pdgn_stream_t stream);
+
+/* Replaces nearestneighbor_cuda_launcher_fast (interpolation/interpolation_cuda_kernel.h:22,
+ * kernel interpolation_cuda_kernel.cu:134-176).  unknown (b,n,3), known (b,m,3) ->
+ * dist2 (b,n,3) squared distances, idx (b,n,3). */
+int pdgn_nearestneighbor(int b, int n, int m, const float *unknown, const float *known,
+                         float *dist2, int32_t *idx, pdgn_stream_t stream);
+
+/* Replaces interpolation_forward_cuda_launcher_fast (interpolation_cuda_kernel.h:23,
+ * kernel :181-195).  points (b,c,m), idx/weight (b,n,3) -> out (b,c,n). */
+int pdgn_interpolation_forward(int b, int c, int m, int n, const float *points,
+                               const int32_t *idx, const float *weight, float *out,
+                               pdgn_stream_t stream);
+
+/* Replaces interpolation_backward_cuda_launcher (interpolation_cuda_kernel.h:20,
+ * kernel :90-114).  grad_out (b,c,n) -> grad_points (b,c,m), ACCUMULATED. */
+int pdgn_interpolation_backward(int b, int c, int n, int m, const float *grad_out,
+                                const int32_t *idx, const float *weight, float *grad_points,
+                                pdgn_stream_t stream);
+
+/* ------------------------------------------------------------------ structural losses
+ * Replaces nndistance (evaluation/pytorch_structural_losses/src/nndistance.cuh:1,
+ * nndistance.cu:2-128).  xyz (b,n,3), xyz2 (b,m,3) -> result/result_i (b,n),
+ * result2/result2_i (b,m): min squared distance and its argmin (lowest index on ties). */
+int pdgn_nndistance(int b, int n, const float *xyz, int m, const float *xyz2, float *result,
+                    int32_t *result_i, float *result2, int32_t *result2_i, pdgn_stream_t stream);
+
+/* Replaces nndistancegrad (nndistance.cuh:2, nndistance.cu:129-154).  Zero-fills
+ * grad_xyz1 (b,n,3) / grad_xyz2 (b,m,3) itself (on `stream`), then accumulates. */
+int pdgn_nndistance_grad(int b, int n, const float *xyz1, int m, const float *xyz2,
+                         const float *grad_dist1, const int32_t *idx1, const float *grad_dist2,
+                         const int32_t *idx2, float *grad_xyz1, float *grad_xyz2,
+                         pdgn_stream_t stream);
+
+/* Replaces approxmatch (src/approxmatch.cuh:6, approxmatch.cu:3-182,299-307).
+ * xyz1 (b,n,3), xyz2 (b,m,3) -> match (b,m,n); temp (b, 2*(n+m)) is scratch. */
+int pdgn_approxmatch(int b, int n, int m, const float *xyz1, const float *xyz2, float *match,
+                     float *temp, pdgn_stream_t stream);
+
+/* Replaces matchcost (approxmatch.cuh:7, approxmatch.cu:184-224,309-316) -> out (b). */
+int pdgn_matchcost(int b, int n, int m, const float *xyz1, const float *xyz2,
+                   const float *match, float *out, pdgn_stream_t stream);
+
+/* Replaces matchcostgrad (approxmatch.cuh:8, approxmatch.cu:229-291,318-326) ->
+ * grad1 (b,n,3), grad2 (b,m,3). */
+int pdgn_matchcost_grad(int b, int n, int m, const float *xyz1, const float *xyz2,
+                        const float *match, float *grad1, float *grad2, pdgn_stream_t stream);
+
+/* Fused forward-only EMD cost for the eval path (evaluation_metrics.py:26-31 calls
+ * ApproxMatch then MatchCost and drops `match`): same arithmetic as
+ * pdgn_approxmatch + pdgn_matchcost but `match` is never written to HBM.
+ * temp (b, 2*(n+m)) scratch, out (b). */
+int pdgn_emd_cost(int b, int n, int m, const float *xyz1, const float *xyz2, float *temp,
+                  float *out, pdgn_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PDGN_HIP_H */

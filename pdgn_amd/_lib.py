@@ -1,0 +1,65 @@
+"""ctypes loader for libpdgn_hip.so (the C ABI declared in include/pdgn_hip.h).
+
+There is NO CPU fallback: if the library is missing or a tensor is not on a ROCm device the
+call raises.  Building is explicit (`python -m pdgn_amd.build` / `__graft_entry__.build()`).
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "libpdgn_hip.so")
+ABI_VERSION = 1
+_lib = None
+
+
+class PdgnHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the ctypes handle of libpdgn_hip.so."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise PdgnHipError(
+                "libpdgn_hip.so is not built (%s missing): run `python -m pdgn_amd.build`; "
+                "pdgn_amd has no CPU fallback" % SO_PATH)
+        handle = ctypes.CDLL(SO_PATH)
+        handle.pdgn_abi_version.restype = ctypes.c_int
+        got = handle.pdgn_abi_version()
+        if got != ABI_VERSION:
+            raise PdgnHipError("libpdgn_hip.so ABI %d != expected %d: rebuild" % (got, ABI_VERSION))
+        _lib = handle
+    return _lib
+
+
+def stream_of(t):
+    """hipStream_t of torch's current stream on t's device."""
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def check(rc, what):
+    if rc != 0:
+        if rc == -1:
+            raise PdgnHipError("%s: argument outside the supported range" % what)
+        raise PdgnHipError("%s: HIP launch failed with hipError_t %d" % (what, rc))
+
+
+def require(t, name, dtype, dim=None):
+    """Reference preconditions (pointops.py:129-130, knnquery_cuda.cpp:12-14) + dtype/device."""
+    if not isinstance(t, torch.Tensor):
+        raise TypeError("%s must be a torch.Tensor" % name)
+    if not t.is_cuda:
+        raise PdgnHipError("%s must live on a ROCm device (pdgn_amd has no CPU path)" % name)
+    if t.dtype != dtype:
+        raise TypeError("%s must be %s, got %s" % (name, dtype, t.dtype))
+    assert t.is_contiguous(), "%s must be contiguous" % name
+    if dim is not None and t.dim() != dim:
+        raise ValueError("%s must have %d dims, got %d" % (name, dim, t.dim()))
+    return t

@@ -1,0 +1,266 @@
+// knn3.hip -- brute-force 3-D kNN (pdgn_knnquery) and 3-NN (pdgn_nearestneighbor) for gfx950.
+//
+// Semantics: lib/pointops/src/knnquery/knnquery_cuda_kernel.cu:6-50 and
+// interpolation/interpolation_cuda_kernel.cu:134-176 of the reference -- ascending
+// (squared distance, index), strict '<', tail idx 0 / +inf when the set is short.
+//
+// Design (not the reference's one-thread-per-query insertion sort): ONE WAVE PER QUERY.
+//   * the candidate set of a batch is staged once per workgroup into LDS as float4
+//     (coalesced global reads, conflict-free ds_read_b128, shared by the block's waves);
+//   * pass A: lane l scans candidates l, l+64, ... and keeps only its minimum; the K-th
+//     smallest of the 64 lane minima (wave bitonic sort over ds_bpermute) is an upper
+//     bound tau of the K-th nearest distance;
+//   * pass B: lanes recompute their distances and compact the survivors (d <= tau) into a
+//     per-wave LDS queue with ballot/popcount prefix sums (typically 25-40 survivors);
+//   * the survivors are sorted, 64 at a time, by (distance, index) with a wave-wide bitonic
+//     network and merged into the running best-K held by lanes 0..K-1.
+// (distance, index) is a strict total order, so the result is bit-identical to the
+// reference's stable insertion regardless of scheduling.
+#include "common.h"
+
+#define KNN_THREADS 256
+#define KNN_WAVES (KNN_THREADS / PDGN_WAVE)
+#define KNN_TILE 4096        // candidates staged per pass: 64 KiB of float4
+#define KNN_QCAP 256         // survivor queue entries per wave
+#define KNN_FAST_MAX_K 32
+
+struct DI {
+    float d;
+    int i;
+};
+
+__device__ __forceinline__ bool di_less(float d0, int i0, float d1, int i1) {
+    return d0 < d1 || (d0 == d1 && i0 < i1);
+}
+
+// Wave-wide bitonic sort (ascending) of one (d, i) pair per lane.
+__device__ __forceinline__ void wave_sort_di(float &d, int &i, int lane) {
+#pragma unroll
+    for (int k2 = 2; k2 <= 64; k2 <<= 1) {
+#pragma unroll
+        for (int j = k2 >> 1; j > 0; j >>= 1) {
+            float pd = __shfl_xor(d, j, 64);
+            int pi = __shfl_xor(i, j, 64);
+            bool keep_min = ((lane & j) == 0) == ((lane & k2) == 0);
+            bool partner_less = di_less(pd, pi, d, i);
+            bool take = keep_min ? partner_less : !partner_less;
+            d = take ? pd : d;
+            i = take ? pi : i;
+        }
+    }
+}
+
+// Wave-wide bitonic sort (ascending) of one float per lane.
+__device__ __forceinline__ float wave_sort_f(float d, int lane) {
+#pragma unroll
+    for (int k2 = 2; k2 <= 64; k2 <<= 1) {
+#pragma unroll
+        for (int j = k2 >> 1; j > 0; j >>= 1) {
+            float pd = __shfl_xor(d, j, 64);
+            bool keep_min = ((lane & j) == 0) == ((lane & k2) == 0);
+            d = keep_min ? fminf(d, pd) : fmaxf(d, pd);
+        }
+    }
+    return d;
+}
+
+// Merge the queued survivors q[0..cnt) into the running best-K (lanes 0..K-1 hold it, sorted).
+__device__ __forceinline__ void knn_flush(const DI *q, int cnt, int K, float &rd, int &ri, int lane) {
+    const int take = 64 - K;
+    __builtin_amdgcn_wave_barrier();            // queue writes of other lanes precede these reads
+    for (int base = 0; base < cnt; base += take) {
+        int src = base + lane - K;
+        bool fresh = lane >= K;
+        float d = rd;
+        int i = ri;
+        if (fresh) {
+            bool ok = src < cnt;
+            d = ok ? q[ok ? src : 0].d : INFINITY;
+            i = ok ? q[ok ? src : 0].i : 0x7fffffff;
+        }
+        wave_sort_di(d, i, lane);
+        rd = d;
+        ri = i;
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+__global__ __launch_bounds__(KNN_THREADS) void knn3_wave_kernel(
+    int n, int m, int K, int qpw, const float *__restrict__ xyz, const float *__restrict__ new_xyz,
+    int32_t *__restrict__ idx, float *__restrict__ dist2) {
+    __shared__ float4 cand[KNN_TILE];
+    __shared__ DI queue[KNN_WAVES][KNN_QCAP];
+
+    const int bs = blockIdx.y;
+    const int lane = lane_id();
+    const int wave = threadIdx.x / PDGN_WAVE;
+    const float *P = xyz + (size_t)bs * n * 3;
+    DI *q = queue[wave];
+
+    // This kernel keeps the running best-K of every query of the wave in registers across
+    // candidate tiles, so the tile loop is outermost only when n > KNN_TILE (rare); the
+    // common case stages once and walks the wave's queries.
+    const int q0 = (blockIdx.x * KNN_WAVES + wave) * qpw;
+
+    for (int qi = 0; qi < qpw; ++qi) {
+        const int query = q0 + qi;              // wave-uniform
+        float rd = INFINITY;                    // running best-K: lanes 0..K-1
+        int ri = 0x7fffffff;
+        float qx = 0.f, qy = 0.f, qz = 0.f;
+        if (query < m) {
+            const float *Q = new_xyz + ((size_t)bs * m + query) * 3;
+            qx = Q[0]; qy = Q[1]; qz = Q[2];
+        }
+        for (int t0 = 0; t0 < n; t0 += KNN_TILE) {
+            const int tn = min(KNN_TILE, n - t0);
+            if (qi == 0 || n > KNN_TILE) {
+                __syncthreads();                // previous tile fully consumed
+                for (int e = threadIdx.x; e < tn * 3; e += KNN_THREADS)
+                    reinterpret_cast<float *>(cand)[(e / 3) * 4 + (e % 3)] = P[(size_t)t0 * 3 + e];
+                __syncthreads();
+            }
+            if (query >= m) continue;
+            // pass A: per-lane minimum -> tau
+            float lmin = INFINITY;
+            for (int c = lane; c < tn; c += 64) {
+                float4 p = cand[c];
+                lmin = fminf(lmin, sqdist3(qx, qy, qz, p.x, p.y, p.z));
+            }
+            float sorted = wave_sort_f(lmin, lane);
+            float tau = __shfl(sorted, K - 1, 64);
+            float worst = __shfl(rd, K - 1, 64);   // K-th best so far (inf until the list fills)
+            tau = fminf(tau, worst);
+            // pass B: compact survivors
+            int cnt = 0;                        // wave-uniform
+            for (int c0 = 0; c0 < tn; c0 += 64) {
+                int c = c0 + lane;
+                float d = INFINITY;
+                if (c < tn) {
+                    float4 p = cand[c];
+                    d = sqdist3(qx, qy, qz, p.x, p.y, p.z);
+                }
+                bool keep = d <= tau && d < INFINITY;
+                unsigned long long mask = __ballot(keep);
+                if (mask) {
+                    int pos = cnt + __popcll(mask & ((1ull << lane) - 1ull));
+                    if (keep) { q[pos].d = d; q[pos].i = t0 + c; }
+                    cnt += __popcll(mask);
+                    if (cnt > KNN_QCAP - 64) {
+                        knn_flush(q, cnt, K, rd, ri, lane);
+                        cnt = 0;
+                        tau = fminf(tau, __shfl(rd, K - 1, 64));
+                    }
+                }
+            }
+            knn_flush(q, cnt, K, rd, ri, lane);
+        }
+        if (query < m && lane < K) {
+            size_t o = ((size_t)bs * m + query) * K + lane;
+            bool valid = rd < INFINITY;
+            idx[o] = valid ? ri : 0;            // reference tail: idx 0 / dist 1e40 -> +inf
+            if (dist2) dist2[o] = rd;
+        }
+    }
+}
+
+// Generic fallback for 32 < nsample <= 200: one thread per query, sorted insertion in
+// per-thread scratch (the reference's own shape; not used by PDGN, which has nsample = 20).
+__global__ __launch_bounds__(KNN_THREADS) void knn3_generic_kernel(
+    int n, int m, int K, const float *__restrict__ xyz, const float *__restrict__ new_xyz,
+    int32_t *__restrict__ idx, float *__restrict__ dist2) {
+    const int bs = blockIdx.y;
+    const int query = blockIdx.x * blockDim.x + threadIdx.x;
+    if (query >= m) return;
+    const float *P = xyz + (size_t)bs * n * 3;
+    const float *Q = new_xyz + ((size_t)bs * m + query) * 3;
+    const float qx = Q[0], qy = Q[1], qz = Q[2];
+    float best[PDGN_KNN_MAX_NSAMPLE];
+    int besti[PDGN_KNN_MAX_NSAMPLE];
+    for (int i = 0; i < K; ++i) { best[i] = INFINITY; besti[i] = 0; }
+    for (int c = 0; c < n; ++c) {
+        float d = sqdist3(qx, qy, qz, P[c * 3], P[c * 3 + 1], P[c * 3 + 2]);
+        if (d < best[K - 1]) {
+            int j = K - 1;
+            while (j > 0 && d < best[j - 1]) { best[j] = best[j - 1]; besti[j] = besti[j - 1]; --j; }
+            best[j] = d;
+            besti[j] = c;
+        }
+    }
+    size_t o = ((size_t)bs * m + query) * K;
+    for (int i = 0; i < K; ++i) {
+        idx[o + i] = besti[i];
+        if (dist2) dist2[o + i] = best[i];
+    }
+}
+
+// 3-NN: one thread per unknown point, `known` staged through LDS; three running minima in
+// registers with the reference's strict '<' cascade (interpolation_cuda_kernel.cu:157-171).
+__global__ __launch_bounds__(KNN_THREADS) void nn3_kernel(
+    int n, int m, const float *__restrict__ unknown, const float *__restrict__ known,
+    float *__restrict__ dist2, int32_t *__restrict__ idx) {
+    __shared__ float4 cand[2048];
+    const int bs = blockIdx.y;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const float *Kn = known + (size_t)bs * m * 3;
+    float ux = 0.f, uy = 0.f, uz = 0.f;
+    if (j < n) {
+        const float *U = unknown + ((size_t)bs * n + j) * 3;
+        ux = U[0]; uy = U[1]; uz = U[2];
+    }
+    float b1 = INFINITY, b2 = INFINITY, b3 = INFINITY;
+    int i1 = 0, i2 = 0, i3 = 0;
+    for (int t0 = 0; t0 < m; t0 += 2048) {
+        const int tn = min(2048, m - t0);
+        __syncthreads();
+        for (int e = threadIdx.x; e < tn * 3; e += KNN_THREADS)
+            reinterpret_cast<float *>(cand)[(e / 3) * 4 + (e % 3)] = Kn[(size_t)t0 * 3 + e];
+        __syncthreads();
+        for (int c = 0; c < tn; ++c) {
+            float4 p = cand[c];
+            float d = sqdist3(ux, uy, uz, p.x, p.y, p.z);
+            int k = t0 + c;
+            if (d < b1) { b3 = b2; i3 = i2; b2 = b1; i2 = i1; b1 = d; i1 = k; }
+            else if (d < b2) { b3 = b2; i3 = i2; b2 = d; i2 = k; }
+            else if (d < b3) { b3 = d; i3 = k; }
+        }
+    }
+    if (j < n) {
+        size_t o = ((size_t)bs * n + j) * 3;
+        dist2[o] = b1; dist2[o + 1] = b2; dist2[o + 2] = b3;
+        idx[o] = i1; idx[o + 1] = i2; idx[o + 2] = i3;
+    }
+}
+
+extern "C" int pdgn_knnquery(int b, int n, int m, int nsample, const float *xyz,
+                             const float *new_xyz, int32_t *idx, float *dist2,
+                             pdgn_stream_t stream) {
+    if (b < 0 || n < 0 || m < 0 || nsample < 1 || nsample > PDGN_KNN_MAX_NSAMPLE) return PDGN_ERR_INVALID;
+    if (b == 0 || m == 0) return 0;
+    if (b > 65535) return PDGN_ERR_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    if (nsample <= KNN_FAST_MAX_K) {
+        // queries per wave: enough workgroups to cover 256 CUs several times over, while
+        // amortising the LDS staging of the candidate set when there are many queries.
+        long long waves = (long long)b * m;
+        int qpw = (int)(waves / 8192);
+        qpw = qpw < 1 ? 1 : (qpw > 8 ? 8 : qpw);
+        dim3 grid(cdiv(m, KNN_WAVES * qpw), b);
+        hipLaunchKernelGGL(knn3_wave_kernel, grid, dim3(KNN_THREADS), 0, s, n, m, nsample, qpw, xyz,
+                           new_xyz, idx, dist2);
+    } else {
+        dim3 grid(cdiv(m, KNN_THREADS), b);
+        hipLaunchKernelGGL(knn3_generic_kernel, grid, dim3(KNN_THREADS), 0, s, n, m, nsample, xyz,
+                           new_xyz, idx, dist2);
+    }
+    return pdgn_launch_status();
+}
+
+extern "C" int pdgn_nearestneighbor(int b, int n, int m, const float *unknown, const float *known,
+                                    float *dist2, int32_t *idx, pdgn_stream_t stream) {
+    if (b < 0 || n < 0 || m < 0 || b > 65535) return PDGN_ERR_INVALID;
+    if (b == 0 || n == 0) return 0;
+    dim3 grid(cdiv(n, KNN_THREADS), b);
+    hipLaunchKernelGGL(nn3_kernel, grid, dim3(KNN_THREADS), 0, (hipStream_t)stream, n, m, unknown,
+                       known, dist2, idx);
+    return pdgn_launch_status();
+}

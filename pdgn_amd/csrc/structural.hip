@@ -1,0 +1,411 @@
+// structural.hip -- Chamfer nearest-neighbour distance and approximate EMD for gfx950.
+//
+// Semantics: evaluation/pytorch_structural_losses/src/nndistance.cu:2-154 and
+// src/approxmatch.cu:3-326 of the reference.
+//
+//  * nndistance: one thread per point, the other cloud staged through LDS as float4 tiles,
+//    both directions in ONE launch (blockIdx.z).  The reference launches a fixed (32,16)
+//    grid twice; here the grid covers (points/256, batch, 2).
+//  * approxmatch: ONE WORKGROUP PER PAIR (the reference pins the grid at 32 blocks and
+//    serialises b/32 pairs per block).  Each thread owns PPT points, so one broadcast
+//    ds_read_b128 of the opposite cloud feeds PPT exp evaluations.  remain/ratio vectors
+//    stay in the caller's `temp` scratch (a few KB per pair, L2-resident).
+//  * emd_cost: the same 9-level auction with phase 3 accumulating match*dist on the fly --
+//    the (b,m,n) match matrix (8.6 GB at b=512, 2048^2) never touches HBM.
+#include "common.h"
+
+#define SL_THREADS 256
+#define SL_TILE 2048
+
+// ---------------------------------------------------------------------------- nn distance
+// nndistance.cu:21-24: d = x2*x2+y2*y2+z2*z2 with x2 = cand - query, contracted by nvcc to
+// fma(z2,z2, fma(y2,y2, x2*x2)); strict '<' => lowest index wins ties (:26, :116).
+__global__ __launch_bounds__(SL_THREADS) void nndist_kernel(
+    int n, int m, const float *__restrict__ xyz, const float *__restrict__ xyz2,
+    float *__restrict__ res, int32_t *__restrict__ res_i, float *__restrict__ res2,
+    int32_t *__restrict__ res2_i) {
+    __shared__ float4 cand[SL_TILE];
+    const int bs = blockIdx.y;
+    const bool rev = blockIdx.z != 0;
+    const int nq = rev ? m : n, nc = rev ? n : m;
+    const float *Q = (rev ? xyz2 : xyz) + (size_t)bs * nq * 3;
+    const float *C = (rev ? xyz : xyz2) + (size_t)bs * nc * 3;
+    float *out = (rev ? res2 : res) + (size_t)bs * nq;
+    int32_t *out_i = (rev ? res2_i : res_i) + (size_t)bs * nq;
+    if ((int)(blockIdx.x * blockDim.x) >= nq) return;   // block-uniform
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    float qx = 0.f, qy = 0.f, qz = 0.f;
+    if (j < nq) { qx = Q[j * 3]; qy = Q[j * 3 + 1]; qz = Q[j * 3 + 2]; }
+    float best = 0.f;
+    int best_i = 0;
+    for (int t0 = 0; t0 < nc; t0 += SL_TILE) {
+        const int tn = min(SL_TILE, nc - t0);
+        __syncthreads();
+        for (int e = threadIdx.x; e < tn * 3; e += SL_THREADS)
+            reinterpret_cast<float *>(cand)[(e / 3) * 4 + (e % 3)] = C[(size_t)t0 * 3 + e];
+        __syncthreads();
+        for (int c = 0; c < tn; ++c) {
+            float4 p = cand[c];
+            float x2 = p.x - qx, y2 = p.y - qy, z2 = p.z - qz;
+            float d = __fmaf_rn(z2, z2, __fmaf_rn(y2, y2, __fmul_rn(x2, x2)));
+            bool better = (t0 + c == 0) || d < best;
+            best = better ? d : best;
+            best_i = better ? t0 + c : best_i;
+        }
+    }
+    if (j < nq) { out[j] = best; out_i[j] = best_i; }
+}
+
+// nndistance.cu:129-148: g = 2*grad; grad1[j] += g*(p1-p2); grad2[idx] -= g*(p1-p2).
+__global__ __launch_bounds__(SL_THREADS) void nndist_grad_kernel(
+    int n, int m, const float *__restrict__ xyz1, const float *__restrict__ xyz2,
+    const float *__restrict__ gd1, const int32_t *__restrict__ idx1, const float *__restrict__ gd2,
+    const int32_t *__restrict__ idx2, float *__restrict__ g1, float *__restrict__ g2) {
+    const int bs = blockIdx.y;
+    const bool rev = blockIdx.z != 0;
+    const int na = rev ? m : n, nb = rev ? n : m;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= na) return;
+    const float *A = (rev ? xyz2 : xyz1) + (size_t)bs * na * 3;
+    const float *B = (rev ? xyz1 : xyz2) + (size_t)bs * nb * 3;
+    const float *gd = (rev ? gd2 : gd1) + (size_t)bs * na;
+    const int32_t *id = (rev ? idx2 : idx1) + (size_t)bs * na;
+    float *ga = (rev ? g2 : g1) + (size_t)bs * na * 3;
+    float *gb = (rev ? g1 : g2) + (size_t)bs * nb * 3;
+    const int j2 = id[j];
+    const float g = gd[j] * 2;
+    for (int c = 0; c < 3; ++c) {
+        float v = g * (A[j * 3 + c] - B[j2 * 3 + c]);
+        atomicAdd(&ga[j * 3 + c], v);
+        atomicAdd(&gb[j2 * 3 + c], -v);
+    }
+}
+
+// ---------------------------------------------------------------------------- approx EMD
+#define AM_THREADS 512
+#define AM_PPT 4                      // points per thread per sweep
+#define AM_SWEEP (AM_THREADS * AM_PPT)
+#define AM_TILE 1024                  // opposite-cloud tile (approxmatch.cu:13 Block=1024)
+
+__device__ __forceinline__ float sq3(float ax, float ay, float az, float bx, float by, float bz) {
+    float dx = ax - bx, dy = ay - by, dz = az - bz;
+    return __fmaf_rn(dz, dz, __fmaf_rn(dy, dy, __fmul_rn(dx, dx)));
+}
+
+// FUSED = false: writes match (b,m,n) like approxmatchkernel (approxmatch.cu:3-182).
+// FUSED = true : accumulates sum match*sqrt(d2) instead (matchcostkernel :184-224 folded in).
+template <bool FUSED>
+__global__ __launch_bounds__(AM_THREADS) void approxmatch_kernel(
+    int n, int m, const float *__restrict__ xyz1, const float *__restrict__ xyz2,
+    float *__restrict__ match, float *__restrict__ temp, float *__restrict__ cost_out) {
+    __shared__ float4 buf[AM_TILE];
+    __shared__ float red[AM_THREADS / PDGN_WAVE];
+    const int pair = blockIdx.x;
+    const float *A = xyz1 + (size_t)pair * n * 3;
+    const float *B = xyz2 + (size_t)pair * m * 3;
+    float *M = FUSED ? nullptr : match + (size_t)pair * n * m;
+    // remainL | remainR | ratioL | ratioR, as approxmatch.cu:4 lays out `temp`
+    float *remainL = temp + (size_t)pair * (n + m) * 2, *remainR = remainL + n,
+          *ratioL = remainR + m, *ratioR = ratioL + n;
+    const float multiL = n >= m ? 1.f : (float)(m / n);     // integer division, :6-12
+    const float multiR = n >= m ? (float)(n / m) : 1.f;
+    const int tid = threadIdx.x;
+    for (int k = tid; k < n; k += AM_THREADS) remainL[k] = multiL;
+    for (int l = tid; l < m; l += AM_THREADS) remainR[l] = multiR;
+    __syncthreads();
+    float cost = 0.f;
+
+    for (int j = 7; j > -2; --j) {                          // 9 levels; the j==-2 branch is dead
+        const float level = -ldexpf(1.0f, 2 * j);           // -4^j
+        // ---- phase 1 (:29-62): ratioL[k] = remainL[k] / (1e-9 + sum_l exp(level*d2)*remainR[l])
+        for (int k0 = 0; k0 < n; k0 += AM_SWEEP) {
+            float px[AM_PPT], py[AM_PPT], pz[AM_PPT], acc[AM_PPT];
+#pragma unroll
+            for (int i = 0; i < AM_PPT; ++i) {
+                int k = k0 + tid + i * AM_THREADS;
+                bool ok = k < n;
+                px[i] = ok ? A[k * 3] : 0.f; py[i] = ok ? A[k * 3 + 1] : 0.f; pz[i] = ok ? A[k * 3 + 2] : 0.f;
+                acc[i] = 1e-9f;
+            }
+            for (int l0 = 0; l0 < m; l0 += AM_TILE) {
+                const int lend = min(AM_TILE, m - l0);
+                __syncthreads();
+                for (int l = tid; l < lend; l += AM_THREADS)
+                    buf[l] = make_float4(B[(l0 + l) * 3], B[(l0 + l) * 3 + 1], B[(l0 + l) * 3 + 2], remainR[l0 + l]);
+                __syncthreads();
+                for (int l = 0; l < lend; ++l) {
+                    float4 q = buf[l];
+#pragma unroll
+                    for (int i = 0; i < AM_PPT; ++i)
+                        acc[i] = __fmaf_rn(__expf(level * sq3(q.x, q.y, q.z, px[i], py[i], pz[i])), q.w, acc[i]);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < AM_PPT; ++i) {
+                int k = k0 + tid + i * AM_THREADS;
+                if (k < n) ratioL[k] = remainL[k] / acc[i];
+            }
+        }
+        __syncthreads();
+        // ---- phase 2 (:78-111)
+        for (int l0 = 0; l0 < m; l0 += AM_SWEEP) {
+            float px[AM_PPT], py[AM_PPT], pz[AM_PPT], acc[AM_PPT];
+#pragma unroll
+            for (int i = 0; i < AM_PPT; ++i) {
+                int l = l0 + tid + i * AM_THREADS;
+                bool ok = l < m;
+                px[i] = ok ? B[l * 3] : 0.f; py[i] = ok ? B[l * 3 + 1] : 0.f; pz[i] = ok ? B[l * 3 + 2] : 0.f;
+                acc[i] = 0.f;
+            }
+            for (int k0 = 0; k0 < n; k0 += AM_TILE) {
+                const int kend = min(AM_TILE, n - k0);
+                __syncthreads();
+                for (int k = tid; k < kend; k += AM_THREADS)
+                    buf[k] = make_float4(A[(k0 + k) * 3], A[(k0 + k) * 3 + 1], A[(k0 + k) * 3 + 2], ratioL[k0 + k]);
+                __syncthreads();
+                for (int k = 0; k < kend; ++k) {
+                    float4 q = buf[k];
+#pragma unroll
+                    for (int i = 0; i < AM_PPT; ++i)
+                        acc[i] = __fmaf_rn(__expf(level * sq3(px[i], py[i], pz[i], q.x, q.y, q.z)), q.w, acc[i]);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < AM_PPT; ++i) {
+                int l = l0 + tid + i * AM_THREADS;
+                if (l < m) {
+                    float r = remainR[l];
+                    float sumr = acc[i] * r;
+                    float consumption = fminf(r / (sumr + 1e-9f), 1.0f);
+                    ratioR[l] = consumption * r;
+                    remainR[l] = fmaxf(0.0f, r - sumr);
+                }
+            }
+        }
+        __syncthreads();
+        // ---- phase 3 (:130-163): w = exp(.)*ratioL[k]*ratioR[l]; match[l,k] += w; remainL -= sum_l w
+        for (int k0 = 0; k0 < n; k0 += AM_SWEEP) {
+            float px[AM_PPT], py[AM_PPT], pz[AM_PPT], rl[AM_PPT], acc[AM_PPT];
+#pragma unroll
+            for (int i = 0; i < AM_PPT; ++i) {
+                int k = k0 + tid + i * AM_THREADS;
+                bool ok = k < n;
+                px[i] = ok ? A[k * 3] : 0.f; py[i] = ok ? A[k * 3 + 1] : 0.f; pz[i] = ok ? A[k * 3 + 2] : 0.f;
+                rl[i] = ok ? ratioL[k] : 0.f;             // the reference reads ratioL[k>=n] OOB (:148)
+                acc[i] = 0.f;
+            }
+            for (int l0 = 0; l0 < m; l0 += AM_TILE) {
+                const int lend = min(AM_TILE, m - l0);
+                __syncthreads();
+                for (int l = tid; l < lend; l += AM_THREADS)
+                    buf[l] = make_float4(B[(l0 + l) * 3], B[(l0 + l) * 3 + 1], B[(l0 + l) * 3 + 2], ratioR[l0 + l]);
+                __syncthreads();
+                for (int l = 0; l < lend; ++l) {
+                    float4 q = buf[l];
+#pragma unroll
+                    for (int i = 0; i < AM_PPT; ++i) {
+                        int k = k0 + tid + i * AM_THREADS;
+                        float d2 = sq3(q.x, q.y, q.z, px[i], py[i], pz[i]);
+                        float w = __expf(level * d2) * rl[i] * q.w;
+                        if (FUSED) {
+                            cost = __fmaf_rn(w, sqrtf(d2), cost);
+                        } else if (k < n) {
+                            float *dst = &M[(size_t)(l0 + l) * n + k];
+                            *dst = (j == 7) ? w : *dst + w;   // first level overwrites: no zero-fill pass
+                        }
+                        acc[i] += w;
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < AM_PPT; ++i) {
+                int k = k0 + tid + i * AM_THREADS;
+                if (k < n) remainL[k] = fmaxf(0.0f, remainL[k] - acc[i]);
+            }
+        }
+        __syncthreads();
+    }
+    if (FUSED) {
+        for (int off = 32; off > 0; off >>= 1) cost += __shfl_down(cost, off, 64);
+        if ((tid & 63) == 0) red[tid >> 6] = cost;
+        __syncthreads();
+        if (tid == 0) {
+            float s = 0.f;
+            for (int w = 0; w < AM_THREADS / PDGN_WAVE; ++w) s += red[w];
+            cost_out[pair] = s;
+        }
+    }
+}
+
+// matchcostkernel approxmatch.cu:184-224: out[b] = sum_{k<m, j<n} match[k*n+j]*sqrt(|xyz2[k]-xyz1[j]|^2)
+__global__ __launch_bounds__(AM_THREADS) void matchcost_kernel(
+    int n, int m, const float *__restrict__ xyz1, const float *__restrict__ xyz2,
+    const float *__restrict__ match, float *__restrict__ out) {
+    __shared__ float4 buf[AM_TILE];
+    __shared__ float red[AM_THREADS / PDGN_WAVE];
+    const int pair = blockIdx.x, tid = threadIdx.x;
+    const float *A = xyz1 + (size_t)pair * n * 3;
+    const float *B = xyz2 + (size_t)pair * m * 3;
+    const float *M = match + (size_t)pair * n * m;
+    float sub = 0.f;
+    for (int k0 = 0; k0 < m; k0 += AM_TILE) {
+        const int kend = min(AM_TILE, m - k0);
+        __syncthreads();
+        for (int k = tid; k < kend; k += AM_THREADS)
+            buf[k] = make_float4(B[(k0 + k) * 3], B[(k0 + k) * 3 + 1], B[(k0 + k) * 3 + 2], 0.f);
+        __syncthreads();
+        for (int j = tid; j < n; j += AM_THREADS) {
+            const float x1 = A[j * 3], y1 = A[j * 3 + 1], z1 = A[j * 3 + 2];
+            for (int k = 0; k < kend; ++k) {
+                float4 q = buf[k];
+                sub = __fmaf_rn(M[(size_t)(k0 + k) * n + j], sqrtf(sq3(q.x, q.y, q.z, x1, y1, z1)), sub);
+            }
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) sub += __shfl_down(sub, off, 64);
+    if ((tid & 63) == 0) red[tid >> 6] = sub;
+    __syncthreads();
+    if (tid == 0) {
+        float s = 0.f;
+        for (int w = 0; w < AM_THREADS / PDGN_WAVE; ++w) s += red[w];
+        out[pair] = s;
+    }
+}
+
+// matchcostgrad1kernel approxmatch.cu:270-291: grad1[l] = sum_k (p1-p2)*match[k,l]*rsqrt(max(d2,1e-20))
+__global__ __launch_bounds__(SL_THREADS) void matchcost_grad1_kernel(
+    int n, int m, const float *__restrict__ xyz1, const float *__restrict__ xyz2,
+    const float *__restrict__ match, float *__restrict__ grad1) {
+    __shared__ float4 buf[AM_TILE];
+    const int pair = blockIdx.y, tid = threadIdx.x;
+    const int l = blockIdx.x * blockDim.x + tid;
+    const float *A = xyz1 + (size_t)pair * n * 3;
+    const float *B = xyz2 + (size_t)pair * m * 3;
+    const float *M = match + (size_t)pair * n * m;
+    float x1 = 0.f, y1 = 0.f, z1 = 0.f;
+    if (l < n) { x1 = A[l * 3]; y1 = A[l * 3 + 1]; z1 = A[l * 3 + 2]; }
+    float gx = 0.f, gy = 0.f, gz = 0.f;
+    for (int k0 = 0; k0 < m; k0 += AM_TILE) {
+        const int kend = min(AM_TILE, m - k0);
+        __syncthreads();
+        for (int k = tid; k < kend; k += SL_THREADS)
+            buf[k] = make_float4(B[(k0 + k) * 3], B[(k0 + k) * 3 + 1], B[(k0 + k) * 3 + 2], 0.f);
+        __syncthreads();
+        if (l < n)
+            for (int k = 0; k < kend; ++k) {
+                float4 q = buf[k];
+                float d = M[(size_t)(k0 + k) * n + l] * rsqrtf(fmaxf(sq3(x1, y1, z1, q.x, q.y, q.z), 1e-20f));
+                gx += (x1 - q.x) * d; gy += (y1 - q.y) * d; gz += (z1 - q.z) * d;
+            }
+    }
+    if (l < n) {
+        float *g = grad1 + ((size_t)pair * n + l) * 3;
+        g[0] = gx; g[1] = gy; g[2] = gz;
+    }
+}
+
+// matchcostgrad2kernel approxmatch.cu:229-269: grad2[k] = sum_j (p2-p1)*match[k,j]*rsqrt(...);
+// one wave per xyz2 point, lanes stride the (contiguous) match row.
+__global__ __launch_bounds__(SL_THREADS) void matchcost_grad2_kernel(
+    int n, int m, const float *__restrict__ xyz1, const float *__restrict__ xyz2,
+    const float *__restrict__ match, float *__restrict__ grad2) {
+    const int pair = blockIdx.y;
+    const int k = blockIdx.x * (SL_THREADS / PDGN_WAVE) + threadIdx.x / PDGN_WAVE;
+    if (k >= m) return;
+    const int lane = lane_id();
+    const float *A = xyz1 + (size_t)pair * n * 3;
+    const float *B = xyz2 + ((size_t)pair * m + k) * 3;
+    const float *M = match + ((size_t)pair * m + k) * n;
+    const float x2 = B[0], y2 = B[1], z2 = B[2];
+    float gx = 0.f, gy = 0.f, gz = 0.f;
+    for (int j = lane; j < n; j += 64) {
+        float x1 = x2 - A[j * 3], y1 = y2 - A[j * 3 + 1], z1 = z2 - A[j * 3 + 2];
+        float d = M[j] * rsqrtf(fmaxf(__fmaf_rn(z1, z1, __fmaf_rn(y1, y1, x1 * x1)), 1e-20f));
+        gx += x1 * d; gy += y1 * d; gz += z1 * d;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        gx += __shfl_down(gx, off, 64); gy += __shfl_down(gy, off, 64); gz += __shfl_down(gz, off, 64);
+    }
+    if (lane == 0) {
+        float *g = grad2 + ((size_t)pair * m + k) * 3;
+        g[0] = gx; g[1] = gy; g[2] = gz;
+    }
+}
+
+// ---------------------------------------------------------------------------- C ABI
+static bool sl_dims_ok(int b, int n, int m) { return b >= 0 && n >= 0 && m >= 0 && b <= 65535; }
+
+extern "C" int pdgn_nndistance(int b, int n, const float *xyz, int m, const float *xyz2, float *result,
+                               int32_t *result_i, float *result2, int32_t *result2_i,
+                               pdgn_stream_t stream) {
+    if (!sl_dims_ok(b, n, m)) return PDGN_ERR_INVALID;
+    if (b == 0 || (n == 0 && m == 0)) return 0;
+    dim3 grid(cdiv(n > m ? n : m, SL_THREADS), b, 2);
+    hipLaunchKernelGGL(nndist_kernel, grid, dim3(SL_THREADS), 0, (hipStream_t)stream, n, m, xyz, xyz2,
+                       result, result_i, result2, result2_i);
+    return pdgn_launch_status();
+}
+
+extern "C" int pdgn_nndistance_grad(int b, int n, const float *xyz1, int m, const float *xyz2,
+                                    const float *grad_dist1, const int32_t *idx1,
+                                    const float *grad_dist2, const int32_t *idx2, float *grad_xyz1,
+                                    float *grad_xyz2, pdgn_stream_t stream) {
+    if (!sl_dims_ok(b, n, m)) return PDGN_ERR_INVALID;
+    if (b == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e;
+    if (n && (e = hipMemsetAsync(grad_xyz1, 0, (size_t)b * n * 3 * sizeof(float), s)) != hipSuccess) return (int)e;
+    if (m && (e = hipMemsetAsync(grad_xyz2, 0, (size_t)b * m * 3 * sizeof(float), s)) != hipSuccess) return (int)e;
+    if (n == 0 || m == 0) return 0;
+    dim3 grid(cdiv(n > m ? n : m, SL_THREADS), b, 2);
+    hipLaunchKernelGGL(nndist_grad_kernel, grid, dim3(SL_THREADS), 0, s, n, m, xyz1, xyz2, grad_dist1, idx1,
+                       grad_dist2, idx2, grad_xyz1, grad_xyz2);
+    return pdgn_launch_status();
+}
+
+static bool am_dims_ok(int b, int n, int m) {
+    // one workgroup per pair; n, m >= 1 (the reference divides n/m or m/n)
+    return b >= 0 && n >= 1 && m >= 1 && (long long)n * m <= 0x7fffffffLL;
+}
+
+extern "C" int pdgn_approxmatch(int b, int n, int m, const float *xyz1, const float *xyz2, float *match,
+                                float *temp, pdgn_stream_t stream) {
+    if (!am_dims_ok(b, n, m)) return PDGN_ERR_INVALID;
+    if (b == 0) return 0;
+    hipLaunchKernelGGL(approxmatch_kernel<false>, dim3(b), dim3(AM_THREADS), 0, (hipStream_t)stream, n, m,
+                       xyz1, xyz2, match, temp, (float *)nullptr);
+    return pdgn_launch_status();
+}
+
+extern "C" int pdgn_emd_cost(int b, int n, int m, const float *xyz1, const float *xyz2, float *temp,
+                             float *out, pdgn_stream_t stream) {
+    if (!am_dims_ok(b, n, m)) return PDGN_ERR_INVALID;
+    if (b == 0) return 0;
+    hipLaunchKernelGGL(approxmatch_kernel<true>, dim3(b), dim3(AM_THREADS), 0, (hipStream_t)stream, n, m,
+                       xyz1, xyz2, (float *)nullptr, temp, out);
+    return pdgn_launch_status();
+}
+
+extern "C" int pdgn_matchcost(int b, int n, int m, const float *xyz1, const float *xyz2,
+                              const float *match, float *out, pdgn_stream_t stream) {
+    if (!am_dims_ok(b, n, m)) return PDGN_ERR_INVALID;
+    if (b == 0) return 0;
+    hipLaunchKernelGGL(matchcost_kernel, dim3(b), dim3(AM_THREADS), 0, (hipStream_t)stream, n, m, xyz1,
+                       xyz2, match, out);
+    return pdgn_launch_status();
+}
+
+extern "C" int pdgn_matchcost_grad(int b, int n, int m, const float *xyz1, const float *xyz2,
+                                   const float *match, float *grad1, float *grad2,
+                                   pdgn_stream_t stream) {
+    if (!am_dims_ok(b, n, m) || b > 65535) return PDGN_ERR_INVALID;
+    if (b == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(matchcost_grad1_kernel, dim3(cdiv(n, SL_THREADS), b), dim3(SL_THREADS), 0, s, n, m,
+                       xyz1, xyz2, match, grad1);
+    hipLaunchKernelGGL(matchcost_grad2_kernel, dim3(cdiv(m, SL_THREADS / PDGN_WAVE), b), dim3(SL_THREADS), 0,
+                       s, n, m, xyz1, xyz2, match, grad2);
+    return pdgn_launch_status();
+}
+
+extern "C" int pdgn_abi_version(void) { return 1; }

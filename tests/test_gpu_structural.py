@@ -1,0 +1,112 @@
+"""GPU parity: pdgn_amd.structural_losses (HIP) vs the C oracle / golden vectors.
+Float tolerance: 1e-4 relative (BASELINE.json north_star), indices bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+from hashweights import hash_tensor
+from oracle import cref
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-4
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.fixture(scope="module")
+def sl():
+    from pdgn_amd import structural_losses
+    return structural_losses
+
+
+def test_nn_distance_golden(sl, golden):
+    g = golden("chamfer.npz")
+    d1, d2 = sl.nn_distance(dev(g["a"]), dev(g["b"]))
+    np.testing.assert_allclose(d1.cpu().numpy(), g["dist_r"], rtol=RTOL, atol=1e-5)
+    np.testing.assert_allclose(d2.cpu().numpy(), g["dist_l"], rtol=RTOL, atol=1e-5)
+
+
+@pytest.mark.parametrize("b,n,m", [(3, 2048, 2048), (2, 700, 1300), (2, 5000, 33), (1, 1, 1)])
+def test_nn_distance_vs_oracle(sl, b, n, m):
+    from pdgn_amd.structural_losses.nn_distance import NNDistance
+    rng = np.random.default_rng(n + m)
+    a = rng.standard_normal((b, n, 3)).astype(np.float32)
+    c = rng.standard_normal((b, m, 3)).astype(np.float32)
+    c[:, : min(n, m) // 3] = a[:, : min(n, m) // 3]
+    rd1, ri1, rd2, ri2 = cref.nndistance(a, c)
+    d1, i1, d2, i2 = NNDistance(dev(a), dev(c))
+    np.testing.assert_array_equal(i1.cpu().numpy(), ri1)
+    np.testing.assert_array_equal(i2.cpu().numpy(), ri2)
+    np.testing.assert_array_equal(d1.cpu().numpy(), rd1)
+    np.testing.assert_array_equal(d2.cpu().numpy(), rd2)
+
+
+def test_nn_distance_backward(sl):
+    rng = np.random.default_rng(1)
+    a = rng.standard_normal((2, 300, 3)).astype(np.float32)
+    c = rng.standard_normal((2, 200, 3)).astype(np.float32)
+    g1 = rng.standard_normal((2, 300)).astype(np.float32)
+    g2 = rng.standard_normal((2, 200)).astype(np.float32)
+    ta, tc = dev(a).requires_grad_(True), dev(c).requires_grad_(True)
+    d1, d2 = sl.nn_distance(ta, tc)
+    ((d1 * dev(g1)).sum() + (d2 * dev(g2)).sum()).backward()
+    _, i1, _, i2 = cref.nndistance(a, c)
+    ra, rc = cref.nndistance_grad(a, c, i1, i2, g1, g2)
+    np.testing.assert_allclose(ta.grad.cpu().numpy(), ra, rtol=RTOL, atol=1e-5)
+    np.testing.assert_allclose(tc.grad.cpu().numpy(), rc, rtol=RTOL, atol=1e-5)
+
+
+@pytest.mark.parametrize("b,n,m", [(3, 256, 256), (2, 512, 512), (2, 300, 100), (2, 100, 250), (1, 2048, 2048)])
+def test_approxmatch_and_cost_vs_oracle(sl, b, n, m):
+    from pdgn_amd.structural_losses.match_cost import ApproxMatch, MatchCost
+    rng = np.random.default_rng(n * 3 + m)
+    a = rng.uniform(-1, 1, (b, n, 3)).astype(np.float32)
+    c = rng.uniform(-1, 1, (b, m, 3)).astype(np.float32)
+    ref_match = cref.approxmatch(a, c)
+    ref_cost = cref.matchcost(a, c, ref_match)
+    match, _ = ApproxMatch(dev(a), dev(c))
+    assert match.shape == (b, m, n)
+    np.testing.assert_allclose(match.cpu().numpy(), ref_match, rtol=2e-3, atol=2e-5)
+    cost = MatchCost(dev(a), dev(c), match)
+    np.testing.assert_allclose(cost.cpu().numpy(), ref_cost, rtol=RTOL)
+    np.testing.assert_allclose(MatchCost(dev(a), dev(c), dev(ref_match)).cpu().numpy(), ref_cost, rtol=1e-5)
+    fused = sl.emd_cost(dev(a), dev(c))
+    np.testing.assert_allclose(fused.cpu().numpy(), ref_cost, rtol=RTOL)
+    with torch.no_grad():
+        np.testing.assert_allclose(sl.match_cost(dev(a), dev(c)).cpu().numpy(), ref_cost, rtol=RTOL)
+
+
+def test_match_cost_backward(sl):
+    rng = np.random.default_rng(2)
+    a = rng.uniform(-1, 1, (2, 200, 3)).astype(np.float32)
+    c = rng.uniform(-1, 1, (2, 200, 3)).astype(np.float32)
+    ta, tc = dev(a).requires_grad_(True), dev(c).requires_grad_(True)
+    w = np.array([0.5, -2.0], np.float32)
+    (sl.match_cost(ta, tc) * dev(w)).sum().backward()
+    match = cref.approxmatch(a, c)
+    g1, g2 = cref.matchcost_grad(a, c, match)
+    np.testing.assert_allclose(ta.grad.cpu().numpy(), g1 * w[:, None, None], rtol=2e-3, atol=2e-5)
+    np.testing.assert_allclose(tc.grad.cpu().numpy(), g2 * w[:, None, None], rtol=2e-3, atol=2e-5)
+
+
+def test_emd_properties_full_size(sl):
+    """BASELINE.json config 5 shape (2048-pt pairs), size-independent properties."""
+    rng = np.random.default_rng(7)
+    b, n = 16, 2048
+    a = rng.uniform(-1, 1, (b, n, 3)).astype(np.float32)
+    c = rng.uniform(-1, 1, (b, n, 3)).astype(np.float32)
+    ta, tc = dev(a), dev(c)
+    same = sl.emd_cost(ta, ta)
+    assert same.abs().max().item() < 1e-3
+    t = torch.tensor([0.002, -0.001, 0.0005], device="cuda")
+    shifted = sl.emd_cost(ta, ta + t) / n
+    np.testing.assert_allclose(shifted.cpu().numpy(), t.norm().item(), rtol=3e-2)
+    perm = torch.randperm(n, device="cuda")
+    np.testing.assert_allclose(sl.emd_cost(ta[:, perm].contiguous(), tc).cpu().numpy(),
+                               sl.emd_cost(ta, tc).cpu().numpy(), rtol=RTOL)
+    d1, d2 = sl.nn_distance(ta, tc)
+    # Chamfer lower-bounds any matching cost: mean NN distance <= EMD/n
+    emd = sl.emd_cost(ta, tc) / n
+    assert (d1.sqrt().mean(1) <= emd * 1.001).all()
