@@ -1,0 +1,151 @@
+#!/usr/bin/env python3
+"""bench.py -- generator+D step throughput of the PDGN hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch 35] [--no-cpu-baseline]
+
+A "step" is one complete training iteration of models/PDGNet_v2.py:171-256 (generator forward
+x2, four discriminator updates, six local-pair shape losses, generator backward, five Adam
+steps) on a synthetic ShapeNet-shaped batch that is already resident in HBM.  Metric (BASELINE.json):
+final-resolution points per second = n_gpus * B * 2048 / t_step, B = 35 per GPU (weak scaling).
+N > 1 is launched by the driver through torch.distributed.run, one rank per GPU over RCCL.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 matrix peak (v_mfma_f32_32x32x2_f32)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=35, help="per-GPU batch (BASELINE.json: 35)")
+    ap.add_argument("--base-points", type=int, default=128, help="128: 256->2048 (reference); 256: 512->4096")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-batch", type=int, default=4)
+    ap.add_argument("--phases", action="store_true", help="also print a per-phase timing breakdown to stderr")
+    return ap.parse_args()
+
+
+def init_dist(args):
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local))
+    else:
+        torch.cuda.set_device(0)
+    if args.gpus != world and rank == 0 and world > 1:
+        print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+    return world, rank, local
+
+
+def barrier(world):
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+
+
+def cpu_baseline(sample_batch):
+    """The oracle's torch-CPU/C restatement of the same iteration (oracle/pdgnet_ref.TrainerRef),
+    timed on this box's host cores on a bounded sample (one step at a small batch)."""
+    from oracle import cref, pdgnet_ref
+    from pdgn_amd.trainer import synthetic_batch
+    cref.build()
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    torch.manual_seed(9999)
+    tr = pdgnet_ref.TrainerRef()
+    g = torch.Generator().manual_seed(1)
+    z = lambda b: torch.randn(b, 128, generator=g) * 0.2
+    tr.step(synthetic_batch(2, "cpu"), z(2), z(2))                 # warm-up (thread pools, allocator)
+    reals = synthetic_batch(sample_batch, "cpu")
+    t0 = time.perf_counter()
+    tr.step(reals, z(sample_batch), z(sample_batch))
+    dt = time.perf_counter() - t0
+    return {"value": sample_batch * 2048 / dt, "unit": "points/s", "cores": torch.get_num_threads(),
+            "kind": "port",
+            "sample": "1 G+D iteration (oracle/pdgnet_ref.TrainerRef, torch-CPU + C pointops) at B=%d, "
+                      "256->2048 pts, %.1f s" % (sample_batch, dt)}
+
+
+def dominant_kernel_roofline(args, device):
+    """Live HIP-event timing of the dominant hand-written kernel at the step's launch shape."""
+    from pdgn_amd import roofline
+    return roofline.measure(args.batch, args.base_points, device)
+
+
+def main():
+    args = parse()
+    world, rank, local = init_dist(args)
+    device = torch.device("cuda", local)
+    from pdgn_amd.trainer import PDGNTrainer, noise, synthetic_batch
+
+    torch.manual_seed(9999 + rank)
+    res = tuple((2 * args.base_points) << i for i in range(4))
+    trainer = PDGNTrainer(device=device, base_points=args.base_points)
+    trainer.train()
+    B = args.batch
+    reals = synthetic_batch(B, device, seed=9999 + rank, n_points=res[3], resolutions=res)
+    gen = torch.Generator().manual_seed(1234 + rank)
+    zs = [(noise(B, device, gen), noise(B, device, gen)) for _ in range(args.warmup + args.steps)]
+
+    for i in range(args.warmup):
+        trainer.step(reals, *zs[i])
+    barrier(world)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = trainer.step(reals, *zs[args.warmup + i])
+    barrier(world)
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    finite = all(torch.isfinite(v).item() for v in out.values())
+
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        line = {
+            "metric": "generator+D step points/sec (B=35, 256->2048 pts)",
+            "value": world * B * res[3] / (dt / args.steps),
+            "unit": "points/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "PDGNet_v2 G+D iteration (models/PDGNet_v2.py:171-256), chair-shaped "
+                                   "synthetic batch, per-GPU batch %d, %d->%d pts, random-init weights"
+                                   % (B, res[0], res[3]),
+                       "global_batch": world * B, "points_all_resolutions_per_s": world * B * sum(res) / (dt / args.steps),
+                       "parallelism": "dp%d" % world, "losses_finite": finite},
+        }
+        try:
+            line["roofline"] = dominant_kernel_roofline(args, device)
+        except Exception as e:                                   # never lose the headline number
+            line["roofline"] = {"error": repr(e)}
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.cpu_sample_batch)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

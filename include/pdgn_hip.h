@@ -103,6 +103,29 @@ int pdgn_matchcost_grad(int b, int n, int m, const float *xyz1, const float *xyz
 int pdgn_emd_cost(int b, int n, int m, const float *xyz1, const float *xyz2, float *temp,
                   float *out, pdgn_stream_t stream);
 
+/* ------------------------------------------------------------------ point-deconvolution stack
+ * Feature-space kNN graph of models/PDGNet_v2.py:447-458 / :488-502 (get_edge_features[_xyz]):
+ * x (b,f,n) channels-first -> idx (b,n,k) int32 = ranks 1..k of the row-wise ascending order of
+ * (-2<x_i,x_j> + |x_i|^2) + |x_j|^2 (rank 0 dropped; ties by index).  sqnorm (b,n) is scratch.
+ * f <= 256, k <= 31, n >= k+1. */
+int pdgn_feature_knn(int b, int f, int n, int k, const float *x, float *sqnorm, int32_t *idx,
+                     pdgn_stream_t stream);
+
+/* Gather half of the re-associated edge convolutions (inte_conv_hk / conv2 / conv_fea / conv_xyz,
+ * models/PDGNet_v2.py:559-625 applied to the edge tensors of :462-477, :505-525):
+ *   out[b,n,p,c] = bias[c] + Y[b,n,offc+c] + sum_{t<T} Y[b, idx[b,n,p+t], off + t*C + c]
+ * Y (b,n,ldy) point-major, idx (b,n,k) with k >= T+P-1, out (b,n,P,C); bias may be NULL;
+ * offc < 0 drops the centre term. */
+int pdgn_window_gather_sum(int b, int n, int k, int ldy, int T, int P, int C, int off, int offc,
+                           const float *Y, const int32_t *idx, const float *bias, float *out,
+                           pdgn_stream_t stream);
+
+/* Its adjoint: dY[b, idx[b,n,p+t], off+t*C+c] += dout[b,n,p,c] (atomic), and
+ * dY[b,n,offc+c] = sum_p dout[b,n,p,c].  dY must be zero-filled by the caller. */
+int pdgn_window_gather_sum_backward(int b, int n, int k, int ldy, int T, int P, int C, int off,
+                                    int offc, const float *dout, const int32_t *idx, float *dY,
+                                    pdgn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -17,79 +17,18 @@
 // (distance, index) is a strict total order, so the result is bit-identical to the
 // reference's stable insertion regardless of scheduling.
 #include "common.h"
+#include "wave_select.h"
 
 #define KNN_THREADS 256
 #define KNN_WAVES (KNN_THREADS / PDGN_WAVE)
 #define KNN_TILE 4096        // candidates staged per pass: 64 KiB of float4
-#define KNN_QCAP 256         // survivor queue entries per wave
 #define KNN_FAST_MAX_K 32
-
-struct DI {
-    float d;
-    int i;
-};
-
-__device__ __forceinline__ bool di_less(float d0, int i0, float d1, int i1) {
-    return d0 < d1 || (d0 == d1 && i0 < i1);
-}
-
-// Wave-wide bitonic sort (ascending) of one (d, i) pair per lane.
-__device__ __forceinline__ void wave_sort_di(float &d, int &i, int lane) {
-#pragma unroll
-    for (int k2 = 2; k2 <= 64; k2 <<= 1) {
-#pragma unroll
-        for (int j = k2 >> 1; j > 0; j >>= 1) {
-            float pd = __shfl_xor(d, j, 64);
-            int pi = __shfl_xor(i, j, 64);
-            bool keep_min = ((lane & j) == 0) == ((lane & k2) == 0);
-            bool partner_less = di_less(pd, pi, d, i);
-            bool take = keep_min ? partner_less : !partner_less;
-            d = take ? pd : d;
-            i = take ? pi : i;
-        }
-    }
-}
-
-// Wave-wide bitonic sort (ascending) of one float per lane.
-__device__ __forceinline__ float wave_sort_f(float d, int lane) {
-#pragma unroll
-    for (int k2 = 2; k2 <= 64; k2 <<= 1) {
-#pragma unroll
-        for (int j = k2 >> 1; j > 0; j >>= 1) {
-            float pd = __shfl_xor(d, j, 64);
-            bool keep_min = ((lane & j) == 0) == ((lane & k2) == 0);
-            d = keep_min ? fminf(d, pd) : fmaxf(d, pd);
-        }
-    }
-    return d;
-}
-
-// Merge the queued survivors q[0..cnt) into the running best-K (lanes 0..K-1 hold it, sorted).
-__device__ __forceinline__ void knn_flush(const DI *q, int cnt, int K, float &rd, int &ri, int lane) {
-    const int take = 64 - K;
-    __builtin_amdgcn_wave_barrier();            // queue writes of other lanes precede these reads
-    for (int base = 0; base < cnt; base += take) {
-        int src = base + lane - K;
-        bool fresh = lane >= K;
-        float d = rd;
-        int i = ri;
-        if (fresh) {
-            bool ok = src < cnt;
-            d = ok ? q[ok ? src : 0].d : INFINITY;
-            i = ok ? q[ok ? src : 0].i : 0x7fffffff;
-        }
-        wave_sort_di(d, i, lane);
-        rd = d;
-        ri = i;
-    }
-    __builtin_amdgcn_wave_barrier();
-}
 
 __global__ __launch_bounds__(KNN_THREADS) void knn3_wave_kernel(
     int n, int m, int K, int qpw, const float *__restrict__ xyz, const float *__restrict__ new_xyz,
     int32_t *__restrict__ idx, float *__restrict__ dist2) {
     __shared__ float4 cand[KNN_TILE];
-    __shared__ DI queue[KNN_WAVES][KNN_QCAP];
+    __shared__ DI queue[KNN_WAVES][WSEL_QCAP];
 
     const int bs = blockIdx.y;
     const int lane = lane_id();
@@ -120,39 +59,9 @@ __global__ __launch_bounds__(KNN_THREADS) void knn3_wave_kernel(
                 __syncthreads();
             }
             if (query >= m) continue;
-            // pass A: per-lane minimum -> tau
-            float lmin = INFINITY;
-            for (int c = lane; c < tn; c += 64) {
-                float4 p = cand[c];
-                lmin = fminf(lmin, sqdist3(qx, qy, qz, p.x, p.y, p.z));
-            }
-            float sorted = wave_sort_f(lmin, lane);
-            float tau = __shfl(sorted, K - 1, 64);
-            float worst = __shfl(rd, K - 1, 64);   // K-th best so far (inf until the list fills)
-            tau = fminf(tau, worst);
-            // pass B: compact survivors
-            int cnt = 0;                        // wave-uniform
-            for (int c0 = 0; c0 < tn; c0 += 64) {
-                int c = c0 + lane;
-                float d = INFINITY;
-                if (c < tn) {
-                    float4 p = cand[c];
-                    d = sqdist3(qx, qy, qz, p.x, p.y, p.z);
-                }
-                bool keep = d <= tau && d < INFINITY;
-                unsigned long long mask = __ballot(keep);
-                if (mask) {
-                    int pos = cnt + __popcll(mask & ((1ull << lane) - 1ull));
-                    if (keep) { q[pos].d = d; q[pos].i = t0 + c; }
-                    cnt += __popcll(mask);
-                    if (cnt > KNN_QCAP - 64) {
-                        knn_flush(q, cnt, K, rd, ri, lane);
-                        cnt = 0;
-                        tau = fminf(tau, __shfl(rd, K - 1, 64));
-                    }
-                }
-            }
-            knn_flush(q, cnt, K, rd, ri, lane);
+            wave_topk_scan(
+                [&](int c) { float4 p = cand[c]; return sqdist3(qx, qy, qz, p.x, p.y, p.z); },
+                tn, t0, q, K, rd, ri, lane);
         }
         if (query < m && lane < K) {
             size_t o = ((size_t)bs * m + query) * K + lane;

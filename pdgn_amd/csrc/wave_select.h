@@ -1,0 +1,100 @@
+// wave_select.h -- wave64 top-K selection primitives shared by the 3-D kNN (knn3.hip) and the
+// feature-space kNN (feat_knn.hip): bitonic sorts over ds_bpermute and the survivor-queue merge.
+#pragma once
+#include "common.h"
+
+struct DI {
+    float d;
+    int i;
+};
+
+__device__ __forceinline__ bool di_less(float d0, int i0, float d1, int i1) {
+    return d0 < d1 || (d0 == d1 && i0 < i1);
+}
+
+// Wave-wide bitonic sort (ascending) of one (d, i) pair per lane.
+__device__ __forceinline__ void wave_sort_di(float &d, int &i, int lane) {
+#pragma unroll
+    for (int k2 = 2; k2 <= 64; k2 <<= 1) {
+#pragma unroll
+        for (int j = k2 >> 1; j > 0; j >>= 1) {
+            float pd = __shfl_xor(d, j, 64);
+            int pi = __shfl_xor(i, j, 64);
+            bool keep_min = ((lane & j) == 0) == ((lane & k2) == 0);
+            bool partner_less = di_less(pd, pi, d, i);
+            bool take = keep_min ? partner_less : !partner_less;
+            d = take ? pd : d;
+            i = take ? pi : i;
+        }
+    }
+}
+
+// Wave-wide bitonic sort (ascending) of one float per lane.
+__device__ __forceinline__ float wave_sort_f(float d, int lane) {
+#pragma unroll
+    for (int k2 = 2; k2 <= 64; k2 <<= 1) {
+#pragma unroll
+        for (int j = k2 >> 1; j > 0; j >>= 1) {
+            float pd = __shfl_xor(d, j, 64);
+            bool keep_min = ((lane & j) == 0) == ((lane & k2) == 0);
+            d = keep_min ? fminf(d, pd) : fmaxf(d, pd);
+        }
+    }
+    return d;
+}
+
+// Merge the queued survivors q[0..cnt) into the running best-K (lanes 0..K-1 hold it, sorted).
+__device__ __forceinline__ void knn_flush(const DI *q, int cnt, int K, float &rd, int &ri, int lane) {
+    const int take = 64 - K;
+    __builtin_amdgcn_wave_barrier();            // queue writes of other lanes precede these reads
+    for (int base = 0; base < cnt; base += take) {
+        int src = base + lane - K;
+        bool fresh = lane >= K;
+        float d = rd;
+        int i = ri;
+        if (fresh) {
+            bool ok = src < cnt;
+            d = ok ? q[ok ? src : 0].d : INFINITY;
+            i = ok ? q[ok ? src : 0].i : 0x7fffffff;
+        }
+        wave_sort_di(d, i, lane);
+        rd = d;
+        ri = i;
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+
+#define WSEL_QCAP 256   // survivor queue entries per wave
+
+// One wave scans `tn` candidates (candidate c has distance dist(c), c in [0, tn), global index
+// t0 + c) and merges the K best into the running list (rd, ri) held by lanes 0..K-1.
+//   pass A: per-lane minimum; tau = K-th smallest lane minimum (>= the K-th nearest distance);
+//   pass B: survivors d <= tau are compacted into the wave's LDS queue `q` and merged.
+// +inf distances never enter (the reference's `d2 < best` against 1e40 never accepts them).
+template <class DistFn>
+__device__ __forceinline__ void wave_topk_scan(DistFn dist, int tn, int t0, DI *q, int K, float &rd,
+                                               int &ri, int lane) {
+    float lmin = INFINITY;
+    for (int c = lane; c < tn; c += 64) lmin = fminf(lmin, dist(c));
+    float sorted = wave_sort_f(lmin, lane);
+    float tau = fminf(__shfl(sorted, K - 1, 64), __shfl(rd, K - 1, 64));
+    int cnt = 0;                                    // wave-uniform
+    for (int c0 = 0; c0 < tn; c0 += 64) {
+        int c = c0 + lane;
+        float d = c < tn ? dist(c) : INFINITY;
+        bool keep = d <= tau && d < INFINITY;
+        unsigned long long mask = __ballot(keep);
+        if (mask) {
+            int pos = cnt + __popcll(mask & ((1ull << lane) - 1ull));
+            if (keep) { q[pos].d = d; q[pos].i = t0 + c; }
+            cnt += __popcll(mask);
+            if (cnt > WSEL_QCAP - 64) {
+                knn_flush(q, cnt, K, rd, ri, lane);
+                cnt = 0;
+                tau = fminf(tau, __shfl(rd, K - 1, 64));
+            }
+        }
+    }
+    knn_flush(q, cnt, K, rd, ri, lane);
+}

@@ -1,0 +1,194 @@
+"""PointDeconv -- the learned point-deconvolution block of PDGN on MI355X.
+
+Reference: ``upsample_edgeConv`` (models/PDGNet_v2.py:547-588) and
+``bilateral_upsample_edgeConv`` (:590-650).  ``PointDeconv(..., bilateral=False/True)``
+computes the same function with the same parameters (identical ``state_dict`` keys and
+shapes) but not the same way:
+
+  reference                                       here
+  ---------                                       ----
+  bmm (B,N,N) + full sort of every row            pdgn_feature_knn: MFMA Gram tile + wave top-(k+1) in LDS
+  materialise e = [x_n, x_j - x_n] (B,2F,N,k)     never materialised
+  Conv2d over e with [1,T] kernels                ONE per-point GEMM  Y = X^T Wcat^T  (all taps of
+                                                  inte_conv_hk, conv2[:, :, :k], conv_fea at once, since
+                                                  sum_t W_t (x_j - x_n) = (W_t x)_j - (W_t x)_n), followed by
+                                                  pdgn_window_gather_sum over the kNN graph
+  conv2 on cat(e, inte*w) (K = 2F*2k)             gather-sum half + one GEMM over inte*w only (K = 2F*k)
+
+which removes ~3.5x of the block's FLOPs and every (B,2F,N,k)-sized edge tensor.
+Activations are point-major / channels-last inside the block: (B, N, [slot,] C).
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch.autograd import Function
+
+from . import _lib
+from ._lib import check, ptr, require, stream_of
+
+F32, I32 = torch.float32, torch.int32
+
+
+def feature_knn(x, k):
+    """models/PDGNet_v2.py:447-458.  x (B,F,N) fp32 -> idx (B,N,k) int32 (ranks 1..k)."""
+    require(x, "x", F32, 3)
+    b, f, n = x.shape
+    idx = torch.empty((b, n, k), dtype=I32, device=x.device)
+    sq = torch.empty((b, n), dtype=F32, device=x.device)
+    check(_lib.lib().pdgn_feature_knn(b, f, n, int(k), ptr(x), ptr(sq), ptr(idx), stream_of(x)),
+          "pdgn_feature_knn")
+    return idx
+
+
+class EdgeGatherSum(Function):
+    """out_i[b,n,p,c] = bias_i[c] + Y[b,n,offc_i+c] + sum_t Y[b, idx[b,n,p+t], off_i + t*C_i + c]
+    for every spec i = (T, P, C, off, offc); one backward fills a single dY."""
+
+    @staticmethod
+    def forward(ctx, Y, idx, specs, *biases):
+        require(Y, "Y", F32, 3)
+        require(idx, "idx", I32, 3)
+        b, n, ldy = Y.shape
+        k = idx.shape[2]
+        outs = []
+        for (T, P, C, off, offc), bias in zip(specs, biases):
+            out = torch.empty((b, n, P, C), dtype=F32, device=Y.device)
+            bias_c = bias.detach().contiguous() if bias is not None else None
+            check(_lib.lib().pdgn_window_gather_sum(b, n, k, ldy, T, P, C, off, offc, ptr(Y), ptr(idx),
+                                                    ptr(bias_c), ptr(out), stream_of(Y)),
+                  "pdgn_window_gather_sum")
+            outs.append(out)
+        ctx.specs, ctx.shape = specs, (b, n, ldy, k)
+        ctx.has_bias = [bias is not None for bias in biases]
+        ctx.save_for_backward(idx)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *douts):
+        (idx,) = ctx.saved_tensors
+        b, n, ldy, k = ctx.shape
+        dY = torch.zeros((b, n, ldy), dtype=F32, device=idx.device)
+        dbias = []
+        for (T, P, C, off, offc), dout, hb in zip(ctx.specs, douts, ctx.has_bias):
+            dout = dout.contiguous()
+            check(_lib.lib().pdgn_window_gather_sum_backward(b, n, k, ldy, T, P, C, off, offc, ptr(dout),
+                                                             ptr(idx), ptr(dY), stream_of(dout)),
+                  "pdgn_window_gather_sum_backward")
+            dbias.append(dout.sum(dim=(0, 1, 2)) if hb else None)
+        return (dY, None, None) + tuple(dbias)
+
+
+class _ConvBN(nn.Module):
+    """Parameter container with the reference's conv2dbr keys (conv.*, bn.*) :530-545."""
+
+    def __init__(self, cin, cout, ksize):
+        super().__init__()
+        self.conv = nn.Conv2d(cin, cout, ksize, 1)
+        self.bn = nn.BatchNorm2d(cout)
+
+
+def _bn(x2d, bn, training):
+    """BatchNorm over the rows of a channels-last (M, C) view with nn.BatchNorm2d semantics."""
+    if training and bn.track_running_stats:
+        bn.num_batches_tracked.add_(1)
+    return F.batch_norm(x2d, bn.running_mean, bn.running_var, bn.weight, bn.bias, training, bn.momentum,
+                        bn.eps)
+
+
+class PointDeconv(nn.Module):
+    """x (B,Fin,N) [, pc (B,3,N)] -> (B,Fout,2N).  ``bilateral=False``: upsample_edgeConv
+    (:547-588); ``bilateral=True``: bilateral_upsample_edgeConv (:590-650)."""
+
+    def __init__(self, Fin, Fout, k, bilateral=True, softmax=True):
+        super().__init__()
+        if k % 2:
+            raise ValueError("k must be even (the reference's view(B,N,C,2,k//2) :576 needs it)")
+        self.k, self.Fin, self.Fout = k, Fin, Fout
+        self.bilateral, self.softmax = bilateral, softmax
+        self.conv2 = _ConvBN(2 * Fin, 2 * Fout, [1, 2 * k])
+        if bilateral:
+            self.conv_xyz = nn.Sequential(nn.Conv2d(6, 16, 1), nn.BatchNorm2d(16), nn.LeakyReLU(inplace=True))
+            self.conv_fea = nn.Sequential(nn.Conv2d(2 * Fin, 16, 1), nn.BatchNorm2d(16),
+                                          nn.LeakyReLU(inplace=True))
+            self.conv_all = nn.Sequential(nn.Conv2d(16, 64, 1), nn.BatchNorm2d(64), nn.LeakyReLU(inplace=True),
+                                          nn.Conv2d(64, 2 * Fin, 1), nn.BatchNorm2d(2 * Fin),
+                                          nn.LeakyReLU(inplace=True))
+        self.inte_conv_hk = nn.Sequential(nn.Conv2d(2 * Fin, 4 * Fin, [1, k // 2 + 1], [1, 1]),
+                                          nn.BatchNorm2d(4 * Fin), nn.LeakyReLU(inplace=True))
+
+    # -- weight re-association (differentiable torch ops on the reference-shaped parameters)
+    def _assemble(self):
+        Fi, Fo, k = self.Fin, self.Fout, self.k
+        T = k // 2 + 1
+        Wi = self.inte_conv_hk[0].weight[:, :, 0, :]                   # (4F, 2F, T)
+        W2 = self.conv2.conv.weight[:, :, 0, :]                        # (2Fo, 2F, 2k)
+        W2a, W2b = W2[:, :, :k], W2[:, :, k:]
+        blocks = [Wi[:, Fi:, :].permute(2, 0, 1).reshape(T * 4 * Fi, Fi),            # taps of inte_conv_hk
+                  (Wi[:, :Fi, :] - Wi[:, Fi:, :]).sum(2),                             # its centre term
+                  W2a[:, Fi:, :].permute(2, 0, 1).reshape(k * 2 * Fo, Fi),            # taps of conv2[..., :k]
+                  (W2a[:, :Fi, :] - W2a[:, Fi:, :]).sum(2)]
+        if self.bilateral:
+            Wf = self.conv_fea[0].weight[:, :, 0, 0]                   # (16, 2F)
+            blocks += [Wf[:, Fi:], Wf[:, :Fi] - Wf[:, Fi:]]
+        Wcat = torch.cat(blocks, 0)
+        P = k - T + 1
+        Wb = W2b.reshape(2 * Fo, 2 * Fi, 2, P).permute(0, 3, 1, 2).reshape(2 * Fo, P * 4 * Fi)
+        return Wcat, Wb, T, P
+
+    def forward(self, x, pc=None, idx=None):
+        B, Fi, N = x.shape
+        Fo, k = self.Fout, self.k
+        training = self.training
+        if idx is None:
+            with torch.no_grad():
+                idx = feature_knn(x.detach().contiguous(), k)
+        elif idx.dtype != I32:
+            idx = idx.to(I32)
+        idx = idx.contiguous()
+        Wcat, Wb, T, P = self._assemble()
+        xt = x.transpose(1, 2).contiguous()                            # (B,N,F)
+        Y = torch.matmul(xt, Wcat.t())                                 # (B,N,Mw) -- per-point GEMM
+        o_i, o_ci = 0, T * 4 * Fi
+        o_a = o_ci + 4 * Fi
+        o_ca = o_a + k * 2 * Fo
+        o_p = o_ca + 2 * Fo
+        specs = [(T, P, 4 * Fi, o_i, o_ci), (k, 1, 2 * Fo, o_a, o_ca)]
+        biases = [self.inte_conv_hk[0].bias, self.conv2.conv.bias]
+        if self.bilateral:
+            specs.append((1, k, 16, o_p, o_p + 16))
+            biases.append(self.conv_fea[0].bias)
+        outs = EdgeGatherSum.apply(Y, idx, tuple(specs), *biases)
+        inte_pre, a_pre = outs[0], outs[1]                             # (B,N,P,4F), (B,N,1,2Fo)
+        inte = F.leaky_relu(_bn(inte_pre.view(-1, 4 * Fi), self.inte_conv_hk[1], training))
+        inte = inte.view(B, N, P, 4 * Fi)
+        if self.bilateral:
+            Wx = self.conv_xyz[0].weight[:, :, 0, 0]                   # (16, 6)
+            pct = pc.transpose(1, 2).contiguous()                      # (B,N,3)
+            Yx = torch.matmul(pct, torch.cat([Wx[:, 3:], Wx[:, :3] - Wx[:, 3:]], 0).t()).contiguous()
+            (xyz_pre,) = EdgeGatherSum.apply(Yx, idx, ((1, k, 16, 0, 16),), self.conv_xyz[0].bias)
+            fea = F.leaky_relu(_bn(outs[2].view(-1, 16), self.conv_fea[1], training))
+            xyzf = F.leaky_relu(_bn(xyz_pre.view(-1, 16), self.conv_xyz[1], training))
+            h = fea * xyzf                                             # (B*N*k, 16)
+            h = F.linear(h, self.conv_all[0].weight[:, :, 0, 0], self.conv_all[0].bias)
+            h = F.leaky_relu(_bn(h, self.conv_all[1], training))
+            h = F.linear(h, self.conv_all[3].weight[:, :, 0, 0], self.conv_all[3].bias)
+            h = F.leaky_relu(_bn(h, self.conv_all[4], training))
+            w = h.view(B, N, k, 2 * Fi)
+            if self.softmax:
+                w = F.softmax(w, dim=2)                                # over the k neighbour slots
+            # w[b,n,s=P*j+p,c'] -> [b,n,p,o=2c'+j]  (the reference's interleave :638-641)
+            w = w.view(B, N, 2, P, 2 * Fi).permute(0, 1, 3, 4, 2).reshape(B, N, P, 4 * Fi)
+            inte = inte * w
+        out_pre = a_pre.view(B * N, 2 * Fo) + F.linear(inte.reshape(B * N, P * 4 * Fi), Wb)
+        out = F.relu(_bn(out_pre, self.conv2.bn, training))            # (B*N, 2Fo)
+        return out.view(B, N, Fo, 2).permute(0, 2, 3, 1).reshape(B, Fo, 2 * N)
+
+
+def upsample_edgeConv(Fin, Fout, k, num=None):
+    """Constructor-compatible alias of the reference class (:552)."""
+    return PointDeconv(Fin, Fout, k, bilateral=False)
+
+
+def bilateral_upsample_edgeConv(Fin, Fout, k, num=None, softmax=True):
+    """Constructor-compatible alias of the reference class (:595)."""
+    return PointDeconv(Fin, Fout, k, bilateral=True, softmax=softmax)

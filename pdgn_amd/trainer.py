@@ -1,0 +1,148 @@
+"""One PDGN training iteration (models/PDGNet_v2.py:171-256) and its batch-axis data parallelism.
+
+Reference parallelism: single-process ``nn.DataParallel`` (:101-105) -- per-replica BatchNorm
+statistics, gradients summed onto GPU 0.  Here: one process per GPU, local batch per rank,
+BatchNorm statistics stay local (same semantics), and gradients are all-reduced over RCCL/xGMI
+as ONE flat fp32 buffer per network (G: 50.8 MB, D1-4: 6.8 MB) -- parameters' ``.grad`` tensors
+are views into that buffer, so there is no bucket copy in or out.
+"""
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .generator import PointDiscriminator, PointGenerator
+from .losses import LocalPairLoss
+
+PAIRS = ((0, 1), (0, 2), (0, 3), (1, 2), (1, 3), (2, 3))   # get_local_pair calls :232-237
+
+
+class FlatGrads:
+    """Make every parameter's ``.grad`` a view into one contiguous buffer (so one collective
+    reduces a whole network and ``zero_grad`` is one memset)."""
+
+    def __init__(self, params):
+        self.params = [p for p in params if p.requires_grad]
+        total = sum(p.numel() for p in self.params)
+        ref = self.params[0]
+        self.buf = torch.zeros(total, dtype=ref.dtype, device=ref.device)
+        off = 0
+        for p in self.params:
+            p.grad = self.buf[off:off + p.numel()].view_as(p)
+            off += p.numel()
+
+    def zero_(self):
+        self.buf.zero_()
+
+    def all_reduce_mean(self, group=None):
+        """Average over ranks (RCCL all-reduce over xGMI when the backend is nccl)."""
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            dist.all_reduce(self.buf, op=dist.ReduceOp.SUM, group=group)
+            self.buf.div_(dist.get_world_size(group))
+
+
+def world_size():
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+class PDGNTrainer:
+    """Generator + D1..D4 + their Adam optimisers (lr 1e-4, betas (0.5, 0.999), :121-125) and the
+    op sequence of one iteration.  ``step`` returns the six logged losses (:259-261) as 0-dim
+    device tensors (no host sync inside the step)."""
+
+    def __init__(self, device="cuda", lr=1e-4, num_k=20, base_points=128, generator=None,
+                 discriminators=None, distributed=None):
+        self.device = torch.device(device)
+        self.G = (generator or PointGenerator(num_k=num_k, base_points=base_points)).to(self.device)
+        self.D = [d.to(self.device) for d in
+                  (discriminators or [PointDiscriminator(i, (2 * base_points) << (i - 1)) for i in (1, 2, 3, 4)])]
+        self.local_pair = LocalPairLoss(20)
+        self.distributed = world_size() > 1 if distributed is None else distributed
+        self.gradG = FlatGrads(self.G.parameters())
+        self.gradD = [FlatGrads(d.parameters()) for d in self.D]
+        adam = lambda m: torch.optim.Adam(m.parameters(), lr=lr, betas=(0.5, 0.999))
+        self.optG, self.optD = adam(self.G), [adam(d) for d in self.D]
+
+    def train(self):
+        self.G.train()
+        for d in self.D:
+            d.train()
+
+    def _freeze_D(self, frozen):
+        for d in self.D:
+            for p in d.parameters():
+                p.requires_grad_(not frozen)
+
+    def similar_loss(self, clouds):
+        """Sum of the 6 like_mu and the 6 like_cov terms, in the reference's order (:251-252)."""
+        mus, covs = [], []
+        for a, b in PAIRS:
+            mu, cov = self.local_pair(clouds[a], clouds[b])
+            mus.append(mu)
+            covs.append(cov)
+        return sum(mus[1:], mus[0]) + sum(covs[1:], covs[0])
+
+    def step(self, reals, z1, z2):
+        """reals: four tensors (B,3,N_k); z1 / z2: noise (B,128) of the two generator passes
+        (:178, :228).  Returns dict of 0-dim tensors."""
+        B = z1.shape[0]
+        ones = torch.ones(B, 1, device=self.device)
+        zeros = torch.zeros(B, 1, device=self.device)
+        ws = world_size() if self.distributed else 1
+        out = {}
+        # generator pass #1 (:179): only its detached outputs are ever used => no graph needed;
+        # BatchNorm running statistics update exactly as in the reference.
+        with torch.no_grad():
+            fakes = self.G(z1)
+        # ---- D1..D4 (:182-224)
+        for i, D in enumerate(self.D):
+            self.gradD[i].zero_()
+            lossD = (F.mse_loss(D(reals[i]), ones) + F.mse_loss(D(fakes[i]), zeros)) / 2.0
+            lossD.backward()
+            if self.distributed:
+                self.gradD[i].all_reduce_mean()
+            self.optD[i].step()
+            out["d_loss%d" % (i + 1)] = lossD.detach()
+        # ---- G (:226-256)
+        self.gradG.zero_()
+        # The reference lets lossG.backward() also fill the discriminators' .grad and throws that
+        # away at the next zero_grad (:183); freezing D here skips those weight-gradient GEMMs.
+        self._freeze_D(True)
+        gen = self.G(z2)
+        similar = self.similar_loss(gen)
+        g_loss = [F.mse_loss(self.D[i](gen[i]), ones) for i in range(4)]
+        adv = 1.2 * g_loss[0] + 1.2 * g_loss[1] + 1.2 * g_loss[2] + g_loss[3]
+        lossG = adv + 0.1 * similar
+        # MSE is a batch MEAN, the shape loss a batch SUM (chamfer_loss.py:16-20): to reproduce one
+        # reference step at the global batch, scale the sum term by world_size before the mean
+        # all-reduce.
+        (adv + (0.1 * ws) * similar if ws > 1 else lossG).backward()
+        self._freeze_D(False)
+        if self.distributed:
+            self.gradG.all_reduce_mean()
+        self.optG.step()
+        out["g_loss"], out["similar_loss"] = lossG.detach(), similar.detach()
+        return out
+
+
+def synthetic_batch(B, device, seed=9999, n_points=2048, resolutions=(256, 512, 1024, 2048)):
+    """ShapeNet-shaped synthetic real clouds: (B,2048,3) ~ N(0,1),
+    per-shape `shape_unit` normalisation (datasets_4point.py:335-337, :353), sub-resolutions
+    drawn WITH replacement (:374-379), transposed to (B,3,N) (:184)."""
+    g = torch.Generator().manual_seed(seed)
+    pts = torch.randn(B, n_points, 3, generator=g)
+    pts = (pts - pts.mean(dim=1, keepdim=True)) / pts.reshape(B, -1).std(dim=1).view(B, 1, 1)
+    reals = []
+    for r in resolutions:
+        if r == n_points:
+            sub = pts
+        else:
+            sel = torch.randint(0, n_points, (B, r), generator=g)
+            sub = torch.gather(pts, 1, sel.unsqueeze(2).expand(B, r, 3))
+        reals.append(sub.transpose(1, 2).contiguous().to(device))
+    return reals
+
+
+def noise(B, device, generator=None):
+    """z ~ N(0, 0.2^2), (B,128) (:178, :228)."""
+    return (torch.randn(B, 128, generator=generator) * 0.2).to(device)

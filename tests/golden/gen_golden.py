@@ -144,7 +144,7 @@ def gen_networks():
         manifest["D%d" % (i + 1)] = {k: list(v.shape) for k, v in d.state_dict().items()}
     with open(os.path.join(HERE, "state_dict_manifest.json"), "w") as f:
         json.dump(manifest, f, indent=0, sort_keys=True)
-    z = hash_tensor("G_z", (2, 128), 0.2)
+    z = hash_tensor("G_z", (6, 128), 0.2)   # B=2 is ill-conditioned: BatchNorm1d over 2 samples
     G.train()
     with torch.no_grad():
         outs = G(z)
@@ -171,7 +171,7 @@ def gen_networks():
         d.train()
         with torch.no_grad():
             d_out["d%d" % (i + 1)] = d(outs[i])
-    save("generator_b2.npz", z=z, p1=outs[0], p2=outs[1], p3=outs[2], p4=outs[3],
+    save("generator_b6.npz", z=z, p1=outs[0], p2=outs[1], p3=outs[2], p4=outs[3],
          idx1=idxs[0].to(torch.int16), idx2=idxs[1].to(torch.int16), idx3=idxs[2].to(torch.int16),
          idx4=idxs[3].to(torch.int16), knn_margins=np.array(margins), **d_out)
     return G, Ds, z, outs
@@ -193,12 +193,11 @@ def gen_losses():
 
 
 # ------------------------------------------------------------------ 6. one G+D iteration (composed)
-def gen_step(G, Ds):
+def gen_step(G, Ds, B):
     """COMPOSED: reference torch modules / ChamferLoss / compute_mean_covariance / Adam with
     the C oracle standing in for the CUDA knnquery+grouping (models/PDGNet_v2.py:171-256).
-    B=2 (BASELINE.json configs[0] uses 256->512; the full 4-stage net is used here because
-    the reference generator cannot stop at 512)."""
-    B = 2
+    BASELINE.json configs[0] uses 256->512; the full 4-stage net is used here because
+    the reference generator cannot stop at 512."""
     fill_module(G, salt=1)
     for i, d in enumerate(Ds):
         fill_module(d, salt=10 + i)
@@ -245,7 +244,7 @@ def gen_step(G, Ds):
     optG.step()
     res.update(g_loss=lossG.item(), similar_loss=sim.item(), g_grad_norm=gnorm,
                g_fc1_w_after=G.fc1[0].weight.detach()[:4, :8].clone())
-    save("step_b2.npz", **res)
+    save("step_b%d.npz" % B, **res)
 
 
 if __name__ == "__main__":
@@ -256,4 +255,5 @@ if __name__ == "__main__":
     gen_losses()
     G, Ds, z, outs = gen_networks()
     if "--no-step" not in sys.argv:
-        gen_step(G, Ds)
+        gen_step(G, Ds, 2)      # BASELINE.json configs[0] batch size (ill-conditioned BN: loose tolerance)
+        gen_step(G, Ds, 4)

@@ -1,0 +1,43 @@
+"""CPU: host logic of PointDeconv (weight re-association + layouts) against the golden vectors
+of the imported reference, with torch stand-ins in place of the two HIP entry points."""
+import numpy as np
+import pytest
+import torch
+
+from hashweights import fill_module
+from torch_standins import EdgeGatherSumTorch
+
+
+@pytest.fixture()
+def deconv(monkeypatch):
+    from pdgn_amd import deconv as m
+    monkeypatch.setattr(m, "EdgeGatherSum", EdgeGatherSumTorch)
+    return m
+
+
+@pytest.mark.parametrize("name", ["plain_k4", "bilateral_k4", "plain_k10", "bilateral_k10"])
+def test_pointdeconv_matches_reference(golden, deconv, name):
+    g = golden("deconv_%s.npz" % name)
+    bilateral = name.startswith("bilateral")
+    mod = deconv.PointDeconv(int(g["F"]), int(g["Fout"]), int(g["k"]), bilateral=bilateral)
+    fill_module(mod, salt=3)
+    x = torch.from_numpy(g["x"]).requires_grad_(True)
+    pc = torch.from_numpy(g["pc"]).requires_grad_(True) if bilateral else None
+    idx = torch.from_numpy(g["idx"]).to(torch.int32)
+    mod.train()
+    y = mod(x, pc, idx=idx)
+    np.testing.assert_allclose(y.detach().numpy(), g["y_train"], rtol=1e-4, atol=2e-5)
+    y.backward(torch.from_numpy(g["gout"]))
+    np.testing.assert_allclose(x.grad.numpy(), g["grad_x"], rtol=1e-3, atol=2e-5)
+    if bilateral:
+        np.testing.assert_allclose(pc.grad.numpy(), g["grad_pc"], rtol=1e-3, atol=2e-5)
+    for n, p in mod.named_parameters():
+        np.testing.assert_allclose(p.grad.numpy(), g["grad." + n], rtol=1e-3, atol=5e-5, err_msg=n)
+    for n, b in mod.named_buffers():
+        if "num_batches" in n:
+            assert int(b) == 1, n
+        else:
+            np.testing.assert_allclose(b.numpy(), g["stat." + n], rtol=1e-4, atol=1e-5, err_msg=n)
+    mod.eval()
+    with torch.no_grad():
+        np.testing.assert_allclose(mod(x, pc, idx=idx).numpy(), g["y_eval"], rtol=1e-4, atol=2e-5)

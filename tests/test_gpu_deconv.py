@@ -1,0 +1,176 @@
+"""GPU parity of the point-deconvolution stack: feature-space kNN, window gather-sum, PointDeconv,
+PointGenerator / discriminators and one G+D step, all through the HIP C ABI.
+Float tolerance 1e-4 relative (BASELINE.json north_star); kNN indices exact outside near-ties."""
+import numpy as np
+import pytest
+import torch
+
+from hashweights import fill_module, hash_tensor
+from oracle import pdgnet_ref
+from torch_standins import EdgeGatherSumTorch
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a):
+    if isinstance(a, np.ndarray):
+        a = torch.from_numpy(np.ascontiguousarray(a))
+    return a.cuda()
+
+
+def knn_agreement(x, k, idx_gpu):
+    """Rows whose oracle top-(k+2) distances are separated by more than the fp32 Gram-form
+    rounding must match exactly; near-tie rows are excused (SURVEY.md section 7 'hard parts')."""
+    idx_ref, dist = pdgnet_ref.feature_knn(x.double(), k)
+    ds = dist.sort(dim=2)[0][:, :, :k + 2]
+    scale = dist.abs().amax(dim=2, keepdim=True) + 1e-12
+    safe = ((ds[:, :, 1:] - ds[:, :, :-1]) / scale).amin(dim=2) > 2e-6
+    same = (idx_ref == idx_gpu.cpu().long()).all(dim=2)
+    return safe, same
+
+
+@pytest.mark.parametrize("B,F,N,k", [(2, 6, 24, 5), (3, 32, 128, 10), (2, 64, 256, 10), (2, 128, 512, 10),
+                                     (2, 256, 1024, 10), (1, 256, 2048, 10), (2, 7, 100, 4), (1, 40, 1500, 16)])
+def test_feature_knn(B, F, N, k):
+    from pdgn_amd.deconv import feature_knn
+    x = torch.from_numpy(np.random.default_rng(F + N).standard_normal((B, F, N)).astype(np.float32))
+    idx = feature_knn(dev(x), k)
+    assert idx.dtype == torch.int32 and idx.shape == (B, N, k)
+    safe, same = knn_agreement(x, k, idx)
+    assert safe.float().mean() > 0.9
+    assert same[safe].all(), "kNN differs on %d well-separated rows" % int((~same[safe]).sum())
+    assert same.float().mean() > 0.99
+
+
+def test_feature_knn_golden(golden):
+    from pdgn_amd.deconv import feature_knn
+    g = golden("edge_features.npz")
+    idx = feature_knn(dev(g["x"]), int(g["k"]))
+    np.testing.assert_array_equal(idx.cpu().numpy(), g["idx"])
+
+
+def test_feature_knn_duplicates_drop_rank0():
+    from pdgn_amd.deconv import feature_knn
+    x = torch.zeros(1, 4, 40)
+    x[0, :, 20:] = 1.0                     # two clusters of identical points: ties by index
+    idx = feature_knn(dev(x), 6).cpu()
+    assert idx[0, 0].tolist() == [1, 2, 3, 4, 5, 6]        # rank 0 (= index 0) dropped
+    assert idx[0, 5].tolist() == [1, 2, 3, 4, 5, 6]        # rank 0 is index 0, NOT self (ref quirk)
+    assert idx[0, 30].tolist() == [21, 22, 23, 24, 25, 26]
+
+
+@pytest.mark.parametrize("B,N,k,ldy,spec", [(2, 50, 10, 64, (6, 5, 8, 0, 48)), (2, 33, 10, 40, (10, 1, 3, 1, 31)),
+                                            (3, 64, 10, 32, (1, 10, 16, 0, 16)), (2, 40, 4, 24, (3, 2, 4, 4, -1)),
+                                            (2, 512, 10, 7200, (6, 5, 1024, 0, 6144))])
+def test_window_gather_sum_forward_backward(B, N, k, ldy, spec):
+    from pdgn_amd.deconv import EdgeGatherSum
+    rng = np.random.default_rng(N)
+    Y = torch.from_numpy(rng.standard_normal((B, N, ldy)).astype(np.float32))
+    idx = torch.from_numpy(rng.integers(0, N, (B, N, k)).astype(np.int32))
+    T, P, C, off, offc = spec
+    bias = torch.from_numpy(rng.standard_normal(C).astype(np.float32))
+    Yg, bg = dev(Y).requires_grad_(True), dev(bias).requires_grad_(True)
+    (out,) = EdgeGatherSum.apply(Yg, dev(idx), (spec,), bg)
+    Yc, bc = Y.clone().requires_grad_(True), bias.clone().requires_grad_(True)
+    (ref,) = EdgeGatherSumTorch.apply(Yc, idx, (spec,), bc)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().numpy(), rtol=1e-5, atol=1e-5)
+    gout = torch.from_numpy(rng.standard_normal((B, N, P, C)).astype(np.float32))
+    out.backward(dev(gout))
+    ref.backward(gout)
+    np.testing.assert_allclose(Yg.grad.cpu().numpy(), Yc.grad.numpy(), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(bg.grad.cpu().numpy(), bc.grad.numpy(), rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize("name", ["plain_k4", "bilateral_k4", "plain_k10", "bilateral_k10"])
+def test_pointdeconv_golden(golden, name):
+    from pdgn_amd.deconv import PointDeconv
+    g = golden("deconv_%s.npz" % name)
+    bilateral = name.startswith("bilateral")
+    mod = fill_module(PointDeconv(int(g["F"]), int(g["Fout"]), int(g["k"]), bilateral=bilateral), salt=3).cuda()
+    x = dev(g["x"]).requires_grad_(True)
+    pc = dev(g["pc"]).requires_grad_(True) if bilateral else None
+    mod.train()
+    y = mod(x, pc)                                     # kNN graph from the HIP kernel
+    if float(g["knn_margin"]) > 1e-5:
+        np.testing.assert_allclose(y.detach().cpu().numpy(), g["y_train"], rtol=1e-4, atol=2e-5)
+    x.grad = None
+    mod2 = fill_module(PointDeconv(int(g["F"]), int(g["Fout"]), int(g["k"]), bilateral=bilateral), salt=3).cuda()
+    mod2.train()
+    y = mod2(x, pc, idx=dev(g["idx"].astype(np.int32)))  # oracle graph: pure float parity
+    np.testing.assert_allclose(y.detach().cpu().numpy(), g["y_train"], rtol=1e-4, atol=2e-5)
+    y.backward(dev(g["gout"]))
+    np.testing.assert_allclose(x.grad.cpu().numpy(), g["grad_x"], rtol=1e-3, atol=2e-5)
+    if bilateral:
+        np.testing.assert_allclose(pc.grad.cpu().numpy(), g["grad_pc"], rtol=1e-3, atol=2e-5)
+    for n, p in mod2.named_parameters():
+        np.testing.assert_allclose(p.grad.cpu().numpy(), g["grad." + n], rtol=1e-3, atol=5e-5, err_msg=n)
+    for n, b in mod2.named_buffers():
+        if "num_batches" not in n:
+            np.testing.assert_allclose(b.cpu().numpy(), g["stat." + n], rtol=1e-4, atol=1e-5, err_msg=n)
+    mod2.eval()
+    with torch.no_grad():
+        y_ev = mod2(x, pc, idx=dev(g["idx"].astype(np.int32)))
+    np.testing.assert_allclose(y_ev.cpu().numpy(), g["y_eval"], rtol=1e-4, atol=2e-5)
+
+
+def test_generator_golden(golden):
+    from pdgn_amd.generator import PointDiscriminator, PointGenerator
+    g = golden("generator_b6.npz")
+    G = fill_module(PointGenerator(), salt=1).cuda().train()
+    with torch.no_grad():
+        outs = G(dev(g["z"]), idx=[dev(g["idx%d" % i].astype(np.int32)) for i in (1, 2, 3, 4)])
+    for i, o in enumerate(outs):
+        gold = g["p%d" % (i + 1)]
+        np.testing.assert_allclose(o.cpu().numpy(), gold, rtol=1e-4, atol=1e-4 * np.abs(gold).max())
+    for i in (1, 2, 3, 4):
+        D = fill_module(PointDiscriminator(i), salt=9 + i).cuda().train()
+        with torch.no_grad():
+            np.testing.assert_allclose(D(dev(g["p%d" % i])).cpu().numpy(), g["d%d" % i], rtol=1e-4, atol=1e-5)
+    # with its own kNN graphs the generator must reproduce the reference except where a graph
+    # near-tie flipped: compare stage 1 (a single graph) only when that graph was well separated
+    G2 = fill_module(PointGenerator(), salt=1).cuda().train()
+    with torch.no_grad():
+        own = G2(dev(g["z"]))
+    assert all(torch.isfinite(o).all() for o in own)
+    if float(g["knn_margins"][0]) > 1e-5:
+        np.testing.assert_allclose(own[0].cpu().numpy(), g["p1"], rtol=1e-4, atol=1e-4)
+
+
+def test_one_step_vs_composed_reference(golden):
+    """models/PDGNet_v2.py:171-256 at B=4, hash weights: logged losses within 2e-3 of the
+    composed-reference fixture (kNN graph flips at near-ties are the dominant difference)."""
+    from pdgn_amd.trainer import PDGNTrainer
+    g = golden("step_b4.npz")
+    B = 4
+    tr = PDGNTrainer(device="cuda", distributed=False)
+    fill_module(tr.G, salt=1)
+    for i, d in enumerate(tr.D):
+        fill_module(d, salt=10 + i)
+    tr.train()
+    reals = [dev(hash_tensor("real%d" % i, (B, 3, n), 0.8)) for i, n in enumerate((256, 512, 1024, 2048))]
+    out = tr.step(reals, dev(hash_tensor("step_z1", (B, 128), 0.2)), dev(hash_tensor("step_z2", (B, 128), 0.2)))
+    for key in ("d_loss1", "d_loss2", "d_loss3", "d_loss4", "g_loss", "similar_loss"):
+        np.testing.assert_allclose(out[key].item(), g[key], rtol=5e-3, err_msg=key)
+    np.testing.assert_allclose(tr.G.fc1[0].weight.detach()[:4, :8].cpu().numpy(), g["g_fc1_w_after"],
+                               rtol=1e-2, atol=1e-5)
+
+
+def test_full_size_step_properties():
+    """BASELINE.json configs[1] shape (B=35, 256->2048): one iteration runs, losses are finite,
+    every G parameter receives a finite gradient, kNN rows are duplicate-free."""
+    from pdgn_amd.deconv import feature_knn
+    from pdgn_amd.trainer import PDGNTrainer, noise, synthetic_batch
+    torch.manual_seed(9999)
+    tr = PDGNTrainer(device="cuda", distributed=False)
+    tr.train()
+    B = 35
+    reals = synthetic_batch(B, "cuda")
+    assert [r.shape[2] for r in reals] == [256, 512, 1024, 2048]
+    out = tr.step(reals, noise(B, "cuda"), noise(B, "cuda"))
+    assert all(torch.isfinite(v) for v in out.values())
+    assert torch.isfinite(tr.gradG.buf).all() and tr.gradG.buf.abs().sum() > 0
+    x = torch.randn(B, 256, 1024, device="cuda")
+    idx = feature_knn(x, 10).long()
+    srt = idx.sort(dim=2)[0]
+    assert (srt[:, :, 1:] != srt[:, :, :-1]).all()
+    assert (idx != torch.arange(1024, device="cuda").view(1, -1, 1)).all()   # self is rank 0 for random data

@@ -168,7 +168,7 @@ def test_state_dict_manifest():
 
 
 def test_generator_and_discriminators(golden):
-    g = golden("generator_b2.npz")
+    g = golden("generator_b6.npz")
     G = fill_module(pdgnet_ref.PointGeneratorRef(), salt=1).train()
     with torch.no_grad():
         outs = G(torch.from_numpy(g["z"]),
