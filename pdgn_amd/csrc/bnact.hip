@@ -1,0 +1,285 @@
+// bnact.hip -- fused BatchNorm + activation over channels-last (rows x C) activations.
+//
+// Every conv of the reference's deconvolution block is followed by BatchNorm2d (training mode:
+// batch statistics over (B,N,k)) and LeakyReLU/ReLU (models/PDGNet_v2.py:561-565, 603-625, 537-545),
+// each a separate pass over a (B,C,N,k) tensor.  In the point-major layout used here these are
+// (rows x C) matrices with C contiguous, and the whole chain is two streaming kernels forward
+// (statistics; normalise+activate) and two backward (the two batch reductions; the input gradient):
+//   forward : y  = act(x * scale[c] + shift[c]),  scale = gamma*invstd, shift = beta - mean*scale
+//   backward: dz = dy * act'(z);  s1 = sum dz;  s2 = sum dz * xhat
+//             dx = scale * (dz - s1/R - xhat * s2/R)      (training)   |   dx = scale * dz  (eval)
+// All four are HBM-bound: float4 per lane, a wave covers 1 KiB of one row (or several short rows).
+// Per-thread partial sums are fp32 over <= a few thousand rows and are combined in fp64 atomics.
+#include "common.h"
+
+#define BN_THREADS 256
+#define ACT_NONE 0
+#define ACT_RELU 1
+#define ACT_LEAKY 2   // negative_slope 0.01 (nn.LeakyReLU default used throughout the reference)
+
+__device__ __forceinline__ float act_fwd(float z, int act) {
+    if (act == ACT_RELU) return fmaxf(z, 0.f);
+    if (act == ACT_LEAKY) return z > 0.f ? z : 0.01f * z;
+    return z;
+}
+__device__ __forceinline__ float act_grad(float z, int act) {
+    if (act == ACT_RELU) return z > 0.f ? 1.f : 0.f;
+    if (act == ACT_LEAKY) return z > 0.f ? 1.f : 0.01f;
+    return 1.f;
+}
+
+// Geometry shared by the reduction kernels: CG = C/4 float4 column groups; thread t owns column
+// group t % CGB of the block's column slice and row lane t / CGB.
+struct ClGeom {
+    int cg, cgb, rl;     // column groups total, per block (<= 256, divides 256 or equals cg), row lanes
+};
+
+// sums[c] += sum_r x[r,c];  sums[C + c] += sum_r x[r,c]^2      (fp64 accumulators, pre-zeroed)
+__global__ __launch_bounds__(BN_THREADS) void cl_stats_kernel(long long R, int C, int cgb, int rows_per_block,
+                                                              const float *__restrict__ x,
+                                                              double *__restrict__ sums) {
+    __shared__ float4 red[2][BN_THREADS];
+    const int cgl = threadIdx.x % cgb, rlane = threadIdx.x / cgb, rl = BN_THREADS / cgb;
+    const int cgi = blockIdx.x * cgb + cgl;                 // global column group
+    const bool cok = cgi * 4 < C;
+    const long long r0 = (long long)blockIdx.y * rows_per_block;
+    const long long r1 = min(R, r0 + rows_per_block);
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f), q = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (cok)
+        for (long long r = r0 + rlane; r < r1; r += rl) {
+            float4 v = *reinterpret_cast<const float4 *>(x + r * C + cgi * 4);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+            q.x = __fmaf_rn(v.x, v.x, q.x); q.y = __fmaf_rn(v.y, v.y, q.y);
+            q.z = __fmaf_rn(v.z, v.z, q.z); q.w = __fmaf_rn(v.w, v.w, q.w);
+        }
+    red[0][threadIdx.x] = s;
+    red[1][threadIdx.x] = q;
+    __syncthreads();
+    if (rlane == 0 && cok) {
+        for (int j = 1; j < rl; ++j) {
+            float4 a = red[0][j * cgb + cgl], b = red[1][j * cgb + cgl];
+            s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+            q.x += b.x; q.y += b.y; q.z += b.z; q.w += b.w;
+        }
+        double *S = sums + cgi * 4, *Q = sums + C + cgi * 4;
+        atomicAdd(S, (double)s.x); atomicAdd(S + 1, (double)s.y); atomicAdd(S + 2, (double)s.z); atomicAdd(S + 3, (double)s.w);
+        atomicAdd(Q, (double)q.x); atomicAdd(Q + 1, (double)q.y); atomicAdd(Q + 2, (double)q.z); atomicAdd(Q + 3, (double)q.w);
+    }
+}
+
+// From the fp64 sums: mean, biased var -> scale/shift/mean/invstd; running stats with momentum and
+// the unbiased variance (nn.BatchNorm semantics).  stats out: [scale | shift | mean | invstd] (4C).
+__global__ void cl_finalize_kernel(long long R, int C, float eps, float momentum, const double *__restrict__ sums,
+                                   const float *__restrict__ gamma, const float *__restrict__ beta,
+                                   float *__restrict__ running_mean, float *__restrict__ running_var,
+                                   float *__restrict__ stats) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double mean = sums[c] / (double)R;
+    double var = sums[C + c] / (double)R - mean * mean;
+    var = var < 0 ? 0 : var;
+    const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    const float scale = g * invstd;
+    stats[c] = scale;
+    stats[C + c] = b - (float)mean * scale;
+    stats[2 * C + c] = (float)mean;
+    stats[3 * C + c] = invstd;
+    if (running_mean) {
+        const double unbiased = R > 1 ? var * (double)R / (double)(R - 1) : var;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+    }
+}
+
+// eval mode: scale/shift from the running statistics
+__global__ void cl_eval_stats_kernel(int C, float eps, const float *__restrict__ gamma, const float *__restrict__ beta,
+                                     const float *__restrict__ running_mean, const float *__restrict__ running_var,
+                                     float *__restrict__ stats) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float invstd = rsqrtf(running_var[c] + eps);
+    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    stats[c] = g * invstd;
+    stats[C + c] = b - running_mean[c] * g * invstd;
+    stats[2 * C + c] = running_mean[c];
+    stats[3 * C + c] = invstd;
+}
+
+// y = act(x*scale + shift) [* mul]
+__global__ __launch_bounds__(BN_THREADS) void cl_apply_kernel(long long total4, int CG, int act,
+                                                              const float *__restrict__ x,
+                                                              const float *__restrict__ stats,
+                                                              const float *__restrict__ mul, float *__restrict__ y) {
+    const long long e = (long long)blockIdx.x * BN_THREADS + threadIdx.x;
+    if (e >= total4) return;
+    const int c4 = (int)(e % CG) * 4;
+    const float4 v = reinterpret_cast<const float4 *>(x)[e];
+    const float4 sc = *reinterpret_cast<const float4 *>(stats + c4);
+    const float4 sh = *reinterpret_cast<const float4 *>(stats + CG * 4 + c4);
+    float4 o;
+    o.x = act_fwd(__fmaf_rn(v.x, sc.x, sh.x), act); o.y = act_fwd(__fmaf_rn(v.y, sc.y, sh.y), act);
+    o.z = act_fwd(__fmaf_rn(v.z, sc.z, sh.z), act); o.w = act_fwd(__fmaf_rn(v.w, sc.w, sh.w), act);
+    if (mul) {
+        const float4 m = reinterpret_cast<const float4 *>(mul)[e];
+        o.x *= m.x; o.y *= m.y; o.z *= m.z; o.w *= m.w;
+    }
+    reinterpret_cast<float4 *>(y)[e] = o;
+}
+
+// bsums[c] += sum dz ; bsums[C+c] += sum dz*xhat   (dz = dy [* mul] * act'(z))
+__global__ __launch_bounds__(BN_THREADS) void cl_bwd_reduce_kernel(long long R, int C, int cgb, int rows_per_block,
+                                                                   int act, const float *__restrict__ x,
+                                                                   const float *__restrict__ dy,
+                                                                   const float *__restrict__ mul,
+                                                                   const float *__restrict__ stats,
+                                                                   double *__restrict__ bsums) {
+    __shared__ float4 red[2][BN_THREADS];
+    const int cgl = threadIdx.x % cgb, rlane = threadIdx.x / cgb, rl = BN_THREADS / cgb;
+    const int cgi = blockIdx.x * cgb + cgl;
+    const bool cok = cgi * 4 < C;
+    const long long r0 = (long long)blockIdx.y * rows_per_block;
+    const long long r1 = min(R, r0 + rows_per_block);
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f), q = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (cok) {
+        const float4 sc = *reinterpret_cast<const float4 *>(stats + cgi * 4);
+        const float4 sh = *reinterpret_cast<const float4 *>(stats + C + cgi * 4);
+        const float4 mu = *reinterpret_cast<const float4 *>(stats + 2 * C + cgi * 4);
+        const float4 is = *reinterpret_cast<const float4 *>(stats + 3 * C + cgi * 4);
+        for (long long r = r0 + rlane; r < r1; r += rl) {
+            const float4 v = *reinterpret_cast<const float4 *>(x + r * C + cgi * 4);
+            float4 g = *reinterpret_cast<const float4 *>(dy + r * C + cgi * 4);
+            if (mul) {
+                const float4 m = *reinterpret_cast<const float4 *>(mul + r * C + cgi * 4);
+                g.x *= m.x; g.y *= m.y; g.z *= m.z; g.w *= m.w;
+            }
+            float dz;
+            dz = g.x * act_grad(__fmaf_rn(v.x, sc.x, sh.x), act); s.x += dz; q.x = __fmaf_rn(dz, (v.x - mu.x) * is.x, q.x);
+            dz = g.y * act_grad(__fmaf_rn(v.y, sc.y, sh.y), act); s.y += dz; q.y = __fmaf_rn(dz, (v.y - mu.y) * is.y, q.y);
+            dz = g.z * act_grad(__fmaf_rn(v.z, sc.z, sh.z), act); s.z += dz; q.z = __fmaf_rn(dz, (v.z - mu.z) * is.z, q.z);
+            dz = g.w * act_grad(__fmaf_rn(v.w, sc.w, sh.w), act); s.w += dz; q.w = __fmaf_rn(dz, (v.w - mu.w) * is.w, q.w);
+        }
+    }
+    red[0][threadIdx.x] = s;
+    red[1][threadIdx.x] = q;
+    __syncthreads();
+    if (rlane == 0 && cok) {
+        for (int j = 1; j < rl; ++j) {
+            float4 a = red[0][j * cgb + cgl], b = red[1][j * cgb + cgl];
+            s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+            q.x += b.x; q.y += b.y; q.z += b.z; q.w += b.w;
+        }
+        double *S = bsums + cgi * 4, *Q = bsums + C + cgi * 4;
+        atomicAdd(S, (double)s.x); atomicAdd(S + 1, (double)s.y); atomicAdd(S + 2, (double)s.z); atomicAdd(S + 3, (double)s.w);
+        atomicAdd(Q, (double)q.x); atomicAdd(Q + 1, (double)q.y); atomicAdd(Q + 2, (double)q.z); atomicAdd(Q + 3, (double)q.w);
+    }
+}
+
+// dx = scale*(dz - s1/R - xhat*s2/R) (training) or scale*dz (eval); optionally dmul = dy*act(z)
+__global__ __launch_bounds__(BN_THREADS) void cl_bwd_apply_kernel(long long total4, long long R, int CG, int act,
+                                                                  int training, const float *__restrict__ x,
+                                                                  const float *__restrict__ dy,
+                                                                  const float *__restrict__ mul,
+                                                                  const float *__restrict__ stats,
+                                                                  const double *__restrict__ bsums,
+                                                                  float *__restrict__ dx, float *__restrict__ dmul) {
+    const long long e = (long long)blockIdx.x * BN_THREADS + threadIdx.x;
+    if (e >= total4) return;
+    const int C = CG * 4, c4 = (int)(e % CG) * 4;
+    const float4 v = reinterpret_cast<const float4 *>(x)[e];
+    float4 g = reinterpret_cast<const float4 *>(dy)[e];
+    const float *vv = reinterpret_cast<const float *>(&v);
+    float *gg = reinterpret_cast<float *>(&g);
+    float4 o, om;
+    float *oo = reinterpret_cast<float *>(&o), *omm = reinterpret_cast<float *>(&om);
+    float4 m = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (mul) m = reinterpret_cast<const float4 *>(mul)[e];
+    const float *mm = reinterpret_cast<const float *>(&m);
+    const float invR = 1.0f / (float)R;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = c4 + j;
+        const float sc = stats[c], z = __fmaf_rn(vv[j], sc, stats[C + c]);
+        omm[j] = gg[j] * act_fwd(z, act);
+        const float dz = gg[j] * mm[j] * act_grad(z, act);
+        if (training) {
+            const float xhat = (vv[j] - stats[2 * C + c]) * stats[3 * C + c];
+            const float m1 = (float)bsums[c] * invR, m2 = (float)bsums[C + c] * invR;
+            oo[j] = sc * (dz - m1 - xhat * m2);
+        } else {
+            oo[j] = sc * dz;
+        }
+    }
+    reinterpret_cast<float4 *>(dx)[e] = o;
+    if (dmul) reinterpret_cast<float4 *>(dmul)[e] = om;
+}
+
+// ---------------------------------------------------------------------------- C ABI
+static void cl_geometry(long long R, int C, int *cgb, int *gx, int *gy, int *rpb) {
+    const int cg = C / 4;
+    *cgb = cg >= BN_THREADS ? BN_THREADS : cg;
+    // cgb must divide BN_THREADS: round up to a power of two for small C
+    int p = 1;
+    while (p < *cgb) p <<= 1;
+    *cgb = p > BN_THREADS ? BN_THREADS : p;
+    *gx = (cg + *cgb - 1) / *cgb;
+    const int rl = BN_THREADS / *cgb;
+    long long want = 2048 / *gx;                           // ~2048 workgroups in flight
+    want = want < 1 ? 1 : want;
+    long long rows = (R + want - 1) / want;
+    const long long min_rows = (long long)rl * 8;
+    rows = rows < min_rows ? min_rows : rows;
+    rows = rows > 65536 ? 65536 : rows;                    // bound the fp32 partial sums
+    rows = (rows + rl - 1) / rl * rl;
+    *rpb = (int)rows;
+    *gy = (int)((R + rows - 1) / rows);
+}
+
+extern "C" int pdgn_bn_stats(long long rows, int c, float eps, float momentum, const float *x, const float *gamma,
+                             const float *beta, float *running_mean, float *running_var, double *sums,
+                             float *stats, pdgn_stream_t stream) {
+    if (rows < 1 || c < 4 || c % 4) return PDGN_ERR_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(sums, 0, 2 * (size_t)c * sizeof(double), s);
+    if (e != hipSuccess) return (int)e;
+    int cgb, gx, gy, rpb;
+    cl_geometry(rows, c, &cgb, &gx, &gy, &rpb);
+    hipLaunchKernelGGL(cl_stats_kernel, dim3(gx, gy), dim3(BN_THREADS), 0, s, rows, c, cgb, rpb, x, sums);
+    hipLaunchKernelGGL(cl_finalize_kernel, dim3(cdiv(c, 256)), dim3(256), 0, s, rows, c, eps, momentum, sums, gamma,
+                       beta, running_mean, running_var, stats);
+    return pdgn_launch_status();
+}
+
+extern "C" int pdgn_bn_eval_stats(int c, float eps, const float *gamma, const float *beta, const float *running_mean,
+                                  const float *running_var, float *stats, pdgn_stream_t stream) {
+    if (c < 1) return PDGN_ERR_INVALID;
+    hipLaunchKernelGGL(cl_eval_stats_kernel, dim3(cdiv(c, 256)), dim3(256), 0, (hipStream_t)stream, c, eps, gamma,
+                       beta, running_mean, running_var, stats);
+    return pdgn_launch_status();
+}
+
+extern "C" int pdgn_bn_act_forward(long long rows, int c, int act, const float *x, const float *stats, const float *mul,
+                                   float *y, pdgn_stream_t stream) {
+    if (rows < 1 || c < 4 || c % 4 || act < 0 || act > 2) return PDGN_ERR_INVALID;
+    const long long total4 = rows * (c / 4);
+    hipLaunchKernelGGL(cl_apply_kernel, dim3(cdiv(total4, BN_THREADS)), dim3(BN_THREADS), 0, (hipStream_t)stream,
+                       total4, c / 4, act, x, stats, mul, y);
+    return pdgn_launch_status();
+}
+
+extern "C" int pdgn_bn_act_backward(long long rows, int c, int act, int training, const float *x, const float *dy,
+                                    const float *mul, const float *stats, double *bsums, float *dx, float *dmul,
+                                    pdgn_stream_t stream) {
+    if (rows < 1 || c < 4 || c % 4 || act < 0 || act > 2) return PDGN_ERR_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(bsums, 0, 2 * (size_t)c * sizeof(double), s);
+    if (e != hipSuccess) return (int)e;
+    int cgb, gx, gy, rpb;
+    cl_geometry(rows, c, &cgb, &gx, &gy, &rpb);
+    hipLaunchKernelGGL(cl_bwd_reduce_kernel, dim3(gx, gy), dim3(BN_THREADS), 0, s, rows, c, cgb, rpb, act, x, dy, mul,
+                       stats, bsums);
+    const long long total4 = rows * (c / 4);
+    hipLaunchKernelGGL(cl_bwd_apply_kernel, dim3(cdiv(total4, BN_THREADS)), dim3(BN_THREADS), 0, s, total4, rows,
+                       c / 4, act, training, x, dy, mul, stats, bsums, dx, dmul);
+    return pdgn_launch_status();
+}

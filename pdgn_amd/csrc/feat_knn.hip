@@ -10,7 +10,9 @@
 // (v_mfma_f32_32x32x2_f32: exact fp32 fma chains over the feature axis, candidates on the MFMA
 // rows, queries on the lanes), written once to LDS as dist[query][candidate], and each query is
 // then selected by a whole wave with the threshold/compaction/bitonic scheme of wave_select.h.
-// Nothing of size N^2 ever reaches HBM.
+// Candidates are walked in chunks of 256 (33 KB of LDS per chunk, two workgroups per CU so one
+// workgroup's MFMA phase overlaps the other's selection phase).  Nothing of size N^2 ever
+// reaches HBM.
 #include "common.h"
 #include "wave_select.h"
 
@@ -39,6 +41,7 @@ __global__ __launch_bounds__(FK_THREADS) void feat_knn_kernel(
     int32_t *__restrict__ idx) {
     constexpr int NCP = NC + 4;
     __shared__ float dist[FK_QB][NCP];
+    __shared__ float bqs[FH][PDGN_WAVE];         // B operand (queries), lane-indexed
     __shared__ float sqc[NC];
     __shared__ DI queue[FK_WAVES][WSEL_QCAP];
 
@@ -51,14 +54,12 @@ __global__ __launch_bounds__(FK_THREADS) void feat_knn_kernel(
     const float *SQ = sq + (size_t)bs * n;
     const int K = k + 1;
 
-    // B operand (queries) lives in registers for the whole kernel: lane holds channel 2s+half
-    // of query q0+col.
-    float bq[FH];
+    // B operand: bqs[s][lane] = channel 2s+half of query q0+col (zero-padded); every wave's
+    // MFMA reads it back with one conflict-free ds_read_b32 per step.
     const int qcol = q0 + col;
-#pragma unroll
-    for (int s = 0; s < FH; ++s) {
+    for (int s = wave; s < FH; s += FK_WAVES) {
         int c = 2 * s + half;
-        bq[s] = (c < f && qcol < n) ? X[(size_t)c * n + qcol] : 0.f;
+        bqs[s][lane] = (c < f && qcol < n) ? X[(size_t)c * n + qcol] : 0.f;
     }
     const float sq_q = qcol < n ? SQ[qcol] : 0.f;
 
@@ -69,19 +70,20 @@ __global__ __launch_bounds__(FK_THREADS) void feat_knn_kernel(
 
     for (int t0 = 0; t0 < n; t0 += NC) {
         const int tn = min(NC, n - t0);
-        __syncthreads();                         // previous chunk's selection finished
+        __syncthreads();                         // previous chunk's selection finished (and bqs ready)
         for (int c = threadIdx.x; c < tn; c += FK_THREADS) sqc[c] = SQ[t0 + c];
         __syncthreads();
         // ---- Gram tiles on the matrix cores
         for (int rt = wave; rt * 32 < tn; rt += FK_WAVES) {
             const int r = t0 + rt * 32 + col;    // candidate row this lane feeds to the A operand
+            const float *Ar = X + (size_t)half * n + min(r, n - 1);
             const bool rok = r < n;
             f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll 8
+#pragma unroll 16
             for (int s = 0; s < FH; ++s) {
                 int c = 2 * s + half;
-                float a = (rok && c < f) ? X[(size_t)c * n + r] : 0.f;
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bq[s], acc, 0, 0, 0);
+                float a = (rok && c < f) ? Ar[(size_t)(2 * s) * n] : 0.f;
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bqs[s][lane], acc, 0, 0, 0);
             }
             // D[row = (reg&3) + 8*(reg>>2) + 4*half][col]: candidate rows, query column
 #pragma unroll
@@ -120,10 +122,7 @@ template <int FH>
 static int launch_fk(int b, int f, int n, int k, const float *x, const float *sq, int32_t *idx,
                      hipStream_t s) {
     dim3 grid(cdiv(n, FK_QB), b);
-    if (n <= 256)
-        hipLaunchKernelGGL((feat_knn_kernel<FH, 256>), grid, dim3(FK_THREADS), 0, s, f, n, k, x, sq, idx);
-    else
-        hipLaunchKernelGGL((feat_knn_kernel<FH, 1024>), grid, dim3(FK_THREADS), 0, s, f, n, k, x, sq, idx);
+    hipLaunchKernelGGL((feat_knn_kernel<FH, 256>), grid, dim3(FK_THREADS), 0, s, f, n, k, x, sq, idx);
     return pdgn_launch_status();
 }
 

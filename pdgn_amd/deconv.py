@@ -25,6 +25,7 @@ from torch.autograd import Function
 
 from . import _lib
 from ._lib import check, ptr, require, stream_of
+from .fused import bn_act
 
 F32, I32 = torch.float32, torch.int32
 
@@ -85,14 +86,6 @@ class _ConvBN(nn.Module):
         super().__init__()
         self.conv = nn.Conv2d(cin, cout, ksize, 1)
         self.bn = nn.BatchNorm2d(cout)
-
-
-def _bn(x2d, bn, training):
-    """BatchNorm over the rows of a channels-last (M, C) view with nn.BatchNorm2d semantics."""
-    if training and bn.track_running_stats:
-        bn.num_batches_tracked.add_(1)
-    return F.batch_norm(x2d, bn.running_mean, bn.running_var, bn.weight, bn.bias, training, bn.momentum,
-                        bn.eps)
 
 
 class PointDeconv(nn.Module):
@@ -159,28 +152,27 @@ class PointDeconv(nn.Module):
             biases.append(self.conv_fea[0].bias)
         outs = EdgeGatherSum.apply(Y, idx, tuple(specs), *biases)
         inte_pre, a_pre = outs[0], outs[1]                             # (B,N,P,4F), (B,N,1,2Fo)
-        inte = F.leaky_relu(_bn(inte_pre.view(-1, 4 * Fi), self.inte_conv_hk[1], training))
-        inte = inte.view(B, N, P, 4 * Fi)
+        w = None
         if self.bilateral:
             Wx = self.conv_xyz[0].weight[:, :, 0, 0]                   # (16, 6)
             pct = pc.transpose(1, 2).contiguous()                      # (B,N,3)
             Yx = torch.matmul(pct, torch.cat([Wx[:, 3:], Wx[:, :3] - Wx[:, 3:]], 0).t()).contiguous()
             (xyz_pre,) = EdgeGatherSum.apply(Yx, idx, ((1, k, 16, 0, 16),), self.conv_xyz[0].bias)
-            fea = F.leaky_relu(_bn(outs[2].view(-1, 16), self.conv_fea[1], training))
-            xyzf = F.leaky_relu(_bn(xyz_pre.view(-1, 16), self.conv_xyz[1], training))
-            h = fea * xyzf                                             # (B*N*k, 16)
+            xyzf = bn_act(xyz_pre.view(-1, 16), self.conv_xyz[1], training)
+            h = bn_act(outs[2].view(-1, 16), self.conv_fea[1], training, mul=xyzf)   # w_fea * w_xyz :632
             h = F.linear(h, self.conv_all[0].weight[:, :, 0, 0], self.conv_all[0].bias)
-            h = F.leaky_relu(_bn(h, self.conv_all[1], training))
+            h = bn_act(h, self.conv_all[1], training)
             h = F.linear(h, self.conv_all[3].weight[:, :, 0, 0], self.conv_all[3].bias)
-            h = F.leaky_relu(_bn(h, self.conv_all[4], training))
+            h = bn_act(h, self.conv_all[4], training)
             w = h.view(B, N, k, 2 * Fi)
             if self.softmax:
                 w = F.softmax(w, dim=2)                                # over the k neighbour slots
             # w[b,n,s=P*j+p,c'] -> [b,n,p,o=2c'+j]  (the reference's interleave :638-641)
-            w = w.view(B, N, 2, P, 2 * Fi).permute(0, 1, 3, 4, 2).reshape(B, N, P, 4 * Fi)
-            inte = inte * w
-        out_pre = a_pre.view(B * N, 2 * Fo) + F.linear(inte.reshape(B * N, P * 4 * Fi), Wb)
-        out = F.relu(_bn(out_pre, self.conv2.bn, training))            # (B*N, 2Fo)
+            w = w.view(B, N, 2, P, 2 * Fi).permute(0, 1, 3, 4, 2).reshape(B * N * P, 4 * Fi)
+        # inte = LeakyReLU(BN(inte_pre)) [* w]  -- one fused pass (:637, :642)
+        inte = bn_act(inte_pre.view(-1, 4 * Fi), self.inte_conv_hk[1], training, mul=w)
+        out_pre = a_pre.view(B * N, 2 * Fo) + F.linear(inte.view(B * N, P * 4 * Fi), Wb)
+        out = bn_act(out_pre, self.conv2.bn, training, act="relu")     # (B*N, 2Fo)
         return out.view(B, N, Fo, 2).permute(0, 2, 3, 1).reshape(B, Fo, 2 * N)
 
 

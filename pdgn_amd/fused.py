@@ -1,0 +1,70 @@
+"""Autograd wrappers of the fused channels-last kernels of libpdgn_hip.so (bnact.hip)."""
+import ctypes
+
+import torch
+from torch.autograd import Function
+
+from . import _lib
+from ._lib import check, ptr, stream_of
+
+F32 = torch.float32
+ACT = {"none": 0, "relu": 1, "leaky_relu": 2}
+
+
+class BNActCL(Function):
+    """y = act(BatchNorm(x)) [* mul] for a channels-last (rows, C) matrix, with nn.BatchNorm
+    semantics (batch statistics + running-stat update in training, running statistics in eval).
+    One Function = the reference's BatchNorm2d + LeakyReLU/ReLU pair (and, with ``mul``, the
+    bilateral product ``inte_x * w`` of models/PDGNet_v2.py:642)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, act, mul):
+        rows, C = x.shape
+        x = x.contiguous()
+        dev = x.device
+        L = _lib.lib()
+        stats = torch.empty(4 * C, dtype=F32, device=dev)
+        g, b = gamma.detach().contiguous(), beta.detach().contiguous()
+        if training:
+            sums = torch.empty(2 * C, dtype=torch.float64, device=dev)
+            check(L.pdgn_bn_stats(ctypes.c_longlong(rows), C, ctypes.c_float(eps), ctypes.c_float(momentum), ptr(x),
+                                  ptr(g), ptr(b), ptr(running_mean), ptr(running_var), ptr(sums), ptr(stats),
+                                  stream_of(x)), "pdgn_bn_stats")
+        else:
+            check(L.pdgn_bn_eval_stats(C, ctypes.c_float(eps), ptr(g), ptr(b), ptr(running_mean),
+                                       ptr(running_var), ptr(stats), stream_of(x)), "pdgn_bn_eval_stats")
+        mul_c = mul.contiguous() if mul is not None else None
+        y = torch.empty_like(x)
+        check(L.pdgn_bn_act_forward(ctypes.c_longlong(rows), C, act, ptr(x), ptr(stats), ptr(mul_c), ptr(y),
+                                    stream_of(x)), "pdgn_bn_act_forward")
+        ctx.save_for_backward(x, stats, mul_c)
+        ctx.cfg = (rows, C, act, bool(training), mul is not None and mul.requires_grad)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, stats, mul = ctx.saved_tensors
+        rows, C, act, training, need_dmul = ctx.cfg
+        dy = dy.contiguous()
+        bsums = torch.empty(2 * C, dtype=torch.float64, device=x.device)
+        dx = torch.empty_like(x)
+        dmul = torch.empty_like(x) if need_dmul else None
+        check(_lib.lib().pdgn_bn_act_backward(ctypes.c_longlong(rows), C, act, int(training), ptr(x), ptr(dy),
+                                              ptr(mul), ptr(stats), ptr(bsums), ptr(dx), ptr(dmul),
+                                              stream_of(x)), "pdgn_bn_act_backward")
+        bs = bsums.to(F32)
+        return dx, bs[C:], bs[:C], None, None, None, None, None, None, dmul
+
+
+def bn_act(x2d, bn, training, act="leaky_relu", mul=None):
+    """Apply an nn.BatchNorm{1,2}d module's parameters/buffers to a channels-last (rows, C) view,
+    followed by `act` (and an optional elementwise product)."""
+    if training and bn.track_running_stats:
+        bn.num_batches_tracked.add_(1)
+    if x2d.shape[1] % 4:                      # odd channel counts: library path
+        y = torch.nn.functional.batch_norm(x2d, bn.running_mean, bn.running_var, bn.weight, bn.bias, training,
+                                           bn.momentum, bn.eps)
+        y = {"none": lambda t: t, "relu": torch.relu, "leaky_relu": torch.nn.functional.leaky_relu}[act](y)
+        return y * mul if mul is not None else y
+    return BNActCL.apply(x2d, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, bn.momentum, bn.eps,
+                         ACT[act], mul)

@@ -5,13 +5,14 @@ import pytest
 import torch
 
 from hashweights import fill_module
-from torch_standins import EdgeGatherSumTorch
+from torch_standins import EdgeGatherSumTorch, bn_act_torch
 
 
 @pytest.fixture()
 def deconv(monkeypatch):
     from pdgn_amd import deconv as m
     monkeypatch.setattr(m, "EdgeGatherSum", EdgeGatherSumTorch)
+    monkeypatch.setattr(m, "bn_act", bn_act_torch)
     return m
 
 

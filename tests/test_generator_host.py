@@ -8,7 +8,7 @@ import pytest
 import torch
 
 from hashweights import fill_module, hash_tensor
-from torch_standins import EdgeGatherSumTorch, feature_knn_torch
+from torch_standins import EdgeGatherSumTorch, bn_act_torch, feature_knn_torch
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
@@ -17,6 +17,7 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 def patched(monkeypatch):
     from pdgn_amd import deconv
     monkeypatch.setattr(deconv, "EdgeGatherSum", EdgeGatherSumTorch)
+    monkeypatch.setattr(deconv, "bn_act", bn_act_torch)
     monkeypatch.setattr(deconv, "feature_knn", feature_knn_torch)
     return deconv
 

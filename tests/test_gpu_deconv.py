@@ -174,3 +174,31 @@ def test_full_size_step_properties():
     srt = idx.sort(dim=2)[0]
     assert (srt[:, :, 1:] != srt[:, :, :-1]).all()
     assert (idx != torch.arange(1024, device="cuda").view(1, -1, 1)).all()   # self is rank 0 for random data
+
+
+@pytest.mark.parametrize("rows,C,act,use_mul,training", [(1000, 16, "leaky_relu", True, True), (5000, 64, "leaky_relu", False, True),
+                                                         (3333, 1024, "leaky_relu", True, True), (777, 24, "relu", False, True),
+                                                         (2048, 512, "relu", False, False), (100000, 32, "none", True, True)])
+def test_fused_bn_act_vs_torch(rows, C, act, use_mul, training):
+    from pdgn_amd.fused import bn_act
+    from torch_standins import bn_act_torch
+    rng = np.random.default_rng(rows + C)
+    x = torch.from_numpy((rng.standard_normal((rows, C)) * 2 + 0.7).astype(np.float32))
+    mul = torch.from_numpy(rng.standard_normal((rows, C)).astype(np.float32)) if use_mul else None
+    gout = torch.from_numpy(rng.standard_normal((rows, C)).astype(np.float32))
+    res = []
+    for impl, to in ((bn_act, dev), (bn_act_torch, lambda t: t.double())):
+        bn = torch.nn.BatchNorm1d(C)
+        fill_module(bn, salt=2)
+        bn = bn.cuda() if impl is bn_act else bn.double()
+        bn.train(training)
+        xi = to(x).requires_grad_(True)
+        mi = to(mul).requires_grad_(True) if use_mul else None
+        y = impl(xi, bn, training, act=act, mul=mi)
+        y.backward(to(gout))
+        res.append([t.detach().cpu().double().numpy() for t in
+                    (y, xi.grad, bn.weight.grad, bn.bias.grad, bn.running_mean, bn.running_var)
+                    + ((mi.grad,) if use_mul else ())])
+    names = ["y", "dx", "dgamma", "dbeta", "running_mean", "running_var", "dmul"]
+    for name, a, b in zip(names, *res):
+        np.testing.assert_allclose(a, b, rtol=1e-4, atol=1e-4 * max(1.0, np.abs(b).max()), err_msg=name)

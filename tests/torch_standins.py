@@ -30,3 +30,13 @@ def feature_knn_torch(x, k):
     sq = (xt ** 2).sum(dim=2, keepdim=True)
     dist = -2 * torch.bmm(xt, x) + sq + sq.transpose(1, 2)
     return dist.sort(dim=2, stable=True)[1][:, :, 1:k + 1].to(torch.int32).contiguous()
+
+
+def bn_act_torch(x2d, bn, training, act="leaky_relu", mul=None):
+    """Same contract as pdgn_amd.fused.bn_act in plain torch ops."""
+    import torch.nn.functional as F
+    if training and bn.track_running_stats:
+        bn.num_batches_tracked.add_(1)
+    y = F.batch_norm(x2d, bn.running_mean, bn.running_var, bn.weight, bn.bias, training, bn.momentum, bn.eps)
+    y = {"none": lambda t: t, "relu": torch.relu, "leaky_relu": F.leaky_relu}[act](y)
+    return y * mul if mul is not None else y
