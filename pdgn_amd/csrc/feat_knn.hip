@@ -6,13 +6,19 @@
 // Ties are ordered by index (the total order (dist, j)).
 //
 // The reference materialises the (B,N,N) matrix with bmm and fully sorts every row.  Here one
-// workgroup owns 32 query points: the Gram tile is produced on the matrix cores
-// (v_mfma_f32_32x32x2_f32: exact fp32 fma chains over the feature axis, candidates on the MFMA
-// rows, queries on the lanes), written once to LDS as dist[query][candidate], and each query is
-// then selected by a whole wave with the threshold/compaction/bitonic scheme of wave_select.h.
-// Candidates are walked in chunks of 256 (33 KB of LDS per chunk, two workgroups per CU so one
-// workgroup's MFMA phase overlaps the other's selection phase).  Nothing of size N^2 ever
-// reaches HBM.
+// workgroup owns 32 query points and walks the candidates in chunks of 512:
+//   * Gram tile on the matrix cores (v_mfma_f32_32x32x2_f32 = exact fp32 fma chains over the
+//     feature axis): queries on the MFMA columns (B operand, staged once in LDS), candidates on
+//     the rows.  Each wave owns a 128-candidate strip and feeds it with ONE 16-byte load per lane
+//     per channel pair: lane (h,a,b) reads x[2s+h][strip + 32a + 4b .. +3] and element j of that
+//     float4 is the A operand of accumulator j, i.e. accumulator j holds candidates
+//     strip + 32a + 4b + j (the MFMA does not care which candidate sits on which row) -- four
+//     MFMAs per global load, fully coalesced 512-byte segments.
+//   * the strip is written to LDS as dist[query][candidate]; every query is then selected by a
+//     whole wave: per-lane minima -> exact K-th smallest by ballot bisection (tau) -> survivors
+//     d <= tau compacted into a per-query LDS queue; one (distance, index) bitonic sort per query
+//     at the end (wave_select.h).
+// Nothing of size N^2 ever reaches HBM.
 #include "common.h"
 #include "wave_select.h"
 
@@ -21,6 +27,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define FK_THREADS 256
 #define FK_WAVES 4
 #define FK_QB 32                 // queries per workgroup
+#define FK_QPW (FK_QB / FK_WAVES)
+#define FK_NC 512                // candidates per chunk = FK_WAVES strips of 128
 #define FK_MAX_K 31              // k+1 <= 32 lanes of running list
 
 // |x_i|^2 over the channel axis: x (b,f,n) -> sq (b,n)
@@ -35,15 +43,15 @@ __global__ __launch_bounds__(256) void sqnorm_kernel(int f, int n, const float *
     sq[(size_t)bs * n + i] = s;
 }
 
-template <int FH, int NC>
+template <int FH>
 __global__ __launch_bounds__(FK_THREADS) void feat_knn_kernel(
     int f, int n, int k, const float *__restrict__ x, const float *__restrict__ sq,
     int32_t *__restrict__ idx) {
-    constexpr int NCP = NC + 4;
+    constexpr int NCP = FK_NC + 4;
     __shared__ float dist[FK_QB][NCP];
     __shared__ float bqs[FH][PDGN_WAVE];         // B operand (queries), lane-indexed
-    __shared__ float sqc[NC];
-    __shared__ DI queue[FK_WAVES][WSEL_QCAP];
+    __shared__ float sqc[FK_NC];
+    __shared__ DI queue[FK_QB][WSEL_PQCAP];
 
     const int bs = blockIdx.y;
     const int q0 = blockIdx.x * FK_QB;
@@ -53,9 +61,9 @@ __global__ __launch_bounds__(FK_THREADS) void feat_knn_kernel(
     const float *X = x + (size_t)bs * f * n;
     const float *SQ = sq + (size_t)bs * n;
     const int K = k + 1;
+    const bool vec_ok = (n & 3) == 0;
 
-    // B operand: bqs[s][lane] = channel 2s+half of query q0+col (zero-padded); every wave's
-    // MFMA reads it back with one conflict-free ds_read_b32 per step.
+    // B operand: bqs[s][lane] = channel 2s+half of query q0+col (zero-padded).
     const int qcol = q0 + col;
     for (int s = wave; s < FH; s += FK_WAVES) {
         int c = 2 * s + half;
@@ -63,58 +71,83 @@ __global__ __launch_bounds__(FK_THREADS) void feat_knn_kernel(
     }
     const float sq_q = qcol < n ? SQ[qcol] : 0.f;
 
-    float rd[FK_QB / FK_WAVES];
-    int ri[FK_QB / FK_WAVES];
+    float rd[FK_QPW];
+    int ri[FK_QPW], cnt[FK_QPW];
 #pragma unroll
-    for (int t = 0; t < FK_QB / FK_WAVES; ++t) { rd[t] = INFINITY; ri[t] = 0x7fffffff; }
+    for (int t = 0; t < FK_QPW; ++t) { rd[t] = INFINITY; ri[t] = 0x7fffffff; cnt[t] = 0; }
 
-    for (int t0 = 0; t0 < n; t0 += NC) {
-        const int tn = min(NC, n - t0);
+    for (int t0 = 0; t0 < n; t0 += FK_NC) {
+        const int tn = min(FK_NC, n - t0);
         __syncthreads();                         // previous chunk's selection finished (and bqs ready)
-        for (int c = threadIdx.x; c < tn; c += FK_THREADS) sqc[c] = SQ[t0 + c];
+        for (int c = threadIdx.x; c < FK_NC; c += FK_THREADS) sqc[c] = c < tn ? SQ[t0 + c] : 0.f;
         __syncthreads();
-        // ---- Gram tiles on the matrix cores
-        for (int rt = wave; rt * 32 < tn; rt += FK_WAVES) {
-            const int r = t0 + rt * 32 + col;    // candidate row this lane feeds to the A operand
-            const float *Ar = X + (size_t)half * n + min(r, n - 1);
-            const bool rok = r < n;
-            f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll 16
+        // ---- Gram strip of this wave: candidates t0 + 128*wave + [0,128)
+        const int strip = 128 * wave;
+        if (strip < tn) {
+            const int a4 = ((lane >> 3) & 3) * 32 + (lane & 7) * 4;     // lane's 4 candidates in the strip
+            const int cand = t0 + strip + a4;
+            const bool full = vec_ok && cand + 3 < n;
+            const float *Ap = X + (size_t)half * n + (full ? cand : 0);
+            f32x16 acc[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+#pragma unroll 8
             for (int s = 0; s < FH; ++s) {
-                int c = 2 * s + half;
-                float a = (rok && c < f) ? Ar[(size_t)(2 * s) * n] : 0.f;
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bqs[s][lane], acc, 0, 0, 0);
-            }
-            // D[row = (reg&3) + 8*(reg>>2) + 4*half][col]: candidate rows, query column
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int lc = rt * 32 + 8 * g + 4 * half;      // local candidate index of reg 4g
-                float4 v;
-                float *vp = reinterpret_cast<float *>(&v);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float d = __fmaf_rn(-2.0f, acc[4 * g + e], sq_q) + sqc[min(lc + e, NC - 1)];
-                    vp[e] = (lc + e < tn) ? d : INFINITY;
+                const int c = 2 * s + half;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (c < f) {
+                    if (full) {
+                        v = *reinterpret_cast<const float4 *>(Ap + (size_t)(2 * s) * n);
+                    } else {
+                        const float *row = X + (size_t)c * n;
+                        v.x = cand < n ? row[cand] : 0.f;
+                        v.y = cand + 1 < n ? row[cand + 1] : 0.f;
+                        v.z = cand + 2 < n ? row[cand + 2] : 0.f;
+                        v.w = cand + 3 < n ? row[cand + 3] : 0.f;
+                    }
                 }
+                const float bv = bqs[s][lane];
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(v.x, bv, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(v.y, bv, acc[1], 0, 0, 0);
+                acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(v.z, bv, acc[2], 0, 0, 0);
+                acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(v.w, bv, acc[3], 0, 0, 0);
+            }
+            // D row i = (r&3) + 8*(r>>2) + 4*half  <->  (a = r>>2, b = (r&3) + 4*half): accumulator j,
+            // register r holds candidate strip + 32a + 4b + j of query `col`.
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int lc = strip + 32 * (r >> 2) + 16 * half + 4 * (r & 3);
+                const float4 sc = *reinterpret_cast<const float4 *>(&sqc[lc]);
+                float4 v;
+                v.x = lc + 0 < tn ? __fmaf_rn(-2.0f, acc[0][r], sq_q) + sc.x : INFINITY;
+                v.y = lc + 1 < tn ? __fmaf_rn(-2.0f, acc[1][r], sq_q) + sc.y : INFINITY;
+                v.z = lc + 2 < tn ? __fmaf_rn(-2.0f, acc[2][r], sq_q) + sc.z : INFINITY;
+                v.w = lc + 3 < tn ? __fmaf_rn(-2.0f, acc[3][r], sq_q) + sc.w : INFINITY;
                 *reinterpret_cast<float4 *>(&dist[col][lc]) = v;
             }
         }
         __syncthreads();
-        // ---- selection: wave w owns queries 8w .. 8w+7
+        // ---- selection: wave w owns queries FK_QPW*w .. +FK_QPW-1
 #pragma unroll
-        for (int t = 0; t < FK_QB / FK_WAVES; ++t) {
-            const int ql = wave * (FK_QB / FK_WAVES) + t;
+        for (int t = 0; t < FK_QPW; ++t) {
+            const int ql = wave * FK_QPW + t;
             if (q0 + ql < n) {
                 const float *row = dist[ql];
-                wave_topk_scan([&](int c) { return row[c]; }, tn, t0, queue[wave], K, rd[t], ri[t], lane);
+                wave_topk_append([&](int c) { return row[c]; }, tn, t0, queue[ql], cnt[t], K, rd[t], ri[t], lane);
             }
         }
     }
 #pragma unroll
-    for (int t = 0; t < FK_QB / FK_WAVES; ++t) {
-        const int qq = q0 + wave * (FK_QB / FK_WAVES) + t;
-        if (qq < n && lane >= 1 && lane <= k)
-            idx[((size_t)bs * n + qq) * k + lane - 1] = rd[t] < INFINITY ? ri[t] : 0;   // rank 0 dropped (:458, :501)
+    for (int t = 0; t < FK_QPW; ++t) {
+        const int ql = wave * FK_QPW + t;
+        const int qq = q0 + ql;
+        if (qq < n) {
+            knn_flush(queue[ql], cnt[t], K, rd[t], ri[t], lane);
+            if (lane >= 1 && lane <= k)                       // rank 0 dropped (:458, :501)
+                idx[((size_t)bs * n + qq) * k + lane - 1] = rd[t] < INFINITY ? ri[t] : 0;
+        }
     }
 }
 
@@ -122,7 +155,7 @@ template <int FH>
 static int launch_fk(int b, int f, int n, int k, const float *x, const float *sq, int32_t *idx,
                      hipStream_t s) {
     dim3 grid(cdiv(n, FK_QB), b);
-    hipLaunchKernelGGL((feat_knn_kernel<FH, 256>), grid, dim3(FK_THREADS), 0, s, f, n, k, x, sq, idx);
+    hipLaunchKernelGGL((feat_knn_kernel<FH>), grid, dim3(FK_THREADS), 0, s, f, n, k, x, sq, idx);
     return pdgn_launch_status();
 }
 

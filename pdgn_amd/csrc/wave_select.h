@@ -98,3 +98,48 @@ __device__ __forceinline__ void wave_topk_scan(DistFn dist, int tn, int t0, DI *
     }
     knn_flush(q, cnt, K, rd, ri, lane);
 }
+
+// K-th smallest (1-based) of the 64 lane values, exact, by bisection on the order-preserving
+// integer image of the floats: 32 ballot/popcount steps on scalar registers, no LDS traffic
+// (the bitonic wave_sort_f costs 21 dependent ds_bpermute round trips).
+__device__ __forceinline__ float wave_kth_smallest(float v, int K) {
+    const unsigned bits = __float_as_uint(v);
+    const unsigned key = bits ^ ((bits >> 31) ? 0xffffffffu : 0x80000000u);
+    unsigned prefix = 0;
+#pragma unroll
+    for (int bit = 31; bit >= 0; --bit) {
+        const unsigned cand = prefix | (1u << bit);
+        const int below = __popcll(__ballot(key < cand));
+        prefix = below < K ? cand : prefix;
+    }
+    const unsigned b = (prefix & 0x80000000u) ? (prefix ^ 0x80000000u) : ~prefix;
+    return __uint_as_float(b);
+}
+
+// Variant of wave_topk_scan with a per-query survivor queue that persists across candidate
+// chunks: survivors are only appended here (threshold from this chunk's lane minima and the
+// running list); the (distance, index) sort runs when the queue is half full or at the end.
+#define WSEL_PQCAP 128
+template <class DistFn>
+__device__ __forceinline__ void wave_topk_append(DistFn dist, int tn, int t0, DI *q, int &cnt, int K,
+                                                 float &rd, int &ri, int lane) {
+    float lmin = INFINITY;
+    for (int c = lane; c < tn; c += 64) lmin = fminf(lmin, dist(c));
+    float tau = fminf(wave_kth_smallest(lmin, K), __shfl(rd, K - 1, 64));
+    for (int c0 = 0; c0 < tn; c0 += 64) {
+        if (cnt > WSEL_PQCAP - 64) {
+            knn_flush(q, cnt, K, rd, ri, lane);
+            cnt = 0;
+            tau = fminf(tau, __shfl(rd, K - 1, 64));
+        }
+        int c = c0 + lane;
+        float d = c < tn ? dist(c) : INFINITY;
+        bool keep = d <= tau && d < INFINITY;
+        unsigned long long mask = __ballot(keep);
+        if (mask) {
+            int pos = cnt + __popcll(mask & ((1ull << lane) - 1ull));
+            if (keep) { q[pos].d = d; q[pos].i = t0 + c; }
+            cnt += __popcll(mask);
+        }
+    }
+}

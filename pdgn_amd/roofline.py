@@ -62,7 +62,7 @@ def feature_knn_stage4(B, base_points, device):
         check(L.pdgn_feature_knn(B, F, N, k, ptr(x), ptr(sq), ptr(idx), stream_of(x)), "pdgn_feature_knn")
     us = _time_us(run)
     flops = 2.0 * B * N * N * F
-    return {"kernel": "feat_knn_kernel<128,1024> (stage-4 kNN graph)", "bound": "mfma",
+    return {"kernel": "feat_knn_kernel<128> (stage-4 kNN graph)", "bound": "mfma",
             "achieved": flops / us / 1e6, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": flops / us / 1e6 / MFMA_F32_PEAK_TFLOPS, "traffic": None, "us_per_launch": us,
             "algorithmic_flops_per_launch": flops}
