@@ -34,7 +34,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=35, help="per-GPU batch (BASELINE.json: 35)")
     ap.add_argument("--base-points", type=int, default=128, help="128: 256->2048 (reference); 256: 512->4096")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-batch", type=int, default=4)
+    ap.add_argument("--cpu-sample-batch", type=int, default=35)
     ap.add_argument("--phases", action="store_true", help="also print a per-phase timing breakdown to stderr")
     return ap.parse_args()
 
@@ -68,7 +68,9 @@ def cpu_baseline(sample_batch):
     from oracle import cref, pdgnet_ref
     from pdgn_amd.trainer import synthetic_batch
     cref.build()
-    cores = os.cpu_count() or 1
+    # 16 threads is the fastest setting measured on the 2x EPYC 9575F GPU-box host (16 thr: 17.7 s,
+    # 32: 20.9 s, 64: 26.3 s, 256: minutes per B=35 iteration -- torch's intra-op pool oversubscribes).
+    cores = min(16, os.cpu_count() or 1)
     torch.set_num_threads(cores)
     torch.manual_seed(9999)
     tr = pdgnet_ref.TrainerRef()
@@ -81,8 +83,8 @@ def cpu_baseline(sample_batch):
     dt = time.perf_counter() - t0
     return {"value": sample_batch * 2048 / dt, "unit": "points/s", "cores": torch.get_num_threads(),
             "kind": "port",
-            "sample": "1 G+D iteration (oracle/pdgnet_ref.TrainerRef, torch-CPU + C pointops) at B=%d, "
-                      "256->2048 pts, %.1f s" % (sample_batch, dt)}
+            "sample": "1 full G+D iteration (oracle/pdgnet_ref.TrainerRef: torch-CPU fp32 + C pointops) at "
+                      "B=%d, 256->2048 pts, after a B=2 warm-up; %.1f s on %d threads" % (sample_batch, dt, cores)}
 
 
 def dominant_kernel_roofline(args, device):

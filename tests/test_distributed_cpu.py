@@ -1,0 +1,128 @@
+"""CPU, world_size 2, gloo: the N>1 path of the G+D step (flat-buffer gradient all-reduce, the
+sum-vs-mean loss scaling of SURVEY.md section 8-e) with torch / C-oracle stand-ins for the HIP ops."""
+import os
+import socket
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _build_trainer(distributed):
+    for p in (ROOT, HERE):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from oracle import pdgnet_ref
+    from pdgn_amd import deconv
+    from pdgn_amd.trainer import PDGNTrainer
+    from torch_standins import EdgeGatherSumTorch, bn_act_torch, feature_knn_torch
+    deconv.EdgeGatherSum, deconv.bn_act, deconv.feature_knn = EdgeGatherSumTorch, bn_act_torch, feature_knn_torch
+    torch.manual_seed(7)                                   # identical initial weights on every rank
+    tr = PDGNTrainer(device="cpu", base_points=16, distributed=distributed)
+
+    class OracleGroup(torch.nn.Module):
+        def forward(self, xyz, new_xyz):
+            return pdgnet_ref.query_and_group_xyz(xyz, new_xyz)
+    tr.local_pair.group = OracleGroup()
+    tr.train()
+    return tr
+
+
+def _batch(rank, B=8):
+    g = torch.Generator().manual_seed(100 + rank)
+    reals = [torch.randn(B, 3, n, generator=g) for n in (32, 64, 128, 256)]
+    return reals, torch.randn(B, 128, generator=g) * 0.2, torch.randn(B, 128, generator=g) * 0.2
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    tr = _build_trainer(distributed=True)
+    reals, z1, z2 = _batch(rank)
+    out = tr.step(reals, z1, z2)
+    flat = torch.cat([p.detach().reshape(-1) for p in tr.G.parameters()] +
+                     [p.detach().reshape(-1) for d in tr.D for p in d.parameters()])
+    gathered = [torch.empty_like(flat) for _ in range(world)]
+    dist.all_gather(gathered, flat)
+    ok_sync = all(torch.equal(gathered[0], g) for g in gathered)
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), sync=ok_sync, params=flat.numpy(),
+             gradG=tr.gradG.buf.numpy(), g_loss=out["g_loss"].item(), finite=bool(torch.isfinite(flat).all()))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_rank_step_gloo():
+    world = 2
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker, args=(world, _free_port(), d), nprocs=world, join=True)
+        r = [dict(np.load(os.path.join(d, "rank%d.npz" % i))) for i in range(world)]
+    assert all(bool(x["sync"]) and bool(x["finite"]) for x in r)
+    np.testing.assert_array_equal(r[0]["params"], r[1]["params"])          # replicas stay identical
+    np.testing.assert_array_equal(r[0]["gradG"], r[1]["gradG"])            # the reduced gradient
+    # expected reduced G gradient from two single-process runs: mean over ranks of
+    # grad(adv_r + 0.1 * world * similar_r)  (MSE is a batch mean, the shape loss a batch sum)
+    import torch.nn.functional as F
+    torch.set_num_threads(2)                               # same reduction order as the workers
+    grads = []
+    for rank in range(world):
+        tr = _build_trainer(distributed=False)
+        reals, z1, z2 = _batch(rank)
+        B = z1.shape[0]
+        ones, zeros = torch.ones(B, 1), torch.zeros(B, 1)
+        with torch.no_grad():
+            fakes = tr.G(z1)
+        # D updates are needed first (the G loss sees the updated discriminators), with the
+        # rank-mean of the D gradients: emulate by averaging the two ranks' D grads
+        grads.append((tr, reals, fakes, z2, ones, zeros))
+    # D step with averaged gradients
+    for i in range(4):
+        for tr, reals, fakes, z2, ones, zeros in grads:
+            tr.gradD[i].zero_()
+            ((F.mse_loss(tr.D[i](reals[i]), ones) + F.mse_loss(tr.D[i](fakes[i]), zeros)) / 2.0).backward()
+        mean = (grads[0][0].gradD[i].buf + grads[1][0].gradD[i].buf) / world
+        for tr, *_ in grads:
+            tr.gradD[i].buf.copy_(mean)
+            tr.optD[i].step()
+    gG = []
+    for tr, reals, fakes, z2, ones, zeros in grads:
+        tr.gradG.zero_()
+        tr._freeze_D(True)
+        gen = tr.G(z2)
+        sim = tr.similar_loss(gen)
+        gl = [F.mse_loss(tr.D[i](gen[i]), ones) for i in range(4)]
+        (1.2 * gl[0] + 1.2 * gl[1] + 1.2 * gl[2] + gl[3] + 0.1 * world * sim).backward()
+        gG.append(tr.gradG.buf.clone())
+    expect = (gG[0] + gG[1]) / world
+    np.testing.assert_allclose(r[0]["gradG"], expect.numpy(), rtol=2e-3, atol=1e-5 * float(expect.abs().max()))
+
+
+def test_flat_grads_views_and_zero():
+    sys.path.insert(0, ROOT)
+    from pdgn_amd.trainer import FlatGrads
+    m = torch.nn.Sequential(torch.nn.Linear(4, 3), torch.nn.Linear(3, 2))
+    fg = FlatGrads(m.parameters())
+    m(torch.randn(5, 4)).sum().backward()
+    assert fg.buf.abs().sum() > 0
+    off = 0
+    for p in m.parameters():
+        assert p.grad.data_ptr() == fg.buf[off:].data_ptr()               # .grad is a view of the buffer
+        off += p.numel()
+    fg.zero_()
+    assert all((p.grad == 0).all() for p in m.parameters())
+    fg.all_reduce_mean()                                                   # no process group: no-op
