@@ -35,7 +35,7 @@ def parse():
     ap.add_argument("--base-points", type=int, default=128, help="128: 256->2048 (reference); 256: 512->4096")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-batch", type=int, default=35)
-    ap.add_argument("--phases", action="store_true", help="also print a per-phase timing breakdown to stderr")
+    ap.add_argument("--no-graph", action="store_true", help="run the step eagerly instead of replaying hipGraphs")
     return ap.parse_args()
 
 
@@ -108,12 +108,20 @@ def main():
     gen = torch.Generator().manual_seed(1234 + rank)
     zs = [(noise(B, device, gen), noise(B, device, gen)) for _ in range(args.warmup + args.steps)]
 
+    step, graphed = trainer.step, False
+    if not args.no_graph:
+        try:                                   # six hipGraphs per iteration (trainer.capture)
+            trainer.capture(reals, *zs[0])
+            step, graphed = trainer.step_graphed, True
+        except Exception as e:                 # a capture problem must not lose the measurement
+            print("hipGraph capture failed (%r): running eagerly" % (e,), file=sys.stderr)
+            torch.cuda.synchronize()
     for i in range(args.warmup):
-        trainer.step(reals, *zs[i])
+        step(reals, *zs[i])
     barrier(world)
     t0 = time.perf_counter()
     for i in range(args.steps):
-        out = trainer.step(reals, *zs[args.warmup + i])
+        out = step(reals, *zs[args.warmup + i])
     barrier(world)
     dt = time.perf_counter() - t0
     if world > 1:
@@ -135,7 +143,7 @@ def main():
                                    "synthetic batch, per-GPU batch %d, %d->%d pts, random-init weights"
                                    % (B, res[0], res[3]),
                        "global_batch": world * B, "points_all_resolutions_per_s": world * B * sum(res) / (dt / args.steps),
-                       "parallelism": "dp%d" % world, "losses_finite": finite},
+                       "parallelism": "dp%d" % world, "losses_finite": finite, "hipgraph": graphed},
         }
         try:
             line["roofline"] = dominant_kernel_roofline(args, device)

@@ -129,17 +129,25 @@ class PointDeconv(nn.Module):
         return Wcat, Wb, T, P
 
     def forward(self, x, pc=None, idx=None):
-        B, Fi, N = x.shape
+        """Reference layout: x (B,Fin,N) [, pc (B,3,N)] -> (B,Fout,2N)."""
+        out = self.forward_cl(x.transpose(1, 2).contiguous(),
+                              pc.transpose(1, 2).contiguous() if pc is not None else None, idx=idx, x_cf=x)
+        return out.transpose(1, 2)
+
+    def forward_cl(self, xt, pct=None, idx=None, x_cf=None):
+        """Point-major layout: xt (B,N,Fin) [, pct (B,N,3)] -> (B,2N,Fout) (pre bn_uc, like the
+        reference block's return value).  x_cf, if given, is the same tensor as (B,Fin,N)."""
+        B, N, Fi = xt.shape
         Fo, k = self.Fout, self.k
         training = self.training
         if idx is None:
             with torch.no_grad():
-                idx = feature_knn(x.detach().contiguous(), k)
+                xc = x_cf if x_cf is not None else xt.transpose(1, 2)
+                idx = feature_knn(xc.detach().contiguous(), k)
         elif idx.dtype != I32:
             idx = idx.to(I32)
         idx = idx.contiguous()
         Wcat, Wb, T, P = self._assemble()
-        xt = x.transpose(1, 2).contiguous()                            # (B,N,F)
         Y = torch.matmul(xt, Wcat.t())                                 # (B,N,Mw) -- per-point GEMM
         o_i, o_ci = 0, T * 4 * Fi
         o_a = o_ci + 4 * Fi
@@ -155,7 +163,6 @@ class PointDeconv(nn.Module):
         w = None
         if self.bilateral:
             Wx = self.conv_xyz[0].weight[:, :, 0, 0]                   # (16, 6)
-            pct = pc.transpose(1, 2).contiguous()                      # (B,N,3)
             Yx = torch.matmul(pct, torch.cat([Wx[:, 3:], Wx[:, :3] - Wx[:, 3:]], 0).t()).contiguous()
             (xyz_pre,) = EdgeGatherSum.apply(Yx, idx, ((1, k, 16, 0, 16),), self.conv_xyz[0].bias)
             xyzf = bn_act(xyz_pre.view(-1, 16), self.conv_xyz[1], training)
@@ -172,8 +179,10 @@ class PointDeconv(nn.Module):
         # inte = LeakyReLU(BN(inte_pre)) [* w]  -- one fused pass (:637, :642)
         inte = bn_act(inte_pre.view(-1, 4 * Fi), self.inte_conv_hk[1], training, mul=w)
         out_pre = a_pre.view(B * N, 2 * Fo) + F.linear(inte.view(B * N, P * 4 * Fi), Wb)
-        out = bn_act(out_pre, self.conv2.bn, training, act="relu")     # (B*N, 2Fo)
-        return out.view(B, N, Fo, 2).permute(0, 2, 3, 1).reshape(B, Fo, 2 * N)
+        out = bn_act(out_pre, self.conv2.bn, training, act="relu")     # (B*N, 2Fo): channel 2c+j
+        # (B,2Fout,N,1) -> view(B,Fout,2,N) -> (B,Fout,2N) (:645-647): point j*N+n of channel c is conv
+        # channel 2c+j at point n; in point-major form that is (B, 2, N, Fout) -> (B, 2N, Fout)
+        return out.view(B, N, Fo, 2).permute(0, 3, 1, 2).reshape(B, 2 * N, Fo)
 
 
 def upsample_edgeConv(Fin, Fout, k, num=None):

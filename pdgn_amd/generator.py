@@ -3,15 +3,45 @@ PointDeconv.  Module / parameter names reproduce the reference's ``state_dict`` 
 (tests/golden/state_dict_manifest.json), so reference checkpoints load unchanged (strip the
 DataParallel ``module.`` prefix, see ``load_reference_state_dict``).
 
-The deconvolution blocks run on the hand-written HIP path (pdgn_amd.deconv); the small dense
-layers around them (Linear / 1x1 Conv1d / BatchNorm1d of the global branch, the MLP heads and
-the PointNet-style discriminators) are plain library GEMMs through PyTorch-ROCm.
+Everything between the noise vector and the emitted clouds runs POINT-MAJOR (B, N, C): a 1x1
+Conv1d is a row-matrix product, a BatchNorm1d over (B,C,N) is the fused channels-last
+BatchNorm+LeakyReLU kernel over B*N rows (pdgn_amd.fused.bn_act), the `cat` of a broadcast
+global vector with per-point features is folded into the following layer's weights
+(W [g; x] = W_g g + W_x x), and no MIOpen convolution / NCHW BatchNorm kernel is involved.
+The public interfaces keep the reference's (B,C,N) layout.
 """
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import deconv as _deconv
 from .deconv import PointDeconv
+
+
+def _bn_act(x2d, bn, training, act="leaky_relu"):
+    return _deconv.bn_act(x2d, bn, training, act=act)      # looked up late: tests patch deconv.bn_act
+
+
+def _conv1x1_rows(rows, conv):
+    """Conv1d(kernel 1) applied to a (rows, C_in) matrix."""
+    return F.linear(rows, conv.weight[:, :, 0], conv.bias)
+
+
+def _head_rows(head, x_rows, B, g=None, n_const=0):
+    """mlp1..mlp4 (:835-862) on point-major rows.  The head's input is cat([g broadcast, x]) along
+    channels (:708-709, :745-746); the first `n_const` input channels (the per-batch vector g)
+    are applied once per batch and broadcast, never concatenated."""
+    c0 = head[0]
+    W = c0.weight[:, :, 0]
+    h = F.linear(x_rows, W[:, n_const:])                                   # (B*M, 256)
+    if g is not None:
+        M = x_rows.shape[0] // B
+        h = (h.view(B, M, -1) + F.linear(g, W[:, :n_const], c0.bias).unsqueeze(1)).view(B * M, -1)
+    else:
+        h = h + c0.bias
+    h = F.leaky_relu(h)
+    h = F.leaky_relu(_conv1x1_rows(h, head[2]))
+    return _conv1x1_rows(h, head[4])                                       # (B*M, 3)
 
 
 class BilateralBlock(nn.Module):
@@ -33,22 +63,33 @@ class BilateralBlock(nn.Module):
         if level < 4:
             self.g_fc = nn.Sequential(nn.Linear(Fout, 512), nn.BatchNorm1d(512), nn.LeakyReLU(inplace=True))
 
-    def forward(self, x, pc=None, idx=None):
-        N2 = 2 * x.shape[2]
-        xs = self.fc(torch.amax(x, dim=2))                      # MaxPool2d((1,N)) over the points
+    def forward_cl(self, xt, pct=None, idx=None):
+        """xt (B,N,Fin) [, pct (B,N,3)] -> xs (B,Fout), x_ec (B,2N,Fout), g (B,512)|None."""
+        B, N, _ = xt.shape
+        xs = self.fc(xt.max(dim=1)[0])                          # MaxPool2d((1,N)) over the points
         if self.level == 1:
-            x_ec = self.upsample_cov[2](self.upsample_cov[1](self.upsample_cov[0](x, idx=idx)))
+            dec, bn = self.upsample_cov[0], self.upsample_cov[1]
         else:
-            x_ec = F.leaky_relu(self.bn_uc(self.upsample_cov(x, pc, idx=idx)))
+            dec, bn = self.upsample_cov, self.bn_uc
+        x_ec = dec.forward_cl(xt, pct, idx=idx)                 # (B,2N,Fout)
+        x_ec = _bn_act(x_ec.reshape(B * 2 * N, -1), bn, self.training).view(B, 2 * N, -1)
+        g = self.g_fc(xs) if self.level < 4 else None
+        return xs, x_ec, g
+
+    def forward(self, x, pc=None, idx=None):
+        """Reference interface: x (B,Fin,N) -> x_out (B,2Fout,2N) [, g_out (B,512+Fout,2N)]."""
+        xs, x_ec, g = self.forward_cl(x.transpose(1, 2).contiguous(),
+                                      pc.transpose(1, 2).contiguous() if pc is not None else None, idx=idx)
+        N2 = x_ec.shape[1]
+        x_ec = x_ec.transpose(1, 2)
         x_out = torch.cat((xs.unsqueeze(2).expand(-1, -1, N2), x_ec), 1)
-        if self.level == 4:
+        if g is None:
             return x_out
-        g = self.g_fc(xs)
         return x_out, torch.cat((g.unsqueeze(2).expand(-1, -1, N2), x_ec), 1)
 
 
 def _mlp_head(cin):
-    """mlp1..mlp4 :835-862."""
+    """mlp1..mlp4 :835-862 (parameter container; applied through _head_rows)."""
     return nn.Sequential(nn.Conv1d(cin, 256, 1), nn.LeakyReLU(inplace=True), nn.Conv1d(256, 64, 1),
                          nn.LeakyReLU(inplace=True), nn.Conv1d(64, 3, 1, bias=True))
 
@@ -72,15 +113,24 @@ class PointGenerator(nn.Module):
         self.mlp3, self.mlp4 = _mlp_head(512 + 128), _mlp_head(512)
 
     def forward(self, z, idx=(None, None, None, None)):
-        x = self.fc1(z).view(z.shape[0], 32, self.base_points)
-        x1, g1 = self.bilateral1(x, idx=idx[0])
-        x1s = self.mlp1(g1)
-        x2, g2 = self.bilateral2(x1, x1s, idx=idx[1])
-        x2s = self.mlp2(g2)
-        x3, g3 = self.bilateral3(x2, x2s, idx=idx[2])
-        x3s = self.mlp3(g3)
-        x4s = self.mlp4(self.bilateral4(x3, x3s, idx=idx[3]))
-        return x1s, x2s, x3s, x4s
+        B = z.shape[0]
+        xt = self.fc1(z).view(B, 32, self.base_points).transpose(1, 2).contiguous()    # (B,N0,32)
+        pct, clouds = None, []
+        blocks = (self.bilateral1, self.bilateral2, self.bilateral3, self.bilateral4)
+        heads = (self.mlp1, self.mlp2, self.mlp3, self.mlp4)
+        for lvl in range(4):
+            xs, x_ec, g = blocks[lvl].forward_cl(xt, pct, idx=idx[lvl])
+            M, Fo = x_ec.shape[1], x_ec.shape[2]
+            rows = x_ec.reshape(B * M, Fo)
+            if lvl < 3:
+                p = _head_rows(heads[lvl], rows, B, g=g, n_const=512)           # head sees cat(g, x_ec)
+            else:
+                p = _head_rows(heads[lvl], rows, B, g=xs, n_const=Fo)           # mlp4 sees cat(xs, x_ec) :875
+            pct = p.view(B, M, 3)
+            clouds.append(pct.transpose(1, 2))                                  # (B,3,M) like the reference
+            if lvl < 3:
+                xt = torch.cat((xs.unsqueeze(1).expand(-1, M, -1), x_ec), 2)    # next block's input :708
+        return tuple(clouds)
 
 
 class PointDiscriminator(nn.Module):
@@ -106,7 +156,11 @@ class PointDiscriminator(nn.Module):
         self.mlp = nn.Sequential(*mlp)
 
     def forward(self, x):
-        return self.mlp(torch.amax(self.fc1(x), dim=2))       # MaxPool1d(num_point) over all points
+        B, _, N = x.shape
+        h = x.transpose(1, 2).reshape(B * N, 3)
+        for i in range(0, len(self.fc1), 3):                    # Conv1d(k=1) + BatchNorm1d + LeakyReLU
+            h = _bn_act(_conv1x1_rows(h, self.fc1[i]), self.fc1[i + 1], self.training)
+        return self.mlp(h.view(B, N, -1).max(dim=1)[0])         # MaxPool1d(num_point) over all points
 
 
 def PointDiscriminator_1(num_point=256):

@@ -60,7 +60,8 @@ class PDGNTrainer:
         self.distributed = world_size() > 1 if distributed is None else distributed
         self.gradG = FlatGrads(self.G.parameters())
         self.gradD = [FlatGrads(d.parameters()) for d in self.D]
-        adam = lambda m: torch.optim.Adam(m.parameters(), lr=lr, betas=(0.5, 0.999))
+        cap = self.device.type == "cuda"                     # device-side step counter: graph-capturable
+        adam = lambda m: torch.optim.Adam(m.parameters(), lr=lr, betas=(0.5, 0.999), capturable=cap)
         self.optG, self.optD = adam(self.G), [adam(d) for d in self.D]
 
     def train(self):
@@ -82,47 +83,106 @@ class PDGNTrainer:
             covs.append(cov)
         return sum(mus[1:], mus[0]) + sum(covs[1:], covs[0])
 
+    # The iteration is written as six SEGMENTS separated by the five gradient all-reduces, so that
+    # each segment can be captured into a hipGraph (no RCCL call inside a capture) and replayed:
+    #   0: G(z1) under no_grad (:179) + D1 forward/backward        -> all-reduce grad D1
+    #   1..3: Adam D_i (:191) + D_{i+1} forward/backward           -> all-reduce grad D_{i+1}
+    #   4: Adam D4 + G(z2), local-pair losses, D(gen), backward    -> all-reduce grad G
+    #   5: Adam G (:256)
+    def _seg_d(self, st, i):
+        D = self.D[i]
+        self.gradD[i].zero_()
+        lossD = (F.mse_loss(D(st["reals"][i]), st["ones"]) + F.mse_loss(D(st["fakes"][i]), st["zeros"])) / 2.0
+        lossD.backward()
+        st["out"]["d_loss%d" % (i + 1)] = lossD.detach()
+
+    def _segment(self, st, k):
+        if k == 0:
+            # generator pass #1 (:179): only its detached outputs are ever used => no graph needed;
+            # BatchNorm running statistics update exactly as in the reference.
+            with torch.no_grad():
+                st["fakes"] = self.G(st["z1"])
+            self._seg_d(st, 0)
+        elif k in (1, 2, 3):
+            self.optD[k - 1].step()
+            self._seg_d(st, k)
+        elif k == 4:
+            self.optD[3].step()
+            self.gradG.zero_()
+            # The reference lets lossG.backward() also fill the discriminators' .grad and throws
+            # that away at the next zero_grad (:183); freezing D skips those weight-gradient GEMMs.
+            self._freeze_D(True)
+            gen = self.G(st["z2"])
+            similar = self.similar_loss(gen)
+            g_loss = [F.mse_loss(self.D[i](gen[i]), st["ones"]) for i in range(4)]
+            adv = 1.2 * g_loss[0] + 1.2 * g_loss[1] + 1.2 * g_loss[2] + g_loss[3]
+            lossG = adv + 0.1 * similar
+            # MSE is a batch MEAN, the shape loss a batch SUM (chamfer_loss.py:16-20): to reproduce
+            # one reference step at the global batch, scale the sum term by world_size before the
+            # mean all-reduce.
+            ws = st["ws"]
+            (adv + (0.1 * ws) * similar if ws > 1 else lossG).backward()
+            self._freeze_D(False)
+            st["out"]["g_loss"], st["out"]["similar_loss"] = lossG.detach(), similar.detach()
+        else:
+            self.optG.step()
+
+    def _comm(self, k):
+        """Collective that follows segment k (RCCL all-reduce of one flat gradient buffer)."""
+        if self.distributed and k < 5:
+            (self.gradD[k] if k < 4 else self.gradG).all_reduce_mean()
+
+    def _state(self, reals, z1, z2):
+        B = z1.shape[0]
+        return {"reals": reals, "z1": z1, "z2": z2, "out": {}, "ws": world_size() if self.distributed else 1,
+                "ones": torch.ones(B, 1, device=self.device), "zeros": torch.zeros(B, 1, device=self.device)}
+
     def step(self, reals, z1, z2):
         """reals: four tensors (B,3,N_k); z1 / z2: noise (B,128) of the two generator passes
-        (:178, :228).  Returns dict of 0-dim tensors."""
-        B = z1.shape[0]
-        ones = torch.ones(B, 1, device=self.device)
-        zeros = torch.zeros(B, 1, device=self.device)
-        ws = world_size() if self.distributed else 1
-        out = {}
-        # generator pass #1 (:179): only its detached outputs are ever used => no graph needed;
-        # BatchNorm running statistics update exactly as in the reference.
-        with torch.no_grad():
-            fakes = self.G(z1)
-        # ---- D1..D4 (:182-224)
-        for i, D in enumerate(self.D):
-            self.gradD[i].zero_()
-            lossD = (F.mse_loss(D(reals[i]), ones) + F.mse_loss(D(fakes[i]), zeros)) / 2.0
-            lossD.backward()
-            if self.distributed:
-                self.gradD[i].all_reduce_mean()
-            self.optD[i].step()
-            out["d_loss%d" % (i + 1)] = lossD.detach()
-        # ---- G (:226-256)
-        self.gradG.zero_()
-        # The reference lets lossG.backward() also fill the discriminators' .grad and throws that
-        # away at the next zero_grad (:183); freezing D here skips those weight-gradient GEMMs.
-        self._freeze_D(True)
-        gen = self.G(z2)
-        similar = self.similar_loss(gen)
-        g_loss = [F.mse_loss(self.D[i](gen[i]), ones) for i in range(4)]
-        adv = 1.2 * g_loss[0] + 1.2 * g_loss[1] + 1.2 * g_loss[2] + g_loss[3]
-        lossG = adv + 0.1 * similar
-        # MSE is a batch MEAN, the shape loss a batch SUM (chamfer_loss.py:16-20): to reproduce one
-        # reference step at the global batch, scale the sum term by world_size before the mean
-        # all-reduce (SURVEY.md section 8-e).
-        (adv + (0.1 * ws) * similar if ws > 1 else lossG).backward()
-        self._freeze_D(False)
-        if self.distributed:
-            self.gradG.all_reduce_mean()
-        self.optG.step()
-        out["g_loss"], out["similar_loss"] = lossG.detach(), similar.detach()
-        return out
+        (:178, :228).  Returns dict of 0-dim device tensors (no host sync inside the step)."""
+        st = self._state(reals, z1, z2)
+        for k in range(6):
+            self._segment(st, k)
+            self._comm(k)
+        return st["out"]
+
+    # ---------------------------------------------------------------- hipGraph replay
+    def capture(self, reals, z1, z2, warmup=3):
+        """Capture the six segments into hipGraphs (static input buffers, one shared memory pool).
+        ~2500 kernel launches per iteration become six graph launches; the all-reduces stay
+        ordinary stream operations between them."""
+        self._static = self._state([r.clone() for r in reals], z1.clone(), z2.clone())
+        side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                for k in range(6):
+                    self._segment(self._static, k)
+                    self._comm(k)
+        torch.cuda.current_stream(self.device).wait_stream(side)
+        torch.cuda.synchronize(self.device)
+        self._graphs, pool = [], None
+        for k in range(6):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=pool):
+                self._segment(self._static, k)
+            pool = g.pool()
+            self._graphs.append(g)
+            self._comm(k)
+        return self
+
+    def step_graphed(self, reals, z1, z2):
+        """Replay of `capture`: copies the inputs into the static buffers, replays the graphs."""
+        st = self._static
+        for dst, src in zip(st["reals"], reals):
+            if dst.data_ptr() != src.data_ptr():
+                dst.copy_(src)
+        st["z1"].copy_(z1)
+        st["z2"].copy_(z2)
+        for k, g in enumerate(self._graphs):
+            g.replay()
+            self._comm(k)
+        return st["out"]
 
 
 def synthetic_batch(B, device, seed=9999, n_points=2048, resolutions=(256, 512, 1024, 2048)):

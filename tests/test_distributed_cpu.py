@@ -67,7 +67,7 @@ def _worker(rank, world, port, out_dir):
 
 
 @pytest.mark.timeout(600)
-def test_two_rank_step_gloo():
+def test_two_rank_step_gloo(request):
     world = 2
     with tempfile.TemporaryDirectory() as d:
         mp.spawn(_worker, args=(world, _free_port(), d), nprocs=world, join=True)
@@ -78,6 +78,7 @@ def test_two_rank_step_gloo():
     # expected reduced G gradient from two single-process runs: mean over ranks of
     # grad(adv_r + 0.1 * world * similar_r)  (MSE is a batch mean, the shape loss a batch sum)
     import torch.nn.functional as F
+    request.addfinalizer(lambda n=torch.get_num_threads(): torch.set_num_threads(n))
     torch.set_num_threads(2)                               # same reduction order as the workers
     grads = []
     for rank in range(world):

@@ -148,7 +148,7 @@ def test_deconv_block(golden, name):
     if bilateral:
         np.testing.assert_allclose(pc.grad.numpy(), g["grad_pc"], rtol=1e-4, atol=1e-6)
     for n, p in mod.named_parameters():
-        np.testing.assert_allclose(p.grad.numpy(), g["grad." + n], rtol=1e-4, atol=2e-6, err_msg=n)
+        np.testing.assert_allclose(p.grad.numpy(), g["grad." + n], rtol=1e-4, atol=1e-5, err_msg=n)
     for n, b in mod.named_buffers():
         if "num_batches" not in n:
             np.testing.assert_allclose(b.numpy(), g["stat." + n], rtol=1e-5, atol=1e-6, err_msg=n)
