@@ -130,12 +130,14 @@ int pdgn_window_gather_sum_backward(int b, int n, int k, int ldy, int T, int P, 
  * nn.BatchNorm2d + LeakyReLU/ReLU pairs of models/PDGNet_v2.py:537-545, 561-565, 603-625 in the
  * point-major layout.  act: 0 none, 1 ReLU, 2 LeakyReLU(0.01).  c % 4 == 0.
  *
- * pdgn_bn_stats: batch statistics (training mode).  sums: 2c doubles of scratch; stats out:
+ * pdgn_bn_scratch_floats(rows, c): number of floats of `scratch` the two reductions below need.
+ * pdgn_bn_stats: batch statistics (training mode), two-stage reduction through `scratch`; stats out:
  * [scale | shift | mean | invstd] (4c floats), scale = gamma*invstd, shift = beta - mean*scale;
  * running_mean/var (may be NULL) are updated with `momentum` and the unbiased variance.
  * pdgn_bn_eval_stats: the same `stats` from the running statistics (eval mode). */
+long long pdgn_bn_scratch_floats(long long rows, int c);
 int pdgn_bn_stats(long long rows, int c, float eps, float momentum, const float *x, const float *gamma,
-                  const float *beta, float *running_mean, float *running_var, double *sums,
+                  const float *beta, float *running_mean, float *running_var, float *scratch,
                   float *stats, pdgn_stream_t stream);
 int pdgn_bn_eval_stats(int c, float eps, const float *gamma, const float *beta,
                        const float *running_mean, const float *running_var, float *stats,
@@ -143,12 +145,12 @@ int pdgn_bn_eval_stats(int c, float eps, const float *gamma, const float *beta,
 /* y = act(x*scale + shift) [* mul]   (mul may be NULL; same shape as x) */
 int pdgn_bn_act_forward(long long rows, int c, int act, const float *x, const float *stats,
                         const float *mul, float *y, pdgn_stream_t stream);
-/* dz = dy [* mul] * act'(z);  bsums[0:c] = sum dz (= dbeta), bsums[c:2c] = sum dz*xhat (= dgamma);
+/* dz = dy [* mul] * act'(z);  bsums (2c floats out): [0:c] = sum dz (= dbeta), [c:2c] = sum dz*xhat (= dgamma);
  * dx = scale*(dz - mean(dz) - xhat*mean(dz*xhat)) if training else scale*dz;
  * dmul (may be NULL) = dy * act(z). */
 int pdgn_bn_act_backward(long long rows, int c, int act, int training, const float *x,
-                         const float *dy, const float *mul, const float *stats, double *bsums,
-                         float *dx, float *dmul, pdgn_stream_t stream);
+                         const float *dy, const float *mul, const float *stats, float *scratch,
+                         float *bsums, float *dx, float *dmul, pdgn_stream_t stream);
 
 #ifdef __cplusplus
 }

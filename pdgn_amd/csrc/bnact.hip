@@ -9,7 +9,8 @@
 //   backward: dz = dy * act'(z);  s1 = sum dz;  s2 = sum dz * xhat
 //             dx = scale * (dz - s1/R - xhat * s2/R)      (training)   |   dx = scale * dz  (eval)
 // All four are HBM-bound: float4 per lane, a wave covers 1 KiB of one row (or several short rows).
-// Per-thread partial sums are fp32 over <= a few thousand rows and are combined in fp64 atomics.
+// Per-block partial sums are fp32 over <= 64K rows; they are combined in fp64 by tiny finalize
+// kernels (two-stage reduction: no atomics, bitwise reproducible).
 #include "common.h"
 
 #define BN_THREADS 256
@@ -34,10 +35,11 @@ struct ClGeom {
     int cg, cgb, rl;     // column groups total, per block (<= 256, divides 256 or equals cg), row lanes
 };
 
-// sums[c] += sum_r x[r,c];  sums[C + c] += sum_r x[r,c]^2      (fp64 accumulators, pre-zeroed)
+// part[blockIdx.y][c] = sum_r x[r,c];  part[blockIdx.y][C + c] = sum_r x[r,c]^2 over the block's rows
+// (fp32 partials over <= 64K rows; the finalize kernels combine them in fp64 -- no atomics).
 __global__ __launch_bounds__(BN_THREADS) void cl_stats_kernel(long long R, int C, int cgb, int rows_per_block,
                                                               const float *__restrict__ x,
-                                                              double *__restrict__ sums) {
+                                                              float *__restrict__ part) {
     __shared__ float4 red[2][BN_THREADS];
     const int cgl = threadIdx.x % cgb, rlane = threadIdx.x / cgb, rl = BN_THREADS / cgb;
     const int cgi = blockIdx.x * cgb + cgl;                 // global column group
@@ -61,22 +63,27 @@ __global__ __launch_bounds__(BN_THREADS) void cl_stats_kernel(long long R, int C
             s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
             q.x += b.x; q.y += b.y; q.z += b.z; q.w += b.w;
         }
-        double *S = sums + cgi * 4, *Q = sums + C + cgi * 4;
-        atomicAdd(S, (double)s.x); atomicAdd(S + 1, (double)s.y); atomicAdd(S + 2, (double)s.z); atomicAdd(S + 3, (double)s.w);
-        atomicAdd(Q, (double)q.x); atomicAdd(Q + 1, (double)q.y); atomicAdd(Q + 2, (double)q.z); atomicAdd(Q + 3, (double)q.w);
+        float *P = part + (size_t)blockIdx.y * 2 * C;
+        *reinterpret_cast<float4 *>(P + cgi * 4) = s;
+        *reinterpret_cast<float4 *>(P + C + cgi * 4) = q;
     }
 }
 
 // From the fp64 sums: mean, biased var -> scale/shift/mean/invstd; running stats with momentum and
 // the unbiased variance (nn.BatchNorm semantics).  stats out: [scale | shift | mean | invstd] (4C).
-__global__ void cl_finalize_kernel(long long R, int C, float eps, float momentum, const double *__restrict__ sums,
-                                   const float *__restrict__ gamma, const float *__restrict__ beta,
-                                   float *__restrict__ running_mean, float *__restrict__ running_var,
-                                   float *__restrict__ stats) {
+__global__ void cl_finalize_kernel(long long R, int C, int nparts, float eps, float momentum,
+                                   const float *__restrict__ part, const float *__restrict__ gamma,
+                                   const float *__restrict__ beta, float *__restrict__ running_mean,
+                                   float *__restrict__ running_var, float *__restrict__ stats) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    const double mean = sums[c] / (double)R;
-    double var = sums[C + c] / (double)R - mean * mean;
+    double s1 = 0, s2 = 0;
+    for (int p = 0; p < nparts; ++p) {
+        s1 += (double)part[(size_t)p * 2 * C + c];
+        s2 += (double)part[(size_t)p * 2 * C + C + c];
+    }
+    const double mean = s1 / (double)R;
+    double var = s2 / (double)R - mean * mean;
     var = var < 0 ? 0 : var;
     const float invstd = (float)(1.0 / sqrt(var + (double)eps));
     const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
@@ -133,7 +140,7 @@ __global__ __launch_bounds__(BN_THREADS) void cl_bwd_reduce_kernel(long long R, 
                                                                    const float *__restrict__ dy,
                                                                    const float *__restrict__ mul,
                                                                    const float *__restrict__ stats,
-                                                                   double *__restrict__ bsums) {
+                                                                   float *__restrict__ part) {
     __shared__ float4 red[2][BN_THREADS];
     const int cgl = threadIdx.x % cgb, rlane = threadIdx.x / cgb, rl = BN_THREADS / cgb;
     const int cgi = blockIdx.x * cgb + cgl;
@@ -169,10 +176,19 @@ __global__ __launch_bounds__(BN_THREADS) void cl_bwd_reduce_kernel(long long R, 
             s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
             q.x += b.x; q.y += b.y; q.z += b.z; q.w += b.w;
         }
-        double *S = bsums + cgi * 4, *Q = bsums + C + cgi * 4;
-        atomicAdd(S, (double)s.x); atomicAdd(S + 1, (double)s.y); atomicAdd(S + 2, (double)s.z); atomicAdd(S + 3, (double)s.w);
-        atomicAdd(Q, (double)q.x); atomicAdd(Q + 1, (double)q.y); atomicAdd(Q + 2, (double)q.z); atomicAdd(Q + 3, (double)q.w);
+        float *P = part + (size_t)blockIdx.y * 2 * C;
+        *reinterpret_cast<float4 *>(P + cgi * 4) = s;
+        *reinterpret_cast<float4 *>(P + C + cgi * 4) = q;
     }
+}
+
+// bsums[c] = sum over partials (fp64 accumulation, fp32 result): [sum dz | sum dz*xhat]
+__global__ void cl_bwd_finalize_kernel(int C, int nparts, const float *__restrict__ part, float *__restrict__ bsums) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= 2 * C) return;
+    double s = 0;
+    for (int p = 0; p < nparts; ++p) s += (double)part[(size_t)p * 2 * C + c];
+    bsums[c] = (float)s;
 }
 
 // dx = scale*(dz - s1/R - xhat*s2/R) (training) or scale*dz (eval); optionally dmul = dy*act(z)
@@ -181,7 +197,7 @@ __global__ __launch_bounds__(BN_THREADS) void cl_bwd_apply_kernel(long long tota
                                                                   const float *__restrict__ dy,
                                                                   const float *__restrict__ mul,
                                                                   const float *__restrict__ stats,
-                                                                  const double *__restrict__ bsums,
+                                                                  const float *__restrict__ bsums,
                                                                   float *__restrict__ dx, float *__restrict__ dmul) {
     const long long e = (long long)blockIdx.x * BN_THREADS + threadIdx.x;
     if (e >= total4) return;
@@ -204,7 +220,7 @@ __global__ __launch_bounds__(BN_THREADS) void cl_bwd_apply_kernel(long long tota
         const float dz = gg[j] * mm[j] * act_grad(z, act);
         if (training) {
             const float xhat = (vv[j] - stats[2 * C + c]) * stats[3 * C + c];
-            const float m1 = (float)bsums[c] * invR, m2 = (float)bsums[C + c] * invR;
+            const float m1 = bsums[c] * invR, m2 = bsums[C + c] * invR;
             oo[j] = sc * (dz - m1 - xhat * m2);
         } else {
             oo[j] = sc * dz;
@@ -217,17 +233,15 @@ __global__ __launch_bounds__(BN_THREADS) void cl_bwd_apply_kernel(long long tota
 // ---------------------------------------------------------------------------- C ABI
 static void cl_geometry(long long R, int C, int *cgb, int *gx, int *gy, int *rpb) {
     const int cg = C / 4;
-    *cgb = cg >= BN_THREADS ? BN_THREADS : cg;
-    // cgb must divide BN_THREADS: round up to a power of two for small C
-    int p = 1;
-    while (p < *cgb) p <<= 1;
-    *cgb = p > BN_THREADS ? BN_THREADS : p;
+    int p = 1;                                             // column groups per block: power of two <= 256
+    while (p < cg && p < BN_THREADS) p <<= 1;
+    *cgb = p;
     *gx = (cg + *cgb - 1) / *cgb;
     const int rl = BN_THREADS / *cgb;
-    long long want = 2048 / *gx;                           // ~2048 workgroups in flight
+    long long want = 1024 / *gx;                           // ~1024 workgroups in flight
     want = want < 1 ? 1 : want;
     long long rows = (R + want - 1) / want;
-    const long long min_rows = (long long)rl * 8;
+    const long long min_rows = (long long)rl * 16;
     rows = rows < min_rows ? min_rows : rows;
     rows = rows > 65536 ? 65536 : rows;                    // bound the fp32 partial sums
     rows = (rows + rl - 1) / rl * rl;
@@ -235,18 +249,24 @@ static void cl_geometry(long long R, int C, int *cgb, int *gx, int *gy, int *rpb
     *gy = (int)((R + rows - 1) / rows);
 }
 
+// Floats of scratch the two reductions need for (rows, c): one [2c] partial per row-block.
+extern "C" long long pdgn_bn_scratch_floats(long long rows, int c) {
+    if (rows < 1 || c < 4 || c % 4) return PDGN_ERR_INVALID;
+    int cgb, gx, gy, rpb;
+    cl_geometry(rows, c, &cgb, &gx, &gy, &rpb);
+    return (long long)gy * 2 * c;
+}
+
 extern "C" int pdgn_bn_stats(long long rows, int c, float eps, float momentum, const float *x, const float *gamma,
-                             const float *beta, float *running_mean, float *running_var, double *sums,
+                             const float *beta, float *running_mean, float *running_var, float *scratch,
                              float *stats, pdgn_stream_t stream) {
     if (rows < 1 || c < 4 || c % 4) return PDGN_ERR_INVALID;
     hipStream_t s = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(sums, 0, 2 * (size_t)c * sizeof(double), s);
-    if (e != hipSuccess) return (int)e;
     int cgb, gx, gy, rpb;
     cl_geometry(rows, c, &cgb, &gx, &gy, &rpb);
-    hipLaunchKernelGGL(cl_stats_kernel, dim3(gx, gy), dim3(BN_THREADS), 0, s, rows, c, cgb, rpb, x, sums);
-    hipLaunchKernelGGL(cl_finalize_kernel, dim3(cdiv(c, 256)), dim3(256), 0, s, rows, c, eps, momentum, sums, gamma,
-                       beta, running_mean, running_var, stats);
+    hipLaunchKernelGGL(cl_stats_kernel, dim3(gx, gy), dim3(BN_THREADS), 0, s, rows, c, cgb, rpb, x, scratch);
+    hipLaunchKernelGGL(cl_finalize_kernel, dim3(cdiv(c, 64)), dim3(64), 0, s, rows, c, gy, eps, momentum, scratch,
+                       gamma, beta, running_mean, running_var, stats);
     return pdgn_launch_status();
 }
 
@@ -268,16 +288,15 @@ extern "C" int pdgn_bn_act_forward(long long rows, int c, int act, const float *
 }
 
 extern "C" int pdgn_bn_act_backward(long long rows, int c, int act, int training, const float *x, const float *dy,
-                                    const float *mul, const float *stats, double *bsums, float *dx, float *dmul,
-                                    pdgn_stream_t stream) {
+                                    const float *mul, const float *stats, float *scratch, float *bsums, float *dx,
+                                    float *dmul, pdgn_stream_t stream) {
     if (rows < 1 || c < 4 || c % 4 || act < 0 || act > 2) return PDGN_ERR_INVALID;
     hipStream_t s = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(bsums, 0, 2 * (size_t)c * sizeof(double), s);
-    if (e != hipSuccess) return (int)e;
     int cgb, gx, gy, rpb;
     cl_geometry(rows, c, &cgb, &gx, &gy, &rpb);
     hipLaunchKernelGGL(cl_bwd_reduce_kernel, dim3(gx, gy), dim3(BN_THREADS), 0, s, rows, c, cgb, rpb, act, x, dy, mul,
-                       stats, bsums);
+                       stats, scratch);
+    hipLaunchKernelGGL(cl_bwd_finalize_kernel, dim3(cdiv(2 * c, 64)), dim3(64), 0, s, c, gy, scratch, bsums);
     const long long total4 = rows * (c / 4);
     hipLaunchKernelGGL(cl_bwd_apply_kernel, dim3(cdiv(total4, BN_THREADS)), dim3(BN_THREADS), 0, s, total4, rows,
                        c / 4, act, training, x, dy, mul, stats, bsums, dx, dmul);

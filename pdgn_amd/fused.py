@@ -11,6 +11,14 @@ F32 = torch.float32
 ACT = {"none": 0, "relu": 1, "leaky_relu": 2}
 
 
+def _scratch_floats(L, rows, C):
+    L.pdgn_bn_scratch_floats.restype = ctypes.c_longlong
+    n = L.pdgn_bn_scratch_floats(ctypes.c_longlong(rows), C)
+    if n < 0:
+        raise _lib.PdgnHipError("pdgn_bn_scratch_floats: argument outside the supported range")
+    return n
+
+
 class BNActCL(Function):
     """y = act(BatchNorm(x)) [* mul] for a channels-last (rows, C) matrix, with nn.BatchNorm
     semantics (batch statistics + running-stat update in training, running statistics in eval).
@@ -26,9 +34,9 @@ class BNActCL(Function):
         stats = torch.empty(4 * C, dtype=F32, device=dev)
         g, b = gamma.detach().contiguous(), beta.detach().contiguous()
         if training:
-            sums = torch.empty(2 * C, dtype=torch.float64, device=dev)
+            scratch = torch.empty(_scratch_floats(L, rows, C), dtype=F32, device=dev)
             check(L.pdgn_bn_stats(ctypes.c_longlong(rows), C, ctypes.c_float(eps), ctypes.c_float(momentum), ptr(x),
-                                  ptr(g), ptr(b), ptr(running_mean), ptr(running_var), ptr(sums), ptr(stats),
+                                  ptr(g), ptr(b), ptr(running_mean), ptr(running_var), ptr(scratch), ptr(stats),
                                   stream_of(x)), "pdgn_bn_stats")
         else:
             check(L.pdgn_bn_eval_stats(C, ctypes.c_float(eps), ptr(g), ptr(b), ptr(running_mean),
@@ -46,13 +54,14 @@ class BNActCL(Function):
         x, stats, mul = ctx.saved_tensors
         rows, C, act, training, need_dmul = ctx.cfg
         dy = dy.contiguous()
-        bsums = torch.empty(2 * C, dtype=torch.float64, device=x.device)
+        L = _lib.lib()
+        scratch = torch.empty(_scratch_floats(L, rows, C), dtype=F32, device=x.device)
+        bs = torch.empty(2 * C, dtype=F32, device=x.device)
         dx = torch.empty_like(x)
         dmul = torch.empty_like(x) if need_dmul else None
-        check(_lib.lib().pdgn_bn_act_backward(ctypes.c_longlong(rows), C, act, int(training), ptr(x), ptr(dy),
-                                              ptr(mul), ptr(stats), ptr(bsums), ptr(dx), ptr(dmul),
-                                              stream_of(x)), "pdgn_bn_act_backward")
-        bs = bsums.to(F32)
+        check(L.pdgn_bn_act_backward(ctypes.c_longlong(rows), C, act, int(training), ptr(x), ptr(dy), ptr(mul),
+                                     ptr(stats), ptr(scratch), ptr(bs), ptr(dx), ptr(dmul), stream_of(x)),
+              "pdgn_bn_act_backward")
         return dx, bs[C:], bs[:C], None, None, None, None, None, None, dmul
 
 

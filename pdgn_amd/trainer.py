@@ -61,7 +61,7 @@ class PDGNTrainer:
         self.gradG = FlatGrads(self.G.parameters())
         self.gradD = [FlatGrads(d.parameters()) for d in self.D]
         cap = self.device.type == "cuda"                     # device-side step counter: graph-capturable
-        adam = lambda m: torch.optim.Adam(m.parameters(), lr=lr, betas=(0.5, 0.999), capturable=cap)
+        adam = lambda m: torch.optim.Adam(m.parameters(), lr=lr, betas=(0.5, 0.999), capturable=cap, fused=cap)
         self.optG, self.optD = adam(self.G), [adam(d) for d in self.D]
 
     def train(self):
