@@ -71,17 +71,36 @@ __global__ __launch_bounds__(BN_THREADS) void cl_stats_kernel(long long R, int C
 
 // From the fp64 sums: mean, biased var -> scale/shift/mean/invstd; running stats with momentum and
 // the unbiased variance (nn.BatchNorm semantics).  stats out: [scale | shift | mean | invstd] (4C).
-__global__ void cl_finalize_kernel(long long R, int C, int nparts, float eps, float momentum,
-                                   const float *__restrict__ part, const float *__restrict__ gamma,
-                                   const float *__restrict__ beta, float *__restrict__ running_mean,
-                                   float *__restrict__ running_var, float *__restrict__ stats) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s1 = 0, s2 = 0;
-    for (int p = 0; p < nparts; ++p) {
-        s1 += (double)part[(size_t)p * 2 * C + c];
-        s2 += (double)part[(size_t)p * 2 * C + C + c];
+#define FIN_CH 16      // channels per finalize block
+#define FIN_PL 16      // part lanes per channel
+
+// Sum `nparts` fp32 partials of channel-slot `c` (stride `ld`) in fp64: 16 lanes per channel, LDS tree.
+__device__ __forceinline__ double fin_reduce(const float *__restrict__ part, int nparts, size_t ld, int c, bool ok,
+                                             double (*red)[FIN_CH]) {
+    const int cl = threadIdx.x % FIN_CH, pl = threadIdx.x / FIN_CH;
+    double s = 0;
+    if (ok)
+        for (int p = pl; p < nparts; p += FIN_PL) s += (double)part[(size_t)p * ld + c];
+    red[pl][cl] = s;
+    __syncthreads();
+    for (int h = FIN_PL / 2; h > 0; h >>= 1) {
+        if (pl < h) red[pl][cl] += red[pl + h][cl];
+        __syncthreads();
     }
+    return red[0][cl];
+}
+
+__global__ __launch_bounds__(FIN_CH * FIN_PL) void cl_finalize_kernel(
+    long long R, int C, int nparts, float eps, float momentum, const float *__restrict__ part,
+    const float *__restrict__ gamma, const float *__restrict__ beta, float *__restrict__ running_mean,
+    float *__restrict__ running_var, float *__restrict__ stats) {
+    __shared__ double red[FIN_PL][FIN_CH];
+    const int c = blockIdx.x * FIN_CH + threadIdx.x % FIN_CH;
+    const bool ok = c < C;
+    const double s1 = fin_reduce(part, nparts, (size_t)2 * C, c, ok, red);
+    __syncthreads();
+    const double s2 = fin_reduce(part, nparts, (size_t)2 * C, C + c, ok, red);
+    if (!ok || threadIdx.x >= FIN_CH) return;
     const double mean = s1 / (double)R;
     double var = s2 / (double)R - mean * mean;
     var = var < 0 ? 0 : var;
@@ -183,12 +202,14 @@ __global__ __launch_bounds__(BN_THREADS) void cl_bwd_reduce_kernel(long long R, 
 }
 
 // bsums[c] = sum over partials (fp64 accumulation, fp32 result): [sum dz | sum dz*xhat]
-__global__ void cl_bwd_finalize_kernel(int C, int nparts, const float *__restrict__ part, float *__restrict__ bsums) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= 2 * C) return;
-    double s = 0;
-    for (int p = 0; p < nparts; ++p) s += (double)part[(size_t)p * 2 * C + c];
-    bsums[c] = (float)s;
+__global__ __launch_bounds__(FIN_CH * FIN_PL) void cl_bwd_finalize_kernel(int C, int nparts,
+                                                                         const float *__restrict__ part,
+                                                                         float *__restrict__ bsums) {
+    __shared__ double red[FIN_PL][FIN_CH];
+    const int c = blockIdx.x * FIN_CH + threadIdx.x % FIN_CH;
+    const bool ok = c < 2 * C;
+    const double s = fin_reduce(part, nparts, (size_t)2 * C, c, ok, red);
+    if (ok && threadIdx.x < FIN_CH) bsums[c] = (float)s;
 }
 
 // dx = scale*(dz - s1/R - xhat*s2/R) (training) or scale*dz (eval); optionally dmul = dy*act(z)
@@ -265,7 +286,7 @@ extern "C" int pdgn_bn_stats(long long rows, int c, float eps, float momentum, c
     int cgb, gx, gy, rpb;
     cl_geometry(rows, c, &cgb, &gx, &gy, &rpb);
     hipLaunchKernelGGL(cl_stats_kernel, dim3(gx, gy), dim3(BN_THREADS), 0, s, rows, c, cgb, rpb, x, scratch);
-    hipLaunchKernelGGL(cl_finalize_kernel, dim3(cdiv(c, 64)), dim3(64), 0, s, rows, c, gy, eps, momentum, scratch,
+    hipLaunchKernelGGL(cl_finalize_kernel, dim3(cdiv(c, FIN_CH)), dim3(FIN_CH * FIN_PL), 0, s, rows, c, gy, eps, momentum, scratch,
                        gamma, beta, running_mean, running_var, stats);
     return pdgn_launch_status();
 }
@@ -296,7 +317,7 @@ extern "C" int pdgn_bn_act_backward(long long rows, int c, int act, int training
     cl_geometry(rows, c, &cgb, &gx, &gy, &rpb);
     hipLaunchKernelGGL(cl_bwd_reduce_kernel, dim3(gx, gy), dim3(BN_THREADS), 0, s, rows, c, cgb, rpb, act, x, dy, mul,
                        stats, scratch);
-    hipLaunchKernelGGL(cl_bwd_finalize_kernel, dim3(cdiv(2 * c, 64)), dim3(64), 0, s, c, gy, scratch, bsums);
+    hipLaunchKernelGGL(cl_bwd_finalize_kernel, dim3(cdiv(2 * c, FIN_CH)), dim3(FIN_CH * FIN_PL), 0, s, c, gy, scratch, bsums);
     const long long total4 = rows * (c / 4);
     hipLaunchKernelGGL(cl_bwd_apply_kernel, dim3(cdiv(total4, BN_THREADS)), dim3(BN_THREADS), 0, s, total4, rows,
                        c / 4, act, training, x, dy, mul, stats, bsums, dx, dmul);

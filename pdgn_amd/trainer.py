@@ -6,6 +6,8 @@ BatchNorm statistics stay local (same semantics), and gradients are all-reduced 
 as ONE flat fp32 buffer per network (G: 50.8 MB, D1-4: 6.8 MB) -- parameters' ``.grad`` tensors
 are views into that buffer, so there is no bucket copy in or out.
 """
+import os
+
 import torch
 import torch.distributed as dist
 import torch.nn as nn
@@ -61,7 +63,7 @@ class PDGNTrainer:
         self.gradG = FlatGrads(self.G.parameters())
         self.gradD = [FlatGrads(d.parameters()) for d in self.D]
         cap = self.device.type == "cuda"                     # device-side step counter: graph-capturable
-        adam = lambda m: torch.optim.Adam(m.parameters(), lr=lr, betas=(0.5, 0.999), capturable=cap, fused=cap)
+        adam = lambda m: torch.optim.Adam(m.parameters(), lr=lr, betas=(0.5, 0.999), capturable=cap, fused=cap and os.environ.get("PDGN_FUSED_ADAM", "1") == "1")
         self.optG, self.optD = adam(self.G), [adam(d) for d in self.D]
 
     def train(self):
@@ -101,7 +103,7 @@ class PDGNTrainer:
             # generator pass #1 (:179): only its detached outputs are ever used => no graph needed;
             # BatchNorm running statistics update exactly as in the reference.
             with torch.no_grad():
-                st["fakes"] = self.G(st["z1"])
+                st["fakes"] = self.G(self._z(st, "z1"))
             self._seg_d(st, 0)
         elif k in (1, 2, 3):
             self.optD[k - 1].step()
@@ -112,7 +114,7 @@ class PDGNTrainer:
             # The reference lets lossG.backward() also fill the discriminators' .grad and throws
             # that away at the next zero_grad (:183); freezing D skips those weight-gradient GEMMs.
             self._freeze_D(True)
-            gen = self.G(st["z2"])
+            gen = self.G(self._z(st, "z2"))
             similar = self.similar_loss(gen)
             g_loss = [F.mse_loss(self.D[i](gen[i]), st["ones"]) for i in range(4)]
             adv = 1.2 * g_loss[0] + 1.2 * g_loss[1] + 1.2 * g_loss[2] + g_loss[3]
@@ -127,14 +129,21 @@ class PDGNTrainer:
         else:
             self.optG.step()
 
+    def _z(self, st, name):
+        """Noise of a generator pass: the caller's tensor, or -- when it is None -- drawn on the
+        device inside the step (z ~ N(0, 0.2^2), :178/:228), which keeps a captured iteration free
+        of host-side inputs."""
+        z = st[name]
+        return z if z is not None else torch.randn(st["B"], 128, device=self.device) * 0.2
+
     def _comm(self, k):
         """Collective that follows segment k (RCCL all-reduce of one flat gradient buffer)."""
         if self.distributed and k < 5:
             (self.gradD[k] if k < 4 else self.gradG).all_reduce_mean()
 
     def _state(self, reals, z1, z2):
-        B = z1.shape[0]
-        return {"reals": reals, "z1": z1, "z2": z2, "out": {}, "ws": world_size() if self.distributed else 1,
+        B = reals[0].shape[0]
+        return {"reals": reals, "z1": z1, "z2": z2, "B": B, "out": {}, "ws": world_size() if self.distributed else 1,
                 "ones": torch.ones(B, 1, device=self.device), "zeros": torch.zeros(B, 1, device=self.device)}
 
     def step(self, reals, z1, z2):
@@ -147,11 +156,19 @@ class PDGNTrainer:
         return st["out"]
 
     # ---------------------------------------------------------------- hipGraph replay
-    def capture(self, reals, z1, z2, warmup=3):
-        """Capture the six segments into hipGraphs (static input buffers, one shared memory pool).
-        ~2500 kernel launches per iteration become six graph launches; the all-reduces stay
-        ordinary stream operations between them."""
-        self._static = self._state([r.clone() for r in reals], z1.clone(), z2.clone())
+    def capture(self, reals, z1=None, z2=None, warmup=3):
+        """Capture the iteration into hipGraphs (static input buffers, one shared memory pool):
+        ~2500 kernel launches become one graph launch (six when gradients are all-reduced
+        between segments).  (Drawing the noise on the device inside the capture is not used: a
+        captured torch.randn faulted on this ROCm build.)
+
+        ROCm 7.2 note (measured on MI355X): an eager kernel enqueued between two graph launches
+        on the same stream is NOT reliably ordered against them (replays with `copy_` of the
+        inputs in between fault, the same replays with a stream synchronise around the copies,
+        or with no eager work in between, are clean) -- hence `_sync()` around every eager
+        operation that sits between replays."""
+        self._static = self._state([r.clone() for r in reals], z1.clone() if z1 is not None else None,
+                                   z2.clone() if z2 is not None else None)
         side = torch.cuda.Stream(device=self.device)
         side.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(side):
@@ -161,27 +178,42 @@ class PDGNTrainer:
                     self._comm(k)
         torch.cuda.current_stream(self.device).wait_stream(side)
         torch.cuda.synchronize(self.device)
+        # One graph per run of segments between collectives: the whole iteration when there is
+        # nothing to all-reduce, six graphs (replayed with the all-reduces between them) otherwise.
+        groups = [[k] for k in range(6)] if self.distributed else [list(range(6))]
         self._graphs, pool = [], None
-        for k in range(6):
+        for group in groups:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, pool=pool):
-                self._segment(self._static, k)
+                for k in group:
+                    self._segment(self._static, k)
             pool = g.pool()
-            self._graphs.append(g)
-            self._comm(k)
+            self._graphs.append((g, group[-1]))
+            self._comm(group[-1])
         return self
 
-    def step_graphed(self, reals, z1, z2):
-        """Replay of `capture`: copies the inputs into the static buffers, replays the graphs."""
+    def _sync(self):
+        torch.cuda.current_stream(self.device).synchronize()
+
+    def step_graphed(self, reals=None, z1=None, z2=None):
+        """Replay of `capture`.  Inputs, when given, are copied into the static buffers first."""
         st = self._static
-        for dst, src in zip(st["reals"], reals):
-            if dst.data_ptr() != src.data_ptr():
-                dst.copy_(src)
-        st["z1"].copy_(z1)
-        st["z2"].copy_(z2)
-        for k, g in enumerate(self._graphs):
+        copies = []
+        if reals is not None:
+            copies += [(d, s) for d, s in zip(st["reals"], reals) if d.data_ptr() != s.data_ptr()]
+        if z1 is not None and st["z1"] is not None:
+            copies += [(st["z1"], z1), (st["z2"], z2)]
+        if copies:
+            self._sync()
+            for d, s in copies:
+                d.copy_(s)
+            self._sync()
+        for g, last in self._graphs:
             g.replay()
-            self._comm(k)
+            if self.distributed and last < 5:
+                self._sync()
+                self._comm(last)
+                self._sync()
         return st["out"]
 
 
