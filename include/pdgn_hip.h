@@ -152,6 +152,26 @@ int pdgn_bn_act_backward(long long rows, int c, int act, int training, const flo
                          const float *dy, const float *mul, const float *stats, float *scratch,
                          float *bsums, float *dx, float *dmul, pdgn_stream_t stream);
 
+/* ------------------------------------------------------------------ local-pair shape loss
+ * Neighbourhood mean / covariance of models/PDGNet_v2.py:127-134 fused with the grouping of
+ * :142-147: xyz (b,n,3), idx (b,m,k) (from pdgn_knnquery) -> mu (b,m,3), cov (b,m,9)
+ * (cov = (1/k) sum_s (p_s - mu)(p_s - mu)^T). */
+int pdgn_local_stats(int b, int n, int m, int k, const float *xyz, const int32_t *idx, float *mu,
+                     float *cov, pdgn_stream_t stream);
+/* Adjoint: dxyz (b,n,3) += scatter of dmu (b,m,3), dcov (b,m,9); dxyz zero-filled by the caller. */
+int pdgn_local_stats_backward(int b, int n, int m, int k, const float *xyz, const int32_t *idx,
+                              const float *dmu, const float *dcov, float *dxyz, pdgn_stream_t stream);
+
+/* utils/chamfer_loss.py:13-38 without the (B,M,N) matrix: P[i,j] = (|x_i|^2 + |y_j|^2) - 2<x_i,y_j>
+ * (Gram form, no clamp); x (b,m,d), y (b,n,d), d <= 16 -> minx/argx (b,m) = min/argmin over j,
+ * miny/argy (b,n) = min/argmin over i (lowest index on ties). */
+int pdgn_chamfer_gram(int b, int m, int n, int d, const float *x, const float *y, float *minx,
+                      int32_t *argx, float *miny, int32_t *argy, pdgn_stream_t stream);
+/* Gradient of sum(gminx*minx) + sum(gminy*miny) wrt x and y (zero-fills gx, gy itself). */
+int pdgn_chamfer_gram_grad(int b, int m, int n, int d, const float *x, const float *y,
+                           const float *gminx, const int32_t *argx, const float *gminy,
+                           const int32_t *argy, float *gx, float *gy, pdgn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,52 +1,126 @@
 """Losses of the PDGN training step: Chamfer (utils/chamfer_loss.py:13-38) and the
-shape-preserving local-statistics loss (models/PDGNet_v2.py:127-155)."""
+shape-preserving local-statistics loss (models/PDGNet_v2.py:127-155), on fused HIP kernels
+(csrc/localpair.hip): no (B,M,N) distance matrix, no (B,3,M,20) grouped tensor, no bmm."""
 import torch
 import torch.nn as nn
+from torch.autograd import Function
 
-from . import pointops
+from . import _lib, pointops
+from ._lib import check, ptr, require, stream_of
+
+F32, I32 = torch.float32, torch.int32
+
+
+class ChamferGram(Function):
+    """x (B,M,D), y (B,N,D) -> (min_j P[i,j] (B,M), min_i P[i,j] (B,N)) with the reference's
+    Gram-form P = |x_i|^2 + |y_j|^2 - 2<x_i,y_j> (chamfer_loss.py:22-38)."""
+
+    @staticmethod
+    def forward(ctx, x, y):
+        x, y = x.contiguous(), y.contiguous()
+        require(x, "x", F32, 3)
+        require(y, "y", F32, 3)
+        b, m, d = x.shape
+        n = y.shape[1]
+        minx = torch.empty((b, m), dtype=F32, device=x.device)
+        miny = torch.empty((b, n), dtype=F32, device=x.device)
+        argx = torch.empty((b, m), dtype=I32, device=x.device)
+        argy = torch.empty((b, n), dtype=I32, device=x.device)
+        check(_lib.lib().pdgn_chamfer_gram(b, m, n, d, ptr(x), ptr(y), ptr(minx), ptr(argx), ptr(miny), ptr(argy),
+                                           stream_of(x)), "pdgn_chamfer_gram")
+        ctx.save_for_backward(x, y, argx, argy)
+        ctx.mark_non_differentiable(argx, argy)
+        return minx, miny
+
+    @staticmethod
+    def backward(ctx, gminx, gminy):
+        x, y, argx, argy = ctx.saved_tensors
+        b, m, d = x.shape
+        n = y.shape[1]
+        gx, gy = torch.empty_like(x), torch.empty_like(y)
+        gminx, gminy = gminx.contiguous(), gminy.contiguous()
+        check(_lib.lib().pdgn_chamfer_gram_grad(b, m, n, d, ptr(x), ptr(y), ptr(gminx), ptr(argx), ptr(gminy),
+                                                ptr(argy), ptr(gx), ptr(gy), stream_of(x)),
+              "pdgn_chamfer_gram_grad")
+        return gx, gy
+
+
+def chamfer_min(x, y):
+    return ChamferGram.apply(x, y)
+
+
+class LocalStats(Function):
+    """xyz (B,N,3), idx (B,M,K) int32 -> mu (B,M,3), cov (B,M,9): grouping (:142-145) +
+    compute_mean_covariance (:127-134) in one pass; backward scatters onto xyz."""
+
+    @staticmethod
+    def forward(ctx, xyz, idx):
+        require(xyz, "xyz", F32, 3)
+        require(idx, "idx", I32, 3)
+        b, n, _ = xyz.shape
+        _, m, k = idx.shape
+        mu = torch.empty((b, m, 3), dtype=F32, device=xyz.device)
+        cov = torch.empty((b, m, 9), dtype=F32, device=xyz.device)
+        check(_lib.lib().pdgn_local_stats(b, n, m, k, ptr(xyz), ptr(idx), ptr(mu), ptr(cov), stream_of(xyz)),
+              "pdgn_local_stats")
+        ctx.save_for_backward(xyz, idx)
+        return mu, cov
+
+    @staticmethod
+    def backward(ctx, dmu, dcov):
+        xyz, idx = ctx.saved_tensors
+        b, n, _ = xyz.shape
+        _, m, k = idx.shape
+        dxyz = torch.zeros_like(xyz)
+        dmu, dcov = dmu.contiguous(), dcov.contiguous()
+        check(_lib.lib().pdgn_local_stats_backward(b, n, m, k, ptr(xyz), ptr(idx), ptr(dmu), ptr(dcov), ptr(dxyz),
+                                                   stream_of(xyz)), "pdgn_local_stats_backward")
+        return dxyz, None
+
+
+def local_stats(xyz, idx):
+    return LocalStats.apply(xyz, idx)
+
+
+def knnquery(nsample, xyz, new_xyz):
+    return pointops.knnquery(nsample, xyz, new_xyz)
 
 
 class ChamferLoss(nn.Module):
-    """utils/chamfer_loss.py:13-38: Gram-form P = |x|^2 + |y|^2 - 2<x,y> (no clamp) and the SUM
-    (not mean) of the row minima and column minima over batch and points."""
+    """utils/chamfer_loss.py:13-38: SUM (not mean) over batch and points of the row minima and
+    the column minima of the Gram-form pairwise matrix."""
 
     def forward(self, preds, gts):
-        P = self.batch_pairwise_dist(gts, preds)
-        return torch.min(P, 1)[0].sum() + torch.min(P, 2)[0].sum()
-
-    @staticmethod
-    def batch_pairwise_dist(x, y):
-        zz = torch.bmm(x, y.transpose(2, 1))
-        rx = (x * x).sum(dim=2, keepdim=True)                  # diag(x x^T), :29-35
-        ry = (y * y).sum(dim=2).unsqueeze(1)
-        return rx + ry - 2 * zz
+        minx, miny = chamfer_min(gts, preds)
+        return miny.sum() + minx.sum()
 
 
 def compute_mean_covariance(points):
-    """models/PDGNet_v2.py:127-134.  points (R,3,k) -> mu (R,3,1), covariance (R,3,3)."""
+    """models/PDGNet_v2.py:127-134 (torch ops; kept for API parity).  points (R,3,k)."""
     mu = points.mean(dim=-1, keepdim=True)
     tmp = points - mu
     return mu, torch.bmm(tmp, tmp.transpose(1, 2)) / points.shape[-1]
 
 
 class LocalPairLoss(nn.Module):
-    """get_local_pair :136-155: group both clouds around pt1's points (k = 20 nearest, HIP kNN +
-    grouping), compare per-neighbourhood means and covariances with Chamfer, divide by M."""
+    """get_local_pair :136-155: neighbourhood (k = 20) means and covariances of both clouds around
+    pt1's points, compared with Chamfer, divided by M."""
 
     def __init__(self, nsample=20):
         super().__init__()
         self.nsample = nsample
-        self.group = pointops.Gen_QueryAndGroupXYZ(radius=None, nsample=nsample, use_xyz=False)
         self.chamfer_loss = ChamferLoss()
 
-    def forward(self, pt1, pt2):
-        B, _, M = pt1.shape
+    def stats(self, cloud_cl, query_cl):
+        """cloud (B,N,3), queries (B,M,3) point-major -> (mu (B,M,3), cov (B,M,9))."""
+        idx = knnquery(self.nsample, cloud_cl, query_cl)
+        return local_stats(cloud_cl, idx)
+
+    def forward(self, pt1, pt2, self_stats=None):
+        """pt1 (B,3,M), pt2 (B,3,N>=M).  `self_stats` = stats(pt1, pt1) when the caller already has
+        them (pt1 is grouped around itself identically in every pair it heads, :232-237)."""
+        M = pt1.shape[2]
         new_xyz = pt1.transpose(1, 2).contiguous()
-        pt2_trans = pt2.transpose(1, 2).contiguous()
-        g1 = self.group(new_xyz, new_xyz).transpose(1, 2).contiguous().view(-1, 3, self.nsample)
-        g2 = self.group(pt2_trans, new_xyz).transpose(1, 2).contiguous().view(-1, 3, self.nsample)
-        mu1, var1 = compute_mean_covariance(g1)
-        mu2, var2 = compute_mean_covariance(g2)
-        like_mu = self.chamfer_loss(mu1.view(B, -1, 3), mu2.view(B, -1, 3)) / float(M)
-        like_var = self.chamfer_loss(var1.view(B, -1, 9), var2.view(B, -1, 9)) / float(M)
-        return like_mu, like_var
+        mu1, var1 = self_stats if self_stats is not None else self.stats(new_xyz, new_xyz)
+        mu2, var2 = self.stats(pt2.transpose(1, 2).contiguous(), new_xyz)
+        return self.chamfer_loss(mu1, mu2) / float(M), self.chamfer_loss(var1, var2) / float(M)

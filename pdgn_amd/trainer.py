@@ -79,8 +79,12 @@ class PDGNTrainer:
     def similar_loss(self, clouds):
         """Sum of the 6 like_mu and the 6 like_cov terms, in the reference's order (:251-252)."""
         mus, covs = [], []
+        own = {}                                 # stats of cloud a around itself: shared by its pairs
         for a, b in PAIRS:
-            mu, cov = self.local_pair(clouds[a], clouds[b])
+            if a not in own:
+                cl = clouds[a].transpose(1, 2).contiguous()
+                own[a] = self.local_pair.stats(cl, cl)
+            mu, cov = self.local_pair(clouds[a], clouds[b], self_stats=own[a])
             mus.append(mu)
             covs.append(cov)
         return sum(mus[1:], mus[0]) + sum(covs[1:], covs[0])

@@ -8,7 +8,7 @@ import pytest
 import torch
 
 from hashweights import fill_module, hash_tensor
-from torch_standins import EdgeGatherSumTorch, bn_act_torch, feature_knn_torch
+from torch_standins import EdgeGatherSumTorch, bn_act_torch, feature_knn_torch, patch_losses
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
@@ -58,7 +58,7 @@ def test_load_reference_checkpoint_prefix(patched):
 
 
 @pytest.mark.parametrize("B,rtol", [(4, 2e-3), (2, 0.1)])
-def test_one_step_matches_composed_reference(golden, patched, B, rtol):
+def test_one_step_matches_composed_reference(golden, patched, monkeypatch, B, rtol):
     """The six logged losses and an Adam-updated weight slice of one iteration equal the
     composed-reference fixture.  B=2 is BASELINE.json configs[0]'s batch size: BatchNorm1d over 2
     samples amplifies fp32 rounding ~100x per stage (the fp32 reference itself is 5e-3 away from
@@ -71,10 +71,7 @@ def test_one_step_matches_composed_reference(golden, patched, B, rtol):
     for i, d in enumerate(tr.D):
         fill_module(d, salt=10 + i)
 
-    class OracleGroup(torch.nn.Module):          # C-oracle kNN + grouping in place of the HIP ops
-        def forward(self, xyz, new_xyz):
-            return pdgnet_ref.query_and_group_xyz(xyz, new_xyz)
-    tr.local_pair.group = OracleGroup()
+    patch_losses(monkeypatch)                     # C-oracle kNN + torch stats/Chamfer for the HIP ops
     tr.train()
     reals = [hash_tensor("real%d" % i, (B, 3, n), 0.8) for i, n in enumerate((256, 512, 1024, 2048))]
     out = tr.step(reals, hash_tensor("step_z1", (B, 128), 0.2), hash_tensor("step_z2", (B, 128), 0.2))

@@ -40,3 +40,35 @@ def bn_act_torch(x2d, bn, training, act="leaky_relu", mul=None):
     y = F.batch_norm(x2d, bn.running_mean, bn.running_var, bn.weight, bn.bias, training, bn.momentum, bn.eps)
     y = {"none": lambda t: t, "relu": torch.relu, "leaky_relu": F.leaky_relu}[act](y)
     return y * mul if mul is not None else y
+
+
+def knnquery_oracle(nsample, xyz, new_xyz):
+    from oracle import cref
+    return torch.from_numpy(cref.knnquery(nsample, xyz.detach().numpy(), new_xyz.detach().numpy())[0])
+
+
+def local_stats_torch(xyz, idx):
+    """Same contract as pdgn_amd.losses.local_stats: gather + mean / covariance in torch ops."""
+    B, N, _ = xyz.shape
+    _, M, K = idx.shape
+    g = torch.gather(xyz, 1, idx.long().reshape(B, M * K, 1).expand(B, M * K, 3)).view(B, M, K, 3)
+    mu = g.mean(dim=2)
+    t = g - mu.unsqueeze(2)
+    cov = torch.einsum("bmka,bmkc->bmac", t, t) / K
+    return mu, cov.reshape(B, M, 9)
+
+
+def chamfer_min_torch(x, y):
+    """Same contract as pdgn_amd.losses.chamfer_min (Gram-form P, minima over both axes)."""
+    P = (x * x).sum(2, keepdim=True) + (y * y).sum(2).unsqueeze(1) - 2 * torch.bmm(x, y.transpose(1, 2))
+    return P.min(2)[0], P.min(1)[0]
+
+
+def patch_losses(monkeypatch_or_module):
+    """Route pdgn_amd.losses' three HIP entry points to the stand-ins above."""
+    from pdgn_amd import losses
+    for name, fn in (("knnquery", knnquery_oracle), ("local_stats", local_stats_torch), ("chamfer_min", chamfer_min_torch)):
+        if hasattr(monkeypatch_or_module, "setattr"):
+            monkeypatch_or_module.setattr(losses, name, fn)
+        else:
+            setattr(losses, name, fn)
