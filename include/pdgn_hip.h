@@ -126,6 +126,16 @@ int pdgn_window_gather_sum_backward(int b, int n, int k, int ldy, int T, int P, 
                                     int offc, const float *dout, const int32_t *idx, float *dY,
                                     pdgn_stream_t stream);
 
+/* Transposed kNN graph (CSR over source points) of idx (b,n,k): rowptr (b,n+1), edges (b,n*k) with
+ * edge records n*32 + s (k <= 31); scratch: 2*b*n ints. */
+int pdgn_knn_graph_transpose(int b, int n, int k, const int32_t *idx, int32_t *rowptr, int32_t *edges,
+                             int32_t *scratch, pdgn_stream_t stream);
+/* Atomic-free form of pdgn_window_gather_sum_backward over the transposed graph: every element of
+ * dY's column blocks [off, off+T*C) and [offc, offc+C) is WRITTEN exactly once (no zero-fill). */
+int pdgn_window_gather_sum_backward_csr(int b, int n, int k, int ldy, int T, int P, int C, int off,
+                                        int offc, const float *dout, const int32_t *rowptr,
+                                        const int32_t *edges, float *dY, pdgn_stream_t stream);
+
 /* Fused BatchNorm + activation over channels-last (rows x c) activations -- the
  * nn.BatchNorm2d + LeakyReLU/ReLU pairs of models/PDGNet_v2.py:537-545, 561-565, 603-625 in the
  * point-major layout.  act: 0 none, 1 ReLU, 2 LeakyReLU(0.01).  c % 4 == 0.

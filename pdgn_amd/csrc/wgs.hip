@@ -94,3 +94,120 @@ extern "C" int pdgn_window_gather_sum_backward(int b, int n, int k, int ldy, int
                        (hipStream_t)stream, total, n, k, ldy, T, P, C, off, offc, dout, idx, dY);
     return pdgn_launch_status();
 }
+
+// ---------------------------------------------------------------------------- atomic-free adjoint
+// Transposed kNN graph (CSR over source points): for every point j the list of edges (n, s) with
+// idx[b,n,s] == j, packed as n*32 + s.  With it the adjoint of the gather-sum becomes a gather
+// itself -- every dY element is written exactly once (no zero-fill pass, no float atomics):
+//   dY[b,j,off+t*C+c] = sum_{(n,s) in in(j), 0 <= s-t < P} dout[b,n,s-t,c]
+//   dY[b,j,offc+c]    = sum_p dout[b,j,p,c]
+__global__ __launch_bounds__(WGS_THREADS) void csr_count_kernel(long long total, int n, int k,
+                                                                const int32_t *__restrict__ idx,
+                                                                int32_t *__restrict__ cnt) {
+    long long e = (long long)blockIdx.x * WGS_THREADS + threadIdx.x;
+    if (e >= total) return;
+    const long long b = e / ((long long)n * k);
+    atomicAdd(&cnt[b * n + idx[e]], 1);
+}
+
+// one workgroup per batch: exclusive scan of cnt (n) -> rowptr (n+1); cursor <- rowptr
+__global__ __launch_bounds__(1024) void csr_scan_kernel(int n, const int32_t *__restrict__ cnt,
+                                                        int32_t *__restrict__ rowptr, int32_t *__restrict__ cursor) {
+    __shared__ int part[1024];
+    const int bs = blockIdx.x, tid = threadIdx.x;
+    const int per = (n + 1023) / 1024;
+    const int32_t *C = cnt + (size_t)bs * n;
+    int s = 0;
+    for (int i = tid * per; i < min(n, (tid + 1) * per); ++i) s += C[i];
+    part[tid] = s;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        int v = tid >= off ? part[tid - off] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    int run = part[tid] - s;                                  // exclusive prefix of this thread's chunk
+    int32_t *R = rowptr + (size_t)bs * (n + 1), *U = cursor + (size_t)bs * n;
+    for (int i = tid * per; i < min(n, (tid + 1) * per); ++i) {
+        R[i] = run; U[i] = run;
+        run += C[i];
+    }
+    if (tid == 1023) R[n] = part[1023];
+}
+
+__global__ __launch_bounds__(WGS_THREADS) void csr_fill_kernel(long long total, int n, int k,
+                                                               const int32_t *__restrict__ idx,
+                                                               int32_t *__restrict__ cursor,
+                                                               int32_t *__restrict__ edges) {
+    long long e = (long long)blockIdx.x * WGS_THREADS + threadIdx.x;
+    if (e >= total) return;
+    const long long nk = (long long)n * k;
+    const long long b = e / nk;
+    const int r = (int)(e - b * nk);                          // n_local * k + s
+    const int pos = atomicAdd(&cursor[b * n + idx[e]], 1);
+    edges[b * nk + pos] = (r / k) * 32 + (r % k);
+}
+
+__global__ __launch_bounds__(WGS_THREADS) void wgs_bwd_csr_kernel(
+    long long total, int n, int k, int ldy, int T, int P, int CV, int off, int offc,
+    const float *__restrict__ dout, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ edges,
+    float *__restrict__ dY) {
+    typedef float vec_t __attribute__((ext_vector_type(4)));
+    long long e = (long long)blockIdx.x * WGS_THREADS + threadIdx.x;
+    if (e >= total) return;
+    const int TT = offc >= 0 ? T + 1 : T;
+    const int cv = (int)(e % CV);
+    long long r = e / CV;
+    const int t = (int)(r % TT);
+    const long long bj = r / TT;                              // b * n + j
+    const long long b = bj / n;
+    const int j = (int)(bj - b * n);
+    const int C = CV * 4, c = cv * 4;
+    vec_t acc = {0.f, 0.f, 0.f, 0.f};
+    if (t == T) {                                             // centre columns
+        const float *src = dout + bj * P * C + c;
+        for (int p = 0; p < P; ++p) acc += *reinterpret_cast<const vec_t *>(src + (size_t)p * C);
+        *reinterpret_cast<vec_t *>(dY + bj * ldy + offc + c) = acc;
+        return;
+    }
+    const int32_t *R = rowptr + b * (n + 1);
+    const int32_t *E = edges + b * (long long)n * k;
+    const int e1 = R[j + 1];
+    for (int q = R[j]; q < e1; ++q) {
+        const int rec = E[q];
+        const int p = (rec & 31) - t;
+        if (p >= 0 && p < P)
+            acc += *reinterpret_cast<const vec_t *>(dout + ((b * n + (rec >> 5)) * P + p) * C + c);
+    }
+    *reinterpret_cast<vec_t *>(dY + bj * ldy + off + t * C + c) = acc;
+}
+
+extern "C" int pdgn_knn_graph_transpose(int b, int n, int k, const int32_t *idx, int32_t *rowptr,
+                                        int32_t *edges, int32_t *scratch, pdgn_stream_t stream) {
+    if (b < 0 || n < 1 || k < 1 || k > 31 || (long long)n * 32 > 0x7fffffffLL) return PDGN_ERR_INVALID;
+    if (b == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    int32_t *cnt = scratch, *cursor = scratch + (size_t)b * n;      // scratch: 2*b*n ints
+    hipError_t e = hipMemsetAsync(cnt, 0, (size_t)b * n * sizeof(int32_t), s);
+    if (e != hipSuccess) return (int)e;
+    const long long total = (long long)b * n * k;
+    hipLaunchKernelGGL(csr_count_kernel, dim3(cdiv(total, WGS_THREADS)), dim3(WGS_THREADS), 0, s, total, n, k, idx, cnt);
+    hipLaunchKernelGGL(csr_scan_kernel, dim3(b), dim3(1024), 0, s, n, cnt, rowptr, cursor);
+    hipLaunchKernelGGL(csr_fill_kernel, dim3(cdiv(total, WGS_THREADS)), dim3(WGS_THREADS), 0, s, total, n, k, idx,
+                       cursor, edges);
+    return pdgn_launch_status();
+}
+
+extern "C" int pdgn_window_gather_sum_backward_csr(int b, int n, int k, int ldy, int T, int P, int C, int off,
+                                                   int offc, const float *dout, const int32_t *rowptr,
+                                                   const int32_t *edges, float *dY, pdgn_stream_t stream) {
+    if (!wgs_ok(b, n, k, ldy, T, P, C, off, offc) || C % 4 || ldy % 4 || off % 4 || (offc >= 0 && offc % 4) || k > 31)
+        return PDGN_ERR_INVALID;
+    if (b == 0) return 0;
+    const int TT = offc >= 0 ? T + 1 : T;
+    const long long total = (long long)b * n * TT * (C / 4);
+    hipLaunchKernelGGL(wgs_bwd_csr_kernel, dim3(cdiv(total, WGS_THREADS)), dim3(WGS_THREADS), 0, (hipStream_t)stream,
+                       total, n, k, ldy, T, P, C / 4, off, offc, dout, rowptr, edges, dY);
+    return pdgn_launch_status();
+}

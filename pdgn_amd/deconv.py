@@ -68,15 +68,45 @@ class EdgeGatherSum(Function):
     def backward(ctx, *douts):
         (idx,) = ctx.saved_tensors
         b, n, ldy, k = ctx.shape
-        dY = torch.zeros((b, n, ldy), dtype=F32, device=idx.device)
+        L = _lib.lib()
+        covered = sum(T * C + (C if offc >= 0 else 0) for (T, P, C, off, offc) in ctx.specs)
+        vec_ok = ldy % 4 == 0 and k <= 31 and all(C % 4 == 0 and off % 4 == 0 and (offc < 0 or offc % 4 == 0)
+                                                 for (T, P, C, off, offc) in ctx.specs)
         dbias = []
+        if vec_ok and covered == ldy:
+            # atomic-free path: the specs tile dY completely, each element is written once
+            rowptr, edges = transposed_graph(idx)
+            dY = torch.empty((b, n, ldy), dtype=F32, device=idx.device)
+            for (T, P, C, off, offc), dout, hb in zip(ctx.specs, douts, ctx.has_bias):
+                dout = dout.contiguous()
+                check(L.pdgn_window_gather_sum_backward_csr(b, n, k, ldy, T, P, C, off, offc, ptr(dout), ptr(rowptr),
+                                                            ptr(edges), ptr(dY), stream_of(dout)),
+                      "pdgn_window_gather_sum_backward_csr")
+                dbias.append(dout.sum(dim=(0, 1, 2)) if hb else None)
+            return (dY, None, None) + tuple(dbias)
+        dY = torch.zeros((b, n, ldy), dtype=F32, device=idx.device)
         for (T, P, C, off, offc), dout, hb in zip(ctx.specs, douts, ctx.has_bias):
             dout = dout.contiguous()
-            check(_lib.lib().pdgn_window_gather_sum_backward(b, n, k, ldy, T, P, C, off, offc, ptr(dout),
-                                                             ptr(idx), ptr(dY), stream_of(dout)),
-                  "pdgn_window_gather_sum_backward")
+            check(L.pdgn_window_gather_sum_backward(b, n, k, ldy, T, P, C, off, offc, ptr(dout), ptr(idx), ptr(dY),
+                                                    stream_of(dout)), "pdgn_window_gather_sum_backward")
             dbias.append(dout.sum(dim=(0, 1, 2)) if hb else None)
         return (dY, None, None) + tuple(dbias)
+
+
+def transposed_graph(idx):
+    """CSR of the transposed kNN graph of idx (B,N,k), memoised on the index tensor (the two
+    gather-sums of a block -- features and xyz -- share one graph)."""
+    cached = getattr(idx, "_pdgn_csr", None)
+    if cached is not None:
+        return cached
+    b, n, k = idx.shape
+    rowptr = torch.empty((b, n + 1), dtype=I32, device=idx.device)
+    edges = torch.empty((b, n * k), dtype=I32, device=idx.device)
+    scratch = torch.empty((2 * b * n,), dtype=I32, device=idx.device)
+    check(_lib.lib().pdgn_knn_graph_transpose(b, n, k, ptr(idx), ptr(rowptr), ptr(edges), ptr(scratch),
+                                              stream_of(idx)), "pdgn_knn_graph_transpose")
+    idx._pdgn_csr = (rowptr, edges)
+    return idx._pdgn_csr
 
 
 class _ConvBN(nn.Module):

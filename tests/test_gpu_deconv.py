@@ -256,3 +256,31 @@ def test_graphed_step_equals_eager_step():
     # differ after the capture warm-up, so only generator-side forward quantities are compared)
     assert all(np.isfinite(list(o.values())).all() for o in res[1])
     np.testing.assert_allclose(res[1][0]["similar_loss"], res[0][0]["similar_loss"], rtol=2e-2)
+
+
+@pytest.mark.parametrize("B,N,k,specs", [(2, 50, 10, ((6, 5, 8, 0, 48),)),                       # ldy = 56, one spec tiles it
+                                         (3, 300, 10, ((6, 5, 16, 0, 96), (10, 1, 8, 112, 192), (1, 10, 4, 200, 204))),
+                                         (2, 1024, 10, ((6, 5, 128, 0, 768), (10, 1, 64, 896, 1536)))])
+def test_window_gather_sum_backward_csr_path(B, N, k, specs):
+    """Specs that tile dY completely take the atomic-free transposed-graph adjoint."""
+    from pdgn_amd.deconv import EdgeGatherSum
+    ldy = sum(T * C + (C if offc >= 0 else 0) for (T, P, C, off, offc) in specs)
+    rng = np.random.default_rng(N + ldy)
+    Y = torch.from_numpy(rng.standard_normal((B, N, ldy)).astype(np.float32))
+    idx = torch.from_numpy(rng.integers(0, N, (B, N, k)).astype(np.int32))
+    idx[:, :, 0] = 3                                          # a hub with in-degree N
+    biases = [torch.from_numpy(rng.standard_normal(C).astype(np.float32)) for (T, P, C, off, offc) in specs]
+    Yg = dev(Y).requires_grad_(True)
+    bg = [dev(b_).requires_grad_(True) for b_ in biases]
+    outs = EdgeGatherSum.apply(Yg, dev(idx), specs, *bg)
+    Yc = Y.double().requires_grad_(True)
+    bc = [b_.double().requires_grad_(True) for b_ in biases]
+    refs = EdgeGatherSumTorch.apply(Yc, idx, specs, *bc)
+    gouts = [torch.from_numpy(rng.standard_normal(tuple(r.shape)).astype(np.float32)) for r in refs]
+    torch.autograd.backward(outs, [dev(g_) for g_ in gouts])
+    torch.autograd.backward(refs, [g_.double() for g_ in gouts])
+    for o, r in zip(outs, refs):
+        np.testing.assert_allclose(o.detach().cpu().numpy(), r.detach().numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(Yg.grad.cpu().numpy(), Yc.grad.numpy(), rtol=1e-4, atol=1e-4)
+    for a_, b_ in zip(bg, bc):
+        np.testing.assert_allclose(a_.grad.cpu().numpy(), b_.grad.numpy(), rtol=1e-4, atol=1e-3)
