@@ -162,6 +162,12 @@ int pdgn_bn_act_backward(long long rows, int c, int act, int training, const flo
                          const float *dy, const float *mul, const float *stats, float *scratch,
                          float *bsums, float *dx, float *dmul, pdgn_stream_t stream);
 
+/* Weight gradient of a point-major dense layer on the fp32 matrix cores, reduction split over
+ * workgroups:  dW (n x k) += dY (m x n)^T  X (m x k), all row-major, m >> n, k.
+ * dW must be zero-filled by the caller; n % 4 == 0, k % 4 == 0. */
+int pdgn_gemm_tn(long long m, int n, int k, const float *dY, const float *X, float *dW,
+                 pdgn_stream_t stream);
+
 /* ------------------------------------------------------------------ local-pair shape loss
  * Neighbourhood mean / covariance of models/PDGNet_v2.py:127-134 fused with the grouping of
  * :142-147: xyz (b,n,3), idx (b,m,k) (from pdgn_knnquery) -> mu (b,m,3), cov (b,m,9)

@@ -25,7 +25,7 @@ from torch.autograd import Function
 
 from . import _lib
 from ._lib import check, ptr, require, stream_of
-from .fused import bn_act
+from .fused import bn_act, linear_cl
 
 F32, I32 = torch.float32, torch.int32
 
@@ -178,7 +178,7 @@ class PointDeconv(nn.Module):
             idx = idx.to(I32)
         idx = idx.contiguous()
         Wcat, Wb, T, P = self._assemble()
-        Y = torch.matmul(xt, Wcat.t())                                 # (B,N,Mw) -- per-point GEMM
+        Y = linear_cl(xt.reshape(B * N, Fi), Wcat).view(B, N, -1)      # (B,N,Mw) -- per-point GEMM
         o_i, o_ci = 0, T * 4 * Fi
         o_a = o_ci + 4 * Fi
         o_ca = o_a + k * 2 * Fo
@@ -197,9 +197,9 @@ class PointDeconv(nn.Module):
             (xyz_pre,) = EdgeGatherSum.apply(Yx, idx, ((1, k, 16, 0, 16),), self.conv_xyz[0].bias)
             xyzf = bn_act(xyz_pre.view(-1, 16), self.conv_xyz[1], training)
             h = bn_act(outs[2].view(-1, 16), self.conv_fea[1], training, mul=xyzf)   # w_fea * w_xyz :632
-            h = F.linear(h, self.conv_all[0].weight[:, :, 0, 0], self.conv_all[0].bias)
+            h = linear_cl(h, self.conv_all[0].weight[:, :, 0, 0], self.conv_all[0].bias)
             h = bn_act(h, self.conv_all[1], training)
-            h = F.linear(h, self.conv_all[3].weight[:, :, 0, 0], self.conv_all[3].bias)
+            h = linear_cl(h, self.conv_all[3].weight[:, :, 0, 0], self.conv_all[3].bias)
             h = bn_act(h, self.conv_all[4], training)
             w = h.view(B, N, k, 2 * Fi)
             if self.softmax:
@@ -208,7 +208,7 @@ class PointDeconv(nn.Module):
             w = w.view(B, N, 2, P, 2 * Fi).permute(0, 1, 3, 4, 2).reshape(B * N * P, 4 * Fi)
         # inte = LeakyReLU(BN(inte_pre)) [* w]  -- one fused pass (:637, :642)
         inte = bn_act(inte_pre.view(-1, 4 * Fi), self.inte_conv_hk[1], training, mul=w)
-        out_pre = a_pre.view(B * N, 2 * Fo) + F.linear(inte.view(B * N, P * 4 * Fi), Wb)
+        out_pre = a_pre.view(B * N, 2 * Fo) + linear_cl(inte.view(B * N, P * 4 * Fi), Wb)
         out = bn_act(out_pre, self.conv2.bn, training, act="relu")     # (B*N, 2Fo): channel 2c+j
         # (B,2Fout,N,1) -> view(B,Fout,2,N) -> (B,Fout,2N) (:645-647): point j*N+n of channel c is conv
         # channel 2c+j at point n; in point-major form that is (B, 2, N, Fout) -> (B, 2N, Fout)

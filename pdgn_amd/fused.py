@@ -77,3 +77,39 @@ def bn_act(x2d, bn, training, act="leaky_relu", mul=None):
         return y * mul if mul is not None else y
     return BNActCL.apply(x2d, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, bn.momentum, bn.eps,
                          ACT[act], mul)
+
+
+class LinearCL(Function):
+    """y = x @ W^T (+ b) for point-major rows x (M, C_in).  Forward and the input gradient are
+    library GEMMs (they already run at 105-140 TFLOP/s on these shapes); the weight gradient
+    dW = dy^T x -- a reduction over 10^4..10^5.5 rows with a small output, which the library does
+    not split -- runs on the hand-written split-reduction MFMA kernel pdgn_gemm_tn."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return torch.nn.functional.linear(x, weight, bias)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = dy.matmul(weight) if ctx.needs_input_grad[0] else None
+        dw = None
+        if ctx.needs_input_grad[1]:
+            m, n = dy.shape
+            k = x.shape[1]
+            if n % 4 == 0 and k % 4 == 0 and x.is_contiguous() and m >= 1024:
+                dw = torch.zeros((n, k), dtype=F32, device=dy.device)
+                check(_lib.lib().pdgn_gemm_tn(ctypes.c_longlong(m), n, k, ptr(dy), ptr(x), ptr(dw), stream_of(dy)),
+                      "pdgn_gemm_tn")
+            else:
+                dw = dy.t().matmul(x)
+        db = dy.sum(dim=0) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        return dx, dw, db
+
+
+def linear_cl(x2d, weight, bias=None):
+    """Dense layer on point-major rows (see LinearCL)."""
+    return LinearCL.apply(x2d, weight, bias)

@@ -22,9 +22,13 @@ def _bn_act(x2d, bn, training, act="leaky_relu"):
     return _deconv.bn_act(x2d, bn, training, act=act)      # looked up late: tests patch deconv.bn_act
 
 
+def _linear(rows, weight, bias=None):
+    return _deconv.linear_cl(rows, weight, bias)              # looked up late: tests patch deconv.linear_cl
+
+
 def _conv1x1_rows(rows, conv):
     """Conv1d(kernel 1) applied to a (rows, C_in) matrix."""
-    return F.linear(rows, conv.weight[:, :, 0], conv.bias)
+    return _linear(rows, conv.weight[:, :, 0], conv.bias)
 
 
 def _head_rows(head, x_rows, B, g=None, n_const=0):
@@ -33,7 +37,7 @@ def _head_rows(head, x_rows, B, g=None, n_const=0):
     are applied once per batch and broadcast, never concatenated."""
     c0 = head[0]
     W = c0.weight[:, :, 0]
-    h = F.linear(x_rows, W[:, n_const:])                                   # (B*M, 256)
+    h = _linear(x_rows, W[:, n_const:].contiguous())                       # (B*M, 256)
     if g is not None:
         M = x_rows.shape[0] // B
         h = (h.view(B, M, -1) + F.linear(g, W[:, :n_const], c0.bias).unsqueeze(1)).view(B * M, -1)
