@@ -100,7 +100,13 @@ class LinearCL(Function):
         if ctx.needs_input_grad[1]:
             m, n = dy.shape
             k = x.shape[1]
-            if n % 4 == 0 and k % 4 == 0 and x.is_contiguous() and m >= 1024:
+            if k % 4 and n % 4 == 0 and m >= 1024:          # e.g. the xyz input layer (k = 3): pad to 4
+                xp = torch.nn.functional.pad(x, (0, 4 - k % 4))
+                dwp = torch.zeros((n, xp.shape[1]), dtype=F32, device=dy.device)
+                check(_lib.lib().pdgn_gemm_tn(ctypes.c_longlong(m), n, xp.shape[1], ptr(dy), ptr(xp), ptr(dwp),
+                                              stream_of(dy)), "pdgn_gemm_tn")
+                dw = dwp[:, :k]
+            elif n % 4 == 0 and k % 4 == 0 and x.is_contiguous() and m >= 1024:
                 dw = torch.zeros((n, k), dtype=F32, device=dy.device)
                 check(_lib.lib().pdgn_gemm_tn(ctypes.c_longlong(m), n, k, ptr(dy), ptr(x), ptr(dw), stream_of(dy)),
                       "pdgn_gemm_tn")
