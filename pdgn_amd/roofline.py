@@ -3,8 +3,15 @@
 Each entry launches ONE kernel of libpdgn_hip.so through the C ABI on torch's current stream
 and times it with HIP events recorded on that same stream (torch.cuda.Event == hipEvent on
 ROCm).  `achieved` = algorithmic bytes (or flops) per launch / average launch duration; the
-per-unit figures are stated in DESIGN.md ("Kernels and rooflines").
+per-unit figures are stated in DESIGN.md section 4.  `traffic` (HBM bytes per launch from the
+rocprofv3 PMC counters FETCH_SIZE / WRITE_SIZE, collected in separate passes and corrected as
+/opt/skills/guides/MI355X_MICROARCH.md prescribes) is read from profiles/traffic.json, which
+tools/pmc_traffic.py writes from a rocprofv3 run of tools/roofline_only.py.
 """
+import ctypes
+import json
+import os
+
 import torch
 
 from . import _lib
@@ -12,6 +19,7 @@ from ._lib import check, ptr, stream_of
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s achievable)
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32-input MFMA peak
+_TRAFFIC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "traffic.json")
 
 
 def _time_us(fn, iters=20, warm=3):
@@ -25,6 +33,60 @@ def _time_us(fn, iters=20, warm=3):
     e.record()
     torch.cuda.synchronize()
     return s.elapsed_time(e) * 1e3 / iters
+
+
+def _entry(name, bound, work, us, **extra):
+    if bound == "hbm":
+        ach, peak, unit = work / us / 1e3, HBM_PEAK_GBS, "GB/s"
+        key = "algorithmic_bytes_per_launch"
+    else:
+        ach, peak, unit = work / us / 1e6, MFMA_F32_PEAK_TFLOPS, "TFLOP/s"
+        key = "algorithmic_flops_per_launch"
+    d = {"kernel": name, "bound": bound, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak,
+         "traffic": None, "us_per_launch": us, key: work}
+    d.update(extra)
+    return d
+
+
+def gemm_tn_stage4(B, base_points, device):
+    """Weight gradient of the stage-4 per-point GEMM: dWcat (12832 x 256) = dY^T X over
+    M = B * 8*base rows.  Algorithmic flops 2*M*N*K."""
+    M, N, K = B * 8 * base_points, 50 * 256 + 32, 256
+    dy = torch.randn(M, N, device=device)
+    x = torch.randn(M, K, device=device)
+    dw = torch.zeros(N, K, device=device)
+    L = _lib.lib()
+
+    def run():
+        dw.zero_()
+        check(L.pdgn_gemm_tn(ctypes.c_longlong(M), N, K, ptr(dy), ptr(x), ptr(dw), stream_of(dy)), "pdgn_gemm_tn")
+    us = _time_us(run)
+    z = _time_us(lambda: dw.zero_())
+    return _entry("gemm_tn_kernel (dWcat of the stage-4 per-point GEMM, M=%d N=%d K=%d)" % (M, N, K), "mfma",
+                  2.0 * M * N * K, us - z, shape=[M, N, K])
+
+
+def bn_act_backward_stage4(B, base_points, device):
+    """BatchNorm+LeakyReLU(+product) backward of inte_conv_hk's output at stage 4: rows = B*N*5,
+    C = 1024.  Algorithmic bytes: reduce reads x, dy, mul; apply reads x, dy, mul and writes dx, dmul
+    = 8 * rows * C * 4."""
+    rows, C = B * 8 * base_points * 5, 1024
+    x = torch.randn(rows, C, device=device)
+    dy = torch.randn(rows, C, device=device)
+    mul = torch.rand(rows, C, device=device)
+    stats = torch.cat([torch.ones(C), torch.zeros(C), torch.zeros(C), torch.ones(C)]).to(device)
+    L = _lib.lib()
+    L.pdgn_bn_scratch_floats.restype = ctypes.c_longlong
+    scratch = torch.empty(L.pdgn_bn_scratch_floats(ctypes.c_longlong(rows), C), device=device)
+    bs = torch.empty(2 * C, device=device)
+    dx, dmul = torch.empty_like(x), torch.empty_like(x)
+
+    def run():
+        check(L.pdgn_bn_act_backward(ctypes.c_longlong(rows), C, 2, 1, ptr(x), ptr(dy), ptr(mul), ptr(stats),
+                                     ptr(scratch), ptr(bs), ptr(dx), ptr(dmul), stream_of(x)), "pdgn_bn_act_backward")
+    us = _time_us(run, iters=10)
+    return _entry("cl_bwd_reduce + cl_bwd_apply (BN+LeakyReLU*w backward, rows=%d C=%d)" % (rows, C), "hbm",
+                  8.0 * rows * C * 4, us)
 
 
 def window_gather_sum_stage4(B, base_points, device):
@@ -43,11 +105,8 @@ def window_gather_sum_stage4(B, base_points, device):
         check(L.pdgn_window_gather_sum(B, N, k, ldy, T, P, C, 0, T * C, ptr(Y), ptr(idx), None, ptr(out),
                                        stream_of(Y)), "pdgn_window_gather_sum")
     us = _time_us(run)
-    bytes_ = B * N * ((T * P + 1 + P) * C * 4 + k * 4)
-    return {"kernel": "wgs_fwd_kernel<4> (inte_conv_hk gather, stage 4)", "bound": "hbm",
-            "achieved": bytes_ / us / 1e3, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": bytes_ / us / 1e3 / HBM_PEAK_GBS, "traffic": None, "us_per_launch": us,
-            "algorithmic_bytes_per_launch": bytes_}
+    return _entry("wgs_fwd_kernel<4> (inte_conv_hk gather, stage 4)", "hbm",
+                  float(B * N * ((T * P + 1 + P) * C * 4 + k * 4)), us)
 
 
 def feature_knn_stage4(B, base_points, device):
@@ -61,17 +120,44 @@ def feature_knn_stage4(B, base_points, device):
     def run():
         check(L.pdgn_feature_knn(B, F, N, k, ptr(x), ptr(sq), ptr(idx), stream_of(x)), "pdgn_feature_knn")
     us = _time_us(run)
-    flops = 2.0 * B * N * N * F
-    return {"kernel": "feat_knn_kernel<128> (stage-4 kNN graph)", "bound": "mfma",
-            "achieved": flops / us / 1e6, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": flops / us / 1e6 / MFMA_F32_PEAK_TFLOPS, "traffic": None, "us_per_launch": us,
-            "algorithmic_flops_per_launch": flops}
+    return _entry("feat_knn_kernel<128> (stage-4 kNN graph)", "mfma", 2.0 * B * N * N * F, us)
+
+
+def knn3_largest(B, base_points, device):
+    """3-D kNN of the local-pair loss at its largest call (n = 16*base, m = 8*base, k = 20):
+    algorithmic bytes B*(12n + 12m + 8mk); VALU-bound."""
+    n, m, k = 16 * base_points, 8 * base_points, 20
+    xyz = torch.randn(B, n, 3, device=device)
+    q = xyz[:, :m].contiguous()
+    idx = torch.empty(B, m, k, device=device, dtype=torch.int32)
+    d2 = torch.empty(B, m, k, device=device)
+    L = _lib.lib()
+
+    def run():
+        check(L.pdgn_knnquery(B, n, m, k, ptr(xyz), ptr(q), ptr(idx), ptr(d2), stream_of(xyz)), "pdgn_knnquery")
+    us = _time_us(run)
+    e = _entry("knn3_wave_kernel (n=%d, m=%d, k=20)" % (n, m), "hbm", float(B * (12 * n + 12 * m + 8 * m * k)), us)
+    e["distance_evals_per_s"] = B * n * m / us * 1e6
+    e["note"] = "VALU-bound: intensity ~80 flop/B; HBM fraction reported because the north star asks for it"
+    return e
+
+
+ENTRIES = (gemm_tn_stage4, bn_act_backward_stage4, window_gather_sum_stage4, feature_knn_stage4, knn3_largest)
 
 
 def measure(B, base_points, device):
-    """Roofline object of the dominant hand-written kernel (+ the runners-up under "others")."""
-    entries = [window_gather_sum_stage4(B, base_points, device), feature_knn_stage4(B, base_points, device)]
-    entries.sort(key=lambda e: -e["us_per_launch"])
+    """Roofline object of the dominant hand-written kernel of the step (largest share of the
+    step's kernel time in profiles/: gemm_tn_kernel) with the runners-up under "others"."""
+    entries = [f(B, base_points, device) for f in ENTRIES]
+    try:
+        with open(_TRAFFIC) as f:
+            traffic = json.load(f)
+        for e in entries:
+            for key, val in traffic.items():
+                if e["kernel"].startswith(key):
+                    e["traffic"] = val
+    except (OSError, ValueError):
+        pass
     top = dict(entries[0])
     top["others"] = entries[1:]
     return top
