@@ -132,25 +132,42 @@ __global__ void cl_eval_stats_kernel(int C, float eps, const float *__restrict__
     stats[3 * C + c] = invstd;
 }
 
-// y = act(x*scale + shift) [* mul]
-__global__ __launch_bounds__(BN_THREADS) void cl_apply_kernel(long long total4, int CG, int act,
+// y = act(x*scale + shift) [* mul].  Same geometry as the reductions: a thread owns one float4
+// column group (its scale/shift live in registers) and streams its rows four at a time.
+__global__ __launch_bounds__(BN_THREADS) void cl_apply_kernel(long long R, int C, int cgb, int rows_per_block, int act,
                                                               const float *__restrict__ x,
                                                               const float *__restrict__ stats,
                                                               const float *__restrict__ mul, float *__restrict__ y) {
-    const long long e = (long long)blockIdx.x * BN_THREADS + threadIdx.x;
-    if (e >= total4) return;
-    const int c4 = (int)(e % CG) * 4;
-    const float4 v = reinterpret_cast<const float4 *>(x)[e];
-    const float4 sc = *reinterpret_cast<const float4 *>(stats + c4);
-    const float4 sh = *reinterpret_cast<const float4 *>(stats + CG * 4 + c4);
-    float4 o;
-    o.x = act_fwd(__fmaf_rn(v.x, sc.x, sh.x), act); o.y = act_fwd(__fmaf_rn(v.y, sc.y, sh.y), act);
-    o.z = act_fwd(__fmaf_rn(v.z, sc.z, sh.z), act); o.w = act_fwd(__fmaf_rn(v.w, sc.w, sh.w), act);
-    if (mul) {
-        const float4 m = reinterpret_cast<const float4 *>(mul)[e];
-        o.x *= m.x; o.y *= m.y; o.z *= m.z; o.w *= m.w;
+    const int cgl = threadIdx.x % cgb, rlane = threadIdx.x / cgb, rl = BN_THREADS / cgb;
+    const int cgi = blockIdx.x * cgb + cgl;
+    if (cgi * 4 >= C) return;
+    const long long r0 = (long long)blockIdx.y * rows_per_block;
+    const long long r1 = min(R, r0 + rows_per_block);
+    const float4 sc = *reinterpret_cast<const float4 *>(stats + cgi * 4);
+    const float4 sh = *reinterpret_cast<const float4 *>(stats + C + cgi * 4);
+    const bool has_mul = mul != nullptr;
+    for (long long r = r0 + rlane; r < r1; r += 4 * rl) {
+        float4 v[4], m[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long long rr = r + (long long)u * rl;
+            if (rr < r1) {
+                v[u] = *reinterpret_cast<const float4 *>(x + rr * C + cgi * 4);
+                if (has_mul) m[u] = *reinterpret_cast<const float4 *>(mul + rr * C + cgi * 4);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long long rr = r + (long long)u * rl;
+            if (rr < r1) {
+                float4 o;
+                o.x = act_fwd(__fmaf_rn(v[u].x, sc.x, sh.x), act); o.y = act_fwd(__fmaf_rn(v[u].y, sc.y, sh.y), act);
+                o.z = act_fwd(__fmaf_rn(v[u].z, sc.z, sh.z), act); o.w = act_fwd(__fmaf_rn(v[u].w, sc.w, sh.w), act);
+                if (has_mul) { o.x *= m[u].x; o.y *= m[u].y; o.z *= m[u].z; o.w *= m[u].w; }
+                *reinterpret_cast<float4 *>(y + rr * C + cgi * 4) = o;
+            }
+        }
     }
-    reinterpret_cast<float4 *>(y)[e] = o;
 }
 
 // bsums[c] += sum dz ; bsums[C+c] += sum dz*xhat   (dz = dy [* mul] * act'(z))
@@ -201,54 +218,80 @@ __global__ __launch_bounds__(BN_THREADS) void cl_bwd_reduce_kernel(long long R, 
     }
 }
 
-// bsums[c] = sum over partials (fp64 accumulation, fp32 result): [sum dz | sum dz*xhat]
-__global__ __launch_bounds__(FIN_CH * FIN_PL) void cl_bwd_finalize_kernel(int C, int nparts,
+// bsums[c] = sum over partials (fp64 accumulation, fp32 result): [sum dz | sum dz*xhat], and the
+// per-channel coefficients of the input gradient: dx = scale*dz - ca - cb*x with
+//   cb = scale*invstd*mean(dz*xhat),  ca = scale*mean(dz) - cb*mean   (zero in eval mode).
+__global__ __launch_bounds__(FIN_CH * FIN_PL) void cl_bwd_finalize_kernel(long long R, int C, int nparts, int training,
                                                                          const float *__restrict__ part,
-                                                                         float *__restrict__ bsums) {
+                                                                         const float *__restrict__ stats,
+                                                                         float *__restrict__ bsums,
+                                                                         float *__restrict__ coef) {
     __shared__ double red[FIN_PL][FIN_CH];
     const int c = blockIdx.x * FIN_CH + threadIdx.x % FIN_CH;
-    const bool ok = c < 2 * C;
-    const double s = fin_reduce(part, nparts, (size_t)2 * C, c, ok, red);
-    if (ok && threadIdx.x < FIN_CH) bsums[c] = (float)s;
+    const bool ok = c < C;
+    const double s1 = fin_reduce(part, nparts, (size_t)2 * C, c, ok, red);
+    __syncthreads();
+    const double s2 = fin_reduce(part, nparts, (size_t)2 * C, C + c, ok, red);
+    if (!ok || threadIdx.x >= FIN_CH) return;
+    bsums[c] = (float)s1;
+    bsums[C + c] = (float)s2;
+    float ca = 0.f, cb = 0.f;
+    if (training) {
+        const float sc = stats[c], mu = stats[2 * C + c], is = stats[3 * C + c];
+        cb = sc * is * (float)(s2 / (double)R);
+        ca = sc * (float)(s1 / (double)R) - cb * mu;
+    }
+    coef[c] = ca;
+    coef[C + c] = cb;
 }
 
-// dx = scale*(dz - s1/R - xhat*s2/R) (training) or scale*dz (eval); optionally dmul = dy*act(z)
-__global__ __launch_bounds__(BN_THREADS) void cl_bwd_apply_kernel(long long total4, long long R, int CG, int act,
-                                                                  int training, const float *__restrict__ x,
+// dx = scale*dz - ca - cb*x   (dz = dy [* mul] * act'(z));  optionally dmul = dy*act(z)
+__global__ __launch_bounds__(BN_THREADS) void cl_bwd_apply_kernel(long long R, int C, int cgb, int rows_per_block, int act,
+                                                                  const float *__restrict__ x,
                                                                   const float *__restrict__ dy,
                                                                   const float *__restrict__ mul,
                                                                   const float *__restrict__ stats,
-                                                                  const float *__restrict__ bsums,
+                                                                  const float *__restrict__ coef,
                                                                   float *__restrict__ dx, float *__restrict__ dmul) {
-    const long long e = (long long)blockIdx.x * BN_THREADS + threadIdx.x;
-    if (e >= total4) return;
-    const int C = CG * 4, c4 = (int)(e % CG) * 4;
-    const float4 v = reinterpret_cast<const float4 *>(x)[e];
-    float4 g = reinterpret_cast<const float4 *>(dy)[e];
-    const float *vv = reinterpret_cast<const float *>(&v);
-    float *gg = reinterpret_cast<float *>(&g);
-    float4 o, om;
-    float *oo = reinterpret_cast<float *>(&o), *omm = reinterpret_cast<float *>(&om);
-    float4 m = make_float4(1.f, 1.f, 1.f, 1.f);
-    if (mul) m = reinterpret_cast<const float4 *>(mul)[e];
-    const float *mm = reinterpret_cast<const float *>(&m);
-    const float invR = 1.0f / (float)R;
+    const int cgl = threadIdx.x % cgb, rlane = threadIdx.x / cgb, rl = BN_THREADS / cgb;
+    const int cgi = blockIdx.x * cgb + cgl;
+    if (cgi * 4 >= C) return;
+    const long long r0 = (long long)blockIdx.y * rows_per_block;
+    const long long r1 = min(R, r0 + rows_per_block);
+    float sc[4], sh[4], ca[4], cb[4];
+    *reinterpret_cast<float4 *>(sc) = *reinterpret_cast<const float4 *>(stats + cgi * 4);
+    *reinterpret_cast<float4 *>(sh) = *reinterpret_cast<const float4 *>(stats + C + cgi * 4);
+    *reinterpret_cast<float4 *>(ca) = *reinterpret_cast<const float4 *>(coef + cgi * 4);
+    *reinterpret_cast<float4 *>(cb) = *reinterpret_cast<const float4 *>(coef + C + cgi * 4);
+    const bool has_mul = mul != nullptr, want_dmul = dmul != nullptr;
+    for (long long r = r0 + rlane; r < r1; r += 2 * rl) {
+        float v[2][4], g[2][4], m[2][4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int c = c4 + j;
-        const float sc = stats[c], z = __fmaf_rn(vv[j], sc, stats[C + c]);
-        omm[j] = gg[j] * act_fwd(z, act);
-        const float dz = gg[j] * mm[j] * act_grad(z, act);
-        if (training) {
-            const float xhat = (vv[j] - stats[2 * C + c]) * stats[3 * C + c];
-            const float m1 = bsums[c] * invR, m2 = bsums[C + c] * invR;
-            oo[j] = sc * (dz - m1 - xhat * m2);
-        } else {
-            oo[j] = sc * dz;
+        for (int u = 0; u < 2; ++u) {
+            const long long rr = r + (long long)u * rl;
+            if (rr < r1) {
+                *reinterpret_cast<float4 *>(v[u]) = *reinterpret_cast<const float4 *>(x + rr * C + cgi * 4);
+                *reinterpret_cast<float4 *>(g[u]) = *reinterpret_cast<const float4 *>(dy + rr * C + cgi * 4);
+                if (has_mul) *reinterpret_cast<float4 *>(m[u]) = *reinterpret_cast<const float4 *>(mul + rr * C + cgi * 4);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const long long rr = r + (long long)u * rl;
+            if (rr < r1) {
+                float o[4], om[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float z = __fmaf_rn(v[u][j], sc[j], sh[j]);
+                    om[j] = g[u][j] * act_fwd(z, act);
+                    const float dz = (has_mul ? g[u][j] * m[u][j] : g[u][j]) * act_grad(z, act);
+                    o[j] = __fmaf_rn(sc[j], dz, -ca[j]) - cb[j] * v[u][j];
+                }
+                *reinterpret_cast<float4 *>(dx + rr * C + cgi * 4) = *reinterpret_cast<float4 *>(o);
+                if (want_dmul) *reinterpret_cast<float4 *>(dmul + rr * C + cgi * 4) = *reinterpret_cast<float4 *>(om);
+            }
         }
     }
-    reinterpret_cast<float4 *>(dx)[e] = o;
-    if (dmul) reinterpret_cast<float4 *>(dmul)[e] = om;
 }
 
 // ---------------------------------------------------------------------------- C ABI
@@ -275,7 +318,7 @@ extern "C" long long pdgn_bn_scratch_floats(long long rows, int c) {
     if (rows < 1 || c < 4 || c % 4) return PDGN_ERR_INVALID;
     int cgb, gx, gy, rpb;
     cl_geometry(rows, c, &cgb, &gx, &gy, &rpb);
-    return (long long)gy * 2 * c;
+    return (long long)gy * 2 * c + 2 * c;                  // partials + the backward's coefficient row
 }
 
 extern "C" int pdgn_bn_stats(long long rows, int c, float eps, float momentum, const float *x, const float *gamma,
@@ -302,9 +345,10 @@ extern "C" int pdgn_bn_eval_stats(int c, float eps, const float *gamma, const fl
 extern "C" int pdgn_bn_act_forward(long long rows, int c, int act, const float *x, const float *stats, const float *mul,
                                    float *y, pdgn_stream_t stream) {
     if (rows < 1 || c < 4 || c % 4 || act < 0 || act > 2) return PDGN_ERR_INVALID;
-    const long long total4 = rows * (c / 4);
-    hipLaunchKernelGGL(cl_apply_kernel, dim3(cdiv(total4, BN_THREADS)), dim3(BN_THREADS), 0, (hipStream_t)stream,
-                       total4, c / 4, act, x, stats, mul, y);
+    int cgb, gx, gy, rpb;
+    cl_geometry(rows, c, &cgb, &gx, &gy, &rpb);
+    hipLaunchKernelGGL(cl_apply_kernel, dim3(gx, gy), dim3(BN_THREADS), 0, (hipStream_t)stream, rows, c, cgb, rpb, act,
+                       x, stats, mul, y);
     return pdgn_launch_status();
 }
 
@@ -317,9 +361,10 @@ extern "C" int pdgn_bn_act_backward(long long rows, int c, int act, int training
     cl_geometry(rows, c, &cgb, &gx, &gy, &rpb);
     hipLaunchKernelGGL(cl_bwd_reduce_kernel, dim3(gx, gy), dim3(BN_THREADS), 0, s, rows, c, cgb, rpb, act, x, dy, mul,
                        stats, scratch);
-    hipLaunchKernelGGL(cl_bwd_finalize_kernel, dim3(cdiv(2 * c, FIN_CH)), dim3(FIN_CH * FIN_PL), 0, s, c, gy, scratch, bsums);
-    const long long total4 = rows * (c / 4);
-    hipLaunchKernelGGL(cl_bwd_apply_kernel, dim3(cdiv(total4, BN_THREADS)), dim3(BN_THREADS), 0, s, total4, rows,
-                       c / 4, act, training, x, dy, mul, stats, bsums, dx, dmul);
+    float *coef = scratch + (size_t)gy * 2 * c;                // [ca | cb], behind the partials
+    hipLaunchKernelGGL(cl_bwd_finalize_kernel, dim3(cdiv(c, FIN_CH)), dim3(FIN_CH * FIN_PL), 0, s, rows, c, gy, training,
+                       scratch, stats, bsums, coef);
+    hipLaunchKernelGGL(cl_bwd_apply_kernel, dim3(gx, gy), dim3(BN_THREADS), 0, s, rows, c, cgb, rpb, act, x, dy, mul,
+                       stats, coef, dx, dmul);
     return pdgn_launch_status();
 }
