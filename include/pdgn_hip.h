@@ -113,12 +113,14 @@ int pdgn_feature_knn(int b, int f, int n, int k, const float *x, float *sqnorm, 
 
 /* Gather half of the re-associated edge convolutions (inte_conv_hk / conv2 / conv_fea / conv_xyz,
  * models/PDGNet_v2.py:559-625 applied to the edge tensors of :462-477, :505-525):
- *   out[b,n,p,c] = bias[c] + Y[b,n,offc+c] + sum_{t<T} Y[b, idx[b,n,p+t], off + t*C + c]
- * Y (b,n,ldy) point-major, idx (b,n,k) with k >= T+P-1, out (b,n,P,C); bias may be NULL;
- * offc < 0 drops the centre term. */
+ *   out[b,n,p,c] = bias[b*bias_bstride + c] + Y[b,n,offc+c] + sum_{t<T} Y[b, idx[b,n,p+t], off + t*C + c]
+ * Y (b,n,ldy) point-major, idx (b,n,k) with k >= T+P-1, out (b,n,P,C); bias may be NULL, is shared
+ * (bias_bstride = 0) or per batch (bias_bstride = C: the contribution of input channels that are
+ * constant over the points of a sample -- the broadcast global vector of :704-708 -- never enters
+ * the per-point GEMM); offc < 0 drops the centre term. */
 int pdgn_window_gather_sum(int b, int n, int k, int ldy, int T, int P, int C, int off, int offc,
-                           const float *Y, const int32_t *idx, const float *bias, float *out,
-                           pdgn_stream_t stream);
+                           const float *Y, const int32_t *idx, const float *bias, int bias_bstride,
+                           float *out, pdgn_stream_t stream);
 
 /* Its adjoint: dY[b, idx[b,n,p+t], off+t*C+c] += dout[b,n,p,c] (atomic), and
  * dY[b,n,offc+c] = sum_p dout[b,n,p,c].  dY must be zero-filled by the caller. */

@@ -5,7 +5,7 @@
 // (inte_conv_hk :562/:622, conv2 :559/:602, conv_fea :609).  Convolution is linear, so
 //     sum_c sum_t W[o,c,t] e[c,n,p+t]  =  sum_t (W2_t X)[o, idx(n,p+t)]  +  ((sum_t W1_t - W2_t) X)[o,n]
 // where Y = [W2_0 X | .. | W2_{T-1} X | Wc X] is ONE dense per-point GEMM (MFMA) and what remains is
-//     out[b,n,p,c] = bias[c] + Y[b,n,offc+c] + sum_{t<T} Y[b, idx[b,n,p+t], off + t*C + c]
+//     out[b,n,p,c] = bias[b*bias_bstride + c] + Y[b,n,offc+c] + sum_{t<T} Y[b, idx[b,n,p+t], off + t*C + c]
 // -- this kernel.  It is a pure row gather (HBM/L2-bound): point-major rows, channels contiguous,
 // float4 per lane, the neighbour index wave-uniform.
 // Backward scatters dout rows back onto dY with contiguous 256-B wave atomics.
@@ -17,7 +17,7 @@ template <int VEC>
 __global__ __launch_bounds__(WGS_THREADS) void wgs_fwd_kernel(
     long long total, int n, int k, int ldy, int T, int P, int CV, int off, int offc,
     const float *__restrict__ Y, const int32_t *__restrict__ idx, const float *__restrict__ bias,
-    float *__restrict__ out) {
+    int bias_bstride, float *__restrict__ out) {
     typedef float vec_t __attribute__((ext_vector_type(VEC)));
     long long e = (long long)blockIdx.x * WGS_THREADS + threadIdx.x;
     if (e >= total) return;
@@ -29,7 +29,7 @@ __global__ __launch_bounds__(WGS_THREADS) void wgs_fwd_kernel(
     const int c = cv * VEC;
     const int32_t *I = idx + bn * k + p;
     vec_t acc;
-    if (bias) acc = *reinterpret_cast<const vec_t *>(bias + c);
+    if (bias) acc = *reinterpret_cast<const vec_t *>(bias + (bn / n) * bias_bstride + c);
     else for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
     if (offc >= 0) acc += *reinterpret_cast<const vec_t *>(Y + bn * ldy + offc + c);
     for (int t = 0; t < T; ++t) {
@@ -66,7 +66,8 @@ static bool wgs_ok(int b, int n, int k, int ldy, int T, int P, int C, int off, i
 }
 
 extern "C" int pdgn_window_gather_sum(int b, int n, int k, int ldy, int T, int P, int C, int off, int offc,
-                                      const float *Y, const int32_t *idx, const float *bias, float *out,
+                                      const float *Y, const int32_t *idx, const float *bias, int bias_bstride,
+                                      float *out,
                                       pdgn_stream_t stream) {
     if (!wgs_ok(b, n, k, ldy, T, P, C, off, offc)) return PDGN_ERR_INVALID;
     if (b == 0) return 0;
@@ -75,11 +76,11 @@ extern "C" int pdgn_window_gather_sum(int b, int n, int k, int ldy, int T, int P
     if (v4) {
         long long total = (long long)b * n * P * (C / 4);
         hipLaunchKernelGGL(wgs_fwd_kernel<4>, dim3(cdiv(total, WGS_THREADS)), dim3(WGS_THREADS), 0, s, total,
-                           n, k, ldy, T, P, C / 4, off, offc, Y, idx, bias, out);
+                           n, k, ldy, T, P, C / 4, off, offc, Y, idx, bias, bias_bstride, out);
     } else {
         long long total = (long long)b * n * P * C;
         hipLaunchKernelGGL(wgs_fwd_kernel<1>, dim3(cdiv(total, WGS_THREADS)), dim3(WGS_THREADS), 0, s, total,
-                           n, k, ldy, T, P, C, off, offc, Y, idx, bias, out);
+                           n, k, ldy, T, P, C, off, offc, Y, idx, bias, bias_bstride, out);
     }
     return pdgn_launch_status();
 }

@@ -55,12 +55,13 @@ class EdgeGatherSum(Function):
         for (T, P, C, off, offc), bias in zip(specs, biases):
             out = torch.empty((b, n, P, C), dtype=F32, device=Y.device)
             bias_c = bias.detach().contiguous() if bias is not None else None
+            bstride = C if (bias is not None and bias.dim() == 2) else 0          # (B,C): per-sample bias
             check(_lib.lib().pdgn_window_gather_sum(b, n, k, ldy, T, P, C, off, offc, ptr(Y), ptr(idx),
-                                                    ptr(bias_c), ptr(out), stream_of(Y)),
+                                                    ptr(bias_c), bstride, ptr(out), stream_of(Y)),
                   "pdgn_window_gather_sum")
             outs.append(out)
         ctx.specs, ctx.shape = specs, (b, n, ldy, k)
-        ctx.has_bias = [bias is not None for bias in biases]
+        ctx.has_bias = [0 if bias is None else bias.dim() for bias in biases]   # 0 none, 1 shared, 2 per sample
         ctx.save_for_backward(idx)
         return tuple(outs)
 
@@ -82,15 +83,21 @@ class EdgeGatherSum(Function):
                 check(L.pdgn_window_gather_sum_backward_csr(b, n, k, ldy, T, P, C, off, offc, ptr(dout), ptr(rowptr),
                                                             ptr(edges), ptr(dY), stream_of(dout)),
                       "pdgn_window_gather_sum_backward_csr")
-                dbias.append(dout.sum(dim=(0, 1, 2)) if hb else None)
+                dbias.append(_dbias(dout, hb))
             return (dY, None, None) + tuple(dbias)
         dY = torch.zeros((b, n, ldy), dtype=F32, device=idx.device)
         for (T, P, C, off, offc), dout, hb in zip(ctx.specs, douts, ctx.has_bias):
             dout = dout.contiguous()
             check(L.pdgn_window_gather_sum_backward(b, n, k, ldy, T, P, C, off, offc, ptr(dout), ptr(idx), ptr(dY),
                                                     stream_of(dout)), "pdgn_window_gather_sum_backward")
-            dbias.append(dout.sum(dim=(0, 1, 2)) if hb else None)
+            dbias.append(_dbias(dout, hb))
         return (dY, None, None) + tuple(dbias)
+
+
+def _dbias(dout, kind):
+    if kind == 0:
+        return None
+    return dout.sum(dim=(0, 1, 2)) if kind == 1 else dout.sum(dim=(1, 2))
 
 
 def transposed_graph(idx):
@@ -164,21 +171,33 @@ class PointDeconv(nn.Module):
                               pc.transpose(1, 2).contiguous() if pc is not None else None, idx=idx, x_cf=x)
         return out.transpose(1, 2)
 
-    def forward_cl(self, xt, pct=None, idx=None, x_cf=None):
-        """Point-major layout: xt (B,N,Fin) [, pct (B,N,3)] -> (B,2N,Fout) (pre bn_uc, like the
-        reference block's return value).  x_cf, if given, is the same tensor as (B,Fin,N)."""
-        B, N, Fi = xt.shape
-        Fo, k = self.Fout, self.k
+    def forward_cl(self, xt, pct=None, idx=None, x_cf=None, const=None):
+        """Point-major layout: xt (B,N,Fv) [, pct (B,N,3)] -> (B,2N,Fout) (pre bn_uc, like the
+        reference block's return value).  x_cf, if given, is the full input as (B,Fin,N).
+        `const` (B,Fc): the first Fc = Fin - Fv input channels when they are constant over the points
+        of a sample (the broadcast global vector xs of :704-708); their contribution to every conv is a
+        per-sample vector, so they never enter the per-point GEMM (half its FLOPs at levels 2-4)."""
+        B, N, Fv = xt.shape
+        Fi, Fo, k = self.Fin, self.Fout, self.k
+        Fc = Fi - Fv
         training = self.training
         if idx is None:
             with torch.no_grad():
-                xc = x_cf if x_cf is not None else xt.transpose(1, 2)
-                idx = feature_knn(xc.detach().contiguous(), k)
+                if x_cf is None:
+                    x_cf = xt.transpose(1, 2)
+                    if const is not None:
+                        x_cf = torch.cat((const.unsqueeze(2).expand(-1, -1, N), x_cf), 1)
+                idx = feature_knn(x_cf.detach().contiguous(), k)
         elif idx.dtype != I32:
             idx = idx.to(I32)
         idx = idx.contiguous()
         Wcat, Wb, T, P = self._assemble()
-        Y = linear_cl(xt.reshape(B * N, Fi), Wcat).view(B, N, -1)      # (B,N,Mw) -- per-point GEMM
+        if const is None:
+            Y = linear_cl(xt.reshape(B * N, Fi), Wcat).view(B, N, -1)  # (B,N,Mw) -- per-point GEMM
+            Yc = None
+        else:
+            Y = linear_cl(xt.reshape(B * N, Fv), Wcat[:, Fc:].contiguous()).view(B, N, -1)
+            Yc = F.linear(const, Wcat[:, :Fc])                         # (B,Mw): per-sample contribution
         o_i, o_ci = 0, T * 4 * Fi
         o_a = o_ci + 4 * Fi
         o_ca = o_a + k * 2 * Fo
@@ -188,6 +207,9 @@ class PointDeconv(nn.Module):
         if self.bilateral:
             specs.append((1, k, 16, o_p, o_p + 16))
             biases.append(self.conv_fea[0].bias)
+        if Yc is not None:                                             # bias_b = bias + centre + sum of taps of Yc
+            biases = [bias.unsqueeze(0) + Yc[:, offc:offc + C] + Yc[:, off:off + T_ * C].reshape(B, T_, C).sum(1)
+                      for (T_, P_, C, off, offc), bias in zip(specs, biases)]
         outs = EdgeGatherSum.apply(Y, idx, tuple(specs), *biases)
         inte_pre, a_pre = outs[0], outs[1]                             # (B,N,P,4F), (B,N,1,2Fo)
         w = None

@@ -67,15 +67,20 @@ class BilateralBlock(nn.Module):
         if level < 4:
             self.g_fc = nn.Sequential(nn.Linear(Fout, 512), nn.BatchNorm1d(512), nn.LeakyReLU(inplace=True))
 
-    def forward_cl(self, xt, pct=None, idx=None):
-        """xt (B,N,Fin) [, pct (B,N,3)] -> xs (B,Fout), x_ec (B,2N,Fout), g (B,512)|None."""
+    def forward_cl(self, xt, pct=None, idx=None, const=None):
+        """xt (B,N,Fv) [, pct (B,N,3)] -> xs (B,Fout), x_ec (B,2N,Fout), g (B,512)|None.  The block's
+        input is cat([const broadcast over the points (B,Fc), xt]) along channels (:708) -- passed in two
+        pieces so that the broadcast half is never materialised per point."""
         B, N, _ = xt.shape
-        xs = self.fc(xt.max(dim=1)[0])                          # MaxPool2d((1,N)) over the points
+        pooled = xt.max(dim=1)[0]                               # MaxPool2d((1,N)) over the points
+        if const is not None:
+            pooled = torch.cat((const, pooled), 1)              # max of a broadcast channel is itself
+        xs = self.fc(pooled)
         if self.level == 1:
             dec, bn = self.upsample_cov[0], self.upsample_cov[1]
         else:
             dec, bn = self.upsample_cov, self.bn_uc
-        x_ec = dec.forward_cl(xt, pct, idx=idx)                 # (B,2N,Fout)
+        x_ec = dec.forward_cl(xt, pct, idx=idx, const=const)    # (B,2N,Fout)
         x_ec = _bn_act(x_ec.reshape(B * 2 * N, -1), bn, self.training).view(B, 2 * N, -1)
         g = self.g_fc(xs) if self.level < 4 else None
         return xs, x_ec, g
@@ -119,11 +124,11 @@ class PointGenerator(nn.Module):
     def forward(self, z, idx=(None, None, None, None)):
         B = z.shape[0]
         xt = self.fc1(z).view(B, 32, self.base_points).transpose(1, 2).contiguous()    # (B,N0,32)
-        pct, clouds = None, []
+        pct, const, clouds = None, None, []
         blocks = (self.bilateral1, self.bilateral2, self.bilateral3, self.bilateral4)
         heads = (self.mlp1, self.mlp2, self.mlp3, self.mlp4)
         for lvl in range(4):
-            xs, x_ec, g = blocks[lvl].forward_cl(xt, pct, idx=idx[lvl])
+            xs, x_ec, g = blocks[lvl].forward_cl(xt, pct, idx=idx[lvl], const=const)
             M, Fo = x_ec.shape[1], x_ec.shape[2]
             rows = x_ec.reshape(B * M, Fo)
             if lvl < 3:
@@ -132,8 +137,7 @@ class PointGenerator(nn.Module):
                 p = _head_rows(heads[lvl], rows, B, g=xs, n_const=Fo)           # mlp4 sees cat(xs, x_ec) :875
             pct = p.view(B, M, 3)
             clouds.append(pct.transpose(1, 2))                                  # (B,3,M) like the reference
-            if lvl < 3:
-                xt = torch.cat((xs.unsqueeze(1).expand(-1, M, -1), x_ec), 2)    # next block's input :708
+            xt, const = x_ec, xs                    # next block's input is cat(xs broadcast, x_ec) :708
         return tuple(clouds)
 
 

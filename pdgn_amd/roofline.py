@@ -102,7 +102,7 @@ def window_gather_sum_stage4(B, base_points, device):
     L = _lib.lib()
 
     def run():
-        check(L.pdgn_window_gather_sum(B, N, k, ldy, T, P, C, 0, T * C, ptr(Y), ptr(idx), None, ptr(out),
+        check(L.pdgn_window_gather_sum(B, N, k, ldy, T, P, C, 0, T * C, ptr(Y), ptr(idx), None, 0, ptr(out),
                                        stream_of(Y)), "pdgn_window_gather_sum")
     us = _time_us(run)
     return _entry("wgs_fwd_kernel<4> (inte_conv_hk gather, stage 4)", "hbm",

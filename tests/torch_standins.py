@@ -20,7 +20,7 @@ class EdgeGatherSumTorch:
                 g = torch.gather(cols, 1, nb.reshape(B, N * P, 1).expand(B, N * P, C)).view(B, N, P, C)
                 acc = acc + g
             if bias is not None:
-                acc = acc + bias
+                acc = acc + (bias if bias.dim() == 1 else bias.view(B, 1, 1, C))   # shared or per-sample
             outs.append(acc)
         return tuple(outs)
 
