@@ -164,6 +164,14 @@ int pdgn_bn_act_backward(long long rows, int c, int act, int training, const flo
                          const float *dy, const float *mul, const float *stats, float *scratch,
                          float *bsums, float *dx, float *dmul, pdgn_stream_t stream);
 
+/* Softmax over the k neighbour slots fused with the slot/channel interleave of
+ * models/PDGNet_v2.py:634-641: h (m,k,c) -> w (m, k/2, 2c) with w[m,p,2c'+j] = softmax_s(h[m,:,c'])[s=(k/2)j+p].
+ * k even, k <= 32. */
+int pdgn_softmax_slots_permute(long long m, int k, int c, const float *h, float *w, pdgn_stream_t stream);
+/* dh[m,s,c'] = w_s (dw_s - sum_s' w_s' dw_s'), w / dw in the permuted layout. */
+int pdgn_softmax_slots_permute_backward(long long m, int k, int c, const float *w, const float *dw,
+                                        float *dh, pdgn_stream_t stream);
+
 /* Weight gradient of a point-major dense layer on the fp32 matrix cores, reduction split over
  * workgroups:  dW (n x k) += dY (m x n)^T  X (m x k), all row-major, m >> n, k.
  * dW must be zero-filled by the caller; n % 4 == 0, k % 4 == 0. */

@@ -71,16 +71,23 @@ __global__ __launch_bounds__(BN_THREADS) void cl_stats_kernel(long long R, int C
 
 // From the fp64 sums: mean, biased var -> scale/shift/mean/invstd; running stats with momentum and
 // the unbiased variance (nn.BatchNorm semantics).  stats out: [scale | shift | mean | invstd] (4C).
-#define FIN_CH 16      // channels per finalize block
-#define FIN_PL 16      // part lanes per channel
+#define FIN_CH 4       // channels per finalize block
+#define FIN_PL 64      // part lanes per channel (short dependent-load chains: nparts/64 steps)
 
-// Sum `nparts` fp32 partials of channel-slot `c` (stride `ld`) in fp64: 16 lanes per channel, LDS tree.
+// Sum `nparts` fp32 partials of channel-slot `c` (stride `ld`) in fp64: 64 lanes per channel, LDS tree.
 __device__ __forceinline__ double fin_reduce(const float *__restrict__ part, int nparts, size_t ld, int c, bool ok,
                                              double (*red)[FIN_CH]) {
     const int cl = threadIdx.x % FIN_CH, pl = threadIdx.x / FIN_CH;
     double s = 0;
-    if (ok)
-        for (int p = pl; p < nparts; p += FIN_PL) s += (double)part[(size_t)p * ld + c];
+    if (ok) {
+        int p = pl;
+        for (; p + 3 * FIN_PL < nparts; p += 4 * FIN_PL) {          // four independent loads in flight
+            const float a0 = part[(size_t)p * ld + c], a1 = part[(size_t)(p + FIN_PL) * ld + c];
+            const float a2 = part[(size_t)(p + 2 * FIN_PL) * ld + c], a3 = part[(size_t)(p + 3 * FIN_PL) * ld + c];
+            s += ((double)a0 + (double)a1) + ((double)a2 + (double)a3);
+        }
+        for (; p < nparts; p += FIN_PL) s += (double)part[(size_t)p * ld + c];
+    }
     red[pl][cl] = s;
     __syncthreads();
     for (int h = FIN_PL / 2; h > 0; h >>= 1) {

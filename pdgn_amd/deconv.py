@@ -25,7 +25,7 @@ from torch.autograd import Function
 
 from . import _lib
 from ._lib import check, ptr, require, stream_of
-from .fused import bn_act, linear_cl
+from .fused import bn_act, linear_cl, softmax_slots_permute
 
 F32, I32 = torch.float32, torch.int32
 
@@ -223,11 +223,11 @@ class PointDeconv(nn.Module):
             h = bn_act(h, self.conv_all[1], training)
             h = linear_cl(h, self.conv_all[3].weight[:, :, 0, 0], self.conv_all[3].bias)
             h = bn_act(h, self.conv_all[4], training)
-            w = h.view(B, N, k, 2 * Fi)
             if self.softmax:
-                w = F.softmax(w, dim=2)                                # over the k neighbour slots
-            # w[b,n,s=P*j+p,c'] -> [b,n,p,o=2c'+j]  (the reference's interleave :638-641)
-            w = w.view(B, N, 2, P, 2 * Fi).permute(0, 1, 3, 4, 2).reshape(B * N * P, 4 * Fi)
+                # softmax over the k slots + interleave w[b,n,s=P*j+p,c'] -> [b,n,p,o=2c'+j] (:634-641), fused
+                w = softmax_slots_permute(h.view(B * N, k, 2 * Fi)).view(B * N * P, 4 * Fi)
+            else:
+                w = h.view(B, N, 2, P, 2 * Fi).permute(0, 1, 3, 4, 2).reshape(B * N * P, 4 * Fi)
         # inte = LeakyReLU(BN(inte_pre)) [* w]  -- one fused pass (:637, :642)
         inte = bn_act(inte_pre.view(-1, 4 * Fi), self.inte_conv_hk[1], training, mul=w)
         out_pre = a_pre.view(B * N, 2 * Fo) + linear_cl(inte.view(B * N, P * 4 * Fi), Wb)

@@ -119,3 +119,33 @@ class LinearCL(Function):
 def linear_cl(x2d, weight, bias=None):
     """Dense layer on point-major rows (see LinearCL)."""
     return LinearCL.apply(x2d, weight, bias)
+
+
+class SoftmaxSlotsPermute(Function):
+    """h (M, k, C) -> softmax over the k slots, written as (M, k/2, 2C) with channel 2c+j of row p
+    holding slot (k/2)*j + p (models/PDGNet_v2.py:634-641 in one pass)."""
+
+    @staticmethod
+    def forward(ctx, h):
+        h = h.contiguous()
+        m, k, c = h.shape
+        w = torch.empty((m, k // 2, 2 * c), dtype=F32, device=h.device)
+        check(_lib.lib().pdgn_softmax_slots_permute(ctypes.c_longlong(m), k, c, ptr(h), ptr(w), stream_of(h)),
+              "pdgn_softmax_slots_permute")
+        ctx.save_for_backward(w)
+        ctx.shape = (m, k, c)
+        return w
+
+    @staticmethod
+    def backward(ctx, dw):
+        (w,) = ctx.saved_tensors
+        m, k, c = ctx.shape
+        dw = dw.contiguous()
+        dh = torch.empty((m, k, c), dtype=F32, device=w.device)
+        check(_lib.lib().pdgn_softmax_slots_permute_backward(ctypes.c_longlong(m), k, c, ptr(w), ptr(dw), ptr(dh),
+                                                             stream_of(w)), "pdgn_softmax_slots_permute_backward")
+        return dh
+
+
+def softmax_slots_permute(h):
+    return SoftmaxSlotsPermute.apply(h)

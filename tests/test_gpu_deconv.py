@@ -312,3 +312,20 @@ def test_gemm_tn_weight_gradient(M, N, K):
     assert ((w2.grad.double() - ref64).abs() / (dy[sub].abs().t().matmul(x[sub].abs())).double().clamp_min(1e-6)).max().item() < 1e-5
     np.testing.assert_allclose(b.grad.cpu().numpy(), dy.sum(0).cpu().numpy(), rtol=1e-4, atol=1e-2)
     np.testing.assert_allclose(xg.grad.cpu().numpy(), dy.matmul(w.detach()).cpu().numpy(), rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize("M,k,C", [(1000, 10, 16), (3584, 10, 512), (77, 4, 24), (500, 32, 3)])
+def test_softmax_slots_permute(M, k, C):
+    from pdgn_amd.fused import softmax_slots_permute
+    from torch_standins import softmax_slots_permute_torch
+    rng = np.random.default_rng(M + C)
+    h = torch.from_numpy((rng.standard_normal((M, k, C)) * 3).astype(np.float32))
+    g = torch.from_numpy(rng.standard_normal((M, k // 2, 2 * C)).astype(np.float32))
+    hd = dev(h).requires_grad_(True)
+    w = softmax_slots_permute(hd)
+    w.backward(dev(g))
+    hr = h.double().requires_grad_(True)
+    wr = softmax_slots_permute_torch(hr)
+    wr.backward(g.double())
+    np.testing.assert_allclose(w.detach().cpu().numpy(), wr.detach().numpy(), rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(hd.grad.cpu().numpy(), hr.grad.numpy(), rtol=1e-3, atol=1e-6)

@@ -76,3 +76,10 @@ def patch_losses(monkeypatch_or_module):
 
 def linear_cl_torch(x2d, weight, bias=None):
     return torch.nn.functional.linear(x2d, weight, bias)
+
+
+def softmax_slots_permute_torch(h):
+    M, k, C = h.shape
+    P = k // 2
+    w = torch.softmax(h, dim=1)
+    return w.view(M, 2, P, C).permute(0, 2, 3, 1).reshape(M, P, 2 * C)
