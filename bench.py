@@ -36,6 +36,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-batch", type=int, default=35)
     ap.add_argument("--no-graph", action="store_true", help="run the step eagerly instead of replaying hipGraphs")
+    ap.add_argument("--no-roofline", action="store_true", help="skip the roofline kernels (for clean rocprof traces)")
     return ap.parse_args()
 
 
@@ -43,8 +44,10 @@ def init_dist(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    force = os.environ.get("PDGN_FORCE_DIST") == "1"        # exercise the RCCL path on a single GPU
+    if world > 1 or force:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", rank=rank, world_size=world,
@@ -57,7 +60,7 @@ def init_dist(args):
 
 
 def barrier(world):
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
     torch.cuda.synchronize()
 
@@ -101,7 +104,8 @@ def main():
 
     torch.manual_seed(9999 + rank)
     res = tuple((2 * args.base_points) << i for i in range(4))
-    trainer = PDGNTrainer(device=device, base_points=args.base_points)
+    trainer = PDGNTrainer(device=device, base_points=args.base_points,
+                          distributed=True if os.environ.get("PDGN_FORCE_DIST") == "1" else None)
     trainer.train()
     B = args.batch
     reals = synthetic_batch(B, device, seed=9999 + rank, n_points=res[3], resolutions=res)
@@ -145,14 +149,15 @@ def main():
                        "global_batch": world * B, "points_all_resolutions_per_s": world * B * sum(res) / (dt / args.steps),
                        "parallelism": "dp%d" % world, "losses_finite": finite, "hipgraph": graphed},
         }
-        try:
-            line["roofline"] = dominant_kernel_roofline(args, device)
-        except Exception as e:                                   # never lose the headline number
-            line["roofline"] = {"error": repr(e)}
+        if not args.no_roofline:
+            try:
+                line["roofline"] = dominant_kernel_roofline(args, device)
+            except Exception as e:                               # never lose the headline number
+                line["roofline"] = {"error": repr(e)}
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.cpu_sample_batch)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

@@ -38,9 +38,10 @@ class FlatGrads:
 
     def all_reduce_mean(self, group=None):
         """Average over ranks (RCCL all-reduce over xGMI when the backend is nccl)."""
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        if dist.is_available() and dist.is_initialized():
             dist.all_reduce(self.buf, op=dist.ReduceOp.SUM, group=group)
-            self.buf.div_(dist.get_world_size(group))
+            if dist.get_world_size(group) > 1:
+                self.buf.div_(dist.get_world_size(group))
 
 
 def world_size():
