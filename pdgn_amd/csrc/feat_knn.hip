@@ -93,7 +93,38 @@ __global__ __launch_bounds__(FK_THREADS) void feat_knn_kernel(
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-#pragma unroll 8
+            // Fast path (wave-uniform): float4 loads, no channel / candidate tail.  The loads run a
+            // fixed PF steps ahead of the MFMAs through a register ring and the index is clamped
+            // instead of branched, so the loop body is branch-free and the compiler keeps PF loads
+            // in flight behind counted vmcnt waits.
+            const bool fast = vec_ok && (t0 + strip + 128 <= n) && (2 * FH == f);
+            if (fast) {
+                constexpr int PF = 8;
+                const float *Af = X + (size_t)half * n + cand;
+                float4 ring[PF];
+                float bring[PF];
+#pragma unroll
+                for (int i = 0; i < PF; ++i) {
+                    ring[i] = *reinterpret_cast<const float4 *>(Af + (size_t)(2 * i) * n);
+                    bring[i] = bqs[i][lane];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                for (int s0 = 0; s0 < FH; s0 += PF) {
+#pragma unroll
+                    for (int i = 0; i < PF; ++i) {
+                        const float4 v = ring[i];
+                        const float bv = bring[i];
+                        const int sn = min(s0 + PF + i, FH - 1);
+                        ring[i] = *reinterpret_cast<const float4 *>(Af + (size_t)(2 * sn) * n);
+                        bring[i] = bqs[sn][lane];
+                        __builtin_amdgcn_sched_barrier(0);      // keep both loads PF steps ahead of their use
+                        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(v.x, bv, acc[0], 0, 0, 0);
+                        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(v.y, bv, acc[1], 0, 0, 0);
+                        acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(v.z, bv, acc[2], 0, 0, 0);
+                        acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(v.w, bv, acc[3], 0, 0, 0);
+                    }
+                }
+            } else
             for (int s = 0; s < FH; ++s) {
                 const int c = 2 * s + half;
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);

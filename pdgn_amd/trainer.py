@@ -20,21 +20,41 @@ PAIRS = ((0, 1), (0, 2), (0, 3), (1, 2), (1, 3), (2, 3))   # get_local_pair call
 
 
 class FlatGrads:
-    """Make every parameter's ``.grad`` a view into one contiguous buffer (so one collective
-    reduces a whole network and ``zero_grad`` is one memset)."""
+    """One contiguous fp32 buffer per network for the gradient all-reduce.
+
+    Single process: autograd simply assigns fresh ``.grad`` tensors (``begin`` clears them, so no
+    per-parameter accumulate kernel runs) and the optimiser consumes them.  Data parallel: after the
+    backward one multi-tensor copy packs the gradients into the buffer, ONE collective reduces the
+    whole network (G: 50.8 MB, D1-4: 6.8 MB) and the parameters' ``.grad`` become views of it."""
 
     def __init__(self, params):
         self.params = [p for p in params if p.requires_grad]
         total = sum(p.numel() for p in self.params)
         ref = self.params[0]
         self.buf = torch.zeros(total, dtype=ref.dtype, device=ref.device)
-        off = 0
+        self.views, off = [], 0
         for p in self.params:
-            p.grad = self.buf[off:off + p.numel()].view_as(p)
+            self.views.append(self.buf[off:off + p.numel()].view_as(p))
             off += p.numel()
 
-    def zero_(self):
+    def begin(self):
+        """Before a backward: drop the old gradients (autograd then writes, never accumulates)."""
+        for p in self.params:
+            p.grad = None
+
+    def zero_(self):                       # kept for callers that accumulate into the views
         self.buf.zero_()
+
+    def pack(self):
+        """Gather the fresh .grad tensors into the flat buffer and re-point .grad at its views."""
+        have = [(v, p) for v, p in zip(self.views, self.params) if p.grad is not None]
+        missing = [v for v, p in zip(self.views, self.params) if p.grad is None]
+        if have:
+            torch._foreach_copy_([v for v, _ in have], [p.grad for _, p in have])
+        for v in missing:
+            v.zero_()
+        for v, p in zip(self.views, self.params):
+            p.grad = v
 
     def all_reduce_mean(self, group=None):
         """Average over ranks (RCCL all-reduce over xGMI when the backend is nccl)."""
@@ -98,7 +118,7 @@ class PDGNTrainer:
     #   5: Adam G (:256)
     def _seg_d(self, st, i):
         D = self.D[i]
-        self.gradD[i].zero_()
+        self.gradD[i].begin()
         lossD = (F.mse_loss(D(st["reals"][i]), st["ones"]) + F.mse_loss(D(st["fakes"][i]), st["zeros"])) / 2.0
         lossD.backward()
         st["out"]["d_loss%d" % (i + 1)] = lossD.detach()
@@ -115,7 +135,7 @@ class PDGNTrainer:
             self._seg_d(st, k)
         elif k == 4:
             self.optD[3].step()
-            self.gradG.zero_()
+            self.gradG.begin()
             # The reference lets lossG.backward() also fill the discriminators' .grad and throws
             # that away at the next zero_grad (:183); freezing D skips those weight-gradient GEMMs.
             self._freeze_D(True)
@@ -144,7 +164,9 @@ class PDGNTrainer:
     def _comm(self, k):
         """Collective that follows segment k (RCCL all-reduce of one flat gradient buffer)."""
         if self.distributed and k < 5:
-            (self.gradD[k] if k < 4 else self.gradG).all_reduce_mean()
+            fg = self.gradD[k] if k < 4 else self.gradG
+            fg.pack()
+            fg.all_reduce_mean()
 
     def _state(self, reals, z1, z2):
         B = reals[0].shape[0]

@@ -92,20 +92,22 @@ def test_two_rank_step_gloo(request):
     # D step with averaged gradients
     for i in range(4):
         for tr, reals, fakes, z2, ones, zeros in grads:
-            tr.gradD[i].zero_()
+            tr.gradD[i].begin()
             ((F.mse_loss(tr.D[i](reals[i]), ones) + F.mse_loss(tr.D[i](fakes[i]), zeros)) / 2.0).backward()
+            tr.gradD[i].pack()
         mean = (grads[0][0].gradD[i].buf + grads[1][0].gradD[i].buf) / world
         for tr, *_ in grads:
             tr.gradD[i].buf.copy_(mean)
             tr.optD[i].step()
     gG = []
     for tr, reals, fakes, z2, ones, zeros in grads:
-        tr.gradG.zero_()
+        tr.gradG.begin()
         tr._freeze_D(True)
         gen = tr.G(z2)
         sim = tr.similar_loss(gen)
         gl = [F.mse_loss(tr.D[i](gen[i]), ones) for i in range(4)]
         (1.2 * gl[0] + 1.2 * gl[1] + 1.2 * gl[2] + gl[3] + 0.1 * world * sim).backward()
+        tr.gradG.pack()
         gG.append(tr.gradG.buf.clone())
     expect = (gG[0] + gG[1]) / world
     np.testing.assert_allclose(r[0]["gradG"], expect.numpy(), rtol=2e-3, atol=1e-5 * float(expect.abs().max()))
@@ -116,12 +118,14 @@ def test_flat_grads_views_and_zero():
     from pdgn_amd.trainer import FlatGrads
     m = torch.nn.Sequential(torch.nn.Linear(4, 3), torch.nn.Linear(3, 2))
     fg = FlatGrads(m.parameters())
+    fg.begin()
     m(torch.randn(5, 4)).sum().backward()
+    fresh = [p.grad.clone() for p in m.parameters()]
+    fg.pack()
     assert fg.buf.abs().sum() > 0
     off = 0
-    for p in m.parameters():
-        assert p.grad.data_ptr() == fg.buf[off:].data_ptr()               # .grad is a view of the buffer
+    for p, g in zip(m.parameters(), fresh):
+        assert p.grad.data_ptr() == fg.buf[off:].data_ptr()               # .grad is now a view of the buffer
+        assert torch.equal(p.grad, g)
         off += p.numel()
-    fg.zero_()
-    assert all((p.grad == 0).all() for p in m.parameters())
     fg.all_reduce_mean()                                                   # no process group: no-op

@@ -192,7 +192,8 @@ def test_full_size_step_properties():
     assert [r.shape[2] for r in reals] == [256, 512, 1024, 2048]
     out = tr.step(reals, noise(B, "cuda"), noise(B, "cuda"))
     assert all(torch.isfinite(v) for v in out.values())
-    assert torch.isfinite(tr.gradG.buf).all() and tr.gradG.buf.abs().sum() > 0
+    grads = [p.grad for p in tr.G.parameters()]
+    assert all(g is not None and torch.isfinite(g).all() for g in grads) and sum(g.abs().sum() for g in grads) > 0
     x = torch.randn(B, 256, 1024, device="cuda")
     idx = feature_knn(x, 10).long()
     srt = idx.sort(dim=2)[0]

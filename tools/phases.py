@@ -22,11 +22,11 @@ for it in range(5):
         fakes = tr.G(z1)
     mark("G fwd #1 (no grad)")
     for i, D in enumerate(tr.D):
-        tr.gradD[i].zero_()
+        tr.gradD[i].begin()
         lossD = (F.mse_loss(D(reals[i]), ones) + F.mse_loss(D(fakes[i]), zeros)) / 2.0
         lossD.backward(); tr.optD[i].step()
     mark("4x D step")
-    tr.gradG.zero_(); tr._freeze_D(True)
+    tr.gradG.begin(); tr._freeze_D(True)
     gen = tr.G(z2)
     mark("G fwd #2 (grad)")
     sim = tr.similar_loss(gen)
