@@ -330,3 +330,36 @@ def test_softmax_slots_permute(M, k, C):
     wr.backward(g.double())
     np.testing.assert_allclose(w.detach().cpu().numpy(), wr.detach().numpy(), rtol=1e-4, atol=1e-6)
     np.testing.assert_allclose(hd.grad.cpu().numpy(), hr.grad.numpy(), rtol=1e-3, atol=1e-6)
+
+
+def test_config_c4_four_stage_512_to_4096():
+    """BASELINE.json configs[3] ("4-stage 256->4096"; SURVEY.md section 8 Note C4: base 256 points):
+    the size-generic blocks run one iteration at 512/1024/2048/4096 points; outputs have the right
+    shapes, losses are finite, and the generator matches the oracle restatement composed from the
+    same blocks on the oracle's kNN graphs."""
+    from pdgn_amd.generator import PointGenerator
+    from pdgn_amd.trainer import PDGNTrainer, noise, synthetic_batch
+    B = 3
+    G = fill_module(PointGenerator(base_points=256), salt=21).cuda().train()
+    R = fill_module(pdgnet_ref.PointGeneratorRef(base_points=256), salt=21).train()
+    z = hash_tensor("c4_z", (B, 128), 0.2)
+    idxs = []
+
+    def grab(mod, inp):
+        idxs.append(pdgnet_ref.feature_knn(inp[0], mod.k)[0])
+    hooks = [m.register_forward_pre_hook(grab) for m in
+             (R.bilateral1.upsample_cov[0], R.bilateral2.upsample_cov, R.bilateral3.upsample_cov, R.bilateral4.upsample_cov)]
+    with torch.no_grad():
+        ref = R(z)
+        out = G(dev(z), idx=[dev(i.to(torch.int32)) for i in idxs])
+    for h in hooks:
+        h.remove()
+    assert [o.shape[2] for o in out] == [512, 1024, 2048, 4096]
+    for o, r in zip(out, ref):
+        np.testing.assert_allclose(o.cpu().numpy(), r.numpy(), rtol=1e-3, atol=2e-3 * float(r.abs().max()))
+    torch.manual_seed(1)
+    tr = PDGNTrainer(device="cuda", base_points=256, distributed=False)
+    tr.train()
+    res = (512, 1024, 2048, 4096)
+    losses = tr.step(synthetic_batch(B, "cuda", n_points=4096, resolutions=res), noise(B, "cuda"), noise(B, "cuda"))
+    assert all(torch.isfinite(v).item() for v in losses.values())
