@@ -172,6 +172,15 @@ int pdgn_softmax_slots_permute(long long m, int k, int c, const float *h, float 
 int pdgn_softmax_slots_permute_backward(long long m, int k, int c, const float *w, const float *dw,
                                         float *dh, pdgn_stream_t stream);
 
+/* Dense contraction of a point-major layer on the fp32 matrix cores:
+ *   C (m x n) = A (m x k) W (n x k)^T (+ bias[n]) (+ addend (m x n)),  all row-major, k % 4 == 0.
+ * (The reference's Conv2d/Conv1d/Linear forward at models/PDGNet_v2.py:559-625, 835-862, 886-1014 in
+ * point-major form; with W^T it is their input gradient.)  stat_part (may be NULL): ceil(m/128) rows of
+ * [2n] floats = per-column sum | sum of squares of every 128-row block of C, the partials that
+ * pdgn_bn_finalize turns into BatchNorm statistics. */
+int pdgn_gemm_nt(long long m, int n, int k, const float *A, const float *W, const float *bias,
+                 const float *addend, float *C, float *stat_part, pdgn_stream_t stream);
+
 /* Weight gradient of a point-major dense layer on the fp32 matrix cores, reduction split over
  * workgroups:  dW (n x k) += dY (m x n)^T  X (m x k), all row-major, m >> n, k.
  * dW must be zero-filled by the caller; n % 4 == 0, k % 4 == 0. */
