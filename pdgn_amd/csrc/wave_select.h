@@ -67,6 +67,8 @@ __device__ __forceinline__ void knn_flush(const DI *q, int cnt, int K, float &rd
 
 #define WSEL_QCAP 256   // survivor queue entries per wave
 
+__device__ __forceinline__ float wave_kth_smallest(float v, int K);
+
 // One wave scans `tn` candidates (candidate c has distance dist(c), c in [0, tn), global index
 // t0 + c) and merges the K best into the running list (rd, ri) held by lanes 0..K-1.
 //   pass A: per-lane minimum; tau = K-th smallest lane minimum (>= the K-th nearest distance);
@@ -77,8 +79,7 @@ __device__ __forceinline__ void wave_topk_scan(DistFn dist, int tn, int t0, DI *
                                                int &ri, int lane) {
     float lmin = INFINITY;
     for (int c = lane; c < tn; c += 64) lmin = fminf(lmin, dist(c));
-    float sorted = wave_sort_f(lmin, lane);
-    float tau = fminf(__shfl(sorted, K - 1, 64), __shfl(rd, K - 1, 64));
+    float tau = fminf(wave_kth_smallest(lmin, K), __shfl(rd, K - 1, 64));   // ballot bisection, no LDS
     int cnt = 0;                                    // wave-uniform
     for (int c0 = 0; c0 < tn; c0 += 64) {
         int c = c0 + lane;

@@ -363,3 +363,29 @@ def test_config_c4_four_stage_512_to_4096():
     res = (512, 1024, 2048, 4096)
     losses = tr.step(synthetic_batch(B, "cuda", n_points=4096, resolutions=res), noise(B, "cuda"), noise(B, "cuda"))
     assert all(torch.isfinite(v).item() for v in losses.values())
+
+
+@pytest.mark.parametrize("M,N,K", [(35840, 512, 128), (5000, 132, 36), (129, 7, 4), (71680, 1024, 256)])
+def test_gemm_nt_with_epilogues(M, N, K):
+    """pdgn_gemm_nt (hand-written fp32 MFMA NT GEMM; kept as the fused-epilogue alternative to the
+    library GEMM, which is faster on MI355X -- DESIGN.md section 4): C = A W^T + bias + addend and the
+    per-128-row-block column statistics."""
+    import ctypes
+    from pdgn_amd import _lib
+    from pdgn_amd._lib import ptr, stream_of
+    g = torch.Generator(device="cuda").manual_seed(M + N)
+    A = torch.randn(M, K, device="cuda", generator=g)
+    W = torch.randn(N, K, device="cuda", generator=g)
+    bias = torch.randn(N, device="cuda", generator=g)
+    add = torch.randn(M, N, device="cuda", generator=g)
+    C = torch.empty(M, N, device="cuda")
+    nb = (M + 127) // 128
+    part = torch.zeros(nb, 2 * N, device="cuda")
+    rc = _lib.lib().pdgn_gemm_nt(ctypes.c_longlong(M), N, K, ptr(A), ptr(W), ptr(bias), ptr(add), ptr(C), ptr(part),
+                                 stream_of(A))
+    assert rc == 0
+    ref = (A.double() @ W.double().t() + bias.double() + add.double())
+    scale = (A.abs() @ W.abs().t()).double() + 1
+    assert ((C.double() - ref).abs() / scale).max().item() < 1e-5
+    np.testing.assert_allclose(part[:, :N].sum(0).cpu().numpy(), ref.sum(0).cpu().numpy(), rtol=1e-3, atol=0.05 * M ** 0.5)
+    np.testing.assert_allclose(part[:, N:].sum(0).cpu().numpy(), (ref * ref).sum(0).cpu().numpy(), rtol=1e-3)
