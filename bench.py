@@ -158,7 +158,7 @@ def main():
                 line["roofline"] = dominant_kernel_roofline(args, device)
             except Exception as e:                               # never lose the headline number
                 line["roofline"] = {"error": repr(e)}
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:          # host baseline: rank 0, N = 1 only
             line["cpu_baseline"] = cpu_baseline(args.cpu_sample_batch)
         print(json.dumps(line), flush=True)
     if dist.is_initialized():
