@@ -164,6 +164,19 @@ int pdgn_bn_act_backward(long long rows, int c, int act, int training, const flo
                          const float *dy, const float *mul, const float *stats, float *scratch,
                          float *bsums, float *dx, float *dmul, pdgn_stream_t stream);
 
+/* BatchNorm + activation + max-pool over the n rows of each sample (the tail of the PointNet-style
+ * discriminators, models/PDGNet_v2.py:886-911): x (b*n, c) -> ymax / yarg (b, c); the activated tensor
+ * is never written.  stats from pdgn_bn_stats / pdgn_bn_eval_stats over all b*n rows.
+ * scratch: pdgn_bn_maxpool_scratch_floats(b, c) floats. */
+long long pdgn_bn_maxpool_scratch_floats(int b, int c);
+int pdgn_bn_act_maxpool(int b, int n, int c, int act, const float *x, const float *stats, float *scratch,
+                        float *ymax, int32_t *yarg, pdgn_stream_t stream);
+/* Its adjoint in one streaming pass: dx (b*n, c) from dout (b, c); bsums (2c) = [dbeta | dgamma];
+ * scratch: b*c + 2c floats. */
+int pdgn_bn_act_maxpool_backward(int b, int n, int c, int act, int training, const float *x,
+                                 const float *dout, const int32_t *yarg, const float *stats,
+                                 float *scratch, float *bsums, float *dx, pdgn_stream_t stream);
+
 /* Softmax over the k neighbour slots fused with the slot/channel interleave of
  * models/PDGNet_v2.py:634-641: h (m,k,c) -> w (m, k/2, 2c) with w[m,p,2c'+j] = softmax_s(h[m,:,c'])[s=(k/2)j+p].
  * k even, k <= 32. */

@@ -375,3 +375,172 @@ extern "C" int pdgn_bn_act_backward(long long rows, int c, int act, int training
                        stats, coef, dx, dmul);
     return pdgn_launch_status();
 }
+
+// ---------------------------------------------------------------------------- BN + act + max-pool
+// The PointNet-style discriminators end their per-point stack with BatchNorm1d + LeakyReLU +
+// MaxPool1d over all points (models/PDGNet_v2.py:886-911 ...).  Only the per-sample maxima leave
+// the layer, so the activated (rows x C) tensor is never written: the apply pass reduces to
+// (max, argmax) per (sample, channel), and the backward pass is ONE streaming pass
+//   dx[r,c] = -ca[c] - cb[c]*x[r,c] + [r == argmax(b,c)] * scale[c]*dz[b,c]
+// because dz is non-zero only at the argmax rows (its two batch sums run over B*C values).
+#define MP_SPLIT 16
+
+__global__ __launch_bounds__(BN_THREADS) void cl_apply_max_kernel(int N, int C, int cgb, int act,
+                                                                  const float *__restrict__ x,
+                                                                  const float *__restrict__ stats,
+                                                                  float *__restrict__ pmax, int32_t *__restrict__ parg) {
+    __shared__ float smax[BN_THREADS][4];
+    __shared__ int sarg[BN_THREADS][4];
+    const int cgl = threadIdx.x % cgb, rlane = threadIdx.x / cgb, rl = BN_THREADS / cgb;
+    const int cgi = blockIdx.x * cgb + cgl;
+    const bool cok = cgi * 4 < C;
+    const int b = blockIdx.z, sp = blockIdx.y;
+    const int per = (N + MP_SPLIT - 1) / MP_SPLIT;
+    const int n0 = sp * per, n1 = min(N, n0 + per);
+    float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    int arg[4] = {n0, n0, n0, n0};
+    if (cok) {
+        float sc[4], sh[4];
+        *reinterpret_cast<float4 *>(sc) = *reinterpret_cast<const float4 *>(stats + cgi * 4);
+        *reinterpret_cast<float4 *>(sh) = *reinterpret_cast<const float4 *>(stats + C + cgi * 4);
+        const float *X = x + ((size_t)b * N) * C + cgi * 4;
+        for (int n = n0 + rlane; n < n1; n += rl) {
+            float v[4];
+            *reinterpret_cast<float4 *>(v) = *reinterpret_cast<const float4 *>(X + (size_t)n * C);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float y = act_fwd(__fmaf_rn(v[j], sc[j], sh[j]), act);
+                if (y > best[j]) { best[j] = y; arg[j] = n; }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { smax[threadIdx.x][j] = best[j]; sarg[threadIdx.x][j] = arg[j]; }
+    __syncthreads();
+    if (rlane == 0 && cok) {
+        for (int q = 1; q < rl; ++q)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float y = smax[q * cgb + cgl][j];
+                const int a = sarg[q * cgb + cgl][j];
+                if (y > best[j] || (y == best[j] && a < arg[j])) { best[j] = y; arg[j] = a; }
+            }
+        const size_t o = ((size_t)b * MP_SPLIT + sp) * C + cgi * 4;
+        *reinterpret_cast<float4 *>(pmax + o) = *reinterpret_cast<float4 *>(best);
+        *reinterpret_cast<int4 *>(parg + o) = *reinterpret_cast<int4 *>(arg);
+    }
+}
+
+__global__ void cl_max_finalize_kernel(int B, int C, const float *__restrict__ pmax, const int32_t *__restrict__ parg,
+                                       float *__restrict__ ymax, int32_t *__restrict__ yarg) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= B * C) return;
+    const int b = e / C, c = e % C;
+    float best = -INFINITY;
+    int arg = 0;
+    for (int s = 0; s < MP_SPLIT; ++s) {                       // splits are in row order: first maximum wins
+        const float y = pmax[((size_t)b * MP_SPLIT + s) * C + c];
+        if (y > best) { best = y; arg = parg[((size_t)b * MP_SPLIT + s) * C + c]; }
+    }
+    ymax[e] = best;
+    yarg[e] = arg;
+}
+
+// per channel: dz[b] = dout[b]*act'(z at the argmax row); bsums = [sum_b dz | sum_b dz*xhat]; coef = [ca | cb]
+__global__ void cl_max_bwd_sums_kernel(int B, int N, int C, int act, int training, const float *__restrict__ x,
+                                       const float *__restrict__ dout, const int32_t *__restrict__ yarg,
+                                       const float *__restrict__ stats, float *__restrict__ dz,
+                                       float *__restrict__ bsums, float *__restrict__ coef) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float sc = stats[c], sh = stats[C + c], mu = stats[2 * C + c], is = stats[3 * C + c];
+    double s1 = 0, s2 = 0;
+    for (int b = 0; b < B; ++b) {
+        const int n = yarg[b * C + c];
+        const float v = x[((size_t)b * N + n) * C + c];
+        const float g = dout[b * C + c] * act_grad(__fmaf_rn(v, sc, sh), act);
+        dz[b * C + c] = g;
+        s1 += g;
+        s2 += (double)g * (double)((v - mu) * is);
+    }
+    bsums[c] = (float)s1;
+    bsums[C + c] = (float)s2;
+    float ca = 0.f, cb = 0.f;
+    if (training) {
+        const double R = (double)B * (double)N;
+        cb = sc * is * (float)(s2 / R);
+        ca = sc * (float)(s1 / R) - cb * mu;
+    }
+    coef[c] = ca;
+    coef[C + c] = cb;
+}
+
+__global__ __launch_bounds__(BN_THREADS) void cl_max_bwd_apply_kernel(int N, int C, int cgb, const float *__restrict__ x,
+                                                                      const float *__restrict__ stats,
+                                                                      const float *__restrict__ coef,
+                                                                      const float *__restrict__ dz,
+                                                                      const int32_t *__restrict__ yarg,
+                                                                      float *__restrict__ dx) {
+    const int cgl = threadIdx.x % cgb, rlane = threadIdx.x / cgb, rl = BN_THREADS / cgb;
+    const int cgi = blockIdx.x * cgb + cgl;
+    if (cgi * 4 >= C) return;
+    const int b = blockIdx.z, sp = blockIdx.y;
+    const int per = (N + MP_SPLIT - 1) / MP_SPLIT;
+    const int n0 = sp * per, n1 = min(N, n0 + per);
+    float sc[4], ca[4], cb[4], g[4];
+    int arg[4];
+    *reinterpret_cast<float4 *>(sc) = *reinterpret_cast<const float4 *>(stats + cgi * 4);
+    *reinterpret_cast<float4 *>(ca) = *reinterpret_cast<const float4 *>(coef + cgi * 4);
+    *reinterpret_cast<float4 *>(cb) = *reinterpret_cast<const float4 *>(coef + C + cgi * 4);
+    *reinterpret_cast<float4 *>(g) = *reinterpret_cast<const float4 *>(dz + (size_t)b * C + cgi * 4);
+    *reinterpret_cast<int4 *>(arg) = *reinterpret_cast<const int4 *>(yarg + (size_t)b * C + cgi * 4);
+    const size_t base = ((size_t)b * N) * C + cgi * 4;
+    for (int n = n0 + rlane; n < n1; n += rl) {
+        float v[4], o[4];
+        *reinterpret_cast<float4 *>(v) = *reinterpret_cast<const float4 *>(x + base + (size_t)n * C);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = (n == arg[j] ? sc[j] * g[j] : 0.f) - ca[j] - cb[j] * v[j];
+        *reinterpret_cast<float4 *>(dx + base + (size_t)n * C) = *reinterpret_cast<float4 *>(o);
+    }
+}
+
+static void mp_geometry(int C, int *cgb, int *gx) {
+    const int cg = C / 4;
+    int p = 1;
+    while (p < cg && p < 64) p <<= 1;                          // <= 64 column groups: >= 4 row lanes per block
+    *cgb = p;
+    *gx = (cg + p - 1) / p;
+}
+
+// ymax/yarg (b,c) = max / argmax over the n rows of each sample of act(x*scale + shift); x (b*n, c).
+// scratch: b*MP_SPLIT*c floats + as many int32 (use pdgn_bn_maxpool_scratch_floats).
+extern "C" long long pdgn_bn_maxpool_scratch_floats(int b, int c) { return 2LL * b * MP_SPLIT * c; }
+
+extern "C" int pdgn_bn_act_maxpool(int b, int n, int c, int act, const float *x, const float *stats, float *scratch,
+                                   float *ymax, int32_t *yarg, pdgn_stream_t stream) {
+    if (b < 1 || n < 1 || c < 4 || c % 4 || act < 0 || act > 2 || b > 65535) return PDGN_ERR_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    int cgb, gx;
+    mp_geometry(c, &cgb, &gx);
+    float *pmax = scratch;
+    int32_t *parg = reinterpret_cast<int32_t *>(scratch + (size_t)b * MP_SPLIT * c);
+    hipLaunchKernelGGL(cl_apply_max_kernel, dim3(gx, MP_SPLIT, b), dim3(BN_THREADS), 0, s, n, c, cgb, act, x, stats, pmax, parg);
+    hipLaunchKernelGGL(cl_max_finalize_kernel, dim3(cdiv((long long)b * c, 256)), dim3(256), 0, s, b, c, pmax, parg, ymax, yarg);
+    return pdgn_launch_status();
+}
+
+// dx (b*n, c) from dout (b,c); bsums (2c) = [dbeta | dgamma]; scratch: b*c + 2c floats.
+extern "C" int pdgn_bn_act_maxpool_backward(int b, int n, int c, int act, int training, const float *x,
+                                            const float *dout, const int32_t *yarg, const float *stats, float *scratch,
+                                            float *bsums, float *dx, pdgn_stream_t stream) {
+    if (b < 1 || n < 1 || c < 4 || c % 4 || act < 0 || act > 2 || b > 65535) return PDGN_ERR_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    float *dz = scratch, *coef = scratch + (size_t)b * c;
+    hipLaunchKernelGGL(cl_max_bwd_sums_kernel, dim3(cdiv(c, 64)), dim3(64), 0, s, b, n, c, act, training, x, dout, yarg,
+                       stats, dz, bsums, coef);
+    int cgb, gx;
+    mp_geometry(c, &cgb, &gx);
+    hipLaunchKernelGGL(cl_max_bwd_apply_kernel, dim3(gx, MP_SPLIT, b), dim3(BN_THREADS), 0, s, n, c, cgb, x, stats, coef, dz,
+                       yarg, dx);
+    return pdgn_launch_status();
+}

@@ -25,7 +25,7 @@ from torch.autograd import Function
 
 from . import _lib
 from ._lib import check, ptr, require, stream_of
-from .fused import bn_act, linear_cl, softmax_slots_permute
+from .fused import bn_act, bn_act_maxpool, flush_bn_counters, linear_cl, softmax_slots_permute  # noqa: F401
 
 F32, I32 = torch.float32, torch.int32
 
@@ -169,6 +169,7 @@ class PointDeconv(nn.Module):
         """Reference layout: x (B,Fin,N) [, pc (B,3,N)] -> (B,Fout,2N)."""
         out = self.forward_cl(x.transpose(1, 2).contiguous(),
                               pc.transpose(1, 2).contiguous() if pc is not None else None, idx=idx, x_cf=x)
+        flush_bn_counters()
         return out.transpose(1, 2)
 
     def forward_cl(self, xt, pct=None, idx=None, x_cf=None, const=None):

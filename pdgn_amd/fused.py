@@ -65,11 +65,24 @@ class BNActCL(Function):
         return dx, bs[C:], bs[:C], None, None, None, None, None, None, dmul
 
 
+# nn.BatchNorm's num_batches_tracked bookkeeping: one tiny int64 add per layer per forward would be
+# ~100 launches per iteration; increments are collected here and applied by flush_bn_counters() with
+# one multi-tensor add (the network-level forward()s and the trainer call it).
+_PENDING_COUNTS = {}
+
+
+def flush_bn_counters():
+    if _PENDING_COUNTS:
+        tensors = list(_PENDING_COUNTS.keys())
+        torch._foreach_add_(tensors, [int(v) for v in _PENDING_COUNTS.values()])
+        _PENDING_COUNTS.clear()
+
+
 def bn_act(x2d, bn, training, act="leaky_relu", mul=None):
     """Apply an nn.BatchNorm{1,2}d module's parameters/buffers to a channels-last (rows, C) view,
     followed by `act` (and an optional elementwise product)."""
     if training and bn.track_running_stats:
-        bn.num_batches_tracked.add_(1)
+        _PENDING_COUNTS[bn.num_batches_tracked] = _PENDING_COUNTS.get(bn.num_batches_tracked, 0) + 1
     if x2d.shape[1] % 4:                      # odd channel counts: library path
         y = torch.nn.functional.batch_norm(x2d, bn.running_mean, bn.running_var, bn.weight, bn.bias, training,
                                            bn.momentum, bn.eps)
@@ -149,3 +162,58 @@ class SoftmaxSlotsPermute(Function):
 
 def softmax_slots_permute(h):
     return SoftmaxSlotsPermute.apply(h)
+
+
+class BNActMaxPool(Function):
+    """(B*N, C) rows -> (B, C): max over the N points of each sample of act(BatchNorm(x)) -- the
+    BatchNorm1d + LeakyReLU + MaxPool1d tail of the discriminators without writing the activated
+    tensor; the backward is one streaming pass."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, act, B, N):
+        x = x.contiguous()
+        rows, C = x.shape
+        dev = x.device
+        L = _lib.lib()
+        stats = torch.empty(4 * C, dtype=F32, device=dev)
+        g, b = gamma.detach().contiguous(), beta.detach().contiguous()
+        if training:
+            scratch = torch.empty(_scratch_floats(L, rows, C), dtype=F32, device=dev)
+            check(L.pdgn_bn_stats(ctypes.c_longlong(rows), C, ctypes.c_float(eps), ctypes.c_float(momentum), ptr(x),
+                                  ptr(g), ptr(b), ptr(running_mean), ptr(running_var), ptr(scratch), ptr(stats),
+                                  stream_of(x)), "pdgn_bn_stats")
+        else:
+            check(L.pdgn_bn_eval_stats(C, ctypes.c_float(eps), ptr(g), ptr(b), ptr(running_mean),
+                                       ptr(running_var), ptr(stats), stream_of(x)), "pdgn_bn_eval_stats")
+        L.pdgn_bn_maxpool_scratch_floats.restype = ctypes.c_longlong
+        scr = torch.empty(L.pdgn_bn_maxpool_scratch_floats(B, C), dtype=F32, device=dev)
+        ymax = torch.empty((B, C), dtype=F32, device=dev)
+        yarg = torch.empty((B, C), dtype=torch.int32, device=dev)
+        check(L.pdgn_bn_act_maxpool(B, N, C, act, ptr(x), ptr(stats), ptr(scr), ptr(ymax), ptr(yarg), stream_of(x)),
+              "pdgn_bn_act_maxpool")
+        ctx.save_for_backward(x, stats, yarg)
+        ctx.cfg = (B, N, C, act, bool(training))
+        return ymax
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, stats, yarg = ctx.saved_tensors
+        B, N, C, act, training = ctx.cfg
+        dout = dout.contiguous()
+        scr = torch.empty(B * C + 2 * C, dtype=F32, device=x.device)
+        bs = torch.empty(2 * C, dtype=F32, device=x.device)
+        dx = torch.empty_like(x)
+        check(_lib.lib().pdgn_bn_act_maxpool_backward(B, N, C, act, int(training), ptr(x), ptr(dout), ptr(yarg),
+                                                      ptr(stats), ptr(scr), ptr(bs), ptr(dx), stream_of(x)),
+              "pdgn_bn_act_maxpool_backward")
+        return dx, bs[C:], bs[:C], None, None, None, None, None, None, None, None
+
+
+def bn_act_maxpool(x2d, bn, training, B, N, act="leaky_relu"):
+    """max over the N points of every sample of act(BN(x2d)); x2d (B*N, C) -> (B, C)."""
+    if training and bn.track_running_stats:
+        _PENDING_COUNTS[bn.num_batches_tracked] = _PENDING_COUNTS.get(bn.num_batches_tracked, 0) + 1
+    if x2d.shape[1] % 4:
+        return bn_act(x2d, bn, False if not training else training, act=act).view(B, N, -1).max(dim=1)[0]
+    return BNActMaxPool.apply(x2d, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, bn.momentum, bn.eps,
+                              ACT[act], B, N)

@@ -89,6 +89,7 @@ class BilateralBlock(nn.Module):
         """Reference interface: x (B,Fin,N) -> x_out (B,2Fout,2N) [, g_out (B,512+Fout,2N)]."""
         xs, x_ec, g = self.forward_cl(x.transpose(1, 2).contiguous(),
                                       pc.transpose(1, 2).contiguous() if pc is not None else None, idx=idx)
+        _deconv.flush_bn_counters()
         N2 = x_ec.shape[1]
         x_ec = x_ec.transpose(1, 2)
         x_out = torch.cat((xs.unsqueeze(2).expand(-1, -1, N2), x_ec), 1)
@@ -138,6 +139,7 @@ class PointGenerator(nn.Module):
             pct = p.view(B, M, 3)
             clouds.append(pct.transpose(1, 2))                                  # (B,3,M) like the reference
             xt, const = x_ec, xs                    # next block's input is cat(xs broadcast, x_ec) :708
+        _deconv.flush_bn_counters()
         return tuple(clouds)
 
 
@@ -166,9 +168,13 @@ class PointDiscriminator(nn.Module):
     def forward(self, x):
         B, _, N = x.shape
         h = x.transpose(1, 2).reshape(B * N, 3)
-        for i in range(0, len(self.fc1), 3):                    # Conv1d(k=1) + BatchNorm1d + LeakyReLU
+        last = len(self.fc1) - 3
+        for i in range(0, last, 3):                             # Conv1d(k=1) + BatchNorm1d + LeakyReLU
             h = _bn_act(_conv1x1_rows(h, self.fc1[i]), self.fc1[i + 1], self.training)
-        return self.mlp(h.view(B, N, -1).max(dim=1)[0])         # MaxPool1d(num_point) over all points
+        # last layer: BatchNorm1d + LeakyReLU + MaxPool1d(num_point) fused (the activated tensor is not written)
+        pooled = _deconv.bn_act_maxpool(_conv1x1_rows(h, self.fc1[last]), self.fc1[last + 1], self.training, B, N)
+        _deconv.flush_bn_counters()
+        return self.mlp(pooled)
 
 
 def PointDiscriminator_1(num_point=256):

@@ -389,3 +389,28 @@ def test_gemm_nt_with_epilogues(M, N, K):
     assert ((C.double() - ref).abs() / scale).max().item() < 1e-5
     np.testing.assert_allclose(part[:, :N].sum(0).cpu().numpy(), ref.sum(0).cpu().numpy(), rtol=1e-3, atol=0.05 * M ** 0.5)
     np.testing.assert_allclose(part[:, N:].sum(0).cpu().numpy(), (ref * ref).sum(0).cpu().numpy(), rtol=1e-3)
+
+
+@pytest.mark.parametrize("B,N,C,training", [(4, 300, 64, True), (35, 2048, 1024, True), (3, 17, 8, True), (5, 512, 256, False)])
+def test_fused_bn_act_maxpool_vs_torch(B, N, C, training):
+    from pdgn_amd.fused import bn_act_maxpool, flush_bn_counters
+    from torch_standins import bn_act_maxpool_torch
+    rng = np.random.default_rng(B * N + C)
+    x = torch.from_numpy((rng.standard_normal((B * N, C)) * 1.5 + 0.3).astype(np.float32))
+    gout = torch.from_numpy(rng.standard_normal((B, C)).astype(np.float32))
+    res = []
+    for impl, to in ((bn_act_maxpool, dev), (bn_act_maxpool_torch, lambda t: t.double())):
+        bn = torch.nn.BatchNorm1d(C)
+        fill_module(bn, salt=5)
+        bn = bn.cuda() if impl is bn_act_maxpool else bn.double()
+        bn.train(training)
+        xi = to(x).requires_grad_(True)
+        y = impl(xi, bn, training, B, N)
+        y.backward(to(gout))
+        flush_bn_counters()
+        res.append([t.detach().cpu().double().numpy() for t in
+                    (y, xi.grad, bn.weight.grad, bn.bias.grad, bn.running_mean, bn.running_var)])
+        if impl is bn_act_maxpool and training:
+            assert int(bn.num_batches_tracked) == 1
+    for name, a, b in zip(["y", "dx", "dgamma", "dbeta", "running_mean", "running_var"], *res):
+        np.testing.assert_allclose(a, b, rtol=1e-4, atol=1e-4 * max(1.0, np.abs(b).max()), err_msg=name)

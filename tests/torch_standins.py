@@ -83,3 +83,11 @@ def softmax_slots_permute_torch(h):
     P = k // 2
     w = torch.softmax(h, dim=1)
     return w.view(M, 2, P, C).permute(0, 2, 3, 1).reshape(M, P, 2 * C)
+
+
+def flush_bn_counters_noop():
+    pass
+
+
+def bn_act_maxpool_torch(x2d, bn, training, B, N, act="leaky_relu"):
+    return bn_act_torch(x2d, bn, training, act=act).view(B, N, -1).max(dim=1)[0]
