@@ -182,11 +182,123 @@ __global__ __launch_bounds__(FK_THREADS) void feat_knn_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------- producer / consumer form
+// Regular shapes (n % 128 == 0, f == 2*FH): 8 waves per workgroup.  Waves 0-3 PRODUCE the Gram strips of
+// chunk i on the matrix cores while waves 4-7 CONSUME (select from) chunk i-1 on the vector ALU; the two
+// dist tiles alternate in LDS and one workgroup barrier per chunk hands them over.  Matrix and vector
+// work of different waves of a SIMD issue side by side, so the selection hides behind the MFMAs.
+// Both operands are fed from global memory (L2-resident) through 8-deep register rings.
+#define FKP_THREADS 512
+#define FKP_QCAP 64
+
+template <int FH>
+__global__ __launch_bounds__(FKP_THREADS) void feat_knn_pc_kernel(
+    int n, int k, const float *__restrict__ x, const float *__restrict__ sq, int32_t *__restrict__ idx) {
+    constexpr int NCP = FK_NC + 4;
+    constexpr int f = 2 * FH;
+    __shared__ float dist[2][FK_QB][NCP];
+    __shared__ DI queue[FK_QB][FKP_QCAP];
+
+    const int bs = blockIdx.y;
+    const int q0 = blockIdx.x * FK_QB;
+    const int lane = lane_id();
+    const int wave = threadIdx.x / PDGN_WAVE;
+    const bool producer = wave < 4;
+    const int col = lane & 31, half = lane >> 5;
+    const float *X = x + (size_t)bs * f * n;
+    const float *SQ = sq + (size_t)bs * n;
+    const int K = k + 1;
+    const int nchunks = (n + FK_NC - 1) / FK_NC;
+
+    float rd[FK_QPW];
+    int ri[FK_QPW], cnt[FK_QPW];
+#pragma unroll
+    for (int t = 0; t < FK_QPW; ++t) { rd[t] = INFINITY; ri[t] = 0x7fffffff; cnt[t] = 0; }
+    const float sq_q = SQ[q0 + col];
+
+    for (int it = 0; it <= nchunks; ++it) {
+        if (producer) {
+            const int t0 = it * FK_NC;
+            const int strip = 128 * wave;
+            if (it < nchunks && t0 + strip < n) {
+                const int a4 = ((lane >> 3) & 3) * 32 + (lane & 7) * 4;
+                const int cand = t0 + strip + a4;
+                const float *Af = X + (size_t)half * n + cand;
+                const float *Bf = X + (size_t)half * n + q0 + col;
+                f32x16 acc[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+                constexpr int PF = FH >= 128 ? 8 : 4;
+                float4 ring[PF];
+                float bring[PF];
+#pragma unroll
+                for (int i = 0; i < PF; ++i) {
+                    ring[i] = *reinterpret_cast<const float4 *>(Af + (size_t)(2 * i) * n);
+                    bring[i] = Bf[(size_t)(2 * i) * n];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                for (int s0 = 0; s0 < FH; s0 += PF) {
+#pragma unroll
+                    for (int i = 0; i < PF; ++i) {
+                        const float4 v = ring[i];
+                        const float bv = bring[i];
+                        const int sn = min(s0 + PF + i, FH - 1);
+                        ring[i] = *reinterpret_cast<const float4 *>(Af + (size_t)(2 * sn) * n);
+                        bring[i] = Bf[(size_t)(2 * sn) * n];
+                        __builtin_amdgcn_sched_barrier(0);
+                        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(v.x, bv, acc[0], 0, 0, 0);
+                        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(v.y, bv, acc[1], 0, 0, 0);
+                        acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(v.z, bv, acc[2], 0, 0, 0);
+                        acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(v.w, bv, acc[3], 0, 0, 0);
+                    }
+                }
+                float (*D)[NCP] = dist[it & 1];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int lc = strip + 32 * (r >> 2) + 16 * half + 4 * (r & 3);
+                    const float4 sc = *reinterpret_cast<const float4 *>(SQ + t0 + lc);
+                    float4 v;
+                    v.x = __fmaf_rn(-2.0f, acc[0][r], sq_q) + sc.x;
+                    v.y = __fmaf_rn(-2.0f, acc[1][r], sq_q) + sc.y;
+                    v.z = __fmaf_rn(-2.0f, acc[2][r], sq_q) + sc.z;
+                    v.w = __fmaf_rn(-2.0f, acc[3][r], sq_q) + sc.w;
+                    *reinterpret_cast<float4 *>(&D[col][lc]) = v;
+                }
+            }
+        } else if (it >= 1) {
+            const int t0 = (it - 1) * FK_NC;
+            const int tn = min(FK_NC, n - t0);
+#pragma unroll
+            for (int t = 0; t < FK_QPW; ++t) {
+                const int ql = (wave - 4) * FK_QPW + t;
+                const float *row = dist[(it - 1) & 1][ql];
+                wave_topk_append_cap([&](int c) { return row[c]; }, tn, t0, queue[ql], cnt[t], FKP_QCAP, K, rd[t], ri[t],
+                                     lane);
+            }
+        }
+        __syncthreads();
+    }
+    if (!producer) {
+#pragma unroll
+        for (int t = 0; t < FK_QPW; ++t) {
+            const int ql = (wave - 4) * FK_QPW + t;
+            knn_flush(queue[ql], cnt[t], K, rd[t], ri[t], lane);
+            if (lane >= 1 && lane <= k)
+                idx[((size_t)bs * n + q0 + ql) * k + lane - 1] = rd[t] < INFINITY ? ri[t] : 0;
+        }
+    }
+}
+
 template <int FH>
 static int launch_fk(int b, int f, int n, int k, const float *x, const float *sq, int32_t *idx,
                      hipStream_t s) {
     dim3 grid(cdiv(n, FK_QB), b);
-    hipLaunchKernelGGL((feat_knn_kernel<FH>), grid, dim3(FK_THREADS), 0, s, f, n, k, x, sq, idx);
+    if (f == 2 * FH && n % 128 == 0)
+        hipLaunchKernelGGL((feat_knn_pc_kernel<FH>), grid, dim3(FKP_THREADS), 0, s, n, k, x, sq, idx);
+    else
+        hipLaunchKernelGGL((feat_knn_kernel<FH>), grid, dim3(FK_THREADS), 0, s, f, n, k, x, sq, idx);
     return pdgn_launch_status();
 }
 

@@ -144,3 +144,32 @@ __device__ __forceinline__ void wave_topk_append(DistFn dist, int tn, int t0, DI
         }
     }
 }
+
+// As wave_topk_append, for a queue of `cap` >= 64 entries: the queue is merged into the running list
+// only when the next 64-candidate step would not fit (wave-uniform test on the exact count).
+template <class DistFn>
+__device__ __forceinline__ void wave_topk_append_cap(DistFn dist, int tn, int t0, DI *q, int &cnt, int cap, int K,
+                                                     float &rd, int &ri, int lane) {
+    float lmin = INFINITY;
+    for (int c = lane; c < tn; c += 64) lmin = fminf(lmin, dist(c));
+    float tau = fminf(wave_kth_smallest(lmin, K), __shfl(rd, K - 1, 64));
+    for (int c0 = 0; c0 < tn; c0 += 64) {
+        int c = c0 + lane;
+        float d = c < tn ? dist(c) : INFINITY;
+        bool keep = d <= tau && d < INFINITY;
+        unsigned long long mask = __ballot(keep);
+        if (mask) {
+            const int add = __popcll(mask);
+            if (cnt + add > cap) {
+                knn_flush(q, cnt, K, rd, ri, lane);
+                cnt = 0;
+                tau = fminf(tau, __shfl(rd, K - 1, 64));
+                keep = keep && d <= tau;                      // tightened threshold: re-filter this step
+                mask = __ballot(keep);
+            }
+            int pos = cnt + __popcll(mask & ((1ull << lane) - 1ull));
+            if (keep) { q[pos].d = d; q[pos].i = t0 + c; }
+            cnt += __popcll(mask);
+        }
+    }
+}
