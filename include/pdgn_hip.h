@@ -220,6 +220,16 @@ int pdgn_chamfer_gram_grad(int b, int m, int n, int d, const float *x, const flo
                            const float *gminx, const int32_t *argx, const float *gminy,
                            const int32_t *argy, float *gx, float *gy, pdgn_stream_t stream);
 
+/* All-pairs evaluation (evaluation/evaluation_metrics.py:85-121 expands every sample against every
+ * reference batch): the same kernels over explicit pair lists, pair p = (cloud ia[p] of the first
+ * tensor, cloud ib[p] of the second); outputs are indexed by p.  temp: npairs*2*(n+m) floats. */
+int pdgn_emd_cost_indexed(int npairs, int n, int m, const float *xyz1, const int32_t *ia,
+                          const float *xyz2, const int32_t *ib, float *temp, float *out,
+                          pdgn_stream_t stream);
+int pdgn_chamfer_gram_indexed(int npairs, int m, int n, int d, const float *x, const int32_t *ia,
+                              const float *y, const int32_t *ib, float *minx, int32_t *argx,
+                              float *miny, int32_t *argy, pdgn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -197,7 +197,8 @@ __global__ __launch_bounds__(FKP_THREADS) void feat_knn_pc_kernel(
     constexpr int NCP = FK_NC + 4;
     constexpr int f = 2 * FH;
     __shared__ float dist[2][FK_QB][NCP];
-    __shared__ DI queue[FK_QB][FKP_QCAP];
+    __shared__ DI queue[FK_QB][FKP_QCAP + 32];       // + room for the running list during a ranked merge
+    __shared__ DI win[4][32];                          // per consumer wave
 
     const int bs = blockIdx.y;
     const int q0 = blockIdx.x * FK_QB;
@@ -239,6 +240,7 @@ __global__ __launch_bounds__(FKP_THREADS) void feat_knn_pc_kernel(
                     bring[i] = Bf[(size_t)(2 * i) * n];
                 }
                 __builtin_amdgcn_sched_barrier(0);
+#ifndef FK_ABLATE_MFMA
                 for (int s0 = 0; s0 < FH; s0 += PF) {
 #pragma unroll
                     for (int i = 0; i < PF; ++i) {
@@ -254,6 +256,7 @@ __global__ __launch_bounds__(FKP_THREADS) void feat_knn_pc_kernel(
                         acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(v.w, bv, acc[3], 0, 0, 0);
                     }
                 }
+#endif
                 float (*D)[NCP] = dist[it & 1];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -274,8 +277,10 @@ __global__ __launch_bounds__(FKP_THREADS) void feat_knn_pc_kernel(
             for (int t = 0; t < FK_QPW; ++t) {
                 const int ql = (wave - 4) * FK_QPW + t;
                 const float *row = dist[(it - 1) & 1][ql];
+#ifndef FK_ABLATE_SELECT
                 wave_topk_append_cap([&](int c) { return row[c]; }, tn, t0, queue[ql], cnt[t], FKP_QCAP, K, rd[t], ri[t],
                                      lane);
+#endif
             }
         }
         __syncthreads();
@@ -284,7 +289,7 @@ __global__ __launch_bounds__(FKP_THREADS) void feat_knn_pc_kernel(
 #pragma unroll
         for (int t = 0; t < FK_QPW; ++t) {
             const int ql = (wave - 4) * FK_QPW + t;
-            knn_flush(queue[ql], cnt[t], K, rd[t], ri[t], lane);
+            knn_flush_ranked(queue[ql], cnt[t], K, rd[t], ri[t], lane, win[wave - 4]);
             if (lane >= 1 && lane <= k)
                 idx[((size_t)bs * n + q0 + ql) * k + lane - 1] = rd[t] < INFINITY ? ri[t] : 0;
         }

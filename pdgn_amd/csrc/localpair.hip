@@ -108,7 +108,7 @@ template <int D>
 __global__ __launch_bounds__(LP_THREADS) void chamfer_gram_kernel(
     int m, int n, int dd, const float *__restrict__ x, const float *__restrict__ y,
     float *__restrict__ minx, int32_t *__restrict__ argx, float *__restrict__ miny,
-    int32_t *__restrict__ argy) {
+    int32_t *__restrict__ argy, const int32_t *__restrict__ ia, const int32_t *__restrict__ ib) {
     constexpr int DS = D > 0 ? D : CH_MAXD;
     __shared__ float cand[CH_TILE * (DS + 1)];
     const int d = D > 0 ? D : dd;
@@ -116,8 +116,9 @@ __global__ __launch_bounds__(LP_THREADS) void chamfer_gram_kernel(
     const bool rev = blockIdx.z != 0;
     const int nq = rev ? n : m, nc = rev ? m : n;
     if ((int)(blockIdx.x * blockDim.x) >= nq) return;           // block-uniform
-    const float *Q = (rev ? y : x) + (size_t)bs * nq * d;
-    const float *C = (rev ? x : y) + (size_t)bs * nc * d;
+    const size_t bx = ia ? (size_t)ia[bs] : (size_t)bs, by = ib ? (size_t)ib[bs] : (size_t)bs;   // pair lists
+    const float *Q = rev ? y + by * nq * d : x + bx * nq * d;
+    const float *C = rev ? x + bx * nc * d : y + by * nc * d;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     float qv[DS];
     float rq = 0.f;
@@ -205,19 +206,34 @@ extern "C" int pdgn_local_stats_backward(int b, int n, int m, int k, const float
     return pdgn_launch_status();
 }
 
+static int chamfer_launch(dim3 grid, hipStream_t s, int m, int n, int d, const float *x, const float *y, float *minx,
+                          int32_t *argx, float *miny, int32_t *argy, const int32_t *ia, const int32_t *ib) {
+    if (d == 3)
+        hipLaunchKernelGGL(chamfer_gram_kernel<3>, grid, dim3(LP_THREADS), 0, s, m, n, d, x, y, minx, argx, miny, argy, ia, ib);
+    else if (d == 9)
+        hipLaunchKernelGGL(chamfer_gram_kernel<9>, grid, dim3(LP_THREADS), 0, s, m, n, d, x, y, minx, argx, miny, argy, ia, ib);
+    else
+        hipLaunchKernelGGL(chamfer_gram_kernel<0>, grid, dim3(LP_THREADS), 0, s, m, n, d, x, y, minx, argx, miny, argy, ia, ib);
+    return pdgn_launch_status();
+}
+
 extern "C" int pdgn_chamfer_gram(int b, int m, int n, int d, const float *x, const float *y, float *minx,
                                  int32_t *argx, float *miny, int32_t *argy, pdgn_stream_t stream) {
     if (b < 0 || m < 1 || n < 1 || d < 1 || d > CH_MAXD || b > 65535) return PDGN_ERR_INVALID;
     if (b == 0) return 0;
     dim3 grid(cdiv(m > n ? m : n, LP_THREADS), b, 2);
     hipStream_t s = (hipStream_t)stream;
-    if (d == 3)
-        hipLaunchKernelGGL(chamfer_gram_kernel<3>, grid, dim3(LP_THREADS), 0, s, m, n, d, x, y, minx, argx, miny, argy);
-    else if (d == 9)
-        hipLaunchKernelGGL(chamfer_gram_kernel<9>, grid, dim3(LP_THREADS), 0, s, m, n, d, x, y, minx, argx, miny, argy);
-    else
-        hipLaunchKernelGGL(chamfer_gram_kernel<0>, grid, dim3(LP_THREADS), 0, s, m, n, d, x, y, minx, argx, miny, argy);
-    return pdgn_launch_status();
+    return chamfer_launch(grid, s, m, n, d, x, y, minx, argx, miny, argy, nullptr, nullptr);
+}
+
+// The same for `npairs` (ia[p], ib[p]) pairs of clouds drawn from x (., m, d) and y (., n, d).
+extern "C" int pdgn_chamfer_gram_indexed(int npairs, int m, int n, int d, const float *x, const int32_t *ia,
+                                         const float *y, const int32_t *ib, float *minx, int32_t *argx,
+                                         float *miny, int32_t *argy, pdgn_stream_t stream) {
+    if (npairs < 0 || m < 1 || n < 1 || d < 1 || d > CH_MAXD || npairs > 65535) return PDGN_ERR_INVALID;
+    if (npairs == 0) return 0;
+    dim3 grid(cdiv(m > n ? m : n, LP_THREADS), npairs, 2);
+    return chamfer_launch(grid, (hipStream_t)stream, m, n, d, x, y, minx, argx, miny, argy, ia, ib);
 }
 
 extern "C" int pdgn_chamfer_gram_grad(int b, int m, int n, int d, const float *x, const float *y,

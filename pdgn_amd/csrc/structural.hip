@@ -97,12 +97,15 @@ __device__ __forceinline__ float sq3(float ax, float ay, float az, float bx, flo
 template <bool FUSED>
 __global__ __launch_bounds__(AM_THREADS) void approxmatch_kernel(
     int n, int m, const float *__restrict__ xyz1, const float *__restrict__ xyz2,
-    float *__restrict__ match, float *__restrict__ temp, float *__restrict__ cost_out) {
+    float *__restrict__ match, float *__restrict__ temp, float *__restrict__ cost_out,
+    const int32_t *__restrict__ ia, const int32_t *__restrict__ ib) {
     __shared__ float4 buf[AM_TILE];
     __shared__ float red[AM_THREADS / PDGN_WAVE];
     const int pair = blockIdx.x;
-    const float *A = xyz1 + (size_t)pair * n * 3;
-    const float *B = xyz2 + (size_t)pair * m * 3;
+    // optional pair lists: pair p matches cloud ia[p] of xyz1 with cloud ib[p] of xyz2 (all-pairs
+    // evaluation without expanding the clouds, evaluation_metrics.py:85-121)
+    const float *A = xyz1 + (size_t)(ia ? ia[pair] : pair) * n * 3;
+    const float *B = xyz2 + (size_t)(ib ? ib[pair] : pair) * m * 3;
     float *M = FUSED ? nullptr : match + (size_t)pair * n * m;
     // remainL | remainR | ratioL | ratioR, as approxmatch.cu:4 lays out `temp`
     float *remainL = temp + (size_t)pair * (n + m) * 2, *remainR = remainL + n,
@@ -373,7 +376,7 @@ extern "C" int pdgn_approxmatch(int b, int n, int m, const float *xyz1, const fl
     if (!am_dims_ok(b, n, m)) return PDGN_ERR_INVALID;
     if (b == 0) return 0;
     hipLaunchKernelGGL(approxmatch_kernel<false>, dim3(b), dim3(AM_THREADS), 0, (hipStream_t)stream, n, m,
-                       xyz1, xyz2, match, temp, (float *)nullptr);
+                       xyz1, xyz2, match, temp, (float *)nullptr, (const int32_t *)nullptr, (const int32_t *)nullptr);
     return pdgn_launch_status();
 }
 
@@ -382,7 +385,18 @@ extern "C" int pdgn_emd_cost(int b, int n, int m, const float *xyz1, const float
     if (!am_dims_ok(b, n, m)) return PDGN_ERR_INVALID;
     if (b == 0) return 0;
     hipLaunchKernelGGL(approxmatch_kernel<true>, dim3(b), dim3(AM_THREADS), 0, (hipStream_t)stream, n, m,
-                       xyz1, xyz2, (float *)nullptr, temp, out);
+                       xyz1, xyz2, (float *)nullptr, temp, out, (const int32_t *)nullptr, (const int32_t *)nullptr);
+    return pdgn_launch_status();
+}
+
+// Fused EMD cost of `npairs` (ia[p], ib[p]) cloud pairs drawn from xyz1 (., n, 3) and xyz2 (., m, 3).
+extern "C" int pdgn_emd_cost_indexed(int npairs, int n, int m, const float *xyz1, const int32_t *ia,
+                                     const float *xyz2, const int32_t *ib, float *temp, float *out,
+                                     pdgn_stream_t stream) {
+    if (!am_dims_ok(npairs, n, m)) return PDGN_ERR_INVALID;
+    if (npairs == 0) return 0;
+    hipLaunchKernelGGL(approxmatch_kernel<true>, dim3(npairs), dim3(AM_THREADS), 0, (hipStream_t)stream, n, m,
+                       xyz1, xyz2, (float *)nullptr, temp, out, ia, ib);
     return pdgn_launch_status();
 }
 

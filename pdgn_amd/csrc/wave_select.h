@@ -173,3 +173,38 @@ __device__ __forceinline__ void wave_topk_append_cap(DistFn dist, int tn, int t0
         }
     }
 }
+
+// Rank-based merge (no sorting network): the running list's valid entries are appended to the queue,
+// every entry computes its rank = #entries smaller in the (distance, index) total order by streaming
+// the queue through broadcast LDS reads (independent loads, no dependent cross-lane chain), and the
+// entries of rank < K drop into win[rank].  Replaces the 21-stage bitonic sort of knn_flush (each stage
+// two dependent ds_bpermute round trips) when a K-entry LDS scratch `win` is available.
+__device__ __forceinline__ void knn_flush_ranked(DI *q, int cnt, int K, float &rd, int &ri, int lane, DI *win) {
+    __builtin_amdgcn_wave_barrier();
+    const bool have = lane < K && rd < INFINITY;
+    const unsigned long long hm = __ballot(have);
+    if (have) {
+        const int pos = cnt + __popcll(hm & ((1ull << lane) - 1ull));
+        q[pos].d = rd; q[pos].i = ri;
+    }
+    cnt += __popcll(hm);
+    if (lane < K) { win[lane].d = INFINITY; win[lane].i = 0x7fffffff; }
+    __builtin_amdgcn_wave_barrier();
+    for (int base = 0; base < cnt; base += 64) {
+        const int me = base + lane;
+        const bool ok = me < cnt;
+        const float d = ok ? q[me].d : INFINITY;
+        const int i = ok ? q[me].i : 0x7fffffff;
+        int rank = 0;
+        for (int j = 0; j < cnt; ++j) {
+            const float dj = q[j].d;
+            const int ij = q[j].i;
+            rank += (dj < d || (dj == d && ij < i)) ? 1 : 0;
+        }
+        if (ok && rank < K) { win[rank].d = d; win[rank].i = i; }
+    }
+    __builtin_amdgcn_wave_barrier();
+    rd = lane < K ? win[lane].d : INFINITY;
+    ri = lane < K ? win[lane].i : 0x7fffffff;
+    __builtin_amdgcn_wave_barrier();
+}

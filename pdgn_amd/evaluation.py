@@ -1,0 +1,112 @@
+"""Evaluation metrics of PDGN's test phase (evaluation/evaluation_metrics.py:26-200) on the fused
+MI355X kernels.
+
+The reference loops over the samples in Python and, for each, expands it against every reference
+batch before calling the CD / EMD extensions (``_pairwise_EMD_CD_`` :85-121; "may take about 2 hours",
+README.md:47).  Here the (N_sample x N_ref) matrices are filled by the pair-list kernels
+``pdgn_chamfer_gram_indexed`` / ``pdgn_emd_cost_indexed``: no expanded clouds, no (B,N,N) or (B,m,n)
+temporaries, tens of thousands of pairs per launch.  MMD / COV / 1-NNA are the reference's small
+torch reductions over those matrices.
+"""
+import torch
+
+from . import _lib
+from ._lib import check, ptr, require, stream_of
+
+F32, I32 = torch.float32, torch.int32
+_MAX_PAIRS = 32768          # per launch (grid.y limit of the Chamfer kernel, scratch of the EMD kernel)
+
+
+def _pair_lists(S, R, start, stop, device):
+    p = torch.arange(start, stop, device=device, dtype=torch.int64)
+    return (p // R).to(I32).contiguous(), (p % R).to(I32).contiguous()
+
+
+def pairwise_emd_cd(sample_pcs, ref_pcs, batch_size=None):
+    """_pairwise_EMD_CD_ (:85-121): all_cd, all_emd of shape (N_sample, N_ref).
+    CD = mean_i min_j P + mean_j min_i P with the Gram-form P of distChamfer (:35-45);
+    EMD = match_cost / N (:26-31).  `batch_size` is accepted for signature parity and ignored."""
+    require(sample_pcs, "sample_pcs", F32, 3)
+    require(ref_pcs, "ref_pcs", F32, 3)
+    S, N, _ = sample_pcs.shape
+    R, M, _ = ref_pcs.shape
+    dev = sample_pcs.device
+    cd = torch.empty(S * R, dtype=F32, device=dev)
+    emd = torch.empty(S * R, dtype=F32, device=dev)
+    L = _lib.lib()
+    for start in range(0, S * R, _MAX_PAIRS):
+        stop = min(S * R, start + _MAX_PAIRS)
+        npairs = stop - start
+        ia, ib = _pair_lists(S, R, start, stop, dev)
+        minx = torch.empty((npairs, N), dtype=F32, device=dev)
+        miny = torch.empty((npairs, M), dtype=F32, device=dev)
+        argx = torch.empty((npairs, N), dtype=I32, device=dev)
+        argy = torch.empty((npairs, M), dtype=I32, device=dev)
+        check(L.pdgn_chamfer_gram_indexed(npairs, N, M, 3, ptr(sample_pcs), ptr(ia), ptr(ref_pcs), ptr(ib), ptr(minx),
+                                          ptr(argx), ptr(miny), ptr(argy), stream_of(sample_pcs)),
+              "pdgn_chamfer_gram_indexed")
+        # distChamfer returns (P.min(1), P.min(2)) = (per ref point, per sample point); :108 adds their means
+        cd[start:stop] = miny.mean(dim=1) + minx.mean(dim=1)
+        temp = torch.empty((npairs, 2 * (N + M)), dtype=F32, device=dev)
+        out = torch.empty((npairs,), dtype=F32, device=dev)
+        check(L.pdgn_emd_cost_indexed(npairs, N, M, ptr(sample_pcs), ptr(ia), ptr(ref_pcs), ptr(ib), ptr(temp), ptr(out),
+                                      stream_of(sample_pcs)), "pdgn_emd_cost_indexed")
+        emd[start:stop] = out / float(N)
+    return cd.view(S, R), emd.view(S, R)
+
+
+def emd_cd(sample_pcs, ref_pcs, batch_size=None, reduced=True):
+    """EMD_CD (:48-82): paired (i, i) Chamfer and EMD."""
+    S = sample_pcs.shape[0]
+    assert S == ref_pcs.shape[0], "REF:%d SMP:%d" % (ref_pcs.shape[0], S)
+    from .losses import chamfer_min
+    from .structural_losses import emd_cost
+    minx, miny = chamfer_min(sample_pcs.contiguous(), ref_pcs.contiguous())
+    cd = miny.mean(dim=1) + minx.mean(dim=1)
+    emd = emd_cost(sample_pcs.contiguous(), ref_pcs.contiguous()) / float(sample_pcs.shape[1])
+    if reduced:
+        cd, emd = cd.mean(), emd.mean()
+    return {"MMD-CD": cd, "MMD-EMD": emd}
+
+
+def lgan_mmd_cov(all_dist):
+    """:157-169."""
+    N_sample, N_ref = all_dist.size(0), all_dist.size(1)
+    min_val_fromsmp, min_idx = torch.min(all_dist, dim=1)
+    min_val, _ = torch.min(all_dist, dim=0)
+    cov = torch.tensor(float(min_idx.unique().view(-1).size(0)) / float(N_ref)).to(all_dist)
+    return {"lgan_mmd": min_val.mean(), "lgan_cov": cov, "lgan_mmd_smp": min_val_fromsmp.mean()}
+
+
+def knn(Mxx, Mxy, Myy, k, sqrt=False):
+    """1-NN two-sample test (:123-154)."""
+    n0, n1 = Mxx.size(0), Myy.size(0)
+    label = torch.cat((torch.ones(n0), torch.zeros(n1))).to(Mxx)
+    M = torch.cat((torch.cat((Mxx, Mxy), 1), torch.cat((Mxy.transpose(0, 1), Myy), 1)), 0)
+    if sqrt:
+        M = M.abs().sqrt()
+    inf_diag = torch.diag(float("inf") * torch.ones(n0 + n1).to(Mxx))
+    _, idx = (M + inf_diag).topk(k, 0, False)
+    count = torch.zeros(n0 + n1).to(Mxx)
+    for i in range(k):
+        count = count + label.index_select(0, idx[i])
+    pred = torch.ge(count, (float(k) / 2) * torch.ones(n0 + n1).to(Mxx)).float()
+    s = {"tp": (pred * label).sum(), "fp": (pred * (1 - label)).sum(),
+         "fn": ((1 - pred) * label).sum(), "tn": ((1 - pred) * (1 - label)).sum()}
+    s.update({"precision": s["tp"] / (s["tp"] + s["fp"] + 1e-10), "recall": s["tp"] / (s["tp"] + s["fn"] + 1e-10),
+              "acc_t": s["tp"] / (s["tp"] + s["fn"] + 1e-10), "acc_f": s["tn"] / (s["tn"] + s["fp"] + 1e-10),
+              "acc": torch.eq(label, pred).float().mean()})
+    return s
+
+
+def compute_all_metrics(sample_pcs, ref_pcs, batch_size=None, accelerated_cd=False):
+    """compute_all_metrics (:172-200): MMD / COV (CD and EMD) and 1-NNA from three all-pairs passes."""
+    results = {}
+    M_rs_cd, M_rs_emd = pairwise_emd_cd(sample_pcs, ref_pcs)
+    results.update({"%s-CD" % k: v for k, v in lgan_mmd_cov(M_rs_cd.t()).items()})
+    results.update({"%s-EMD" % k: v for k, v in lgan_mmd_cov(M_rs_emd.t()).items()})
+    M_rr_cd, M_rr_emd = pairwise_emd_cd(ref_pcs, ref_pcs)
+    M_ss_cd, M_ss_emd = pairwise_emd_cd(sample_pcs, sample_pcs)
+    results.update({"1-NN-CD-%s" % k: v for k, v in knn(M_rr_cd, M_rs_cd, M_ss_cd, 1).items() if "acc" in k})
+    results.update({"1-NN-EMD-%s" % k: v for k, v in knn(M_rr_emd, M_rs_emd, M_ss_emd, 1).items() if "acc" in k})
+    return results

@@ -192,6 +192,27 @@ def gen_losses():
          dist_l=dl, dist_r=dr, mc_points=pts, mc_mu=mu, mc_cov=cov)
 
 
+# ------------------------------------------------------------------ 5b. evaluation metrics
+def gen_eval():
+    """evaluation/evaluation_metrics.py: lgan_mmd_cov (:157-169), knn (:123-154) on hash matrices, and the
+    all-pairs Chamfer matrix of _pairwise_EMD_CD_ (:85-121) built with the reference's distChamfer."""
+    from evaluation.evaluation_metrics import knn as ref_knn, lgan_mmd_cov as ref_lgan
+    D = hash_tensor("eval_all_dist", (7, 9)).abs()
+    lg = ref_lgan(D)
+    Mxx = hash_tensor("eval_mxx", (6, 6)).abs(); Mxx = Mxx + Mxx.t()
+    Myy = hash_tensor("eval_myy", (8, 8)).abs(); Myy = Myy + Myy.t()
+    Mxy = hash_tensor("eval_mxy", (6, 8)).abs()
+    kn = ref_knn(Mxx, Mxy, Myy, 1, sqrt=False)
+    smp = hash_tensor("eval_smp", (5, 64, 3))
+    refc = hash_tensor("eval_ref", (6, 64, 3), salt=1)
+    cd = torch.zeros(5, 6)
+    for i in range(5):
+        dl, dr = ref_distChamfer(smp[i:i + 1].expand(6, -1, -1).contiguous(), refc)
+        cd[i] = dl.mean(dim=1) + dr.mean(dim=1)
+    save("eval_metrics.npz", all_dist=D, lgan_mmd=lg["lgan_mmd"], lgan_cov=lg["lgan_cov"], lgan_mmd_smp=lg["lgan_mmd_smp"],
+         Mxx=Mxx, Mxy=Mxy, Myy=Myy, **{"knn_" + k: v for k, v in kn.items()}, smp=smp, ref=refc, all_cd=cd)
+
+
 # ------------------------------------------------------------------ 6. one G+D iteration (composed)
 def gen_step(G, Ds, B):
     """COMPOSED: reference torch modules / ChamferLoss / compute_mean_covariance / Adam with
@@ -253,6 +274,7 @@ if __name__ == "__main__":
     gen_edges()
     gen_deconv()
     gen_losses()
+    gen_eval()
     G, Ds, z, outs = gen_networks()
     if "--no-step" not in sys.argv:
         gen_step(G, Ds, 2)      # BASELINE.json configs[0] batch size (ill-conditioned BN: loose tolerance)

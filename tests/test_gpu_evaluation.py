@@ -1,0 +1,80 @@
+"""All-pairs evaluation on the pair-list kernels (through the C ABI) against the reference's
+distChamfer fixture and the C oracle of approxmatch/matchcost."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    return torch.device("cuda:0")
+
+
+def test_pairwise_cd_golden_and_emd_oracle(golden):
+    from oracle import cref
+    from pdgn_amd import evaluation as ev
+    g = golden("eval_metrics.npz")
+    smp = torch.from_numpy(g["smp"]).to(_dev())
+    ref = torch.from_numpy(g["ref"]).to(_dev())
+    cd, emd = ev.pairwise_emd_cd(smp, ref)
+    np.testing.assert_allclose(cd.cpu().numpy(), g["all_cd"], rtol=1e-4, atol=1e-6)   # Gram form, fp32
+    S, R = g["smp"].shape[0], g["ref"].shape[0]
+    want = np.zeros((S, R), np.float32)
+    for i in range(S):
+        want[i] = cref.emd_approx(np.repeat(g["smp"][i:i + 1], R, axis=0), g["ref"])
+    np.testing.assert_allclose(emd.cpu().numpy(), want, rtol=1e-4, atol=1e-6)
+
+
+def test_indexed_equals_expanded_bitwise():
+    """pair lists must give exactly what the reference's expand-and-call gives"""
+    from pdgn_amd import evaluation as ev
+    from pdgn_amd.losses import chamfer_min
+    from pdgn_amd.structural_losses import emd_cost
+    torch.manual_seed(3)
+    smp = torch.randn(7, 256, 3, device=_dev())
+    ref = torch.randn(5, 256, 3, device=_dev())
+    cd, emd = ev.pairwise_emd_cd(smp, ref)
+    for i in range(7):
+        a = smp[i:i + 1].expand(5, -1, -1).contiguous()
+        minx, miny = chamfer_min(a, ref)
+        assert torch.equal(cd[i], miny.mean(1) + minx.mean(1))
+        assert torch.equal(emd[i], emd_cost(a, ref) / 256.0)
+
+
+def test_pairwise_chunking(monkeypatch):
+    from pdgn_amd import evaluation as ev
+    torch.manual_seed(4)
+    smp = torch.randn(9, 64, 3, device=_dev())
+    ref = torch.randn(11, 64, 3, device=_dev())
+    cd0, emd0 = ev.pairwise_emd_cd(smp, ref)
+    monkeypatch.setattr(ev, "_MAX_PAIRS", 13)
+    cd1, emd1 = ev.pairwise_emd_cd(smp, ref)
+    assert torch.equal(cd0, cd1) and torch.equal(emd0, emd1)
+
+
+def test_compute_all_metrics_keys_and_sanity():
+    from pdgn_amd import evaluation as ev
+    torch.manual_seed(5)
+    ref = torch.randn(12, 128, 3, device=_dev())
+    res = ev.compute_all_metrics(ref.clone(), ref)
+    want = {"lgan_mmd-CD", "lgan_cov-CD", "lgan_mmd_smp-CD", "lgan_mmd-EMD", "lgan_cov-EMD", "lgan_mmd_smp-EMD",
+            "1-NN-CD-acc_t", "1-NN-CD-acc_f", "1-NN-CD-acc", "1-NN-EMD-acc_t", "1-NN-EMD-acc_f", "1-NN-EMD-acc"}
+    assert set(res) == want
+    # identical sets: every reference cloud is matched by itself -> full coverage, ~zero MMD
+    assert float(res["lgan_cov-CD"]) == 1.0 and float(res["lgan_cov-EMD"]) == 1.0
+    assert float(res["lgan_mmd-CD"]) < 1e-5
+    r2 = ev.emd_cd(ref, ref)
+    assert float(r2["MMD-CD"]) < 1e-5
+
+
+def test_emd_cd_paired_matches_oracle():
+    from oracle import cref
+    from pdgn_amd import evaluation as ev
+    torch.manual_seed(6)
+    a = torch.randn(4, 128, 3)
+    b = torch.randn(4, 128, 3)
+    r = ev.emd_cd(a.to(_dev()), b.to(_dev()), reduced=False)
+    d1, _, d2, _ = cref.nndistance(a.numpy(), b.numpy())
+    np.testing.assert_allclose(r["MMD-CD"].cpu().numpy(), d1.mean(1) + d2.mean(1), rtol=2e-4, atol=1e-6)
+    np.testing.assert_allclose(r["MMD-EMD"].cpu().numpy(), cref.emd_approx(a.numpy(), b.numpy()), rtol=1e-4, atol=1e-6)
