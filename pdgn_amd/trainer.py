@@ -13,6 +13,7 @@ import torch.distributed as dist
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .fused import flush_bn_counters
 from .generator import PointDiscriminator, PointGenerator
 from .losses import LocalPairLoss
 
@@ -91,6 +92,61 @@ class PDGNTrainer:
         self.G.train()
         for d in self.D:
             d.train()
+
+    # ---- checkpoints in the reference's own two-file format (models/PDGNet_v2.py:384-408 save, :331-382 load)
+    @staticmethod
+    def _ref_model_state(module):
+        # the reference wraps every net in nn.DataParallel (:101-105): its files carry 'module.'-prefixed keys
+        return {"module." + k: v.detach().cpu() for k, v in module.state_dict().items()}
+
+    @staticmethod
+    def _ref_optim_state(opt):
+        sd = opt.state_dict()
+        state = {}
+        for i, st in sd["state"].items():
+            # capturable/fused Adam keeps `step` as a device tensor; the reference's torch 1.7 Adam holds an int
+            state[i] = {k: (int(v.item()) if k == "step" else v.detach().cpu()) if torch.is_tensor(v) else v
+                        for k, v in st.items()}
+        keep = ("lr", "betas", "eps", "weight_decay", "amsgrad", "params")
+        groups = [{k: g[k] for k in keep} for g in sd["param_groups"]]
+        return {"state": state, "param_groups": groups}
+
+    def save(self, checkpoint_dir, index_epoch, category="chair"):
+        """Writes `<epoch>_<category>_G.pth` / `_D.pth` with the reference's keys (:391-407) so that either code
+        base can resume from the other's files."""
+        os.makedirs(checkpoint_dir, exist_ok=True)
+        stem = os.path.join(checkpoint_dir, "%s_%s" % (index_epoch, category))
+        flush_bn_counters()
+        torch.save({"G_model": self._ref_model_state(self.G), "G_optimizer": self._ref_optim_state(self.optG),
+                    "G_epoch": index_epoch}, stem + "_G.pth")
+        dfile = {"D_epoch": index_epoch}
+        for i, (d, o) in enumerate(zip(self.D, self.optD), 1):
+            dfile["D_model%d" % i] = self._ref_model_state(d)
+            dfile["D_optimizer%d" % i] = self._ref_optim_state(o)
+        torch.save(dfile, stem + "_D.pth")
+        return stem + "_G.pth", stem + "_D.pth"
+
+    @staticmethod
+    def _load_optim(opt, sd):
+        groups = []
+        for mine, theirs in zip(opt.state_dict()["param_groups"], sd["param_groups"]):
+            g = dict(mine)                                   # keep this build's capturable/fused/foreach flags
+            g.update({k: theirs[k] for k in ("lr", "betas", "eps", "weight_decay", "amsgrad") if k in theirs})
+            groups.append(g)
+        opt.load_state_dict({"state": sd["state"], "param_groups": groups})
+
+    def load(self, path_G, path_D):
+        """Resume from a reference (or own) checkpoint pair; returns the stored epoch (:352, :374).
+        A missing file raises FileNotFoundError (the reference calls exit(), :345-347)."""
+        from .generator import load_reference_state_dict
+        g = torch.load(path_G, map_location="cpu")
+        d = torch.load(path_D, map_location="cpu")
+        load_reference_state_dict(self.G, g["G_model"])
+        self._load_optim(self.optG, g["G_optimizer"])
+        for i, (m, o) in enumerate(zip(self.D, self.optD), 1):
+            load_reference_state_dict(m, d["D_model%d" % i])
+            self._load_optim(o, d["D_optimizer%d" % i])
+        return g["G_epoch"]
 
     def _freeze_D(self, frozen):
         for d in self.D:

@@ -213,6 +213,41 @@ def gen_eval():
          Mxx=Mxx, Mxy=Mxy, Myy=Myy, **{"knn_" + k: v for k, v in kn.items()}, smp=smp, ref=refc, all_cd=cd)
 
 
+# ------------------------------------------------------------------ 5c. checkpoint layout
+def gen_checkpoint_manifest():
+    """Structure of the two files PDGNet_v2.save writes (models/PDGNet_v2.py:384-408): nn.DataParallel-wrapped
+    modules (:101-105) => 'module.'-prefixed keys; Adam(lr 1e-4, betas (0.5, 0.999)) state (:121-125) indexed by
+    parameter ORDER.  Only names / shapes / hyper-parameters are recorded (the tensors are 50 MB)."""
+    import torch.nn as nn
+    G = nn.DataParallel(ref.PointGenerator())
+    Ds = [nn.DataParallel(m) for m in (ref.PointDiscriminator_1(), ref.PointDiscriminator_2(),
+                                       ref.PointDiscriminator_3(), ref.PointDiscriminator_4())]
+
+    def describe(model):
+        opt = torch.optim.Adam(model.parameters(), lr=0.0001, betas=(0.5, 0.999))
+        for p_ in model.parameters():
+            p_.grad = torch.zeros_like(p_)
+        opt.step()
+        sd, od = model.state_dict(), opt.state_dict()
+        names = [n for n, _ in model.named_parameters()]
+        grp = {k: v for k, v in od["param_groups"][0].items() if k in ("lr", "betas", "eps", "weight_decay", "amsgrad")}
+        return {"model_keys": [[k, list(v.shape)] for k, v in sd.items()],
+                "param_order": names,
+                "n_param_groups": len(od["param_groups"]),
+                "group_params": od["param_groups"][0]["params"],
+                "group_hyper": grp,
+                "state_entry_keys": sorted(od["state"][0].keys()),
+                "state_shapes": [list(od["state"][i]["exp_avg"].shape) for i in range(len(names))]}
+    man = {"G_file": {"keys": ["G_model", "G_optimizer", "G_epoch"], "G": describe(G)},
+           "D_file": {"keys": ["D_model1", "D_model2", "D_model3", "D_model4", "D_optimizer1", "D_optimizer2",
+                               "D_optimizer3", "D_optimizer4", "D_epoch"]}}
+    for i, d in enumerate(Ds):
+        man["D_file"]["D%d" % (i + 1)] = describe(d)
+    with open(os.path.join(HERE, "checkpoint_manifest.json"), "w") as f:
+        json.dump(man, f, indent=0)
+    print("wrote checkpoint_manifest.json")
+
+
 # ------------------------------------------------------------------ 6. one G+D iteration (composed)
 def gen_step(G, Ds, B):
     """COMPOSED: reference torch modules / ChamferLoss / compute_mean_covariance / Adam with
@@ -275,6 +310,7 @@ if __name__ == "__main__":
     gen_deconv()
     gen_losses()
     gen_eval()
+    gen_checkpoint_manifest()
     G, Ds, z, outs = gen_networks()
     if "--no-step" not in sys.argv:
         gen_step(G, Ds, 2)      # BASELINE.json configs[0] batch size (ill-conditioned BN: loose tolerance)
