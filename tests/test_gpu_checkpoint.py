@@ -25,8 +25,8 @@ def test_gpu_checkpoint_roundtrip_and_resume(tmp_path):
     for (ka, va), (kb, vb) in zip(t.G.state_dict().items(), u.G.state_dict().items()):
         assert ka == kb and torch.equal(va, vb), ka
     z1, z2 = noise(4, dev, g), noise(4, dev, g)
-    la = [float(x) for x in t.step(reals, z1, z2)]
-    lb = [float(x) for x in u.step(reals, z1, z2)]
+    la = [float(x) for x in t.step(reals, z1, z2).values()]
+    lb = [float(x) for x in u.step(reals, z1, z2).values()]
     # same weights, Adam moments and inputs; only atomics' summation order differs between the two runs
     for a, b in zip(la, lb):
         assert abs(a - b) <= 2e-3 * max(1.0, abs(a)), (la, lb)
