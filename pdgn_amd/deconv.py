@@ -25,7 +25,8 @@ from torch.autograd import Function
 
 from . import _lib
 from ._lib import check, ptr, require, stream_of
-from .fused import bn_act, bn_act_maxpool, flush_bn_counters, linear_cl, softmax_slots_permute  # noqa: F401
+from .fused import (bn_act, bn_act_maxpool, flush_bn_counters, has_zero_colsum, linear_cl,  # noqa: F401
+                    softmax_slots_permute)
 
 F32, I32 = torch.float32, torch.int32
 
@@ -79,6 +80,7 @@ class EdgeGatherSum(Function):
             rowptr, edges = transposed_graph(idx)
             dY = torch.empty((b, n, ldy), dtype=F32, device=idx.device)
             for (T, P, C, off, offc), dout, hb in zip(ctx.specs, douts, ctx.has_bias):
+                hb = 3 if hb == 1 and has_zero_colsum(dout) else hb
                 dout = dout.contiguous()
                 check(L.pdgn_window_gather_sum_backward_csr(b, n, k, ldy, T, P, C, off, offc, ptr(dout), ptr(rowptr),
                                                             ptr(edges), ptr(dY), stream_of(dout)),
@@ -87,6 +89,7 @@ class EdgeGatherSum(Function):
             return (dY, None, None) + tuple(dbias)
         dY = torch.zeros((b, n, ldy), dtype=F32, device=idx.device)
         for (T, P, C, off, offc), dout, hb in zip(ctx.specs, douts, ctx.has_bias):
+            hb = 3 if hb == 1 and has_zero_colsum(dout) else hb
             dout = dout.contiguous()
             check(L.pdgn_window_gather_sum_backward(b, n, k, ldy, T, P, C, off, offc, ptr(dout), ptr(idx), ptr(dY),
                                                     stream_of(dout)), "pdgn_window_gather_sum_backward")
@@ -97,6 +100,8 @@ class EdgeGatherSum(Function):
 def _dbias(dout, kind):
     if kind == 0:
         return None
+    if kind == 3:                                  # feeds a training-mode BatchNorm: identically zero (fused.py)
+        return torch.zeros(dout.shape[-1], dtype=F32, device=dout.device)
     return dout.sum(dim=(0, 1, 2)) if kind == 1 else dout.sum(dim=(1, 2))
 
 

@@ -1,5 +1,6 @@
 """Autograd wrappers of the fused channels-last kernels of libpdgn_hip.so (bnact.hip)."""
 import ctypes
+import weakref
 
 import torch
 from torch.autograd import Function
@@ -17,6 +18,30 @@ def _scratch_floats(L, rows, C):
     if n < 0:
         raise _lib.PdgnHipError("pdgn_bn_scratch_floats: argument outside the supported range")
     return n
+
+
+# The gradient of a training-mode BatchNorm with respect to its input has zero column sums:
+#   dx = g*rstd*(dz - mean(dz) - xhat*mean(dz*xhat))  =>  sum_rows dx = -g*rstd*mean(dz*xhat)*sum_rows(xhat) = 0,
+# so the bias of the conv / linear layer that FEEDS the BatchNorm (all conv2dbr-style pairs of the reference)
+# has an identically zero gradient; what a row-sum of dx would return is fp32 rounding residue.  The BatchNorm
+# backward marks its dx, and the producer's backward (LinearCL, EdgeGatherSum) skips that full pass over dy.
+# Keyed by data pointer, validated through a weak reference to the marked tensor (same object or a view of it).
+_ZERO_COLSUM = {}
+
+
+def mark_zero_colsum(dx):
+    _ZERO_COLSUM[dx.data_ptr()] = weakref.ref(dx)
+
+
+def has_zero_colsum(dy):
+    ref = _ZERO_COLSUM.pop(dy.data_ptr(), None)
+    src = ref() if ref is not None else None
+    return src is not None and (src is dy or dy._base is src) and dy.numel() == src.numel() \
+        and dy.shape[-1] == src.shape[-1]
+
+
+def clear_zero_colsum():
+    _ZERO_COLSUM.clear()
 
 
 class BNActCL(Function):
@@ -62,6 +87,8 @@ class BNActCL(Function):
         check(L.pdgn_bn_act_backward(ctypes.c_longlong(rows), C, act, int(training), ptr(x), ptr(dy), ptr(mul),
                                      ptr(stats), ptr(scratch), ptr(bs), ptr(dx), ptr(dmul), stream_of(x)),
               "pdgn_bn_act_backward")
+        if training:
+            mark_zero_colsum(dx)
         return dx, bs[C:], bs[:C], None, None, None, None, None, None, dmul
 
 
@@ -107,6 +134,7 @@ class LinearCL(Function):
     @staticmethod
     def backward(ctx, dy):
         x, weight = ctx.saved_tensors
+        zero_db = has_zero_colsum(dy)
         dy = dy.contiguous()
         dx = dy.matmul(weight) if ctx.needs_input_grad[0] else None
         dw = None
@@ -125,7 +153,9 @@ class LinearCL(Function):
                       "pdgn_gemm_tn")
             else:
                 dw = dy.t().matmul(x)
-        db = dy.sum(dim=0) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        db = None
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = torch.zeros(dy.shape[1], dtype=F32, device=dy.device) if zero_db else dy.sum(dim=0)
         return dx, dw, db
 
 
@@ -206,6 +236,8 @@ class BNActMaxPool(Function):
         check(_lib.lib().pdgn_bn_act_maxpool_backward(B, N, C, act, int(training), ptr(x), ptr(dout), ptr(yarg),
                                                       ptr(stats), ptr(scr), ptr(bs), ptr(dx), stream_of(x)),
               "pdgn_bn_act_maxpool_backward")
+        if training:
+            mark_zero_colsum(dx)
         return dx, bs[C:], bs[:C], None, None, None, None, None, None, None, None
 
 

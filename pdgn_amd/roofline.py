@@ -49,9 +49,10 @@ def _entry(name, bound, work, us, **extra):
 
 
 def gemm_tn_stage4(B, base_points, device):
-    """Weight gradient of the stage-4 per-point GEMM: dWcat (12832 x 256) = dY^T X over
-    M = B * 8*base rows.  Algorithmic flops 2*M*N*K."""
-    M, N, K = B * 8 * base_points, 50 * 256 + 32, 256
+    """Largest weight-gradient GEMM of the step: conv2's dense half at stage 4, dW (512 x 5120) = dY^T (inte*w)
+    over M = B * 8*base rows (N = 2*Fout, K = 5 positions * 4F).  Algorithmic flops 2*M*N*K; algorithmic bytes
+    (M*N + M*K + N*K) * 4."""
+    M, N, K = B * 8 * base_points, 512, 5120
     dy = torch.randn(M, N, device=device)
     x = torch.randn(M, K, device=device)
     dw = torch.zeros(N, K, device=device)
@@ -62,8 +63,10 @@ def gemm_tn_stage4(B, base_points, device):
         check(L.pdgn_gemm_tn(ctypes.c_longlong(M), N, K, ptr(dy), ptr(x), ptr(dw), stream_of(dy)), "pdgn_gemm_tn")
     us = _time_us(run)
     z = _time_us(lambda: dw.zero_())
-    return _entry("gemm_tn_kernel (dWcat of the stage-4 per-point GEMM, M=%d N=%d K=%d)" % (M, N, K), "mfma",
-                  2.0 * M * N * K, us - z, shape=[M, N, K])
+    e = _entry("gemm_tn_kernel (dW of conv2's dense half, stage 4, M=%d N=%d K=%d)" % (M, N, K), "mfma",
+               2.0 * M * N * K, us - z, shape=[M, N, K])
+    e["algorithmic_bytes_per_launch"] = 4.0 * (M * N + M * K + N * K)
+    return e
 
 
 def bn_act_backward_stage4(B, base_points, device):

@@ -13,7 +13,7 @@ import torch.distributed as dist
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .fused import flush_bn_counters
+from .fused import clear_zero_colsum, flush_bn_counters
 from .generator import PointDiscriminator, PointGenerator
 from .losses import LocalPairLoss
 
@@ -42,6 +42,7 @@ class FlatGrads:
         """Before a backward: drop the old gradients (autograd then writes, never accumulates)."""
         for p in self.params:
             p.grad = None
+        clear_zero_colsum()
 
     def zero_(self):                       # kept for callers that accumulate into the views
         self.buf.zero_()

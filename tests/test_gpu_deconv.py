@@ -414,3 +414,33 @@ def test_fused_bn_act_maxpool_vs_torch(B, N, C, training):
             assert int(bn.num_batches_tracked) == 1
     for name, a, b in zip(["y", "dx", "dgamma", "dbeta", "running_mean", "running_var"], *res):
         np.testing.assert_allclose(a, b, rtol=1e-4, atol=1e-4 * max(1.0, np.abs(b).max()), err_msg=name)
+
+
+def test_bias_feeding_training_batchnorm_gets_analytic_zero_grad():
+    """sum_rows d(BN input) == 0 in training mode: the producer's bias gradient is returned as exact zeros and
+    the full pass over dy is skipped; the skipped sum is rounding residue (checked here), eval mode is untouched."""
+    import torch.nn as nn
+    from pdgn_amd import fused
+    dev = torch.device("cuda:0")
+    torch.manual_seed(11)
+    lin = nn.Linear(64, 128).to(dev)
+    bn = nn.BatchNorm1d(128).to(dev)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.uniform_(-0.5, 0.5)
+    x = torch.randn(4096, 64, device=dev)
+    t = torch.randn(4096, 128, device=dev)
+    for training in (True, False):
+        lin.zero_grad()
+        h = fused.linear_cl(x, lin.weight, lin.bias)
+        h.retain_grad()
+        y = fused.bn_act(h, bn, training, act="leaky_relu")
+        (y * t).sum().backward()
+        resid = h.grad.sum(0).abs().max().item()
+        scale = h.grad.abs().sum(0).max().item()
+        if training:
+            assert torch.count_nonzero(lin.bias.grad).item() == 0
+            assert resid <= 1e-5 * scale                      # what the skipped row-sum would have produced
+        else:
+            torch.testing.assert_close(lin.bias.grad, h.grad.sum(0), rtol=1e-4, atol=1e-4 * scale)
+            assert resid > 1e-3 * scale
