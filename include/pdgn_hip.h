@@ -181,6 +181,11 @@ int pdgn_bn_act_maxpool_backward(int b, int n, int c, int act, int training, con
  * models/PDGNet_v2.py:634-641: h (m,k,c) -> w (m, k/2, 2c) with w[m,p,2c'+j] = softmax_s(h[m,:,c'])[s=(k/2)j+p].
  * k even, k <= 32. */
 int pdgn_softmax_slots_permute(long long m, int k, int c, const float *h, float *w, pdgn_stream_t stream);
+/* Same with the preceding BatchNorm + activation folded in (conv_all.4 + LeakyReLU, models/PDGNet_v2.py:623-625):
+ * x (m,k,c) is the raw conv output, stats the [scale|shift|mean|invstd] row of pdgn_bn_stats / pdgn_bn_eval_stats,
+ * act as in pdgn_bn_act_forward; the activated logits are never written.  c even. */
+int pdgn_bn_softmax_slots_permute(long long m, int k, int c, int act, const float *x, const float *stats,
+                                  float *w, pdgn_stream_t stream);
 /* dh[m,s,c'] = w_s (dw_s - sum_s' w_s' dw_s'), w / dw in the permuted layout. */
 int pdgn_softmax_slots_permute_backward(long long m, int k, int c, const float *w, const float *dw,
                                         float *dh, pdgn_stream_t stream);

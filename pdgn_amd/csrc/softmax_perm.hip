@@ -35,6 +35,59 @@ __global__ __launch_bounds__(SP_THREADS) void softmax_perm_fwd_kernel(long long 
         if (p < P) *reinterpret_cast<float2 *>(W + (size_t)p * 2 * C) = make_float2(v[p] * inv, v[P + p] * inv);
 }
 
+// Same, with the BatchNorm + activation that precedes the softmax folded in (conv_all.4 + LeakyReLU,
+// models/PDGNet_v2.py:623-625): x is the RAW conv output, stats = [scale | shift | ...] of pdgn_bn_stats; the
+// activated logits never reach HBM.  One thread owns a channel PAIR: float2 reads, float4 writes.
+__device__ __forceinline__ float sp_act(float z, int act) {
+    return act == 2 ? (z > 0.f ? z : 0.01f * z) : (act == 1 ? fmaxf(z, 0.f) : z);
+}
+
+template <int KT>   // compile-time k (0 = runtime k <= SP_MAXK): branch-free unrolled loads, all k in flight at once
+__global__ __launch_bounds__(SP_THREADS) void bn_softmax_perm_fwd_kernel(long long total2, int k_rt, int C, int act,
+                                                                         const float *__restrict__ x,
+                                                                         const float *__restrict__ stats,
+                                                                         float *__restrict__ w) {
+    const long long e = (long long)blockIdx.x * SP_THREADS + threadIdx.x;
+    if (e >= total2) return;
+    constexpr int KM = KT ? KT : SP_MAXK;
+    const int k = KT ? KT : k_rt;
+    const int C2 = C / 2, c = (int)(e % C2) * 2;
+    const long long m = e / C2;
+    const int P = k / 2;
+    const float2 sc = *reinterpret_cast<const float2 *>(stats + c), sh = *reinterpret_cast<const float2 *>(stats + C + c);
+    const float *H = x + m * k * C + c;
+    float2 v[KM];
+    float mx0 = -INFINITY, mx1 = -INFINITY;
+#pragma unroll
+    for (int s = 0; s < KM; ++s)
+        if (KT || s < k) v[s] = *reinterpret_cast<const float2 *>(H + (size_t)s * C);
+#pragma unroll
+    for (int s = 0; s < KM; ++s)
+        if (KT || s < k) {
+            const float2 r = v[s];
+            v[s].x = sp_act(__fmaf_rn(r.x, sc.x, sh.x), act);
+            v[s].y = sp_act(__fmaf_rn(r.y, sc.y, sh.y), act);
+            mx0 = fmaxf(mx0, v[s].x);
+            mx1 = fmaxf(mx1, v[s].y);
+        }
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int s = 0; s < KM; ++s)
+        if (KT || s < k) {
+            v[s].x = __expf(v[s].x - mx0);
+            v[s].y = __expf(v[s].y - mx1);
+            s0 += v[s].x;
+            s1 += v[s].y;
+        }
+    const float i0 = 1.0f / s0, i1 = 1.0f / s1;
+    float *W = w + m * k * C + 2 * c;                       // row (m, p): 2C floats; [2c, 2c+1, 2c+2, 2c+3]
+#pragma unroll
+    for (int p = 0; p < KM / 2; ++p)
+        if (KT || p < P)
+            *reinterpret_cast<float4 *>(W + (size_t)p * 2 * C) =
+                make_float4(v[p].x * i0, v[P + p].x * i0, v[p].y * i1, v[P + p].y * i1);
+}
+
 __global__ __launch_bounds__(SP_THREADS) void softmax_perm_bwd_kernel(long long total, int k, int C,
                                                                       const float *__restrict__ w,
                                                                       const float *__restrict__ dw,
@@ -66,6 +119,19 @@ extern "C" int pdgn_softmax_slots_permute(long long m, int k, int c, const float
     const long long total = m * c;
     hipLaunchKernelGGL(softmax_perm_fwd_kernel, dim3(cdiv(total, SP_THREADS)), dim3(SP_THREADS), 0, (hipStream_t)stream,
                        total, k, c, h, w);
+    return pdgn_launch_status();
+}
+
+extern "C" int pdgn_bn_softmax_slots_permute(long long m, int k, int c, int act, const float *x, const float *stats,
+                                             float *w, pdgn_stream_t stream) {
+    if (m < 1 || k < 2 || k > SP_MAXK || (k & 1) || c < 2 || (c & 1) || act < 0 || act > 2) return PDGN_ERR_INVALID;
+    const long long total2 = m * (c / 2);
+    const dim3 grid(cdiv(total2, SP_THREADS)), block(SP_THREADS);
+    hipStream_t s = (hipStream_t)stream;
+    if (k == 10) hipLaunchKernelGGL(bn_softmax_perm_fwd_kernel<10>, grid, block, 0, s, total2, k, c, act, x, stats, w);
+    else if (k == 20) hipLaunchKernelGGL(bn_softmax_perm_fwd_kernel<20>, grid, block, 0, s, total2, k, c, act, x, stats, w);
+    else if (k == 4) hipLaunchKernelGGL(bn_softmax_perm_fwd_kernel<4>, grid, block, 0, s, total2, k, c, act, x, stats, w);
+    else hipLaunchKernelGGL(bn_softmax_perm_fwd_kernel<0>, grid, block, 0, s, total2, k, c, act, x, stats, w);
     return pdgn_launch_status();
 }
 

@@ -25,8 +25,8 @@ from torch.autograd import Function
 
 from . import _lib
 from ._lib import check, ptr, require, stream_of
-from .fused import (bn_act, bn_act_maxpool, flush_bn_counters, has_zero_colsum, linear_cl,  # noqa: F401
-                    softmax_slots_permute)
+from .fused import (bn_act, bn_act_maxpool, bn_softmax_slots_permute, flush_bn_counters,  # noqa: F401
+                    has_zero_colsum, linear_cl, softmax_slots_permute)
 
 F32, I32 = torch.float32, torch.int32
 
@@ -228,11 +228,12 @@ class PointDeconv(nn.Module):
             h = linear_cl(h, self.conv_all[0].weight[:, :, 0, 0], self.conv_all[0].bias)
             h = bn_act(h, self.conv_all[1], training)
             h = linear_cl(h, self.conv_all[3].weight[:, :, 0, 0], self.conv_all[3].bias)
-            h = bn_act(h, self.conv_all[4], training)
             if self.softmax:
-                # softmax over the k slots + interleave w[b,n,s=P*j+p,c'] -> [b,n,p,o=2c'+j] (:634-641), fused
-                w = softmax_slots_permute(h.view(B * N, k, 2 * Fi)).view(B * N * P, 4 * Fi)
+                # conv_all.4 + LeakyReLU + softmax over the k slots + interleave w[b,n,s=P*j+p,c'] -> [b,n,p,o=2c'+j]
+                # (:623-625, :634-641) in one pass over the raw conv output
+                w = bn_softmax_slots_permute(h, self.conv_all[4], training, k).view(B * N * P, 4 * Fi)
             else:
+                h = bn_act(h, self.conv_all[4], training)
                 w = h.view(B, N, 2, P, 2 * Fi).permute(0, 1, 3, 4, 2).reshape(B * N * P, 4 * Fi)
         # inte = LeakyReLU(BN(inte_pre)) [* w]  -- one fused pass (:637, :642)
         inte = bn_act(inte_pre.view(-1, 4 * Fi), self.inte_conv_hk[1], training, mul=w)

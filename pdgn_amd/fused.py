@@ -194,6 +194,64 @@ def softmax_slots_permute(h):
     return SoftmaxSlotsPermute.apply(h)
 
 
+class BNSoftmaxSlotsPermute(Function):
+    """softmax_slots_permute(act(BatchNorm(x))) for x (M*k, C) raw conv outputs: the statistics pass, then ONE
+    pass that normalises, activates, soft-maxes over the k slots and writes the interleaved weights; the
+    activated logits never exist in HBM.  Backward: softmax adjoint, then the BatchNorm+act adjoint on x."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, act, k):
+        rows, C = x.shape
+        m = rows // k
+        x = x.contiguous()
+        L = _lib.lib()
+        stats = torch.empty(4 * C, dtype=F32, device=x.device)
+        g, b = gamma.detach().contiguous(), beta.detach().contiguous()
+        if training:
+            scratch = torch.empty(_scratch_floats(L, rows, C), dtype=F32, device=x.device)
+            check(L.pdgn_bn_stats(ctypes.c_longlong(rows), C, ctypes.c_float(eps), ctypes.c_float(momentum), ptr(x),
+                                  ptr(g), ptr(b), ptr(running_mean), ptr(running_var), ptr(scratch), ptr(stats),
+                                  stream_of(x)), "pdgn_bn_stats")
+        else:
+            check(L.pdgn_bn_eval_stats(C, ctypes.c_float(eps), ptr(g), ptr(b), ptr(running_mean),
+                                       ptr(running_var), ptr(stats), stream_of(x)), "pdgn_bn_eval_stats")
+        w = torch.empty((m, k // 2, 2 * C), dtype=F32, device=x.device)
+        check(L.pdgn_bn_softmax_slots_permute(ctypes.c_longlong(m), k, C, act, ptr(x), ptr(stats), ptr(w),
+                                              stream_of(x)), "pdgn_bn_softmax_slots_permute")
+        ctx.save_for_backward(x, stats, w)
+        ctx.cfg = (rows, C, act, bool(training), k)
+        return w
+
+    @staticmethod
+    def backward(ctx, dw):
+        x, stats, w = ctx.saved_tensors
+        rows, C, act, training, k = ctx.cfg
+        L = _lib.lib()
+        dw = dw.contiguous()
+        dh = torch.empty((rows, C), dtype=F32, device=x.device)
+        check(L.pdgn_softmax_slots_permute_backward(ctypes.c_longlong(rows // k), k, C, ptr(w), ptr(dw), ptr(dh),
+                                                    stream_of(w)), "pdgn_softmax_slots_permute_backward")
+        scratch = torch.empty(_scratch_floats(L, rows, C), dtype=F32, device=x.device)
+        bs = torch.empty(2 * C, dtype=F32, device=x.device)
+        dx = torch.empty_like(x)
+        check(L.pdgn_bn_act_backward(ctypes.c_longlong(rows), C, act, int(training), ptr(x), ptr(dh), ptr(None),
+                                     ptr(stats), ptr(scratch), ptr(bs), ptr(dx), ptr(None), stream_of(x)),
+              "pdgn_bn_act_backward")
+        if training:
+            mark_zero_colsum(dx)
+        return dx, bs[C:], bs[:C], None, None, None, None, None, None, None
+
+
+def bn_softmax_slots_permute(x2d, bn, training, k, act="leaky_relu"):
+    """x2d (M*k, C) -> (M, k/2, 2C): nn.BatchNorm2d `bn` + `act` + softmax over the k slots + interleave."""
+    if x2d.shape[1] % 4:
+        return softmax_slots_permute(bn_act(x2d, bn, training, act=act).view(-1, k, x2d.shape[1]))
+    if training and bn.track_running_stats:
+        _PENDING_COUNTS[bn.num_batches_tracked] = _PENDING_COUNTS.get(bn.num_batches_tracked, 0) + 1
+    return BNSoftmaxSlotsPermute.apply(x2d, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, bn.momentum,
+                                       bn.eps, ACT[act], k)
+
+
 class BNActMaxPool(Function):
     """(B*N, C) rows -> (B, C): max over the N points of each sample of act(BatchNorm(x)) -- the
     BatchNorm1d + LeakyReLU + MaxPool1d tail of the discriminators without writing the activated

@@ -332,6 +332,39 @@ def test_softmax_slots_permute(M, k, C):
     np.testing.assert_allclose(hd.grad.cpu().numpy(), hr.grad.numpy(), rtol=1e-3, atol=1e-6)
 
 
+@pytest.mark.parametrize("M,k,C,training", [(1000, 10, 16, True), (1792, 10, 512, True), (77, 4, 24, True), (300, 10, 64, False)])
+def test_bn_softmax_slots_permute(M, k, C, training):
+    """conv_all.4 + LeakyReLU + slot softmax + interleave in one pass vs BatchNorm -> act -> softmax in fp64."""
+    import torch.nn as nn
+    from pdgn_amd.fused import bn_softmax_slots_permute
+    from torch_standins import bn_softmax_slots_permute_torch
+    rng = np.random.default_rng(M + C)
+    x = torch.from_numpy((rng.standard_normal((M * k, C)) * 2 + 0.5).astype(np.float32))
+    g = torch.from_numpy(rng.standard_normal((M, k // 2, 2 * C)).astype(np.float32))
+    bn = nn.BatchNorm2d(C)
+    with torch.no_grad():
+        bn.weight.copy_(torch.from_numpy(rng.uniform(0.5, 1.5, C).astype(np.float32)))
+        bn.bias.copy_(torch.from_numpy(rng.uniform(-0.5, 0.5, C).astype(np.float32)))
+        bn.running_mean.copy_(torch.from_numpy(rng.uniform(-0.2, 0.8, C).astype(np.float32)))
+        bn.running_var.copy_(torch.from_numpy(rng.uniform(2.0, 5.0, C).astype(np.float32)))
+    import copy
+    bnr = copy.deepcopy(bn).double()
+    bnd = bn.cuda()
+    xd = dev(x).requires_grad_(True)
+    w = bn_softmax_slots_permute(xd, bnd, training, k)
+    w.backward(dev(g))
+    xr = x.double().requires_grad_(True)
+    wr = bn_softmax_slots_permute_torch(xr, bnr, training, k)
+    wr.backward(g.double())
+    np.testing.assert_allclose(w.detach().cpu().numpy(), wr.detach().numpy(), rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(xd.grad.cpu().numpy(), xr.grad.numpy(), rtol=2e-3, atol=2e-6)
+    np.testing.assert_allclose(bnd.weight.grad.cpu().numpy(), bnr.weight.grad.numpy(), rtol=2e-3, atol=1e-4)
+    np.testing.assert_allclose(bnd.bias.grad.cpu().numpy(), bnr.bias.grad.numpy(), rtol=2e-3, atol=1e-4)
+    if training:
+        np.testing.assert_allclose(bnd.running_mean.cpu().numpy(), bnr.running_mean.numpy(), rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(bnd.running_var.cpu().numpy(), bnr.running_var.numpy(), rtol=1e-5, atol=1e-6)
+
+
 def test_config_c4_four_stage_512_to_4096():
     """BASELINE.json configs[3] ("4-stage 256->4096"; SURVEY.md section 8 Note C4: base 256 points):
     the size-generic blocks run one iteration at 512/1024/2048/4096 points; outputs have the right

@@ -78,6 +78,11 @@ def linear_cl_torch(x2d, weight, bias=None):
     return torch.nn.functional.linear(x2d, weight, bias)
 
 
+def bn_softmax_slots_permute_torch(x2d, bn, training, k, act="leaky_relu"):
+    h = bn_act_torch(x2d, bn, training, act=act)
+    return softmax_slots_permute_torch(h.view(-1, k, x2d.shape[1]))
+
+
 def softmax_slots_permute_torch(h):
     M, k, C = h.shape
     P = k // 2
