@@ -47,13 +47,27 @@ __global__ __launch_bounds__(BN_THREADS) void cl_stats_kernel(long long R, int C
     const long long r0 = (long long)blockIdx.y * rows_per_block;
     const long long r1 = min(R, r0 + rows_per_block);
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f), q = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (cok)
-        for (long long r = r0 + rlane; r < r1; r += rl) {
-            float4 v = *reinterpret_cast<const float4 *>(x + r * C + cgi * 4);
+    if (cok) {
+        const float *X = x + cgi * 4;
+        long long r = r0 + rlane;
+        for (; r + 3LL * rl < r1; r += 4LL * rl) {              // four independent row loads in flight
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4 *>(X + (r + (long long)u * rl) * C);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w;
+                q.x = __fmaf_rn(v[u].x, v[u].x, q.x); q.y = __fmaf_rn(v[u].y, v[u].y, q.y);
+                q.z = __fmaf_rn(v[u].z, v[u].z, q.z); q.w = __fmaf_rn(v[u].w, v[u].w, q.w);
+            }
+        }
+        for (; r < r1; r += rl) {
+            const float4 v = *reinterpret_cast<const float4 *>(X + r * C);
             s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
             q.x = __fmaf_rn(v.x, v.x, q.x); q.y = __fmaf_rn(v.y, v.y, q.y);
             q.z = __fmaf_rn(v.z, v.z, q.z); q.w = __fmaf_rn(v.w, v.w, q.w);
         }
+    }
     red[0][threadIdx.x] = s;
     red[1][threadIdx.x] = q;
     __syncthreads();

@@ -25,10 +25,17 @@ from torch.autograd import Function
 
 from . import _lib
 from ._lib import check, ptr, require, stream_of
-from .fused import (bn_act, bn_act_maxpool, bn_softmax_slots_permute, flush_bn_counters,  # noqa: F401
+from .fused import (_zeros, bn_act, bn_act_maxpool, bn_softmax_slots_permute, flush_bn_counters,  # noqa: F401
                     has_zero_colsum, linear_cl, softmax_slots_permute)
 
 F32, I32 = torch.float32, torch.int32
+
+
+def _w2d(conv):
+    """(C_out, C_in, 1[, 1]) kernel-1 conv weight as a (C_out, C_in) VIEW: unlike weight[:, :, 0, 0] its backward
+    is a reshape, not two zero-fill + copy launches."""
+    w = conv.weight
+    return w.view(w.shape[0], w.shape[1])
 
 
 def feature_knn(x, k):
@@ -101,7 +108,7 @@ def _dbias(dout, kind):
     if kind == 0:
         return None
     if kind == 3:                                  # feeds a training-mode BatchNorm: identically zero (fused.py)
-        return torch.zeros(dout.shape[-1], dtype=F32, device=dout.device)
+        return _zeros((dout.shape[-1],), dout.device)
     return dout.sum(dim=(0, 1, 2)) if kind == 1 else dout.sum(dim=(1, 2))
 
 
@@ -155,15 +162,15 @@ class PointDeconv(nn.Module):
     def _assemble(self):
         Fi, Fo, k = self.Fin, self.Fout, self.k
         T = k // 2 + 1
-        Wi = self.inte_conv_hk[0].weight[:, :, 0, :]                   # (4F, 2F, T)
-        W2 = self.conv2.conv.weight[:, :, 0, :]                        # (2Fo, 2F, 2k)
+        Wi = self.inte_conv_hk[0].weight.squeeze(2)                   # (4F, 2F, T)
+        W2 = self.conv2.conv.weight.squeeze(2)                        # (2Fo, 2F, 2k)
         W2a, W2b = W2[:, :, :k], W2[:, :, k:]
         blocks = [Wi[:, Fi:, :].permute(2, 0, 1).reshape(T * 4 * Fi, Fi),            # taps of inte_conv_hk
                   (Wi[:, :Fi, :] - Wi[:, Fi:, :]).sum(2),                             # its centre term
                   W2a[:, Fi:, :].permute(2, 0, 1).reshape(k * 2 * Fo, Fi),            # taps of conv2[..., :k]
                   (W2a[:, :Fi, :] - W2a[:, Fi:, :]).sum(2)]
         if self.bilateral:
-            Wf = self.conv_fea[0].weight[:, :, 0, 0]                   # (16, 2F)
+            Wf = _w2d(self.conv_fea[0])                   # (16, 2F)
             blocks += [Wf[:, Fi:], Wf[:, :Fi] - Wf[:, Fi:]]
         Wcat = torch.cat(blocks, 0)
         P = k - T + 1
@@ -220,14 +227,14 @@ class PointDeconv(nn.Module):
         inte_pre, a_pre = outs[0], outs[1]                             # (B,N,P,4F), (B,N,1,2Fo)
         w = None
         if self.bilateral:
-            Wx = self.conv_xyz[0].weight[:, :, 0, 0]                   # (16, 6)
+            Wx = _w2d(self.conv_xyz[0])                   # (16, 6)
             Yx = torch.matmul(pct, torch.cat([Wx[:, 3:], Wx[:, :3] - Wx[:, 3:]], 0).t()).contiguous()
             (xyz_pre,) = EdgeGatherSum.apply(Yx, idx, ((1, k, 16, 0, 16),), self.conv_xyz[0].bias)
             xyzf = bn_act(xyz_pre.view(-1, 16), self.conv_xyz[1], training)
             h = bn_act(outs[2].view(-1, 16), self.conv_fea[1], training, mul=xyzf)   # w_fea * w_xyz :632
-            h = linear_cl(h, self.conv_all[0].weight[:, :, 0, 0], self.conv_all[0].bias)
+            h = linear_cl(h, _w2d(self.conv_all[0]), self.conv_all[0].bias)
             h = bn_act(h, self.conv_all[1], training)
-            h = linear_cl(h, self.conv_all[3].weight[:, :, 0, 0], self.conv_all[3].bias)
+            h = linear_cl(h, _w2d(self.conv_all[3]), self.conv_all[3].bias)
             if self.softmax:
                 # conv_all.4 + LeakyReLU + softmax over the k slots + interleave w[b,n,s=P*j+p,c'] -> [b,n,p,o=2c'+j]
                 # (:623-625, :634-641) in one pass over the raw conv output

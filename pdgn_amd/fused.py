@@ -44,6 +44,43 @@ def clear_zero_colsum():
     _ZERO_COLSUM.clear()
 
 
+# gemm_tn accumulates split partial sums with atomics, so every weight gradient starts from zeros (and the
+# analytically-zero bias gradients are zeros): ~90 tiny fill launches per iteration.  A caller that brackets its
+# backward passes (FlatGrads.begin) gets them as slices of ONE zero-filled arena, sized from the previous pass.
+_ARENA = {"buf": None, "off": 0, "need": 0, "owner": None}
+
+
+def reset_zero_arena(device, owner):
+    """Start a backward pass of `owner` (any object; its attribute `zero_arena_floats` remembers how many zero
+    floats its previous pass asked for)."""
+    a = _ARENA
+    if a["owner"] is not None:
+        a["owner"].zero_arena_floats = max(getattr(a["owner"], "zero_arena_floats", 0), a["need"])
+    size = getattr(owner, "zero_arena_floats", 0)
+    a["buf"] = torch.zeros(size, dtype=F32, device=device) if size else None
+    a["off"] = a["need"] = 0
+    a["owner"] = owner
+
+
+def release_zero_arena():
+    _ARENA["buf"] = None
+
+
+def _zeros(shape, device):
+    n = 1
+    for d in shape:
+        n *= d
+    step = (n + 63) // 64 * 64
+    a = _ARENA
+    a["need"] += step
+    buf = a["buf"]
+    if buf is None or buf.device != device or a["off"] + step > buf.numel():
+        return torch.zeros(shape, dtype=F32, device=device)
+    v = buf[a["off"]:a["off"] + n].view(shape)
+    a["off"] += step
+    return v
+
+
 class BNActCL(Function):
     """y = act(BatchNorm(x)) [* mul] for a channels-last (rows, C) matrix, with nn.BatchNorm
     semantics (batch statistics + running-stat update in training, running statistics in eval).
@@ -143,19 +180,19 @@ class LinearCL(Function):
             k = x.shape[1]
             if k % 4 and n % 4 == 0 and m >= 1024:          # e.g. the xyz input layer (k = 3): pad to 4
                 xp = torch.nn.functional.pad(x, (0, 4 - k % 4))
-                dwp = torch.zeros((n, xp.shape[1]), dtype=F32, device=dy.device)
+                dwp = _zeros((n, xp.shape[1]), dy.device)
                 check(_lib.lib().pdgn_gemm_tn(ctypes.c_longlong(m), n, xp.shape[1], ptr(dy), ptr(xp), ptr(dwp),
                                               stream_of(dy)), "pdgn_gemm_tn")
                 dw = dwp[:, :k]
             elif n % 4 == 0 and k % 4 == 0 and x.is_contiguous() and m >= 1024:
-                dw = torch.zeros((n, k), dtype=F32, device=dy.device)
+                dw = _zeros((n, k), dy.device)
                 check(_lib.lib().pdgn_gemm_tn(ctypes.c_longlong(m), n, k, ptr(dy), ptr(x), ptr(dw), stream_of(dy)),
                       "pdgn_gemm_tn")
             else:
                 dw = dy.t().matmul(x)
         db = None
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = torch.zeros(dy.shape[1], dtype=F32, device=dy.device) if zero_db else dy.sum(dim=0)
+            db = _zeros((dy.shape[1],), dy.device) if zero_db else dy.sum(dim=0)
         return dx, dw, db
 
 

@@ -28,7 +28,7 @@ def _linear(rows, weight, bias=None):
 
 def _conv1x1_rows(rows, conv):
     """Conv1d(kernel 1) applied to a (rows, C_in) matrix."""
-    return _linear(rows, conv.weight[:, :, 0], conv.bias)
+    return _linear(rows, _deconv._w2d(conv), conv.bias)
 
 
 def _head_rows(head, x_rows, B, g=None, n_const=0):
@@ -36,7 +36,7 @@ def _head_rows(head, x_rows, B, g=None, n_const=0):
     channels (:708-709, :745-746); the first `n_const` input channels (the per-batch vector g)
     are applied once per batch and broadcast, never concatenated."""
     c0 = head[0]
-    W = c0.weight[:, :, 0]
+    W = _deconv._w2d(c0)
     h = _linear(x_rows, W[:, n_const:].contiguous())                       # (B*M, 256)
     if g is not None:
         M = x_rows.shape[0] // B

@@ -13,7 +13,7 @@ import torch.distributed as dist
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .fused import clear_zero_colsum, flush_bn_counters
+from .fused import clear_zero_colsum, flush_bn_counters, release_zero_arena, reset_zero_arena
 from .generator import PointDiscriminator, PointGenerator
 from .losses import LocalPairLoss
 
@@ -43,6 +43,8 @@ class FlatGrads:
         for p in self.params:
             p.grad = None
         clear_zero_colsum()
+        if self.params and self.params[0].is_cuda:
+            reset_zero_arena(self.params[0].device, self)
 
     def zero_(self):                       # kept for callers that accumulate into the views
         self.buf.zero_()
