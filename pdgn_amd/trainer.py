@@ -167,7 +167,7 @@ class PDGNTrainer:
             mu, cov = self.local_pair(clouds[a], clouds[b], self_stats=own[a])
             mus.append(mu)
             covs.append(cov)
-        return sum(mus[1:], mus[0]) + sum(covs[1:], covs[0])
+        return torch.stack(mus + covs).sum()
 
     # The iteration is written as six SEGMENTS separated by the five gradient all-reduces, so that
     # each segment can be captured into a hipGraph (no RCCL call inside a capture) and replayed:

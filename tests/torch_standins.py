@@ -64,10 +64,16 @@ def chamfer_min_torch(x, y):
     return P.min(2)[0], P.min(1)[0]
 
 
+def chamfer_sum_torch(x, y, scale=1.0):
+    minx, miny = chamfer_min_torch(x, y)
+    return (minx.sum() + miny.sum()) * scale
+
+
 def patch_losses(monkeypatch_or_module):
     """Route pdgn_amd.losses' three HIP entry points to the stand-ins above."""
     from pdgn_amd import losses
-    for name, fn in (("knnquery", knnquery_oracle), ("local_stats", local_stats_torch), ("chamfer_min", chamfer_min_torch)):
+    for name, fn in (("knnquery", knnquery_oracle), ("local_stats", local_stats_torch), ("chamfer_min", chamfer_min_torch),
+                     ("chamfer_sum", chamfer_sum_torch)):
         if hasattr(monkeypatch_or_module, "setattr"):
             monkeypatch_or_module.setattr(losses, name, fn)
         else:
