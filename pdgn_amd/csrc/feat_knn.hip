@@ -193,15 +193,20 @@ __global__ __launch_bounds__(FK_THREADS) void feat_knn_kernel(
 
 template <int FH>
 __global__ __launch_bounds__(FKP_THREADS) void feat_knn_pc_kernel(
-    int n, int k, const float *__restrict__ x, const float *__restrict__ sq, int32_t *__restrict__ idx) {
+    int b, int n, int k, const float *__restrict__ x, const float *__restrict__ sq, int32_t *__restrict__ idx) {
     constexpr int NCP = FK_NC + 4;
     constexpr int f = 2 * FH;
     __shared__ float dist[2][FK_QB][NCP];
     __shared__ DI queue[FK_QB][FKP_QCAP + 32];       // + room for the running list during a ranked merge
     __shared__ DI win[4][32];                          // per consumer wave
 
-    const int bs = blockIdx.y;
-    const int q0 = blockIdx.x * FK_QB;
+    // XCD-aware decode: workgroup ids go round-robin over the 8 XCDs; every query tile of a sample streams
+    // that sample's whole feature matrix, so all tiles of sample s are given ids = s (mod 8): one L2
+    // fetches the sample once instead of each of the 8 L2s fetching every sample.
+    const int tiles = n / FK_QB, pid = blockIdx.x;
+    const int bs = ((pid >> 3) / tiles) * 8 + (pid & 7);
+    if (bs >= b) return;
+    const int q0 = ((pid >> 3) % tiles) * FK_QB;
     const int lane = lane_id();
     const int wave = threadIdx.x / PDGN_WAVE;
     const bool producer = wave < 4;
@@ -301,7 +306,8 @@ static int launch_fk(int b, int f, int n, int k, const float *x, const float *sq
                      hipStream_t s) {
     dim3 grid(cdiv(n, FK_QB), b);
     if (f == 2 * FH && n % 128 == 0)
-        hipLaunchKernelGGL((feat_knn_pc_kernel<FH>), grid, dim3(FKP_THREADS), 0, s, n, k, x, sq, idx);
+        hipLaunchKernelGGL((feat_knn_pc_kernel<FH>), dim3((unsigned)((b + 7) / 8 * 8 * (n / FK_QB))), dim3(FKP_THREADS), 0, s, b,
+                           n, k, x, sq, idx);
     else
         hipLaunchKernelGGL((feat_knn_kernel<FH>), grid, dim3(FK_THREADS), 0, s, f, n, k, x, sq, idx);
     return pdgn_launch_status();

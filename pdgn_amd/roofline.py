@@ -123,7 +123,7 @@ def feature_knn_stage4(B, base_points, device):
     def run():
         check(L.pdgn_feature_knn(B, F, N, k, ptr(x), ptr(sq), ptr(idx), stream_of(x)), "pdgn_feature_knn")
     us = _time_us(run)
-    return _entry("feat_knn_kernel<128> (stage-4 kNN graph)", "mfma", 2.0 * B * N * N * F, us)
+    return _entry("feat_knn_pc_kernel<128> (stage-4 kNN graph)", "mfma", 2.0 * B * N * N * F, us)
 
 
 def knn3_largest(B, base_points, device):

@@ -15,7 +15,7 @@ KERNELS = {   # roofline entry prefix -> (kernel-name substrings, FETCH_SIZE cor
     "gemm_tn_kernel": (["gemm_tn_kernel"], 2.0),
     "cl_bwd_reduce + cl_bwd_apply": (["cl_bwd_reduce_kernel", "cl_bwd_apply_kernel"], 2.0),
     "wgs_fwd_kernel<4>": (["wgs_fwd_kernel"], 2.0),
-    "feat_knn_kernel<128>": (["feat_knn_kernel"], 2.0),
+    "feat_knn_pc_kernel<128>": (["feat_knn_pc_kernel"], 2.0),
     "knn3_wave_kernel": (["knn3_wave_kernel"], 1.0),
 }
 
