@@ -122,7 +122,9 @@ class PointGenerator(nn.Module):
         self.mlp1, self.mlp2 = _mlp_head(512 + 32), _mlp_head(512 + 64)
         self.mlp3, self.mlp4 = _mlp_head(512 + 128), _mlp_head(512)
 
-    def forward(self, z, idx=(None, None, None, None)):
+    def forward(self, z, idx=(None, None, None, None), stage_hook=None):
+        """`stage_hook(level, cloud)`, if given, is called as soon as the cloud of a level exists (the trainer starts
+        that level's discriminator update on another stream while the deeper levels are still being generated)."""
         B = z.shape[0]
         xt = self.fc1(z).view(B, 32, self.base_points).transpose(1, 2).contiguous()    # (B,N0,32)
         pct, const, clouds = None, None, []
@@ -138,6 +140,9 @@ class PointGenerator(nn.Module):
                 p = _head_rows(heads[lvl], rows, B, g=xs, n_const=Fo)           # mlp4 sees cat(xs, x_ec) :875
             pct = p.view(B, M, 3)
             clouds.append(pct.transpose(1, 2))                                  # (B,3,M) like the reference
+            if stage_hook is not None:
+                _deconv.flush_bn_counters()
+                stage_hook(lvl, clouds[-1])
             xt, const = x_ec, xs                    # next block's input is cat(xs broadcast, x_ec) :708
         _deconv.flush_bn_counters()
         return tuple(clouds)

@@ -90,6 +90,9 @@ class PDGNTrainer:
         cap = self.device.type == "cuda"                     # device-side step counter: graph-capturable
         adam = lambda m: torch.optim.Adam(m.parameters(), lr=lr, betas=(0.5, 0.999), capturable=cap, fused=cap and os.environ.get("PDGN_FUSED_ADAM", "1") == "1")
         self.optG, self.optD = adam(self.G), [adam(d) for d in self.D]
+        # stream-overlapped schedule of the eager step (see _step_overlapped); PDGN_OVERLAP=0 turns it off
+        self.overlap = cap and os.environ.get("PDGN_OVERLAP", "1") == "1"
+        self._side = None
 
     def train(self):
         self.G.train()
@@ -235,10 +238,61 @@ class PDGNTrainer:
     def step(self, reals, z1, z2):
         """reals: four tensors (B,3,N_k); z1 / z2: noise (B,128) of the two generator passes
         (:178, :228).  Returns dict of 0-dim device tensors (no host sync inside the step)."""
+        if self.overlap:
+            return self._step_overlapped(reals, z1, z2)
         st = self._state(reals, z1, z2)
         for k in range(6):
             self._segment(st, k)
             self._comm(k)
+        return st["out"]
+
+    def _step_overlapped(self, reals, z1, z2):
+        """Same iteration, scheduled for the GPU: the four discriminator updates are independent of each other
+        and of everything the generator does after emitting their resolution, and they are chains of small
+        kernels (D1-D3 see 256-1024 points) that leave most CUs idle.  D_k's update (forward real + fake,
+        backward, all-reduce, Adam) is enqueued on its own HIP stream the moment G(z1) has produced level k,
+        so it runs underneath the deeper levels' GEMMs / gather-sums; D4's runs underneath G(z2).  The
+        default stream joins the four streams before D(G(z2)).  Results are those of the sequential order
+        (the reference's D updates do not read each other)."""
+        st = self._state(reals, z1, z2)
+        main = torch.cuda.current_stream(self.device)
+        if self._side is None:
+            self._side = [torch.cuda.Stream(device=self.device) for _ in range(4)]
+            self._side_lp = torch.cuda.Stream(device=self.device)
+        st["fakes"] = [None] * 4
+
+        def d_update(level, cloud):
+            st["fakes"][level] = cloud
+            side = self._side[level]
+            side.wait_stream(main)
+            with torch.cuda.stream(side), torch.enable_grad():
+                self._seg_d(st, level)
+                self._comm(level)
+                self.optD[level].step()
+
+        with torch.no_grad():
+            self.G(self._z(st, "z1"), stage_hook=d_update)
+        self.gradG.begin()
+        self._freeze_D(True)
+        gen = self.G(self._z(st, "z2"))
+        # the shape-preserving loss (12 kNN + Chamfer terms) and the four D(gen) passes read the same clouds and
+        # nothing of each other: the former runs on its own stream, forward and (autograd keeps an op's
+        # backward on its forward's stream) backward
+        self._side_lp.wait_stream(main)
+        with torch.cuda.stream(self._side_lp):
+            similar = self.similar_loss(gen)
+        for side in self._side:
+            main.wait_stream(side)
+        g_loss = [F.mse_loss(self.D[i](gen[i]), st["ones"]) for i in range(4)]
+        adv = 1.2 * g_loss[0] + 1.2 * g_loss[1] + 1.2 * g_loss[2] + g_loss[3]
+        main.wait_stream(self._side_lp)
+        lossG = adv + 0.1 * similar
+        ws = st["ws"]
+        (adv + (0.1 * ws) * similar if ws > 1 else lossG).backward()
+        self._freeze_D(False)
+        st["out"]["g_loss"], st["out"]["similar_loss"] = lossG.detach(), similar.detach()
+        self._comm(4)
+        self.optG.step()
         return st["out"]
 
     # ---------------------------------------------------------------- hipGraph replay
