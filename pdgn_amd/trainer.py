@@ -246,7 +246,7 @@ class PDGNTrainer:
             self._comm(k)
         return st["out"]
 
-    def _step_overlapped(self, reals, z1, z2):
+    def _step_overlapped(self, reals, z1, z2, st=None):
         """Same iteration, scheduled for the GPU: the four discriminator updates are independent of each other
         and of everything the generator does after emitting their resolution, and they are chains of small
         kernels (D1-D3 see 256-1024 points) that leave most CUs idle.  D_k's update (forward real + fake,
@@ -254,7 +254,7 @@ class PDGNTrainer:
         so it runs underneath the deeper levels' GEMMs / gather-sums; D4's runs underneath G(z2).  The
         default stream joins the four streams before D(G(z2)).  Results are those of the sequential order
         (the reference's D updates do not read each other)."""
-        st = self._state(reals, z1, z2)
+        st = st if st is not None else self._state(reals, z1, z2)
         main = torch.cuda.current_stream(self.device)
         if self._side is None:
             self._side = [torch.cuda.Stream(device=self.device) for _ in range(4)]
@@ -322,6 +322,16 @@ class PDGNTrainer:
         # nothing to all-reduce, six graphs (replayed with the all-reduces between them) otherwise.
         groups = [[k] for k in range(6)] if self.distributed else [list(range(6))]
         self._graphs, pool = [], None
+        if self.overlap and not self.distributed:
+            if self._side is None:
+                self._side = [torch.cuda.Stream(device=self.device) for _ in range(4)]
+                self._side_lp = torch.cuda.Stream(device=self.device)
+            # the stream-overlapped schedule as ONE graph: the side streams fork from / join the capturing stream
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._step_overlapped(None, None, None, st=self._static)
+            self._graphs.append((g, 5))
+            return self
         for group in groups:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, pool=pool):
