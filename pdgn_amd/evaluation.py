@@ -110,3 +110,88 @@ def compute_all_metrics(sample_pcs, ref_pcs, batch_size=None, accelerated_cd=Fal
     results.update({"1-NN-CD-%s" % k: v for k, v in knn(M_rr_cd, M_rs_cd, M_ss_cd, 1).items() if "acc" in k})
     results.update({"1-NN-EMD-%s" % k: v for k, v in knn(M_rr_emd, M_rs_emd, M_ss_emd, 1).items() if "acc" in k})
     return results
+
+
+# ---------------------------------------------------------------------------- JSD (evaluation_metrics.py:206-321)
+def unit_cube_grid_point_cloud(resolution, clip_sphere=False, device="cpu"):
+    """Cell centres of a resolution^3 grid over the unit cube (:206-224); clip_sphere keeps |c| <= 0.5."""
+    spacing = 1.0 / float(resolution - 1)
+    ax = torch.arange(resolution, dtype=F32, device=device) * spacing - 0.5
+    grid = torch.stack(torch.meshgrid(ax, ax, ax, indexing="ij"), dim=-1)
+    if clip_sphere:
+        grid = grid.reshape(-1, 3)
+        grid = grid[grid.double().norm(dim=1) <= 0.5]
+    return grid, spacing
+
+
+def occupancy_grid_counters(pclouds, grid_resolution, in_sphere=False):
+    """grid_counters and per-cell Bernoulli counts of entropy_of_occupancy_grid (:242-283): every point votes for
+    its nearest grid cell.  The reference loops over clouds with sklearn's NearestNeighbors; here ALL points go
+    through one brute-force 1-NN launch (pdgn_knnquery) and two bincounts."""
+    from . import pointops
+    require(pclouds, "pclouds", F32, 3)
+    S, N, _ = pclouds.shape
+    grid, _ = unit_cube_grid_point_cloud(grid_resolution, in_sphere, device=pclouds.device)
+    grid = grid.reshape(1, -1, 3).contiguous()
+    G = grid.shape[1]
+    idx = pointops.knnquery(1, grid, pclouds.reshape(1, S * N, 3).contiguous()).view(S, N).long()
+    counters = torch.bincount(idx.reshape(-1), minlength=G).double()
+    cloud = torch.arange(S, device=pclouds.device).view(S, 1).expand(S, N)
+    pairs = torch.unique(cloud.reshape(-1) * G + idx.reshape(-1))          # one vote per (cloud, cell)
+    bernoulli = torch.bincount(pairs % G, minlength=G).double()
+    return counters, bernoulli
+
+
+def _entropy(p, base=None):
+    p = p / p.sum()
+    nz = p > 0
+    h = -(p[nz] * torch.log(p[nz])).sum()
+    return h / torch.log(torch.tensor(float(base), dtype=p.dtype, device=p.device)) if base else h
+
+
+def entropy_of_occupancy_grid(pclouds, grid_resolution, in_sphere=False):
+    """:242-283 -> (mean Bernoulli entropy per cell, grid_counters)."""
+    counters, bern = occupancy_grid_counters(pclouds, grid_resolution, in_sphere)
+    p = bern[bern > 0] / float(pclouds.shape[0])
+    q = 1.0 - p
+    h = -(p * torch.log(p)).sum() - (q[q > 0] * torch.log(q[q > 0])).sum()
+    return h / counters.numel(), counters
+
+
+def jensen_shannon_divergence(P, Q):
+    """:286-305 (base-2 entropies)."""
+    if bool((P < 0).any()) or bool((Q < 0).any()):
+        raise ValueError("Negative values.")
+    if P.numel() != Q.numel():
+        raise ValueError("Non equal size.")
+    P_, Q_ = P / P.sum(), Q / Q.sum()
+    return _entropy((P_ + Q_) / 2.0, 2) - (_entropy(P_, 2) + _entropy(Q_, 2)) / 2.0
+
+
+def jsd_between_point_cloud_sets(sample_pcs, ref_pcs, resolution=28):
+    """:227-239: JSD between the occupancy distributions of two sets of clouds (unit-sphere grid)."""
+    s = entropy_of_occupancy_grid(sample_pcs, resolution, True)[1]
+    r = entropy_of_occupancy_grid(ref_pcs, resolution, True)[1]
+    return jensen_shannon_divergence(s, r)
+
+
+# ---------------------------------------------------------------------------- the test phase (models/PDGNet_v2.py:296-331)
+@torch.no_grad()
+def generate_and_evaluate(generator, ref_pcs, batch_size, normalize=None, rng=None, with_jsd=True):
+    """PDGNet_v2.test: draw ceil(N_ref / batch_size) batches of z ~ N(0, 1) (:304 -- sigma 1, unlike training's
+    0.2), keep the finest cloud of each, truncate to N_ref, normalise like the reference set (`normalize` =
+    the data set's scale mode: shape_unit / shape_bbox / None), then compute_all_metrics (+ 'jsd').
+    Returns (generated clouds (N_ref, N, 3), results dict of floats-on-device)."""
+    from .data import normalize_point_clouds
+    dev = ref_pcs.device
+    n_ref = ref_pcs.shape[0]
+    gen = []
+    for _ in range((n_ref + batch_size - 1) // batch_size):
+        z = torch.randn(batch_size, 128, generator=rng, device=dev if rng is None or rng.device.type != "cpu" else "cpu").to(dev)
+        gen.append(generator(z)[3].transpose(2, 1).contiguous())
+    gen_pcs = torch.cat(gen, dim=0)[:n_ref].contiguous()
+    gen_pcs = normalize_point_clouds(gen_pcs, normalize)
+    results = compute_all_metrics(gen_pcs, ref_pcs, batch_size)
+    if with_jsd:
+        results["jsd"] = jsd_between_point_cloud_sets(gen_pcs, ref_pcs)
+    return gen_pcs, results

@@ -213,6 +213,57 @@ def gen_eval():
          Mxx=Mxx, Mxy=Mxy, Myy=Myy, **{"knn_" + k: v for k, v in kn.items()}, smp=smp, ref=refc, all_cd=cd)
 
 
+# ------------------------------------------------------------------ 5d. data ingestion + JSD
+def gen_data_and_jsd():
+    """datasets_4point.ShapeNetCore (:266-380) over an in-memory stand-in for the HDF5 FILE (h5py is not installed;
+    the stub module gets a `File` that returns a dict with the file's layout -- the class under test is the
+    reference's own), all five scale modes; and evaluation_metrics.jsd_between_point_cloud_sets (:227-305)."""
+    import tempfile
+    import datasets_4point as ds
+    from evaluation.evaluation_metrics import jsd_between_point_cloud_sets as ref_jsd, entropy_of_occupancy_grid as ref_ent
+    raw = {}
+    for ci, sid in enumerate(("03001627", "02691156")):
+        raw[sid] = {sp: (hash_tensor("h5_%s_%s" % (sid, sp), (n, 96, 3), salt=ci) * (0.3 + 0.2 * ci) + 0.1 * ci).numpy()
+                    for sp, n in (("train", 7), ("val", 3), ("test", 5))}
+
+    class FakeFile(dict):
+        def __init__(self, path, mode="r"):
+            super().__init__(raw)
+
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *a):
+            return False
+    sys.modules["h5py"].File = FakeFile
+    out = {}
+    for sid, splits in raw.items():
+        for sp, arr in splits.items():
+            out["raw_%s_%s" % (sid, sp)] = arr
+    with tempfile.TemporaryDirectory() as tmp:
+        for mode in ("global_unit", "shape_unit", "shape_bbox", "shape_half", "shape_34", None):
+            d = ds.ShapeNetCore(path=os.path.join(tmp, "fake_%s.hdf5" % mode), cates_list="chair", split="test", scale_mode=mode)
+            tag = str(mode)
+            out["pc_" + tag] = torch.stack([x["pointcloud"] for x in d.pointclouds])
+            out["shift_" + tag] = torch.stack([x["shift"] for x in d.pointclouds])
+            out["scale_" + tag] = torch.stack([x["scale"] for x in d.pointclouds])
+            out["ids_" + tag] = np.array([x["id"] for x in d.pointclouds])
+        out["stats_mean"], out["stats_std"] = d.stats["mean"], d.stats["std"]
+        d = ds.ShapeNetCore(path=os.path.join(tmp, "fake_train.hdf5"), cates_list="airplane", split="train", scale_mode="shape_unit")
+        np.random.seed(1234)
+        a, b, c, full, cate = d[2]
+        out["item_256"], out["item_512"], out["item_1024"], out["item_full"] = a, b, c, full
+        assert cate == "airplane"
+    # JSD: clouds inside the unit sphere (the metric's assumption)
+    smp = (hash_tensor("jsd_smp", (6, 128, 3)) * 0.22).numpy()
+    refc = (hash_tensor("jsd_ref", (5, 128, 3), salt=3) * 0.25 + 0.03).numpy()
+    for res in (8, 28):
+        out["jsd_%d" % res] = ref_jsd(smp, refc, resolution=res)
+        ent, counters = ref_ent(smp, res, True)
+        out["ent_%d" % res], out["counters_%d" % res] = ent, counters
+    save("data_jsd.npz", jsd_smp=smp, jsd_ref=refc, **out)
+
+
 # ------------------------------------------------------------------ 5c. checkpoint layout
 def gen_checkpoint_manifest():
     """Structure of the two files PDGNet_v2.save writes (models/PDGNet_v2.py:384-408): nn.DataParallel-wrapped
@@ -311,6 +362,7 @@ if __name__ == "__main__":
     gen_losses()
     gen_eval()
     gen_checkpoint_manifest()
+    gen_data_and_jsd()
     G, Ds, z, outs = gen_networks()
     if "--no-step" not in sys.argv:
         gen_step(G, Ds, 2)      # BASELINE.json configs[0] batch size (ill-conditioned BN: loose tolerance)

@@ -78,3 +78,39 @@ def test_emd_cd_paired_matches_oracle():
     d1, _, d2, _ = cref.nndistance(a.numpy(), b.numpy())
     np.testing.assert_allclose(r["MMD-CD"].cpu().numpy(), d1.mean(1) + d2.mean(1), rtol=2e-4, atol=1e-6)
     np.testing.assert_allclose(r["MMD-EMD"].cpu().numpy(), cref.emd_approx(a.numpy(), b.numpy()), rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("res", [8, 28])
+def test_jsd_matches_reference(golden, res):
+    """occupancy counters (one brute-force 1-NN launch over the sphere-clipped grid) and JSD against the imported
+    reference's sklearn / scipy implementation (tests/golden/data_jsd.npz)."""
+    from pdgn_amd import evaluation as ev
+    g = golden("data_jsd.npz")
+    smp = torch.from_numpy(g["jsd_smp"]).to(_dev())
+    ref = torch.from_numpy(g["jsd_ref"]).to(_dev())
+    ent, counters = ev.entropy_of_occupancy_grid(smp, res, True)
+    np.testing.assert_array_equal(counters.cpu().numpy(), g["counters_%d" % res])
+    np.testing.assert_allclose(float(ent), float(g["ent_%d" % res]), rtol=1e-9)
+    np.testing.assert_allclose(float(ev.jsd_between_point_cloud_sets(smp, ref, resolution=res)), float(g["jsd_%d" % res]),
+                               rtol=1e-9, atol=1e-12)
+    assert float(ev.jsd_between_point_cloud_sets(smp, smp, resolution=res)) < 1e-12
+
+
+def test_generate_and_evaluate_test_phase():
+    """the reference's test() flow end to end on a small generator: shapes, keys, finite values, determinism of the
+    seeded noise, and that a set evaluated against itself has full coverage"""
+    from pdgn_amd import evaluation as ev
+    from pdgn_amd.data import normalize_clouds
+    from pdgn_amd.generator import PointGenerator
+    torch.manual_seed(2)
+    G = PointGenerator(base_points=16).to(_dev()).eval()
+    ref = normalize_clouds(torch.randn(10, 256, 3, device=_dev()) * 0.3, "shape_bbox")[0] * 0.45
+    rng = torch.Generator().manual_seed(5)
+    gen, res = ev.generate_and_evaluate(G, ref, batch_size=4, normalize="shape_bbox", rng=rng)
+    assert gen.shape == (10, 256, 3)
+    assert abs(float(gen.abs().max()) - 1.0) < 1e-5                         # shape_bbox: longest side spans [-1, 1]
+    assert {"lgan_mmd-CD", "lgan_cov-EMD", "1-NN-CD-acc", "1-NN-EMD-acc", "jsd"} <= set(res)
+    assert all(torch.isfinite(torch.as_tensor(v)).all() for v in res.values())
+    gen2, _ = ev.generate_and_evaluate(G, ref, batch_size=4, normalize="shape_bbox", rng=torch.Generator().manual_seed(5),
+                                       with_jsd=False)
+    assert torch.equal(gen, gen2)
