@@ -235,6 +235,38 @@ int pdgn_chamfer_gram_indexed(int npairs, int m, int n, int d, const float *x, c
                               const float *y, const int32_t *ib, float *minx, int32_t *argx,
                               float *miny, int32_t *argy, pdgn_stream_t stream);
 
+/* ---- pointops entry points PDGN itself never calls, same argument meaning as the
+ * reference launchers; index outputs int32, label statistics int32, caller allocates (and zero-fills where the
+ * reference's Python does). */
+/* ballquery_cuda_launcher_fast (ballquery/ballquery_cuda_kernel.h:10): first <= nsample points with d2 < r^2 in
+ * index order; the first hit fills every slot; an empty ball leaves idx untouched (caller zero-fills, pointops.py:190). */
+int pdgn_ballquery(int b, int n, int m, float radius, int nsample, const float *new_xyz, const float *xyz,
+                   int32_t *idx, pdgn_stream_t stream);
+/* furthestsampling_cuda_launcher (sampling/sampling_cuda_kernel.h:13): xyz (b,n,3), temp (b,n) pre-filled with 1e10
+ * (pointops.py:24), idx (b,m); starts at point 0; exact ties go to the lowest index. */
+int pdgn_furthestsampling(int b, int n, int m, const float *xyz, float *temp, int32_t *idx, pdgn_stream_t stream);
+/* gathering_{forward,backward}_cuda_launcher (sampling_cuda_kernel.h:10-11), also featuregather
+ * (featuredistribute_cuda_kernel.h:12-13): out[b,c,j] = points[b,c,idx[b,j]]; the adjoint accumulates (+=). */
+int pdgn_gathering_forward(int b, int c, int n, int m, const float *points, const int32_t *idx, float *out,
+                           pdgn_stream_t stream);
+int pdgn_gathering_backward(int b, int c, int n, int m, const float *grad_out, const int32_t *idx,
+                            float *grad_points, pdgn_stream_t stream);
+/* grouping_int_forward_cuda_launcher_fast (grouping_int/grouping_int_cuda_kernel.h:10): int64 features. */
+int pdgn_grouping_int_forward(int b, int c, int n, int m, int nsample, const long long *points, const int32_t *idx,
+                              long long *out, pdgn_stream_t stream);
+/* featuredistribute_cuda_launcher (featuredistribute_cuda_kernel.h:10): nearest max_xyz (b,n,3) point of every
+ * xyz (b,m,3) point. */
+int pdgn_featuredistribute(int b, int n, int m, const float *max_xyz, const float *xyz, int32_t *distribute_idx,
+                           pdgn_stream_t stream);
+/* labelstat_* launchers (labelstat/labelstat_cuda_kernel.h:10-17). */
+int pdgn_labelstat_idx(int b, int n, int m, int nsample, int nclass, const int32_t *label_stat, const int32_t *idx,
+                       int32_t *new_label_stat, pdgn_stream_t stream);
+int pdgn_labelstat_ballrange(int b, int n, int m, float radius, int nclass, const float *new_xyz, const float *xyz,
+                             const int32_t *label_stat, int32_t *new_label_stat, pdgn_stream_t stream);
+int pdgn_labelstat_and_ballquery(int b, int n, int m, float radius, int nsample, int nclass, const float *new_xyz,
+                                 const float *xyz, const int32_t *label_stat, int32_t *idx, int32_t *new_label_stat,
+                                 pdgn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

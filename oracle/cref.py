@@ -161,3 +161,88 @@ def emd_approx(xyz1, xyz2):
     """evaluation/evaluation_metrics.py:26-31: match_cost / N."""
     match = approxmatch(xyz1, xyz2)
     return matchcost(xyz1, xyz2, match) / np.float32(xyz1.shape[1])
+
+
+# ---- entry points PDGN never calls (parity unpinned: no Python twin / test in the reference) ----
+def ballquery(radius, nsample, xyz, new_xyz):
+    xyz, new_xyz = _f32(xyz), _f32(new_xyz)
+    b, n, _ = xyz.shape
+    m = new_xyz.shape[1]
+    idx = np.zeros((b, m, nsample), np.int32)
+    lib().oracle_ballquery(b, n, m, ctypes.c_float(radius), nsample, _p(new_xyz), _p(xyz), _p(idx))
+    return idx
+
+
+def furthestsampling(xyz, m):
+    xyz = _f32(xyz)
+    b, n, _ = xyz.shape
+    temp = np.full((b, n), 1e10, np.float32)
+    idx = np.zeros((b, m), np.int32)
+    lib().oracle_furthestsampling(b, n, m, _p(xyz), _p(temp), _p(idx))
+    return idx
+
+
+def gathering_forward(points, idx):
+    points, idx = _f32(points), _i32(idx)
+    b, c, n = points.shape
+    m = idx.shape[1]
+    out = np.empty((b, c, m), np.float32)
+    lib().oracle_gathering_forward(b, c, n, m, _p(points), _p(idx), _p(out))
+    return out
+
+
+def gathering_backward(grad_out, idx, n):
+    grad_out, idx = _f32(grad_out), _i32(idx)
+    b, c, m = grad_out.shape
+    g = np.zeros((b, c, n), np.float32)
+    lib().oracle_gathering_backward(b, c, n, m, _p(grad_out), _p(idx), _p(g))
+    return g
+
+
+def grouping_int_forward(points, idx):
+    points = np.ascontiguousarray(points, dtype=np.int64)
+    idx = _i32(idx)
+    b, c, n = points.shape
+    _, m, ns = idx.shape
+    out = np.empty((b, c, m, ns), np.int64)
+    lib().oracle_grouping_int_forward(b, c, n, m, ns, _p(points), _p(idx), _p(out))
+    return out
+
+
+def featuredistribute(max_xyz, xyz):
+    max_xyz, xyz = _f32(max_xyz), _f32(xyz)
+    b, n, _ = max_xyz.shape
+    m = xyz.shape[1]
+    out = np.empty((b, m), np.int32)
+    lib().oracle_featuredistribute(b, n, m, _p(max_xyz), _p(xyz), _p(out))
+    return out
+
+
+def labelstat_idx(nsample, label_stat, idx):
+    label_stat, idx = _i32(label_stat), _i32(idx)
+    b, n, nclass = label_stat.shape
+    m = idx.shape[1]
+    out = np.empty((b, m, nclass), np.int32)
+    lib().oracle_labelstat_idx(b, n, m, nsample, nclass, _p(label_stat), _p(idx), _p(out))
+    return out
+
+
+def labelstat_ballrange(radius, xyz, new_xyz, label_stat):
+    xyz, new_xyz, label_stat = _f32(xyz), _f32(new_xyz), _i32(label_stat)
+    b, n, nclass = label_stat.shape
+    m = new_xyz.shape[1]
+    out = np.empty((b, m, nclass), np.int32)
+    lib().oracle_labelstat_ball(b, n, m, ctypes.c_float(radius), 0, nclass, 0, _p(new_xyz), _p(xyz), _p(label_stat),
+                                None, _p(out))
+    return out
+
+
+def labelstat_and_ballquery(radius, nsample, xyz, new_xyz, label_stat):
+    xyz, new_xyz, label_stat = _f32(xyz), _f32(new_xyz), _i32(label_stat)
+    b, n, nclass = label_stat.shape
+    m = new_xyz.shape[1]
+    out = np.empty((b, m, nclass), np.int32)
+    idx = np.zeros((b, m, nsample), np.int32)
+    lib().oracle_labelstat_ball(b, n, m, ctypes.c_float(radius), nsample, nclass, 1, _p(new_xyz), _p(xyz),
+                                _p(label_stat), _p(idx), _p(out))
+    return out, idx

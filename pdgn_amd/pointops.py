@@ -10,6 +10,7 @@ instead of the ``pointops_cuda`` pybind module.  Differences, all deliberate:
   * launch failures raise ``PdgnHipError`` (the reference calls ``exit(-1)``).
 There is no CPU path: CPU tensors raise.
 """
+import ctypes
 from typing import Tuple
 
 import numpy as np
@@ -180,88 +181,123 @@ def knnquery_exclude(nsample, xyz, new_xyz=None):
     return _naive_sorted_idx(xyz, new_xyz)[:, :, 1:nsample + 1].int()
 
 
-def gathering(features, idx):
-    """pointops.py:33-58: features (b,c,n), idx (b,m) -> (b,c,m) (differentiable via torch.gather)."""
-    b, c, _ = features.shape
-    return torch.gather(features, 2, idx.long().unsqueeze(1).expand(b, c, idx.shape[1]))
+class Gathering(Function):
+    """pointops.py:33-58.  features (b,c,n), idx (b,m) int32 -> (b,c,m); backward = scatter-add into (b,c,n)."""
+
+    @staticmethod
+    def forward(ctx, features, idx):
+        require(features, "features", F32, 3)
+        require(idx, "idx", I32, 2)
+        b, c, n = features.shape
+        m = idx.shape[1]
+        out = torch.empty((b, c, m), dtype=F32, device=features.device)
+        check(_lib.lib().pdgn_gathering_forward(b, c, n, m, ptr(features), ptr(idx), ptr(out), stream_of(features)),
+              "pdgn_gathering_forward")
+        ctx.for_backwards = (idx, c, n)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        idx, c, n = ctx.for_backwards
+        b, m = idx.shape
+        grad_out = grad_out.contiguous()
+        grad = torch.zeros((b, c, n), dtype=F32, device=grad_out.device)
+        check(_lib.lib().pdgn_gathering_backward(b, c, n, m, ptr(grad_out), ptr(idx), ptr(grad), stream_of(grad_out)),
+              "pdgn_gathering_backward")
+        return grad, None
+
+
+gathering = Gathering.apply
+featuregather = Gathering.apply            # pointops.py:225-260: same contraction (max_feature (b,c,n), idx (b,m))
 
 
 def grouping_int(features, idx):
-    """pointops.py:154-173: int64 features (b,c,n), idx (b,m,ns) -> (b,c,m,ns) int64."""
-    b, c, _ = features.shape
+    """pointops.py:154-173: int64 features (b,c,n), idx (b,m,ns) int32 -> (b,c,m,ns) int64."""
+    require(features, "features", torch.int64, 3)
+    require(idx, "idx", I32, 3)
+    b, c, n = features.shape
     _, m, ns = idx.shape
-    flat = idx.long().reshape(b, 1, m * ns).expand(b, c, m * ns)
-    return torch.gather(features, 2, flat).view(b, c, m, ns)
+    out = torch.empty((b, c, m, ns), dtype=torch.int64, device=features.device)
+    check(_lib.lib().pdgn_grouping_int_forward(b, c, n, m, ns, ptr(features), ptr(idx), ptr(out), stream_of(features)),
+          "pdgn_grouping_int_forward")
+    return out
 
 
 def ballquery(radius, nsample, xyz, new_xyz):
-    """pointops.py:176-198 / ballquery_cuda_kernel.cu:47-80: the first <= nsample points with
-    d2 < r^2 in index order, padded with the first hit (idx 0 when the ball is empty)."""
-    d2 = (new_xyz.unsqueeze(2) - xyz.unsqueeze(1)).pow(2).sum(dim=3)           # (b,m,n)
-    n = xyz.shape[1]
-    inside = d2 < radius * radius
-    order = torch.where(inside, torch.arange(n, device=xyz.device).expand_as(d2),
-                        torch.full_like(d2, n, dtype=torch.long))
-    first = order.sort(dim=2)[0][:, :, :nsample]
-    if first.shape[2] < nsample:
-        first = torch.cat([first, first.new_full(first.shape[:2] + (nsample - first.shape[2],), n)], 2)
-    head = first[:, :, :1]
-    head = torch.where(head == n, torch.zeros_like(head), head)
-    return torch.where(first == n, head.expand_as(first), first).int()
+    """pointops.py:176-198 / ballquery_cuda_kernel.cu:47-80: the first <= nsample points with d2 < r^2 in index
+    order, padded with the first hit (idx 0 when the ball is empty: the output starts zeroed, :190)."""
+    require(xyz, "xyz", F32, 3)
+    require(new_xyz, "new_xyz", F32, 3)
+    b, n, _ = xyz.shape
+    m = new_xyz.shape[1]
+    idx = torch.zeros((b, m, nsample), dtype=I32, device=xyz.device)
+    check(_lib.lib().pdgn_ballquery(b, n, m, ctypes.c_float(radius), int(nsample), ptr(new_xyz), ptr(xyz), ptr(idx),
+                                    stream_of(xyz)), "pdgn_ballquery")
+    return idx
 
 
 def furthestsampling(xyz, m):
-    """pointops.py:12-30 / sampling_cuda_kernel.cu:59-168: iterative farthest point sampling
-    starting from point 0 (torch ops; not on PDGN's path)."""
+    """pointops.py:12-30 / sampling_cuda_kernel.cu:59-168: iterative farthest point sampling from point 0."""
+    require(xyz, "xyz", F32, 3)
     b, n, _ = xyz.shape
-    idx = torch.zeros((b, m), dtype=torch.long, device=xyz.device)
-    temp = torch.full((b, n), 1e10, device=xyz.device)
-    last = torch.zeros((b,), dtype=torch.long, device=xyz.device)
-    ar = torch.arange(b, device=xyz.device)
-    for j in range(1, m):
-        d = (xyz - xyz[ar, last].unsqueeze(1)).pow(2).sum(dim=2)
-        temp = torch.minimum(temp, d)
-        last = temp.argmax(dim=1)
-        idx[:, j] = last
-    return idx.int()
+    idx = torch.zeros((b, m), dtype=I32, device=xyz.device)
+    temp = torch.full((b, n), 1e10, dtype=F32, device=xyz.device)
+    check(_lib.lib().pdgn_furthestsampling(b, n, int(m), ptr(xyz), ptr(temp), ptr(idx), stream_of(xyz)),
+          "pdgn_furthestsampling")
+    return idx
 
 
 def featuredistribute(max_xyz, xyz):
-    """pointops.py:201-222: index of the nearest max_xyz point for every xyz point."""
-    d2 = (xyz.unsqueeze(2) - max_xyz.unsqueeze(1)).pow(2).sum(dim=3)
-    return d2.argmin(dim=2).int()
-
-
-def featuregather(max_feature, distribute_idx):
-    """pointops.py:225-260."""
-    return gathering(max_feature, distribute_idx)
+    """pointops.py:201-222: index of the nearest max_xyz (b,n,3) point for every xyz (b,m,3) point."""
+    require(max_xyz, "max_xyz", F32, 3)
+    require(xyz, "xyz", F32, 3)
+    b, n, _ = max_xyz.shape
+    m = xyz.shape[1]
+    out = torch.empty((b, m), dtype=I32, device=xyz.device)
+    check(_lib.lib().pdgn_featuredistribute(b, n, m, ptr(max_xyz), ptr(xyz), ptr(out), stream_of(xyz)),
+          "pdgn_featuredistribute")
+    return out
 
 
 def labelstat_idx(nsample, label_stat, idx):
-    """pointops.py:291-315: new_label_stat[b,j,:] = sum_s label_stat[b, idx[b,j,s], :]."""
+    """pointops.py:291-315: new_label_stat[b,j,:] = sum_s label_stat[b, idx[b,j,s], :] (int32)."""
+    require(label_stat, "label_stat", I32, 3)
+    require(idx, "idx", I32, 3)
     b, n, nclass = label_stat.shape
     m = idx.shape[1]
-    flat = idx.long().reshape(b, m * nsample, 1).expand(b, m * nsample, nclass)
-    return torch.gather(label_stat, 1, flat).view(b, m, nsample, nclass).sum(dim=2).int()
+    out = torch.empty((b, m, nclass), dtype=I32, device=idx.device)
+    check(_lib.lib().pdgn_labelstat_idx(b, n, m, int(nsample), nclass, ptr(label_stat), ptr(idx), ptr(out),
+                                        stream_of(idx)), "pdgn_labelstat_idx")
+    return out
 
 
 def labelstat_ballrange(radius, xyz, new_xyz, label_stat):
     """pointops.py:263-288: label histogram over all points with d2 < r^2."""
-    d2 = (new_xyz.unsqueeze(2) - xyz.unsqueeze(1)).pow(2).sum(dim=3)
-    return torch.bmm((d2 < radius * radius).float(), label_stat.float()).int()
+    require(xyz, "xyz", F32, 3)
+    require(new_xyz, "new_xyz", F32, 3)
+    require(label_stat, "label_stat", I32, 3)
+    b, n, nclass = label_stat.shape
+    m = new_xyz.shape[1]
+    out = torch.empty((b, m, nclass), dtype=I32, device=xyz.device)
+    check(_lib.lib().pdgn_labelstat_ballrange(b, n, m, ctypes.c_float(radius), nclass, ptr(new_xyz), ptr(xyz),
+                                              ptr(label_stat), ptr(out), stream_of(xyz)), "pdgn_labelstat_ballrange")
+    return out
 
 
 def labelstat_and_ballquery(radius, nsample, xyz, new_xyz, label_stat):
-    """pointops.py:318-343."""
-    idx = ballquery(radius, nsample, xyz, new_xyz)
-    d2 = (new_xyz.unsqueeze(2) - xyz.unsqueeze(1)).pow(2).sum(dim=3)
-    cnt = (d2 < radius * radius).sum(dim=2, keepdim=True).clamp(max=nsample)
-    valid = (torch.arange(nsample, device=xyz.device).view(1, 1, -1) < cnt).unsqueeze(3)
-    b, m = idx.shape[:2]
-    nclass = label_stat.shape[2]
-    flat = idx.long().reshape(b, m * nsample, 1).expand(b, m * nsample, nclass)
-    stat = (torch.gather(label_stat, 1, flat).view(b, m, nsample, nclass) * valid).sum(dim=2)
-    return stat.int(), idx
+    """pointops.py:318-343 -> (new_label_stat (b,m,nclass), idx (b,m,nsample)): ball query whose kept hits are also
+    summed into the label histogram."""
+    require(xyz, "xyz", F32, 3)
+    require(new_xyz, "new_xyz", F32, 3)
+    require(label_stat, "label_stat", I32, 3)
+    b, n, nclass = label_stat.shape
+    m = new_xyz.shape[1]
+    out = torch.empty((b, m, nclass), dtype=I32, device=xyz.device)
+    idx = torch.zeros((b, m, nsample), dtype=I32, device=xyz.device)
+    check(_lib.lib().pdgn_labelstat_and_ballquery(b, n, m, ctypes.c_float(radius), int(nsample), nclass, ptr(new_xyz),
+                                                  ptr(xyz), ptr(label_stat), ptr(idx), ptr(out), stream_of(xyz)),
+          "pdgn_labelstat_and_ballquery")
+    return out, idx
 
 
 # ------------------------------------------------------------------ grouping Modules

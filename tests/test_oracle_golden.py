@@ -193,3 +193,49 @@ def test_chamfer_and_local_stats(golden):
     mu, cov = pdgnet_ref.mean_covariance(t("mc_points"))
     np.testing.assert_allclose(mu.numpy(), g["mc_mu"], rtol=1e-6, atol=1e-7)
     np.testing.assert_allclose(cov.numpy(), g["mc_cov"], rtol=1e-6, atol=1e-7)
+
+
+def test_oracle_extra_pointops_known_answers():
+    """the C restatements of the entry points PDGN never calls (parity unpinned): numpy brute force / properties"""
+    rng = np.random.default_rng(21)
+    xyz = rng.standard_normal((2, 120, 3)).astype(np.float32)
+    q = rng.standard_normal((2, 30, 3)).astype(np.float32)
+    r, ns = 0.8, 6
+    idx = cref.ballquery(r, ns, xyz, q)
+    d2 = ((q[:, :, None, :].astype(np.float64) - xyz[:, None, :, :]) ** 2).sum(-1)
+    for b in range(2):
+        for j in range(30):
+            inside = np.nonzero(d2[b, j] < r * r)[0]
+            if len(inside) == 0:
+                assert (idx[b, j] == 0).all()
+                continue
+            k = min(ns, len(inside))
+            np.testing.assert_array_equal(idx[b, j, :k], inside[:k])
+            assert (idx[b, j, k:] == inside[0]).all()
+    fps = cref.furthestsampling(xyz, 10)
+    for b in range(2):
+        sel, mind = [0], ((xyz[b] - xyz[b, 0]) ** 2).sum(1)
+        for _ in range(9):
+            nxt = int(mind.argmax())
+            sel.append(nxt)
+            mind = np.minimum(mind, ((xyz[b] - xyz[b, nxt]) ** 2).sum(1))
+        np.testing.assert_array_equal(fps[b], sel)
+    feat = rng.standard_normal((2, 4, 120)).astype(np.float32)
+    gi = rng.integers(0, 120, (2, 50)).astype(np.int32)
+    np.testing.assert_array_equal(cref.gathering_forward(feat, gi), np.take_along_axis(feat, gi[:, None, :].astype(np.int64), 2))
+    g = rng.standard_normal((2, 4, 50)).astype(np.float32)
+    want = np.zeros((2, 4, 120), np.float32)
+    for b in range(2):
+        np.add.at(want[b], (slice(None), gi[b]), g[b])
+    np.testing.assert_allclose(cref.gathering_backward(g, gi, 120), want, rtol=1e-6, atol=1e-6)
+    np.testing.assert_array_equal(cref.featuredistribute(xyz, q), d2.argmin(2).astype(np.int32))
+    stat = np.zeros((2, 120, 5), np.int32)
+    np.put_along_axis(stat, rng.integers(0, 5, (2, 120))[:, :, None], 1, 2)
+    np.testing.assert_array_equal(cref.labelstat_ballrange(r, xyz, q, stat),
+                                  np.einsum("bmn,bnc->bmc", (d2 < r * r).astype(np.int64), stat).astype(np.int32))
+    st, bi = cref.labelstat_and_ballquery(r, ns, xyz, q, stat)
+    np.testing.assert_array_equal(bi, idx)
+    gathered = np.take_along_axis(stat, idx.reshape(2, -1)[:, :, None].astype(np.int64), 1).reshape(2, 30, ns, 5).sum(2)
+    np.testing.assert_array_equal(cref.labelstat_idx(ns, stat, idx), gathered)
+    cnt = np.minimum((d2 < r * r).sum(2), ns)
+    np.testing.assert_array_equal(st.sum(2), cnt)
