@@ -1,5 +1,7 @@
 """Autograd wrappers of the fused channels-last kernels of libpdgn_hip.so (bnact.hip)."""
 import ctypes
+import os
+import warnings
 import weakref
 
 import torch
@@ -156,6 +158,51 @@ def bn_act(x2d, bn, training, act="leaky_relu", mul=None):
                          ACT[act], mul)
 
 
+# PyTorch-ROCm ships two GEMM back ends (rocBLAS, hipBLASLt) and neither wins everywhere on the step's fp32
+# shapes (tools/blas_pref.py: rows x 64 @ 64 x 512 runs 232 us under rocBLAS and 334 us under hipBLASLt, while the
+# NN-form input gradients of the thin layers are 2-3x faster under hipBLASLt).  Large library GEMMs are therefore
+# timed once per (form, shape) under both back ends -- three launches each, during the first iteration -- and the
+# winner is selected before every later call (a host-side flag, no device work).
+_BLAS = {"choice": {}, "tune": os.environ.get("PDGN_BLAS_TUNE", "1") == "1", "default": None}
+_BLAS_MIN_ROWS = 4096
+
+
+def _timed(fn):
+    fn()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(3):
+        fn()
+    e.record()
+    e.synchronize()
+    return s.elapsed_time(e)
+
+
+def _library_gemm(form, a, b, bias=None):
+    """form 'nt': a @ b^T (+ bias) = F.linear(a, b, bias); form 'nn': a @ b."""
+    if not (_BLAS["tune"] and a.is_cuda and a.shape[0] >= _BLAS_MIN_ROWS):
+        return torch.nn.functional.linear(a, b, bias) if form == "nt" else a.matmul(b)
+    key = (form, a.shape, b.shape, a.is_contiguous(), b.is_contiguous())
+    pick = _BLAS["choice"].get(key)
+    setpref = torch._C._set_blas_preferred_backend
+    if pick is None:
+        run = (lambda: torch.nn.functional.linear(a, b, bias)) if form == "nt" else (lambda: a.matmul(b))
+        if torch.cuda.is_current_stream_capturing():
+            return run()
+        if _BLAS["default"] is None:
+            _BLAS["default"] = torch._C._get_blas_preferred_backend()
+        times = {}
+        with torch.no_grad():
+            for lib in (torch._C._BlasBackend.Cublaslt, torch._C._BlasBackend.Cublas):
+                setpref(lib)
+                times[lib] = _timed(run)
+        pick = _BLAS["choice"][key] = min(times, key=times.get)
+    setpref(pick)
+    out = torch.nn.functional.linear(a, b, bias) if form == "nt" else a.matmul(b)
+    setpref(_BLAS["default"])
+    return out
+
+
 class LinearCL(Function):
     """y = x @ W^T (+ b) for point-major rows x (M, C_in).  Forward and the input gradient are
     library GEMMs (they already run at 105-140 TFLOP/s on these shapes); the weight gradient
@@ -166,14 +213,14 @@ class LinearCL(Function):
     def forward(ctx, x, weight, bias):
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
-        return torch.nn.functional.linear(x, weight, bias)
+        return _library_gemm("nt", x, weight, bias)
 
     @staticmethod
     def backward(ctx, dy):
         x, weight = ctx.saved_tensors
         zero_db = has_zero_colsum(dy)
         dy = dy.contiguous()
-        dx = dy.matmul(weight) if ctx.needs_input_grad[0] else None
+        dx = _library_gemm("nn", dy, weight) if ctx.needs_input_grad[0] else None
         dw = None
         if ctx.needs_input_grad[1]:
             m, n = dy.shape
