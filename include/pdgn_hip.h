@@ -146,12 +146,15 @@ int pdgn_window_gather_sum_backward_csr(int b, int n, int k, int ldy, int T, int
  * pdgn_bn_stats: batch statistics (training mode), two-stage reduction through `scratch`; stats out:
  * [scale | shift | mean | invstd] (4c floats), scale = gamma*invstd, shift = beta - mean*scale;
  * running_mean/var (may be NULL) are updated with `momentum` and the unbiased variance.
- * pdgn_bn_eval_stats: the same `stats` from the running statistics (eval mode). */
+ * pdgn_bn_eval_stats: the same `stats` from the running statistics (eval mode).
+ * pre_bias (may be NULL, c floats): the bias of the conv / linear layer that produced x when the caller left it
+ * OUT of x (BatchNorm(x + b) == BatchNorm(x), so the GEMM needs no bias epilogue); it only enters the running mean
+ * (training) and the effective mean (eval), which keeps nn.BatchNorm's buffers identical to the reference's. */
 long long pdgn_bn_scratch_floats(long long rows, int c);
 int pdgn_bn_stats(long long rows, int c, float eps, float momentum, const float *x, const float *gamma,
-                  const float *beta, float *running_mean, float *running_var, float *scratch,
-                  float *stats, pdgn_stream_t stream);
-int pdgn_bn_eval_stats(int c, float eps, const float *gamma, const float *beta,
+                  const float *beta, const float *pre_bias, float *running_mean, float *running_var,
+                  float *scratch, float *stats, pdgn_stream_t stream);
+int pdgn_bn_eval_stats(int c, float eps, const float *gamma, const float *beta, const float *pre_bias,
                        const float *running_mean, const float *running_var, float *stats,
                        pdgn_stream_t stream);
 /* y = act(x*scale + shift) [* mul]   (mul may be NULL; same shape as x) */

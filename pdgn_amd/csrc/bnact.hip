@@ -113,8 +113,8 @@ __device__ __forceinline__ double fin_reduce(const float *__restrict__ part, int
 
 __global__ __launch_bounds__(FIN_CH * FIN_PL) void cl_finalize_kernel(
     long long R, int C, int nparts, float eps, float momentum, const float *__restrict__ part,
-    const float *__restrict__ gamma, const float *__restrict__ beta, float *__restrict__ running_mean,
-    float *__restrict__ running_var, float *__restrict__ stats) {
+    const float *__restrict__ gamma, const float *__restrict__ beta, const float *__restrict__ pre_bias,
+    float *__restrict__ running_mean, float *__restrict__ running_var, float *__restrict__ stats) {
     __shared__ double red[FIN_PL][FIN_CH];
     const int c = blockIdx.x * FIN_CH + threadIdx.x % FIN_CH;
     const bool ok = c < C;
@@ -134,22 +134,25 @@ __global__ __launch_bounds__(FIN_CH * FIN_PL) void cl_finalize_kernel(
     stats[3 * C + c] = invstd;
     if (running_mean) {
         const double unbiased = R > 1 ? var * (double)R / (double)(R - 1) : var;
-        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+        // pre_bias: the producer's bias, left out of x (BatchNorm(x + b) = BatchNorm(x)); only the running mean sees it
+        const float mb = (float)mean + (pre_bias ? pre_bias[c] : 0.f);
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mb;
         running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
     }
 }
 
 // eval mode: scale/shift from the running statistics
 __global__ void cl_eval_stats_kernel(int C, float eps, const float *__restrict__ gamma, const float *__restrict__ beta,
-                                     const float *__restrict__ running_mean, const float *__restrict__ running_var,
-                                     float *__restrict__ stats) {
+                                     const float *__restrict__ pre_bias, const float *__restrict__ running_mean,
+                                     const float *__restrict__ running_var, float *__restrict__ stats) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     const float invstd = rsqrtf(running_var[c] + eps);
     const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    const float m = running_mean[c] - (pre_bias ? pre_bias[c] : 0.f);     // mean of x when x excludes the producer's bias
     stats[c] = g * invstd;
-    stats[C + c] = b - running_mean[c] * g * invstd;
-    stats[2 * C + c] = running_mean[c];
+    stats[C + c] = b - m * g * invstd;
+    stats[2 * C + c] = m;
     stats[3 * C + c] = invstd;
 }
 
@@ -343,23 +346,24 @@ extern "C" long long pdgn_bn_scratch_floats(long long rows, int c) {
 }
 
 extern "C" int pdgn_bn_stats(long long rows, int c, float eps, float momentum, const float *x, const float *gamma,
-                             const float *beta, float *running_mean, float *running_var, float *scratch,
-                             float *stats, pdgn_stream_t stream) {
+                             const float *beta, const float *pre_bias, float *running_mean, float *running_var,
+                             float *scratch, float *stats, pdgn_stream_t stream) {
     if (rows < 1 || c < 4 || c % 4) return PDGN_ERR_INVALID;
     hipStream_t s = (hipStream_t)stream;
     int cgb, gx, gy, rpb;
     cl_geometry(rows, c, &cgb, &gx, &gy, &rpb);
     hipLaunchKernelGGL(cl_stats_kernel, dim3(gx, gy), dim3(BN_THREADS), 0, s, rows, c, cgb, rpb, x, scratch);
     hipLaunchKernelGGL(cl_finalize_kernel, dim3(cdiv(c, FIN_CH)), dim3(FIN_CH * FIN_PL), 0, s, rows, c, gy, eps, momentum, scratch,
-                       gamma, beta, running_mean, running_var, stats);
+                       gamma, beta, pre_bias, running_mean, running_var, stats);
     return pdgn_launch_status();
 }
 
-extern "C" int pdgn_bn_eval_stats(int c, float eps, const float *gamma, const float *beta, const float *running_mean,
-                                  const float *running_var, float *stats, pdgn_stream_t stream) {
+extern "C" int pdgn_bn_eval_stats(int c, float eps, const float *gamma, const float *beta, const float *pre_bias,
+                                  const float *running_mean, const float *running_var, float *stats,
+                                  pdgn_stream_t stream) {
     if (c < 1) return PDGN_ERR_INVALID;
     hipLaunchKernelGGL(cl_eval_stats_kernel, dim3(cdiv(c, 256)), dim3(256), 0, (hipStream_t)stream, c, eps, gamma,
-                       beta, running_mean, running_var, stats);
+                       beta, pre_bias, running_mean, running_var, stats);
     return pdgn_launch_status();
 }
 

@@ -232,15 +232,18 @@ class PointDeconv(nn.Module):
             (xyz_pre,) = EdgeGatherSum.apply(Yx, idx, ((1, k, 16, 0, 16),), self.conv_xyz[0].bias)
             xyzf = bn_act(xyz_pre.view(-1, 16), self.conv_xyz[1], training)
             h = bn_act(outs[2].view(-1, 16), self.conv_fea[1], training, mul=xyzf)   # w_fea * w_xyz :632
-            h = linear_cl(h, _w2d(self.conv_all[0]), self.conv_all[0].bias)
-            h = bn_act(h, self.conv_all[1], training)
-            h = linear_cl(h, _w2d(self.conv_all[3]), self.conv_all[3].bias)
+            # conv biases in front of a BatchNorm are not added by the GEMM (no bias epilogue / broadcast pass):
+            # they cancel in the normalisation and reach only the running mean (bn_act's pre_bias)
+            h = linear_cl(h, _w2d(self.conv_all[0]))
+            h = bn_act(h, self.conv_all[1], training, pre_bias=self.conv_all[0].bias)
+            h = linear_cl(h, _w2d(self.conv_all[3]))
             if self.softmax:
                 # conv_all.4 + LeakyReLU + softmax over the k slots + interleave w[b,n,s=P*j+p,c'] -> [b,n,p,o=2c'+j]
                 # (:623-625, :634-641) in one pass over the raw conv output
-                w = bn_softmax_slots_permute(h, self.conv_all[4], training, k).view(B * N * P, 4 * Fi)
+                w = bn_softmax_slots_permute(h, self.conv_all[4], training, k,
+                                             pre_bias=self.conv_all[3].bias).view(B * N * P, 4 * Fi)
             else:
-                h = bn_act(h, self.conv_all[4], training)
+                h = bn_act(h, self.conv_all[4], training, pre_bias=self.conv_all[3].bias)
                 w = h.view(B, N, 2, P, 2 * Fi).permute(0, 1, 3, 4, 2).reshape(B * N * P, 4 * Fi)
         # inte = LeakyReLU(BN(inte_pre)) [* w]  -- one fused pass (:637, :642)
         inte = bn_act(inte_pre.view(-1, 4 * Fi), self.inte_conv_hk[1], training, mul=w)

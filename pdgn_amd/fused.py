@@ -83,6 +83,37 @@ def _zeros(shape, device):
     return v
 
 
+def _bn_stats(L, x, rows, C, g, b, pre_bias, running_mean, running_var, training, momentum, eps):
+    """[scale|shift|mean|invstd] of a BatchNorm over x (rows, C) -- batch statistics (+ running-stat update) in
+    training, running statistics in eval.  pre_bias: see include/pdgn_hip.h (the producer's bias, left out of x)."""
+    stats = torch.empty(4 * C, dtype=F32, device=x.device)
+    pb = pre_bias.detach().contiguous() if pre_bias is not None else None
+    if training:
+        scratch = torch.empty(_scratch_floats(L, rows, C), dtype=F32, device=x.device)
+        check(L.pdgn_bn_stats(ctypes.c_longlong(rows), C, ctypes.c_float(eps), ctypes.c_float(momentum), ptr(x),
+                              ptr(g), ptr(b), ptr(pb), ptr(running_mean), ptr(running_var), ptr(scratch), ptr(stats),
+                              stream_of(x)), "pdgn_bn_stats")
+    else:
+        check(L.pdgn_bn_eval_stats(C, ctypes.c_float(eps), ptr(g), ptr(b), ptr(pb), ptr(running_mean),
+                                   ptr(running_var), ptr(stats), stream_of(x)), "pdgn_bn_eval_stats")
+    return stats
+
+
+_NO_FOLD = os.environ.get("PDGN_FOLD_BIAS", "1") == "0"       # A/B switch for benchmarking only
+
+
+def _fold_pre_bias(x2d, pre_bias, training):
+    """The fused kernels fold a producer bias only where its gradient is known without a pass over dx: training mode
+    (identically zero) or no gradient needed.  Otherwise it is added explicitly and autograd does the rest."""
+    if pre_bias is not None and (_NO_FOLD or (not training and torch.is_grad_enabled() and pre_bias.requires_grad)):
+        return x2d + pre_bias, None
+    return x2d, pre_bias
+
+
+def _pre_bias_grad(ctx_has, C, device):
+    return _zeros((C,), device) if ctx_has else None
+
+
 class BNActCL(Function):
     """y = act(BatchNorm(x)) [* mul] for a channels-last (rows, C) matrix, with nn.BatchNorm
     semantics (batch statistics + running-stat update in training, running statistics in eval).
@@ -90,21 +121,13 @@ class BNActCL(Function):
     bilateral product ``inte_x * w`` of models/PDGNet_v2.py:642)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, act, mul):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, act, mul, pre_bias=None):
         rows, C = x.shape
         x = x.contiguous()
-        dev = x.device
         L = _lib.lib()
-        stats = torch.empty(4 * C, dtype=F32, device=dev)
         g, b = gamma.detach().contiguous(), beta.detach().contiguous()
-        if training:
-            scratch = torch.empty(_scratch_floats(L, rows, C), dtype=F32, device=dev)
-            check(L.pdgn_bn_stats(ctypes.c_longlong(rows), C, ctypes.c_float(eps), ctypes.c_float(momentum), ptr(x),
-                                  ptr(g), ptr(b), ptr(running_mean), ptr(running_var), ptr(scratch), ptr(stats),
-                                  stream_of(x)), "pdgn_bn_stats")
-        else:
-            check(L.pdgn_bn_eval_stats(C, ctypes.c_float(eps), ptr(g), ptr(b), ptr(running_mean),
-                                       ptr(running_var), ptr(stats), stream_of(x)), "pdgn_bn_eval_stats")
+        stats = _bn_stats(L, x, rows, C, g, b, pre_bias, running_mean, running_var, training, momentum, eps)
+        ctx.has_pre_bias = pre_bias is not None
         mul_c = mul.contiguous() if mul is not None else None
         y = torch.empty_like(x)
         check(L.pdgn_bn_act_forward(ctypes.c_longlong(rows), C, act, ptr(x), ptr(stats), ptr(mul_c), ptr(y),
@@ -128,7 +151,7 @@ class BNActCL(Function):
               "pdgn_bn_act_backward")
         if training:
             mark_zero_colsum(dx)
-        return dx, bs[C:], bs[:C], None, None, None, None, None, None, dmul
+        return dx, bs[C:], bs[:C], None, None, None, None, None, None, dmul, _pre_bias_grad(ctx.has_pre_bias, C, x.device)
 
 
 # nn.BatchNorm's num_batches_tracked bookkeeping: one tiny int64 add per layer per forward would be
@@ -144,18 +167,22 @@ def flush_bn_counters():
         _PENDING_COUNTS.clear()
 
 
-def bn_act(x2d, bn, training, act="leaky_relu", mul=None):
+def bn_act(x2d, bn, training, act="leaky_relu", mul=None, pre_bias=None):
     """Apply an nn.BatchNorm{1,2}d module's parameters/buffers to a channels-last (rows, C) view,
-    followed by `act` (and an optional elementwise product)."""
+    followed by `act` (and an optional elementwise product).  `pre_bias`: the bias of the layer that produced
+    x2d, when the caller did not add it (it cancels inside the BatchNorm; only the running mean sees it)."""
     if training and bn.track_running_stats:
         _PENDING_COUNTS[bn.num_batches_tracked] = _PENDING_COUNTS.get(bn.num_batches_tracked, 0) + 1
+    x2d, pre_bias = _fold_pre_bias(x2d, pre_bias, training)
     if x2d.shape[1] % 4:                      # odd channel counts: library path
+        if pre_bias is not None:
+            x2d = x2d + pre_bias
         y = torch.nn.functional.batch_norm(x2d, bn.running_mean, bn.running_var, bn.weight, bn.bias, training,
                                            bn.momentum, bn.eps)
         y = {"none": lambda t: t, "relu": torch.relu, "leaky_relu": torch.nn.functional.leaky_relu}[act](y)
         return y * mul if mul is not None else y
     return BNActCL.apply(x2d, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, bn.momentum, bn.eps,
-                         ACT[act], mul)
+                         ACT[act], mul, pre_bias)
 
 
 # PyTorch-ROCm ships two GEMM back ends (rocBLAS, hipBLASLt) and neither wins everywhere on the step's fp32
@@ -171,7 +198,7 @@ def _timed(fn):
     fn()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
-    for _ in range(3):
+    for _ in range(5):
         fn()
     e.record()
     e.synchronize()
@@ -196,7 +223,13 @@ def _library_gemm(form, a, b, bias=None):
             for lib in (torch._C._BlasBackend.Cublaslt, torch._C._BlasBackend.Cublas):
                 setpref(lib)
                 times[lib] = _timed(run)
-        pick = _BLAS["choice"][key] = min(times, key=times.get)
+        # hipBLASLt is torch's default here; rocBLAS has to win clearly (the first iteration's timings are noisy:
+        # other streams are busy) to replace it
+        lt, rb = torch._C._BlasBackend.Cublaslt, torch._C._BlasBackend.Cublas
+        pick = _BLAS["choice"][key] = rb if times[rb] < 0.92 * times[lt] else lt
+        if os.environ.get("PDGN_BLAS_LOG") == "1":
+            print("blas %s %s x %s bias=%s: hipblaslt %.3f ms rocblas %.3f ms -> %s" % (
+                form, tuple(a.shape), tuple(b.shape), bias is not None, times[lt] / 5, times[rb] / 5, pick), flush=True)
     setpref(pick)
     out = torch.nn.functional.linear(a, b, bias) if form == "nt" else a.matmul(b)
     setpref(_BLAS["default"])
@@ -284,21 +317,14 @@ class BNSoftmaxSlotsPermute(Function):
     activated logits never exist in HBM.  Backward: softmax adjoint, then the BatchNorm+act adjoint on x."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, act, k):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, act, k, pre_bias=None):
         rows, C = x.shape
         m = rows // k
         x = x.contiguous()
         L = _lib.lib()
-        stats = torch.empty(4 * C, dtype=F32, device=x.device)
         g, b = gamma.detach().contiguous(), beta.detach().contiguous()
-        if training:
-            scratch = torch.empty(_scratch_floats(L, rows, C), dtype=F32, device=x.device)
-            check(L.pdgn_bn_stats(ctypes.c_longlong(rows), C, ctypes.c_float(eps), ctypes.c_float(momentum), ptr(x),
-                                  ptr(g), ptr(b), ptr(running_mean), ptr(running_var), ptr(scratch), ptr(stats),
-                                  stream_of(x)), "pdgn_bn_stats")
-        else:
-            check(L.pdgn_bn_eval_stats(C, ctypes.c_float(eps), ptr(g), ptr(b), ptr(running_mean),
-                                       ptr(running_var), ptr(stats), stream_of(x)), "pdgn_bn_eval_stats")
+        stats = _bn_stats(L, x, rows, C, g, b, pre_bias, running_mean, running_var, training, momentum, eps)
+        ctx.has_pre_bias = pre_bias is not None
         w = torch.empty((m, k // 2, 2 * C), dtype=F32, device=x.device)
         check(L.pdgn_bn_softmax_slots_permute(ctypes.c_longlong(m), k, C, act, ptr(x), ptr(stats), ptr(w),
                                               stream_of(x)), "pdgn_bn_softmax_slots_permute")
@@ -323,17 +349,18 @@ class BNSoftmaxSlotsPermute(Function):
               "pdgn_bn_act_backward")
         if training:
             mark_zero_colsum(dx)
-        return dx, bs[C:], bs[:C], None, None, None, None, None, None, None
+        return dx, bs[C:], bs[:C], None, None, None, None, None, None, None, _pre_bias_grad(ctx.has_pre_bias, C, x.device)
 
 
-def bn_softmax_slots_permute(x2d, bn, training, k, act="leaky_relu"):
+def bn_softmax_slots_permute(x2d, bn, training, k, act="leaky_relu", pre_bias=None):
     """x2d (M*k, C) -> (M, k/2, 2C): nn.BatchNorm2d `bn` + `act` + softmax over the k slots + interleave."""
+    x2d, pre_bias = _fold_pre_bias(x2d, pre_bias, training)
     if x2d.shape[1] % 4:
-        return softmax_slots_permute(bn_act(x2d, bn, training, act=act).view(-1, k, x2d.shape[1]))
+        return softmax_slots_permute(bn_act(x2d, bn, training, act=act, pre_bias=pre_bias).view(-1, k, x2d.shape[1]))
     if training and bn.track_running_stats:
         _PENDING_COUNTS[bn.num_batches_tracked] = _PENDING_COUNTS.get(bn.num_batches_tracked, 0) + 1
     return BNSoftmaxSlotsPermute.apply(x2d, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, bn.momentum,
-                                       bn.eps, ACT[act], k)
+                                       bn.eps, ACT[act], k, pre_bias)
 
 
 class BNActMaxPool(Function):
@@ -342,21 +369,14 @@ class BNActMaxPool(Function):
     tensor; the backward is one streaming pass."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, act, B, N):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, act, B, N, pre_bias=None):
         x = x.contiguous()
         rows, C = x.shape
         dev = x.device
         L = _lib.lib()
-        stats = torch.empty(4 * C, dtype=F32, device=dev)
         g, b = gamma.detach().contiguous(), beta.detach().contiguous()
-        if training:
-            scratch = torch.empty(_scratch_floats(L, rows, C), dtype=F32, device=dev)
-            check(L.pdgn_bn_stats(ctypes.c_longlong(rows), C, ctypes.c_float(eps), ctypes.c_float(momentum), ptr(x),
-                                  ptr(g), ptr(b), ptr(running_mean), ptr(running_var), ptr(scratch), ptr(stats),
-                                  stream_of(x)), "pdgn_bn_stats")
-        else:
-            check(L.pdgn_bn_eval_stats(C, ctypes.c_float(eps), ptr(g), ptr(b), ptr(running_mean),
-                                       ptr(running_var), ptr(stats), stream_of(x)), "pdgn_bn_eval_stats")
+        stats = _bn_stats(L, x, rows, C, g, b, pre_bias, running_mean, running_var, training, momentum, eps)
+        ctx.has_pre_bias = pre_bias is not None
         L.pdgn_bn_maxpool_scratch_floats.restype = ctypes.c_longlong
         scr = torch.empty(L.pdgn_bn_maxpool_scratch_floats(B, C), dtype=F32, device=dev)
         ymax = torch.empty((B, C), dtype=F32, device=dev)
@@ -380,14 +400,16 @@ class BNActMaxPool(Function):
               "pdgn_bn_act_maxpool_backward")
         if training:
             mark_zero_colsum(dx)
-        return dx, bs[C:], bs[:C], None, None, None, None, None, None, None, None
+        return (dx, bs[C:], bs[:C], None, None, None, None, None, None, None, None,
+                _pre_bias_grad(ctx.has_pre_bias, C, x.device))
 
 
-def bn_act_maxpool(x2d, bn, training, B, N, act="leaky_relu"):
+def bn_act_maxpool(x2d, bn, training, B, N, act="leaky_relu", pre_bias=None):
     """max over the N points of every sample of act(BN(x2d)); x2d (B*N, C) -> (B, C)."""
+    x2d, pre_bias = _fold_pre_bias(x2d, pre_bias, training)
+    if x2d.shape[1] % 4:
+        return bn_act(x2d, bn, training, act=act, pre_bias=pre_bias).view(B, N, -1).max(dim=1)[0]
     if training and bn.track_running_stats:
         _PENDING_COUNTS[bn.num_batches_tracked] = _PENDING_COUNTS.get(bn.num_batches_tracked, 0) + 1
-    if x2d.shape[1] % 4:
-        return bn_act(x2d, bn, False if not training else training, act=act).view(B, N, -1).max(dim=1)[0]
     return BNActMaxPool.apply(x2d, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, bn.momentum, bn.eps,
-                              ACT[act], B, N)
+                              ACT[act], B, N, pre_bias)

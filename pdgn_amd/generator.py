@@ -18,8 +18,8 @@ from . import deconv as _deconv
 from .deconv import PointDeconv
 
 
-def _bn_act(x2d, bn, training, act="leaky_relu"):
-    return _deconv.bn_act(x2d, bn, training, act=act)      # looked up late: tests patch deconv.bn_act
+def _bn_act(x2d, bn, training, act="leaky_relu", pre_bias=None):
+    return _deconv.bn_act(x2d, bn, training, act=act, pre_bias=pre_bias)      # looked up late: tests patch deconv.bn_act
 
 
 def _linear(rows, weight, bias=None):
@@ -175,9 +175,11 @@ class PointDiscriminator(nn.Module):
         h = x.transpose(1, 2).reshape(B * N, 3)
         last = len(self.fc1) - 3
         for i in range(0, last, 3):                             # Conv1d(k=1) + BatchNorm1d + LeakyReLU
-            h = _bn_act(_conv1x1_rows(h, self.fc1[i]), self.fc1[i + 1], self.training)
+            # the conv bias is folded into the BatchNorm (pre_bias): the GEMM runs without a bias epilogue
+            h = _bn_act(_linear(h, _deconv._w2d(self.fc1[i])), self.fc1[i + 1], self.training, pre_bias=self.fc1[i].bias)
         # last layer: BatchNorm1d + LeakyReLU + MaxPool1d(num_point) fused (the activated tensor is not written)
-        pooled = _deconv.bn_act_maxpool(_conv1x1_rows(h, self.fc1[last]), self.fc1[last + 1], self.training, B, N)
+        pooled = _deconv.bn_act_maxpool(_linear(h, _deconv._w2d(self.fc1[last])), self.fc1[last + 1], self.training, B, N,
+                                        pre_bias=self.fc1[last].bias)
         _deconv.flush_bn_counters()
         return self.mlp(pooled)
 

@@ -477,3 +477,42 @@ def test_bias_feeding_training_batchnorm_gets_analytic_zero_grad():
         else:
             torch.testing.assert_close(lin.bias.grad, h.grad.sum(0), rtol=1e-4, atol=1e-4 * scale)
             assert resid > 1e-3 * scale
+
+
+@pytest.mark.parametrize("training", [True, False])
+def test_pre_bias_folded_into_batchnorm(training):
+    """bn_act(x, pre_bias=b) == bn_act(x + b): outputs, running statistics and gradients (the producer's bias is
+    never added to the tensor; training: its gradient is the analytic zero; eval: falls back to the explicit add)."""
+    import copy
+    import torch.nn as nn
+    from pdgn_amd import fused
+    torch.manual_seed(13)
+    dev_ = torch.device("cuda:0")
+    bn_a = nn.BatchNorm1d(64).to(dev_)
+    with torch.no_grad():
+        bn_a.weight.uniform_(0.5, 1.5); bn_a.bias.uniform_(-0.5, 0.5)
+        bn_a.running_mean.uniform_(-0.3, 0.3); bn_a.running_var.uniform_(0.5, 2.0)
+    bn_b = copy.deepcopy(bn_a)
+    x = torch.randn(5000, 64, device=dev_)
+    bias_a = (torch.randn(64, device=dev_) * 0.7).requires_grad_(True)
+    bias_b = bias_a.detach().clone().requires_grad_(True)
+    xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    t = torch.randn(5000, 64, device=dev_)
+    ya = fused.bn_act(xa, bn_a, training, pre_bias=bias_a)
+    yb = fused.bn_act(xb + bias_b, bn_b, training)
+    torch.testing.assert_close(ya, yb, rtol=1e-5, atol=1e-5)
+    (ya * t).sum().backward()
+    (yb * t).sum().backward()
+    torch.testing.assert_close(xa.grad, xb.grad, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(bn_a.weight.grad, bn_b.weight.grad, rtol=1e-4, atol=1e-3)
+    torch.testing.assert_close(bn_a.bias.grad, bn_b.bias.grad, rtol=1e-4, atol=1e-3)
+    torch.testing.assert_close(bn_a.running_mean, bn_b.running_mean, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(bn_a.running_var, bn_b.running_var, rtol=1e-5, atol=1e-6)
+    if training:
+        assert torch.count_nonzero(bias_a.grad).item() == 0
+        assert bias_b.grad.abs().max().item() <= 1e-4 * xb.grad.abs().sum(0).max().item()
+    else:
+        torch.testing.assert_close(bias_a.grad, bias_b.grad, rtol=1e-4, atol=1e-4)
+        with torch.no_grad():                                    # no-grad eval: folded into the eval statistics
+            torch.testing.assert_close(fused.bn_act(x, bn_a, False, pre_bias=bias_a), fused.bn_act(x + bias_a, bn_a, False),
+                                       rtol=1e-5, atol=1e-5)

@@ -32,9 +32,11 @@ def feature_knn_torch(x, k):
     return dist.sort(dim=2, stable=True)[1][:, :, 1:k + 1].to(torch.int32).contiguous()
 
 
-def bn_act_torch(x2d, bn, training, act="leaky_relu", mul=None):
+def bn_act_torch(x2d, bn, training, act="leaky_relu", mul=None, pre_bias=None):
     """Same contract as pdgn_amd.fused.bn_act in plain torch ops."""
     import torch.nn.functional as F
+    if pre_bias is not None:
+        x2d = x2d + pre_bias
     if training and bn.track_running_stats:
         bn.num_batches_tracked.add_(1)
     y = F.batch_norm(x2d, bn.running_mean, bn.running_var, bn.weight, bn.bias, training, bn.momentum, bn.eps)
@@ -84,8 +86,8 @@ def linear_cl_torch(x2d, weight, bias=None):
     return torch.nn.functional.linear(x2d, weight, bias)
 
 
-def bn_softmax_slots_permute_torch(x2d, bn, training, k, act="leaky_relu"):
-    h = bn_act_torch(x2d, bn, training, act=act)
+def bn_softmax_slots_permute_torch(x2d, bn, training, k, act="leaky_relu", pre_bias=None):
+    h = bn_act_torch(x2d, bn, training, act=act, pre_bias=pre_bias)
     return softmax_slots_permute_torch(h.view(-1, k, x2d.shape[1]))
 
 
@@ -100,5 +102,5 @@ def flush_bn_counters_noop():
     pass
 
 
-def bn_act_maxpool_torch(x2d, bn, training, B, N, act="leaky_relu"):
-    return bn_act_torch(x2d, bn, training, act=act).view(B, N, -1).max(dim=1)[0]
+def bn_act_maxpool_torch(x2d, bn, training, B, N, act="leaky_relu", pre_bias=None):
+    return bn_act_torch(x2d, bn, training, act=act, pre_bias=pre_bias).view(B, N, -1).max(dim=1)[0]

@@ -22,7 +22,7 @@ for rows, C in ((179200, 1024), (358400, 512), (89600, 512), (358400, 64), (7168
     stats = torch.empty(4 * C, device="cuda"); bs = torch.empty(2 * C, device="cuda")
     scr = torch.empty(L.pdgn_bn_scratch_floats(ctypes.c_longlong(rows), C), device="cuda")
     gb = rows * C * 4 / 1e9
-    a = t(lambda: L.pdgn_bn_stats(ctypes.c_longlong(rows), C, ctypes.c_float(1e-5), ctypes.c_float(0.1), ptr(x), ptr(g), ptr(b), ptr(rm), ptr(rv), ptr(scr), ptr(stats), stream_of(x)))
+    a = t(lambda: L.pdgn_bn_stats(ctypes.c_longlong(rows), C, ctypes.c_float(1e-5), ctypes.c_float(0.1), ptr(x), ptr(g), ptr(b), None, ptr(rm), ptr(rv), ptr(scr), ptr(stats), stream_of(x)))
     f = t(lambda: L.pdgn_bn_act_forward(ctypes.c_longlong(rows), C, 2, ptr(x), ptr(stats), None, ptr(y), stream_of(x)))
     fm = t(lambda: L.pdgn_bn_act_forward(ctypes.c_longlong(rows), C, 2, ptr(x), ptr(stats), ptr(mul), ptr(y), stream_of(x)))
     bw = t(lambda: L.pdgn_bn_act_backward(ctypes.c_longlong(rows), C, 2, 1, ptr(x), ptr(dy), None, ptr(stats), ptr(scr), ptr(bs), ptr(dx), None, stream_of(x)))
