@@ -92,7 +92,12 @@ class EdgeGatherSum(Function):
                 check(L.pdgn_window_gather_sum_backward_csr(b, n, k, ldy, T, P, C, off, offc, ptr(dout), ptr(rowptr),
                                                             ptr(edges), ptr(dY), stream_of(dout)),
                       "pdgn_window_gather_sum_backward_csr")
-                dbias.append(_dbias(dout, hb))
+                if hb == 2 and offc >= 0:
+                    # per-sample bias: sum over (n, p) of dout = sum over n of the centre columns the kernel just
+                    # wrote (dY[b,j,offc+c] = sum_p dout[b,j,p,c]) -- P times less data than dout itself
+                    dbias.append(dY[:, :, offc:offc + C].sum(dim=1))
+                else:
+                    dbias.append(_dbias(dout, hb))
             return (dY, None, None) + tuple(dbias)
         dY = torch.zeros((b, n, ldy), dtype=F32, device=idx.device)
         for (T, P, C, off, offc), dout, hb in zip(ctx.specs, douts, ctx.has_bias):
