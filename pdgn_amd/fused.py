@@ -218,6 +218,9 @@ def _library_gemm(form, a, b, bias=None):
             return run()
         if _BLAS["default"] is None:
             _BLAS["default"] = torch._C._get_blas_preferred_backend()
+            with warnings.catch_warnings():                     # one-time "experimental feature" notice
+                warnings.simplefilter("ignore")
+                setpref(_BLAS["default"])
         times = {}
         with torch.no_grad():
             for lib in (torch._C._BlasBackend.Cublaslt, torch._C._BlasBackend.Cublas):
