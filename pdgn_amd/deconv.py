@@ -233,7 +233,7 @@ class PointDeconv(nn.Module):
         w = None
         if self.bilateral:
             Wx = _w2d(self.conv_xyz[0])                   # (16, 6)
-            Yx = torch.matmul(pct, torch.cat([Wx[:, 3:], Wx[:, :3] - Wx[:, 3:]], 0).t()).contiguous()
+            Yx = linear_cl(pct.reshape(B * N, 3), torch.cat([Wx[:, 3:], Wx[:, :3] - Wx[:, 3:]], 0)).view(B, N, -1)
             (xyz_pre,) = EdgeGatherSum.apply(Yx, idx, ((1, k, 16, 0, 16),), self.conv_xyz[0].bias)
             xyzf = bn_act(xyz_pre.view(-1, 16), self.conv_xyz[1], training)
             h = bn_act(outs[2].view(-1, 16), self.conv_fea[1], training, mul=xyzf)   # w_fea * w_xyz :632

@@ -261,16 +261,16 @@ class LinearCL(Function):
         if ctx.needs_input_grad[1]:
             m, n = dy.shape
             k = x.shape[1]
-            if k % 4 and n % 4 == 0 and m >= 1024:          # e.g. the xyz input layer (k = 3): pad to 4
-                xp = torch.nn.functional.pad(x, (0, 4 - k % 4))
-                dwp = _zeros((n, xp.shape[1]), dy.device)
-                check(_lib.lib().pdgn_gemm_tn(ctypes.c_longlong(m), n, xp.shape[1], ptr(dy), ptr(xp), ptr(dwp),
+            if m >= 1024:
+                # pdgn_gemm_tn wants channel counts in multiples of 4: the xyz input layers (k = 3) and the MLP heads'
+                # last conv (n = 3) are zero-padded to 4 (a 3-row output handed to the library is a 3-workgroup
+                # GEMM over 10^4..10^5 rows: ~250 us)
+                dyp = dy if n % 4 == 0 else torch.nn.functional.pad(dy, (0, 4 - n % 4))
+                xp = x if (k % 4 == 0 and x.is_contiguous()) else torch.nn.functional.pad(x, (0, (4 - k % 4) % 4)).contiguous()
+                dwp = _zeros((dyp.shape[1], xp.shape[1]), dy.device)
+                check(_lib.lib().pdgn_gemm_tn(ctypes.c_longlong(m), dyp.shape[1], xp.shape[1], ptr(dyp), ptr(xp), ptr(dwp),
                                               stream_of(dy)), "pdgn_gemm_tn")
-                dw = dwp[:, :k]
-            elif n % 4 == 0 and k % 4 == 0 and x.is_contiguous() and m >= 1024:
-                dw = _zeros((n, k), dy.device)
-                check(_lib.lib().pdgn_gemm_tn(ctypes.c_longlong(m), n, k, ptr(dy), ptr(x), ptr(dw), stream_of(dy)),
-                      "pdgn_gemm_tn")
+                dw = dwp if (dyp is dy and xp.shape[1] == k) else dwp[:n, :k]
             else:
                 dw = dy.t().matmul(x)
         db = None
