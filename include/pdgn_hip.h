@@ -189,6 +189,12 @@ int pdgn_softmax_slots_permute(long long m, int k, int c, const float *h, float 
  * act as in pdgn_bn_act_forward; the activated logits are never written.  c even. */
 int pdgn_bn_softmax_slots_permute(long long m, int k, int c, int act, const float *x, const float *stats,
                                   float *w, pdgn_stream_t stream);
+/* The whole bilateral weighting (models/PDGNet_v2.py:623-642) in one pass: w as above and
+ * y = act_u(u*scale_u + shift_u) * w for u (m, k/2, 2c) the raw inte_conv_hk output (stats_u: its 4*(2c) statistics
+ * row); w may be NULL (not needed when no backward pass follows). */
+int pdgn_bn_softmax_slots_permute_mul(long long m, int k, int c, int act, const float *x, const float *stats,
+                                      int act_u, const float *u, const float *stats_u, float *w, float *y,
+                                      pdgn_stream_t stream);
 /* dh[m,s,c'] = w_s (dw_s - sum_s' w_s' dw_s'), w / dw in the permuted layout. */
 int pdgn_softmax_slots_permute_backward(long long m, int k, int c, const float *w, const float *dw,
                                         float *dh, pdgn_stream_t stream);

@@ -88,6 +88,70 @@ __global__ __launch_bounds__(SP_THREADS) void bn_softmax_perm_fwd_kernel(long lo
                 make_float4(v[p].x * i0, v[P + p].x * i0, v[p].y * i1, v[P + p].y * i1);
 }
 
+// The bilateral weighting of a deconvolution block in ONE pass (models/PDGNet_v2.py:623-642):
+//   w = softmax_slots(act(BN_a(x)))  (interleaved layout),   y = act_i(BN_i(u)) * w
+// x (M, k, C) raw conv_all.3 output, u (M, k/2, 2C) raw inte_conv_hk output -- already in w's layout, so the thread
+// that owns channel pair c of point m holds exactly the float4s of u it has to scale.  w is written only when the
+// backward pass will need it (w_out != NULL); y always.  Neither activated tensor makes an extra HBM round trip.
+template <int KT>
+__global__ __launch_bounds__(SP_THREADS) void bn_softmax_perm_mul_fwd_kernel(
+    long long total2, int k_rt, int C, int act, const float *__restrict__ x, const float *__restrict__ stats,
+    int act_u, const float *__restrict__ u, const float *__restrict__ stats_u, float *__restrict__ w_out,
+    float *__restrict__ y) {
+    const long long e = (long long)blockIdx.x * SP_THREADS + threadIdx.x;
+    if (e >= total2) return;
+    constexpr int KM = KT ? KT : SP_MAXK;
+    const int k = KT ? KT : k_rt;
+    const int C2 = C / 2, c = (int)(e % C2) * 2;
+    const long long m = e / C2;
+    const int P = k / 2;
+    const float2 sc = *reinterpret_cast<const float2 *>(stats + c), sh = *reinterpret_cast<const float2 *>(stats + C + c);
+    const float4 su = *reinterpret_cast<const float4 *>(stats_u + 2 * c);
+    const float4 hu = *reinterpret_cast<const float4 *>(stats_u + 2 * C + 2 * c);
+    const float *H = x + m * k * C + c;
+    const size_t o = (size_t)m * k * C + 2 * c;                // row (m, p): 2C floats; [2c .. 2c+3]
+    float2 v[KM];
+    float4 uu[KM / 2];
+#pragma unroll
+    for (int s = 0; s < KM; ++s)
+        if (KT || s < k) v[s] = *reinterpret_cast<const float2 *>(H + (size_t)s * C);
+#pragma unroll
+    for (int p = 0; p < KM / 2; ++p)
+        if (KT || p < P) uu[p] = *reinterpret_cast<const float4 *>(u + o + (size_t)p * 2 * C);
+    float mx0 = -INFINITY, mx1 = -INFINITY;
+#pragma unroll
+    for (int s = 0; s < KM; ++s)
+        if (KT || s < k) {
+            const float2 r = v[s];
+            v[s].x = sp_act(__fmaf_rn(r.x, sc.x, sh.x), act);
+            v[s].y = sp_act(__fmaf_rn(r.y, sc.y, sh.y), act);
+            mx0 = fmaxf(mx0, v[s].x);
+            mx1 = fmaxf(mx1, v[s].y);
+        }
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int s = 0; s < KM; ++s)
+        if (KT || s < k) {
+            v[s].x = __expf(v[s].x - mx0);
+            v[s].y = __expf(v[s].y - mx1);
+            s0 += v[s].x;
+            s1 += v[s].y;
+        }
+    const float i0 = 1.0f / s0, i1 = 1.0f / s1;
+#pragma unroll
+    for (int p = 0; p < KM / 2; ++p)
+        if (KT || p < P) {
+            const float4 wv = make_float4(v[p].x * i0, v[P + p].x * i0, v[p].y * i1, v[P + p].y * i1);
+            if (w_out) *reinterpret_cast<float4 *>(w_out + o + (size_t)p * 2 * C) = wv;
+            float4 r;
+            r.x = sp_act(__fmaf_rn(uu[p].x, su.x, hu.x), act_u) * wv.x;
+            r.y = sp_act(__fmaf_rn(uu[p].y, su.y, hu.y), act_u) * wv.y;
+            r.z = sp_act(__fmaf_rn(uu[p].z, su.z, hu.z), act_u) * wv.z;
+            r.w = sp_act(__fmaf_rn(uu[p].w, su.w, hu.w), act_u) * wv.w;
+            *reinterpret_cast<float4 *>(y + o + (size_t)p * 2 * C) = r;
+        }
+}
+
 __global__ __launch_bounds__(SP_THREADS) void softmax_perm_bwd_kernel(long long total, int k, int C,
                                                                       const float *__restrict__ w,
                                                                       const float *__restrict__ dw,
@@ -132,6 +196,25 @@ extern "C" int pdgn_bn_softmax_slots_permute(long long m, int k, int c, int act,
     else if (k == 20) hipLaunchKernelGGL(bn_softmax_perm_fwd_kernel<20>, grid, block, 0, s, total2, k, c, act, x, stats, w);
     else if (k == 4) hipLaunchKernelGGL(bn_softmax_perm_fwd_kernel<4>, grid, block, 0, s, total2, k, c, act, x, stats, w);
     else hipLaunchKernelGGL(bn_softmax_perm_fwd_kernel<0>, grid, block, 0, s, total2, k, c, act, x, stats, w);
+    return pdgn_launch_status();
+}
+
+extern "C" int pdgn_bn_softmax_slots_permute_mul(long long m, int k, int c, int act, const float *x, const float *stats,
+                                                 int act_u, const float *u, const float *stats_u, float *w, float *y,
+                                                 pdgn_stream_t stream) {
+    if (m < 1 || k < 2 || k > SP_MAXK || (k & 1) || c < 2 || (c & 1) || act < 0 || act > 2 || act_u < 0 || act_u > 2)
+        return PDGN_ERR_INVALID;
+    const long long total2 = m * (c / 2);
+    const dim3 grid(cdiv(total2, SP_THREADS)), block(SP_THREADS);
+    hipStream_t s = (hipStream_t)stream;
+    if (k == 10)
+        hipLaunchKernelGGL(bn_softmax_perm_mul_fwd_kernel<10>, grid, block, 0, s, total2, k, c, act, x, stats, act_u, u, stats_u, w, y);
+    else if (k == 20)
+        hipLaunchKernelGGL(bn_softmax_perm_mul_fwd_kernel<20>, grid, block, 0, s, total2, k, c, act, x, stats, act_u, u, stats_u, w, y);
+    else if (k == 4)
+        hipLaunchKernelGGL(bn_softmax_perm_mul_fwd_kernel<4>, grid, block, 0, s, total2, k, c, act, x, stats, act_u, u, stats_u, w, y);
+    else
+        hipLaunchKernelGGL(bn_softmax_perm_mul_fwd_kernel<0>, grid, block, 0, s, total2, k, c, act, x, stats, act_u, u, stats_u, w, y);
     return pdgn_launch_status();
 }
 

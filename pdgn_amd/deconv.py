@@ -25,7 +25,7 @@ from torch.autograd import Function
 
 from . import _lib
 from ._lib import check, ptr, require, stream_of
-from .fused import (_zeros, bn_act, bn_act_maxpool, bn_softmax_slots_permute, flush_bn_counters,  # noqa: F401
+from .fused import (_zeros, bilateral_weighting, bn_act, bn_act_maxpool, bn_softmax_slots_permute, flush_bn_counters,  # noqa: F401
                     has_zero_colsum, linear_cl, softmax_slots_permute)
 
 F32, I32 = torch.float32, torch.int32
@@ -244,14 +244,16 @@ class PointDeconv(nn.Module):
             h = linear_cl(h, _w2d(self.conv_all[3]))
             if self.softmax:
                 # conv_all.4 + LeakyReLU + softmax over the k slots + interleave w[b,n,s=P*j+p,c'] -> [b,n,p,o=2c'+j]
-                # (:623-625, :634-641) in one pass over the raw conv output
-                w = bn_softmax_slots_permute(h, self.conv_all[4], training, k,
-                                             pre_bias=self.conv_all[3].bias).view(B * N * P, 4 * Fi)
+                # (:623-625, :634-641) AND inte = LeakyReLU(BN(inte_pre)) * w (:637, :642): one pass over both raw tensors
+                inte = bilateral_weighting(h, self.conv_all[4], inte_pre.view(-1, 4 * Fi), self.inte_conv_hk[1], training, k,
+                                           pre_bias_x=self.conv_all[3].bias)
             else:
                 h = bn_act(h, self.conv_all[4], training, pre_bias=self.conv_all[3].bias)
                 w = h.view(B, N, 2, P, 2 * Fi).permute(0, 1, 3, 4, 2).reshape(B * N * P, 4 * Fi)
-        # inte = LeakyReLU(BN(inte_pre)) [* w]  -- one fused pass (:637, :642)
-        inte = bn_act(inte_pre.view(-1, 4 * Fi), self.inte_conv_hk[1], training, mul=w)
+                inte = bn_act(inte_pre.view(-1, 4 * Fi), self.inte_conv_hk[1], training, mul=w)
+        else:
+            # inte = LeakyReLU(BN(inte_pre))  (:637)
+            inte = bn_act(inte_pre.view(-1, 4 * Fi), self.inte_conv_hk[1], training)
         out_pre = a_pre.view(B * N, 2 * Fo) + linear_cl(inte.view(B * N, P * 4 * Fi), Wb)
         out = bn_act(out_pre, self.conv2.bn, training, act="relu")     # (B*N, 2Fo): channel 2c+j
         # (B,2Fout,N,1) -> view(B,Fout,2,N) -> (B,Fout,2N) (:645-647): point j*N+n of channel c is conv

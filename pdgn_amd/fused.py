@@ -366,6 +366,81 @@ def bn_softmax_slots_permute(x2d, bn, training, k, act="leaky_relu", pre_bias=No
                                        bn.eps, ACT[act], k, pre_bias)
 
 
+class BilateralWeighting(Function):
+    """y = act(BN_u(u)) * softmax_slots_permute(act(BN_x(x)))  -- the bilateral weighting of a deconvolution block
+    (models/PDGNet_v2.py:623-642) with both BatchNorms, both activations, the slot softmax, the channel interleave and
+    the product in one pass over x (M*k, C) and u (M*k/2, 2C).  Saved for backward: x, u, w and the two statistics
+    rows; under no_grad w is not even written."""
+
+    @staticmethod
+    def forward(ctx, x, u, gx, bx, rmx, rvx, pbx, gu, bu, rmu, rvu, pbu, training, momentum_x, eps_x, momentum_u, eps_u,
+                act, k):
+        rows, C = x.shape
+        m = rows // k
+        x, u = x.contiguous(), u.contiguous()
+        L = _lib.lib()
+        stats_x = _bn_stats(L, x, rows, C, gx.detach().contiguous(), bx.detach().contiguous(), pbx, rmx, rvx, training,
+                            momentum_x, eps_x)
+        stats_u = _bn_stats(L, u, u.shape[0], 2 * C, gu.detach().contiguous(), bu.detach().contiguous(), pbu, rmu, rvu,
+                            training, momentum_u, eps_u)
+        need_w = any(ctx.needs_input_grad)
+        w = torch.empty((m, k // 2, 2 * C), dtype=F32, device=x.device) if need_w else None
+        y = torch.empty_like(u)
+        check(L.pdgn_bn_softmax_slots_permute_mul(ctypes.c_longlong(m), k, C, act, ptr(x), ptr(stats_x), act, ptr(u),
+                                                  ptr(stats_u), ptr(w), ptr(y), stream_of(x)),
+              "pdgn_bn_softmax_slots_permute_mul")
+        ctx.save_for_backward(x, u, w, stats_x, stats_u)
+        ctx.cfg = (rows, C, act, bool(training), k, pbx is not None, pbu is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, u, w, stats_x, stats_u = ctx.saved_tensors
+        rows, C, act, training, k, has_pbx, has_pbu = ctx.cfg
+        L = _lib.lib()
+        dy = dy.contiguous()
+        rows_u, Cu = u.shape
+        # y = act(BN(u)) * w: adjoint wrt u, the BatchNorm parameters and w
+        scr = torch.empty(_scratch_floats(L, rows_u, Cu), dtype=F32, device=x.device)
+        bsu = torch.empty(2 * Cu, dtype=F32, device=x.device)
+        du, dw = torch.empty_like(u), torch.empty_like(u)
+        check(L.pdgn_bn_act_backward(ctypes.c_longlong(rows_u), Cu, act, int(training), ptr(u), ptr(dy), ptr(w),
+                                     ptr(stats_u), ptr(scr), ptr(bsu), ptr(du), ptr(dw), stream_of(x)),
+              "pdgn_bn_act_backward")
+        # w = softmax_slots_permute(act(BN(x)))
+        dh = torch.empty((rows, C), dtype=F32, device=x.device)
+        check(L.pdgn_softmax_slots_permute_backward(ctypes.c_longlong(rows // k), k, C, ptr(w), ptr(dw), ptr(dh),
+                                                    stream_of(x)), "pdgn_softmax_slots_permute_backward")
+        scr = torch.empty(_scratch_floats(L, rows, C), dtype=F32, device=x.device)
+        bsx = torch.empty(2 * C, dtype=F32, device=x.device)
+        dx = torch.empty_like(x)
+        check(L.pdgn_bn_act_backward(ctypes.c_longlong(rows), C, act, int(training), ptr(x), ptr(dh), ptr(None),
+                                     ptr(stats_x), ptr(scr), ptr(bsx), ptr(dx), ptr(None), stream_of(x)),
+              "pdgn_bn_act_backward")
+        if training:
+            mark_zero_colsum(du)
+            mark_zero_colsum(dx)
+        return (dx, du, bsx[C:], bsx[:C], None, None, _pre_bias_grad(has_pbx, C, x.device), bsu[Cu:], bsu[:Cu], None, None,
+                _pre_bias_grad(has_pbu, Cu, x.device), None, None, None, None, None, None, None)
+
+
+def bilateral_weighting(x2d, bn_x, u2d, bn_u, training, k, act="leaky_relu", pre_bias_x=None, pre_bias_u=None):
+    """x2d (M*k, C) raw conv_all.3 output, u2d (M*k/2, 2C) raw inte_conv_hk output ->
+    act(bn_u(u2d)) * softmax_slots_permute(act(bn_x(x2d))), shape of u2d."""
+    x2d, pre_bias_x = _fold_pre_bias(x2d, pre_bias_x, training)
+    u2d, pre_bias_u = _fold_pre_bias(u2d, pre_bias_u, training)
+    if x2d.shape[1] % 4:
+        w = bn_softmax_slots_permute(x2d, bn_x, training, k, act=act, pre_bias=pre_bias_x)
+        return bn_act(u2d, bn_u, training, act=act, mul=w.view(u2d.shape), pre_bias=pre_bias_u)
+    if training:
+        for bn in (bn_x, bn_u):
+            if bn.track_running_stats:
+                _PENDING_COUNTS[bn.num_batches_tracked] = _PENDING_COUNTS.get(bn.num_batches_tracked, 0) + 1
+    return BilateralWeighting.apply(x2d, u2d, bn_x.weight, bn_x.bias, bn_x.running_mean, bn_x.running_var, pre_bias_x,
+                                    bn_u.weight, bn_u.bias, bn_u.running_mean, bn_u.running_var, pre_bias_u, training,
+                                    bn_x.momentum, bn_x.eps, bn_u.momentum, bn_u.eps, ACT[act], k)
+
+
 class BNActMaxPool(Function):
     """(B*N, C) rows -> (B, C): max over the N points of each sample of act(BatchNorm(x)) -- the
     BatchNorm1d + LeakyReLU + MaxPool1d tail of the discriminators without writing the activated

@@ -5,7 +5,7 @@ import pytest
 import torch
 
 from hashweights import fill_module
-from torch_standins import EdgeGatherSumTorch, linear_cl_torch, softmax_slots_permute_torch, bn_softmax_slots_permute_torch, bn_act_maxpool_torch, bn_act_torch
+from torch_standins import EdgeGatherSumTorch, linear_cl_torch, softmax_slots_permute_torch, bn_softmax_slots_permute_torch, bilateral_weighting_torch, bn_act_maxpool_torch, bn_act_torch
 
 
 @pytest.fixture()
@@ -18,6 +18,7 @@ def deconv(monkeypatch):
     monkeypatch.setattr(m, "flush_bn_counters", lambda: None)
     monkeypatch.setattr(m, "softmax_slots_permute", softmax_slots_permute_torch)
     monkeypatch.setattr(m, "bn_softmax_slots_permute", bn_softmax_slots_permute_torch)
+    monkeypatch.setattr(m, "bilateral_weighting", bilateral_weighting_torch)
     return m
 
 

@@ -30,13 +30,14 @@ def _build_trainer(distributed):
     from oracle import pdgnet_ref
     from pdgn_amd import deconv
     from pdgn_amd.trainer import PDGNTrainer
-    from torch_standins import EdgeGatherSumTorch, linear_cl_torch, softmax_slots_permute_torch, bn_softmax_slots_permute_torch, bn_act_maxpool_torch, bn_act_torch, feature_knn_torch, patch_losses
+    from torch_standins import EdgeGatherSumTorch, linear_cl_torch, softmax_slots_permute_torch, bn_softmax_slots_permute_torch, bilateral_weighting_torch, bn_act_maxpool_torch, bn_act_torch, feature_knn_torch, patch_losses
     deconv.EdgeGatherSum, deconv.bn_act, deconv.feature_knn = EdgeGatherSumTorch, bn_act_torch, feature_knn_torch
     deconv.linear_cl = linear_cl_torch
     deconv.bn_act_maxpool = bn_act_maxpool_torch
     deconv.flush_bn_counters = lambda: None
     deconv.softmax_slots_permute = softmax_slots_permute_torch
     deconv.bn_softmax_slots_permute = bn_softmax_slots_permute_torch
+    deconv.bilateral_weighting = bilateral_weighting_torch
     torch.manual_seed(7)                                   # identical initial weights on every rank
     tr = PDGNTrainer(device="cpu", base_points=16, distributed=distributed)
     patch_losses(None)

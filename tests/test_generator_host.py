@@ -8,7 +8,7 @@ import pytest
 import torch
 
 from hashweights import fill_module, hash_tensor
-from torch_standins import EdgeGatherSumTorch, linear_cl_torch, softmax_slots_permute_torch, bn_softmax_slots_permute_torch, bn_act_maxpool_torch, bn_act_torch, feature_knn_torch, patch_losses
+from torch_standins import EdgeGatherSumTorch, linear_cl_torch, softmax_slots_permute_torch, bn_softmax_slots_permute_torch, bilateral_weighting_torch, bn_act_maxpool_torch, bn_act_torch, feature_knn_torch, patch_losses
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
@@ -23,6 +23,7 @@ def patched(monkeypatch):
     monkeypatch.setattr(deconv, "flush_bn_counters", lambda: None)
     monkeypatch.setattr(deconv, "softmax_slots_permute", softmax_slots_permute_torch)
     monkeypatch.setattr(deconv, "bn_softmax_slots_permute", bn_softmax_slots_permute_torch)
+    monkeypatch.setattr(deconv, "bilateral_weighting", bilateral_weighting_torch)
     monkeypatch.setattr(deconv, "feature_knn", feature_knn_torch)
     return deconv
 

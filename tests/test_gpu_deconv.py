@@ -365,6 +365,50 @@ def test_bn_softmax_slots_permute(M, k, C, training):
         np.testing.assert_allclose(bnd.running_var.cpu().numpy(), bnr.running_var.numpy(), rtol=1e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize("M,k,C,training", [(640, 10, 16, True), (896, 10, 256, True), (33, 4, 24, True), (200, 10, 64, False)])
+def test_bilateral_weighting(M, k, C, training):
+    """both BatchNorms + activations + slot softmax + interleave + product in one pass vs the same chain in fp64"""
+    import copy
+    import torch.nn as nn
+    from pdgn_amd.fused import bilateral_weighting
+    from torch_standins import bilateral_weighting_torch
+    rng = np.random.default_rng(M + C)
+    x = torch.from_numpy((rng.standard_normal((M * k, C)) * 2 + 0.5).astype(np.float32))
+    u = torch.from_numpy((rng.standard_normal((M * k // 2, 2 * C)) * 1.5 - 0.2).astype(np.float32))
+    g = torch.from_numpy(rng.standard_normal((M * k // 2, 2 * C)).astype(np.float32))
+    pb = torch.from_numpy(rng.standard_normal(C).astype(np.float32))
+    bns = []
+    for ch in (C, 2 * C):
+        bn = nn.BatchNorm2d(ch)
+        with torch.no_grad():
+            bn.weight.copy_(torch.from_numpy(rng.uniform(0.5, 1.5, ch).astype(np.float32)))
+            bn.bias.copy_(torch.from_numpy(rng.uniform(-0.5, 0.5, ch).astype(np.float32)))
+            bn.running_mean.copy_(torch.from_numpy(rng.uniform(-0.2, 0.8, ch).astype(np.float32)))
+            bn.running_var.copy_(torch.from_numpy(rng.uniform(2.0, 5.0, ch).astype(np.float32)))
+        bns.append(bn)
+    ref_bns = [copy.deepcopy(b).double() for b in bns]
+    dev_bns = [b.cuda() for b in bns]
+    xd, ud = dev(x).requires_grad_(True), dev(u).requires_grad_(True)
+    y = bilateral_weighting(xd, dev_bns[0], ud, dev_bns[1], training, k, pre_bias_x=dev(pb) if training else None)
+    y.backward(dev(g))
+    xr, ur = x.double().requires_grad_(True), u.double().requires_grad_(True)
+    yr = bilateral_weighting_torch(xr, ref_bns[0], ur, ref_bns[1], training, k, pre_bias_x=pb.double() if training else None)
+    yr.backward(g.double())
+    np.testing.assert_allclose(y.detach().cpu().numpy(), yr.detach().numpy(), rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(xd.grad.cpu().numpy(), xr.grad.numpy(), rtol=2e-3, atol=2e-6)
+    np.testing.assert_allclose(ud.grad.cpu().numpy(), ur.grad.numpy(), rtol=2e-3, atol=2e-6)
+    for a, b in zip(dev_bns, ref_bns):
+        np.testing.assert_allclose(a.weight.grad.cpu().numpy(), b.weight.grad.numpy(), rtol=2e-3, atol=1e-4)
+        np.testing.assert_allclose(a.bias.grad.cpu().numpy(), b.bias.grad.numpy(), rtol=2e-3, atol=1e-4)
+        if training:
+            np.testing.assert_allclose(a.running_mean.cpu().numpy(), b.running_mean.numpy(), rtol=1e-5, atol=1e-6)
+            np.testing.assert_allclose(a.running_var.cpu().numpy(), b.running_var.numpy(), rtol=1e-5, atol=1e-6)
+    with torch.no_grad():                                       # no-grad path: w is not written, same y
+        y2 = bilateral_weighting(dev(x), copy.deepcopy(dev_bns[0]), dev(u), copy.deepcopy(dev_bns[1]), False, k)
+        yr2 = bilateral_weighting_torch(x.double(), ref_bns[0], u.double(), ref_bns[1], False, k)
+    np.testing.assert_allclose(y2.cpu().numpy(), yr2.numpy(), rtol=1e-4, atol=1e-6)
+
+
 def test_config_c4_four_stage_512_to_4096():
     """BASELINE.json configs[3] ("4-stage 256->4096"; SURVEY.md section 8 Note C4: base 256 points):
     the size-generic blocks run one iteration at 512/1024/2048/4096 points; outputs have the right

@@ -91,6 +91,11 @@ def bn_softmax_slots_permute_torch(x2d, bn, training, k, act="leaky_relu", pre_b
     return softmax_slots_permute_torch(h.view(-1, k, x2d.shape[1]))
 
 
+def bilateral_weighting_torch(x2d, bn_x, u2d, bn_u, training, k, act="leaky_relu", pre_bias_x=None, pre_bias_u=None):
+    w = bn_softmax_slots_permute_torch(x2d, bn_x, training, k, act=act, pre_bias=pre_bias_x)
+    return bn_act_torch(u2d, bn_u, training, act=act, mul=w.reshape(u2d.shape), pre_bias=pre_bias_u)
+
+
 def softmax_slots_permute_torch(h):
     M, k, C = h.shape
     P = k // 2
