@@ -121,6 +121,12 @@ int pdgn_feature_knn(int b, int f, int n, int k, const float *x, float *sqnorm, 
 int pdgn_window_gather_sum(int b, int n, int k, int ldy, int T, int P, int C, int off, int offc,
                            const float *Y, const int32_t *idx, const float *bias, int bias_bstride,
                            float *out, pdgn_stream_t stream);
+/* The same, also emitting the BatchNorm partial statistics of out viewed as (b*n*P, C) rows into `scratch`
+ * (>= pdgn_bn_scratch_floats(b*n*P, C) floats; finish with pdgn_bn_stats_from_partials): the BatchNorm that follows
+ * the gather-sum needs no statistics pass.  float4 path only (C, ldy, off, offc, bias_bstride multiples of 4). */
+int pdgn_window_gather_sum_stats(int b, int n, int k, int ldy, int T, int P, int C, int off, int offc,
+                                 const float *Y, const int32_t *idx, const float *bias, int bias_bstride,
+                                 float *out, float *scratch, pdgn_stream_t stream);
 
 /* Its adjoint: dY[b, idx[b,n,p+t], off+t*C+c] += dout[b,n,p,c] (atomic), and
  * dY[b,n,offc+c] = sum_p dout[b,n,p,c].  dY must be zero-filled by the caller. */
@@ -157,6 +163,11 @@ int pdgn_bn_stats(long long rows, int c, float eps, float momentum, const float 
 int pdgn_bn_eval_stats(int c, float eps, const float *gamma, const float *beta, const float *pre_bias,
                        const float *running_mean, const float *running_var, float *stats,
                        pdgn_stream_t stream);
+/* Statistics whose first stage was done by a producer: `scratch` holds the per-row-block partial sums of x in the
+ * layout of pdgn_bn_stats (pdgn_window_gather_sum_stats writes them while producing x). */
+int pdgn_bn_stats_from_partials(long long rows, int c, float eps, float momentum, const float *gamma,
+                                const float *beta, const float *pre_bias, float *running_mean, float *running_var,
+                                const float *scratch, float *stats, pdgn_stream_t stream);
 /* y = act(x*scale + shift) [* mul]   (mul may be NULL; same shape as x) */
 int pdgn_bn_act_forward(long long rows, int c, int act, const float *x, const float *stats,
                         const float *mul, float *y, pdgn_stream_t stream);

@@ -13,7 +13,7 @@
 // kernels (two-stage reduction: no atomics, bitwise reproducible).
 #include "common.h"
 
-#define BN_THREADS 256
+#include "bn_geom.h"
 #define ACT_NONE 0
 #define ACT_RELU 1
 #define ACT_LEAKY 2   // negative_slope 0.01 (nn.LeakyReLU default used throughout the reference)
@@ -319,24 +319,6 @@ __global__ __launch_bounds__(BN_THREADS) void cl_bwd_apply_kernel(long long R, i
 }
 
 // ---------------------------------------------------------------------------- C ABI
-static void cl_geometry(long long R, int C, int *cgb, int *gx, int *gy, int *rpb) {
-    const int cg = C / 4;
-    int p = 1;                                             // column groups per block: power of two <= 256
-    while (p < cg && p < BN_THREADS) p <<= 1;
-    *cgb = p;
-    *gx = (cg + *cgb - 1) / *cgb;
-    const int rl = BN_THREADS / *cgb;
-    long long want = 1024 / *gx;                           // ~1024 workgroups in flight
-    want = want < 1 ? 1 : want;
-    long long rows = (R + want - 1) / want;
-    const long long min_rows = (long long)rl * 16;
-    rows = rows < min_rows ? min_rows : rows;
-    rows = rows > 65536 ? 65536 : rows;                    // bound the fp32 partial sums
-    rows = (rows + rl - 1) / rl * rl;
-    *rpb = (int)rows;
-    *gy = (int)((R + rows - 1) / rows);
-}
-
 // Floats of scratch the two reductions need for (rows, c): one [2c] partial per row-block.
 extern "C" long long pdgn_bn_scratch_floats(long long rows, int c) {
     if (rows < 1 || c < 4 || c % 4) return PDGN_ERR_INVALID;
@@ -355,6 +337,19 @@ extern "C" int pdgn_bn_stats(long long rows, int c, float eps, float momentum, c
     hipLaunchKernelGGL(cl_stats_kernel, dim3(gx, gy), dim3(BN_THREADS), 0, s, rows, c, cgb, rpb, x, scratch);
     hipLaunchKernelGGL(cl_finalize_kernel, dim3(cdiv(c, FIN_CH)), dim3(FIN_CH * FIN_PL), 0, s, rows, c, gy, eps, momentum, scratch,
                        gamma, beta, pre_bias, running_mean, running_var, stats);
+    return pdgn_launch_status();
+}
+
+// Second stage only: `scratch` already holds the per-row-block partial sums (written by a producer's epilogue,
+// e.g. pdgn_window_gather_sum_stats, in the geometry of bn_geom.h).
+extern "C" int pdgn_bn_stats_from_partials(long long rows, int c, float eps, float momentum, const float *gamma,
+                                           const float *beta, const float *pre_bias, float *running_mean,
+                                           float *running_var, const float *scratch, float *stats, pdgn_stream_t stream) {
+    if (rows < 1 || c < 4 || c % 4) return PDGN_ERR_INVALID;
+    int cgb, gx, gy, rpb;
+    cl_geometry(rows, c, &cgb, &gx, &gy, &rpb);
+    hipLaunchKernelGGL(cl_finalize_kernel, dim3(cdiv(c, FIN_CH)), dim3(FIN_CH * FIN_PL), 0, (hipStream_t)stream, rows, c, gy, eps,
+                       momentum, scratch, gamma, beta, pre_bias, running_mean, running_var, stats);
     return pdgn_launch_status();
 }
 

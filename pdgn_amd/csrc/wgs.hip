@@ -10,6 +10,7 @@
 // float4 per lane, the neighbour index wave-uniform.
 // Backward scatters dout rows back onto dY with contiguous 256-B wave atomics.
 #include "common.h"
+#include "bn_geom.h"
 
 #define WGS_THREADS 256
 
@@ -37,6 +38,83 @@ __global__ __launch_bounds__(WGS_THREADS) void wgs_fwd_kernel(
         acc += *reinterpret_cast<const vec_t *>(Y + row * ldy + off + t * CV * VEC + c);
     }
     *reinterpret_cast<vec_t *>(out + e * VEC) = acc;
+}
+
+// The same gather-sum in the geometry of the BatchNorm reductions (bn_geom.h): a thread owns one float4 column group
+// and walks its row lane of the block's rows, so it can also accumulate the per-column sum / sum of squares of what
+// it writes.  part[blockIdx.y][c], [C + c] are exactly what cl_stats_kernel would produce for `out`: the BatchNorm
+// that follows (inte_conv_hk.1) needs no statistics pass over the tensor.
+template <int TT>   // compile-time tap count (inte_conv_hk: k/2+1 = 6 at k = 10), 0 = runtime T <= 8
+__global__ __launch_bounds__(WGS_THREADS) void wgs_fwd_stats_kernel(
+    long long R, int n, int k, int ldy, int T, int P, int C, int cgb, int rows_per_block, int off, int offc,
+    const float *__restrict__ Y, const int32_t *__restrict__ idx, const float *__restrict__ bias, int bias_bstride,
+    float *__restrict__ out, float *__restrict__ part) {
+    __shared__ float4 red[2][WGS_THREADS];
+    const int cgl = threadIdx.x % cgb, rlane = threadIdx.x / cgb, rl = WGS_THREADS / cgb;
+    const int cgi = blockIdx.x * cgb + cgl;
+    const bool cok = cgi * 4 < C;
+    const int c = cgi * 4;
+    const long long r0 = (long long)blockIdx.y * rows_per_block;
+    const long long r1 = min(R, r0 + rows_per_block);
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f), q = make_float4(0.f, 0.f, 0.f, 0.f);
+    // A thread walks ~rows_per_block/rl rows one after the other, and a row is a two-level dependent chain (index ->
+    // gathered row), so WGS_U rows are kept in flight at once: all their index loads, then all their row loads.
+    constexpr int WGS_U = TT ? 4 : 2, WGS_MAXT = TT ? TT : 8;
+    if (cok) {
+        for (long long rb = r0 + rlane; rb < r1; rb += (long long)WGS_U * rl) {
+            long long bn[WGS_U], bs[WGS_U];
+            int nb[WGS_U][WGS_MAXT];
+            bool live[WGS_U];
+#pragma unroll
+            for (int u = 0; u < WGS_U; ++u) {
+                const long long r = rb + (long long)u * rl;
+                live[u] = r < r1;
+                const long long rr = live[u] ? r : rb;
+                bn[u] = rr / P;
+                bs[u] = bn[u] / n;
+                const int32_t *I = idx + bn[u] * k + (int)(rr % P);
+#pragma unroll
+                for (int t = 0; t < WGS_MAXT; ++t)
+                    if (TT || t < T) nb[u][t] = I[t];
+            }
+            float4 acc[WGS_U], ctr[WGS_U], tap[WGS_U][WGS_MAXT];
+#pragma unroll
+            for (int u = 0; u < WGS_U; ++u) {
+                acc[u] = bias ? *reinterpret_cast<const float4 *>(bias + bs[u] * bias_bstride + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+                ctr[u] = offc >= 0 ? *reinterpret_cast<const float4 *>(Y + bn[u] * ldy + offc + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int t = 0; t < WGS_MAXT; ++t)
+                    if (TT || t < T) tap[u][t] = *reinterpret_cast<const float4 *>(Y + (bs[u] * n + nb[u][t]) * ldy + off + t * C + c);
+            }
+#pragma unroll
+            for (int u = 0; u < WGS_U; ++u) {
+                float4 a = acc[u];
+                a.x += ctr[u].x; a.y += ctr[u].y; a.z += ctr[u].z; a.w += ctr[u].w;
+#pragma unroll
+                for (int t = 0; t < WGS_MAXT; ++t)
+                    if (TT || t < T) { a.x += tap[u][t].x; a.y += tap[u][t].y; a.z += tap[u][t].z; a.w += tap[u][t].w; }
+                if (live[u]) {
+                    *reinterpret_cast<float4 *>(out + (rb + (long long)u * rl) * C + c) = a;
+                    s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+                    q.x = __fmaf_rn(a.x, a.x, q.x); q.y = __fmaf_rn(a.y, a.y, q.y);
+                    q.z = __fmaf_rn(a.z, a.z, q.z); q.w = __fmaf_rn(a.w, a.w, q.w);
+                }
+            }
+        }
+    }
+    red[0][threadIdx.x] = s;
+    red[1][threadIdx.x] = q;
+    __syncthreads();
+    if (rlane == 0 && cok) {
+        for (int j = 1; j < rl; ++j) {
+            const float4 a = red[0][j * cgb + cgl], b = red[1][j * cgb + cgl];
+            s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+            q.x += b.x; q.y += b.y; q.z += b.z; q.w += b.w;
+        }
+        float *Pp = part + (size_t)blockIdx.y * 2 * C;
+        *reinterpret_cast<float4 *>(Pp + c) = s;
+        *reinterpret_cast<float4 *>(Pp + C + c) = q;
+    }
 }
 
 __global__ __launch_bounds__(WGS_THREADS) void wgs_bwd_kernel(
@@ -82,6 +160,26 @@ extern "C" int pdgn_window_gather_sum(int b, int n, int k, int ldy, int T, int P
         hipLaunchKernelGGL(wgs_fwd_kernel<1>, dim3(cdiv(total, WGS_THREADS)), dim3(WGS_THREADS), 0, s, total,
                            n, k, ldy, T, P, C, off, offc, Y, idx, bias, bias_bstride, out);
     }
+    return pdgn_launch_status();
+}
+
+// pdgn_window_gather_sum + the BatchNorm partial statistics of `out` viewed as (b*n*P, C) rows: `scratch` (>=
+// pdgn_bn_scratch_floats(b*n*P, C) floats) receives what pdgn_bn_stats' first stage would compute; finish with
+// pdgn_bn_stats_from_partials.  Needs the float4 path (C, ldy, off, offc multiples of 4), else -1.
+extern "C" int pdgn_window_gather_sum_stats(int b, int n, int k, int ldy, int T, int P, int C, int off, int offc,
+                                            const float *Y, const int32_t *idx, const float *bias, int bias_bstride,
+                                            float *out, float *scratch, pdgn_stream_t stream) {
+    if (!wgs_ok(b, n, k, ldy, T, P, C, off, offc) || b < 1 || T > 8) return PDGN_ERR_INVALID;
+    if ((C % 4) || (ldy % 4) || (off % 4) || (offc >= 0 && offc % 4) || (bias && bias_bstride % 4)) return PDGN_ERR_INVALID;
+    const long long R = (long long)b * n * P;
+    int cgb, gx, gy, rpb;
+    cl_geometry(R, C, &cgb, &gx, &gy, &rpb);
+    if (T == 6)
+        hipLaunchKernelGGL(wgs_fwd_stats_kernel<6>, dim3(gx, gy), dim3(WGS_THREADS), 0, (hipStream_t)stream, R, n, k, ldy, T, P,
+                           C, cgb, rpb, off, offc, Y, idx, bias, bias_bstride, out, scratch);
+    else
+        hipLaunchKernelGGL(wgs_fwd_stats_kernel<0>, dim3(gx, gy), dim3(WGS_THREADS), 0, (hipStream_t)stream, R, n, k, ldy, T, P,
+                           C, cgb, rpb, off, offc, Y, idx, bias, bias_bstride, out, scratch);
     return pdgn_launch_status();
 }
 

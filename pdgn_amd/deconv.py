@@ -18,6 +18,8 @@ shapes) but not the same way:
 which removes ~3.5x of the block's FLOPs and every (B,2F,N,k)-sized edge tensor.
 Activations are point-major / channels-last inside the block: (B, N, [slot,] C).
 """
+import ctypes
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -51,7 +53,9 @@ def feature_knn(x, k):
 
 class EdgeGatherSum(Function):
     """out_i[b,n,p,c] = bias_i[c] + Y[b,n,offc_i+c] + sum_t Y[b, idx[b,n,p+t], off_i + t*C_i + c]
-    for every spec i = (T, P, C, off, offc); one backward fills a single dY."""
+    for every spec i = (T, P, C, off, offc[, want_stats]); one backward fills a single dY.  For a spec with
+    want_stats the BatchNorm partial statistics of out_i (viewed as (b*n*P, C)) are returned as an extra trailing
+    output (bn_act / bilateral_weighting take them as `partials`)."""
 
     @staticmethod
     def forward(ctx, Y, idx, specs, *biases):
@@ -59,23 +63,37 @@ class EdgeGatherSum(Function):
         require(idx, "idx", I32, 3)
         b, n, ldy = Y.shape
         k = idx.shape[2]
-        outs = []
-        for (T, P, C, off, offc), bias in zip(specs, biases):
+        outs, partials = [], []
+        L = _lib.lib()
+        for spec, bias in zip(specs, biases):
+            T, P, C, off, offc = spec[:5]
             out = torch.empty((b, n, P, C), dtype=F32, device=Y.device)
             bias_c = bias.detach().contiguous() if bias is not None else None
             bstride = C if (bias is not None and bias.dim() == 2) else 0          # (B,C): per-sample bias
-            check(_lib.lib().pdgn_window_gather_sum(b, n, k, ldy, T, P, C, off, offc, ptr(Y), ptr(idx),
-                                                    ptr(bias_c), bstride, ptr(out), stream_of(Y)),
-                  "pdgn_window_gather_sum")
+            if len(spec) > 5 and spec[5]:
+                # the consumer is a training-mode BatchNorm over (b*n*P, C): emit its partial statistics here
+                L.pdgn_bn_scratch_floats.restype = ctypes.c_longlong
+                scr = torch.empty(L.pdgn_bn_scratch_floats(ctypes.c_longlong(b * n * P), C), dtype=F32, device=Y.device)
+                check(L.pdgn_window_gather_sum_stats(b, n, k, ldy, T, P, C, off, offc, ptr(Y), ptr(idx), ptr(bias_c),
+                                                     bstride, ptr(out), ptr(scr), stream_of(Y)),
+                      "pdgn_window_gather_sum_stats")
+                partials.append(scr)
+            else:
+                check(L.pdgn_window_gather_sum(b, n, k, ldy, T, P, C, off, offc, ptr(Y), ptr(idx),
+                                               ptr(bias_c), bstride, ptr(out), stream_of(Y)),
+                      "pdgn_window_gather_sum")
             outs.append(out)
+        specs = tuple(tuple(spec[:5]) for spec in specs)
+        ctx.mark_non_differentiable(*partials)
         ctx.specs, ctx.shape = specs, (b, n, ldy, k)
         ctx.has_bias = [0 if bias is None else bias.dim() for bias in biases]   # 0 none, 1 shared, 2 per sample
         ctx.save_for_backward(idx)
-        return tuple(outs)
+        return tuple(outs) + tuple(partials)
 
     @staticmethod
     def backward(ctx, *douts):
         (idx,) = ctx.saved_tensors
+        douts = douts[:len(ctx.specs)]                              # trailing outputs are statistics partials
         b, n, ldy, k = ctx.shape
         L = _lib.lib()
         covered = sum(T * C + (C if offc >= 0 else 0) for (T, P, C, off, offc) in ctx.specs)
@@ -220,16 +238,18 @@ class PointDeconv(nn.Module):
         o_a = o_ci + 4 * Fi
         o_ca = o_a + k * 2 * Fo
         o_p = o_ca + 2 * Fo
-        specs = [(T, P, 4 * Fi, o_i, o_ci), (k, 1, 2 * Fo, o_a, o_ca)]
+        fuse_stats = training and xt.is_cuda and Fi % 4 == 0 and Y.shape[2] % 4 == 0
+        specs = [(T, P, 4 * Fi, o_i, o_ci, fuse_stats), (k, 1, 2 * Fo, o_a, o_ca)]
         biases = [self.inte_conv_hk[0].bias, self.conv2.conv.bias]
         if self.bilateral:
             specs.append((1, k, 16, o_p, o_p + 16))
             biases.append(self.conv_fea[0].bias)
         if Yc is not None:                                             # bias_b = bias + centre + sum of taps of Yc
-            biases = [bias.unsqueeze(0) + Yc[:, offc:offc + C] + Yc[:, off:off + T_ * C].reshape(B, T_, C).sum(1)
-                      for (T_, P_, C, off, offc), bias in zip(specs, biases)]
+            biases = [bias.unsqueeze(0) + Yc[:, sp[4]:sp[4] + sp[2]] + Yc[:, sp[3]:sp[3] + sp[0] * sp[2]].reshape(B, sp[0], sp[2]).sum(1)
+                      for sp, bias in zip(specs, biases)]            # sp = (T, P, C, off, offc[, want_stats])
         outs = EdgeGatherSum.apply(Y, idx, tuple(specs), *biases)
         inte_pre, a_pre = outs[0], outs[1]                             # (B,N,P,4F), (B,N,1,2Fo)
+        part_i = outs[-1] if fuse_stats else None                      # BatchNorm partials of inte_pre
         w = None
         if self.bilateral:
             Wx = _w2d(self.conv_xyz[0])                   # (16, 6)
@@ -246,14 +266,14 @@ class PointDeconv(nn.Module):
                 # conv_all.4 + LeakyReLU + softmax over the k slots + interleave w[b,n,s=P*j+p,c'] -> [b,n,p,o=2c'+j]
                 # (:623-625, :634-641) AND inte = LeakyReLU(BN(inte_pre)) * w (:637, :642): one pass over both raw tensors
                 inte = bilateral_weighting(h, self.conv_all[4], inte_pre.view(-1, 4 * Fi), self.inte_conv_hk[1], training, k,
-                                           pre_bias_x=self.conv_all[3].bias)
+                                           pre_bias_x=self.conv_all[3].bias, partials_u=part_i)
             else:
                 h = bn_act(h, self.conv_all[4], training, pre_bias=self.conv_all[3].bias)
                 w = h.view(B, N, 2, P, 2 * Fi).permute(0, 1, 3, 4, 2).reshape(B * N * P, 4 * Fi)
-                inte = bn_act(inte_pre.view(-1, 4 * Fi), self.inte_conv_hk[1], training, mul=w)
+                inte = bn_act(inte_pre.view(-1, 4 * Fi), self.inte_conv_hk[1], training, mul=w, partials=part_i)
         else:
             # inte = LeakyReLU(BN(inte_pre))  (:637)
-            inte = bn_act(inte_pre.view(-1, 4 * Fi), self.inte_conv_hk[1], training)
+            inte = bn_act(inte_pre.view(-1, 4 * Fi), self.inte_conv_hk[1], training, partials=part_i)
         out_pre = a_pre.view(B * N, 2 * Fo) + linear_cl(inte.view(B * N, P * 4 * Fi), Wb)
         out = bn_act(out_pre, self.conv2.bn, training, act="relu")     # (B*N, 2Fo): channel 2c+j
         # (B,2Fout,N,1) -> view(B,Fout,2,N) -> (B,Fout,2N) (:645-647): point j*N+n of channel c is conv

@@ -83,12 +83,16 @@ def _zeros(shape, device):
     return v
 
 
-def _bn_stats(L, x, rows, C, g, b, pre_bias, running_mean, running_var, training, momentum, eps):
+def _bn_stats(L, x, rows, C, g, b, pre_bias, running_mean, running_var, training, momentum, eps, partials=None):
     """[scale|shift|mean|invstd] of a BatchNorm over x (rows, C) -- batch statistics (+ running-stat update) in
     training, running statistics in eval.  pre_bias: see include/pdgn_hip.h (the producer's bias, left out of x)."""
     stats = torch.empty(4 * C, dtype=F32, device=x.device)
     pb = pre_bias.detach().contiguous() if pre_bias is not None else None
-    if training:
+    if training and partials is not None:                       # first stage done by x's producer (its epilogue)
+        check(L.pdgn_bn_stats_from_partials(ctypes.c_longlong(rows), C, ctypes.c_float(eps), ctypes.c_float(momentum),
+                                            ptr(g), ptr(b), ptr(pb), ptr(running_mean), ptr(running_var), ptr(partials),
+                                            ptr(stats), stream_of(x)), "pdgn_bn_stats_from_partials")
+    elif training:
         scratch = torch.empty(_scratch_floats(L, rows, C), dtype=F32, device=x.device)
         check(L.pdgn_bn_stats(ctypes.c_longlong(rows), C, ctypes.c_float(eps), ctypes.c_float(momentum), ptr(x),
                               ptr(g), ptr(b), ptr(pb), ptr(running_mean), ptr(running_var), ptr(scratch), ptr(stats),
@@ -121,12 +125,13 @@ class BNActCL(Function):
     bilateral product ``inte_x * w`` of models/PDGNet_v2.py:642)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, act, mul, pre_bias=None):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, act, mul, pre_bias=None,
+                partials=None):
         rows, C = x.shape
         x = x.contiguous()
         L = _lib.lib()
         g, b = gamma.detach().contiguous(), beta.detach().contiguous()
-        stats = _bn_stats(L, x, rows, C, g, b, pre_bias, running_mean, running_var, training, momentum, eps)
+        stats = _bn_stats(L, x, rows, C, g, b, pre_bias, running_mean, running_var, training, momentum, eps, partials)
         ctx.has_pre_bias = pre_bias is not None
         mul_c = mul.contiguous() if mul is not None else None
         y = torch.empty_like(x)
@@ -151,7 +156,8 @@ class BNActCL(Function):
               "pdgn_bn_act_backward")
         if training:
             mark_zero_colsum(dx)
-        return dx, bs[C:], bs[:C], None, None, None, None, None, None, dmul, _pre_bias_grad(ctx.has_pre_bias, C, x.device)
+        return (dx, bs[C:], bs[:C], None, None, None, None, None, None, dmul, _pre_bias_grad(ctx.has_pre_bias, C, x.device),
+                None)
 
 
 # nn.BatchNorm's num_batches_tracked bookkeeping: one tiny int64 add per layer per forward would be
@@ -167,7 +173,7 @@ def flush_bn_counters():
         _PENDING_COUNTS.clear()
 
 
-def bn_act(x2d, bn, training, act="leaky_relu", mul=None, pre_bias=None):
+def bn_act(x2d, bn, training, act="leaky_relu", mul=None, pre_bias=None, partials=None):
     """Apply an nn.BatchNorm{1,2}d module's parameters/buffers to a channels-last (rows, C) view,
     followed by `act` (and an optional elementwise product).  `pre_bias`: the bias of the layer that produced
     x2d, when the caller did not add it (it cancels inside the BatchNorm; only the running mean sees it)."""
@@ -182,7 +188,7 @@ def bn_act(x2d, bn, training, act="leaky_relu", mul=None, pre_bias=None):
         y = {"none": lambda t: t, "relu": torch.relu, "leaky_relu": torch.nn.functional.leaky_relu}[act](y)
         return y * mul if mul is not None else y
     return BNActCL.apply(x2d, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, bn.momentum, bn.eps,
-                         ACT[act], mul, pre_bias)
+                         ACT[act], mul, pre_bias, partials)
 
 
 # PyTorch-ROCm ships two GEMM back ends (rocBLAS, hipBLASLt) and neither wins everywhere on the step's fp32
@@ -374,7 +380,7 @@ class BilateralWeighting(Function):
 
     @staticmethod
     def forward(ctx, x, u, gx, bx, rmx, rvx, pbx, gu, bu, rmu, rvu, pbu, training, momentum_x, eps_x, momentum_u, eps_u,
-                act, k):
+                act, k, partials_u=None):
         rows, C = x.shape
         m = rows // k
         x, u = x.contiguous(), u.contiguous()
@@ -382,7 +388,7 @@ class BilateralWeighting(Function):
         stats_x = _bn_stats(L, x, rows, C, gx.detach().contiguous(), bx.detach().contiguous(), pbx, rmx, rvx, training,
                             momentum_x, eps_x)
         stats_u = _bn_stats(L, u, u.shape[0], 2 * C, gu.detach().contiguous(), bu.detach().contiguous(), pbu, rmu, rvu,
-                            training, momentum_u, eps_u)
+                            training, momentum_u, eps_u, partials_u)
         need_w = any(ctx.needs_input_grad)
         w = torch.empty((m, k // 2, 2 * C), dtype=F32, device=x.device) if need_w else None
         y = torch.empty_like(u)
@@ -421,24 +427,25 @@ class BilateralWeighting(Function):
             mark_zero_colsum(du)
             mark_zero_colsum(dx)
         return (dx, du, bsx[C:], bsx[:C], None, None, _pre_bias_grad(has_pbx, C, x.device), bsu[Cu:], bsu[:Cu], None, None,
-                _pre_bias_grad(has_pbu, Cu, x.device), None, None, None, None, None, None, None)
+                _pre_bias_grad(has_pbu, Cu, x.device), None, None, None, None, None, None, None, None)
 
 
-def bilateral_weighting(x2d, bn_x, u2d, bn_u, training, k, act="leaky_relu", pre_bias_x=None, pre_bias_u=None):
+def bilateral_weighting(x2d, bn_x, u2d, bn_u, training, k, act="leaky_relu", pre_bias_x=None, pre_bias_u=None,
+                        partials_u=None):
     """x2d (M*k, C) raw conv_all.3 output, u2d (M*k/2, 2C) raw inte_conv_hk output ->
     act(bn_u(u2d)) * softmax_slots_permute(act(bn_x(x2d))), shape of u2d."""
     x2d, pre_bias_x = _fold_pre_bias(x2d, pre_bias_x, training)
     u2d, pre_bias_u = _fold_pre_bias(u2d, pre_bias_u, training)
     if x2d.shape[1] % 4:
         w = bn_softmax_slots_permute(x2d, bn_x, training, k, act=act, pre_bias=pre_bias_x)
-        return bn_act(u2d, bn_u, training, act=act, mul=w.view(u2d.shape), pre_bias=pre_bias_u)
+        return bn_act(u2d, bn_u, training, act=act, mul=w.view(u2d.shape), pre_bias=pre_bias_u, partials=partials_u)
     if training:
         for bn in (bn_x, bn_u):
             if bn.track_running_stats:
                 _PENDING_COUNTS[bn.num_batches_tracked] = _PENDING_COUNTS.get(bn.num_batches_tracked, 0) + 1
     return BilateralWeighting.apply(x2d, u2d, bn_x.weight, bn_x.bias, bn_x.running_mean, bn_x.running_var, pre_bias_x,
                                     bn_u.weight, bn_u.bias, bn_u.running_mean, bn_u.running_var, pre_bias_u, training,
-                                    bn_x.momentum, bn_x.eps, bn_u.momentum, bn_u.eps, ACT[act], k)
+                                    bn_x.momentum, bn_x.eps, bn_u.momentum, bn_u.eps, ACT[act], k, partials_u)
 
 
 class BNActMaxPool(Function):

@@ -409,6 +409,44 @@ def test_bilateral_weighting(M, k, C, training):
     np.testing.assert_allclose(y2.cpu().numpy(), yr2.numpy(), rtol=1e-4, atol=1e-6)
 
 
+@pytest.mark.parametrize("b,n,k,T,P,C", [(3, 64, 10, 6, 5, 64), (2, 128, 10, 6, 5, 1024), (2, 50, 4, 3, 2, 8)])
+def test_window_gather_sum_with_statistics_epilogue(b, n, k, T, P, C):
+    """pdgn_window_gather_sum_stats: the same output bit for bit, and BatchNorm statistics (incl. running buffers)
+    finished from its partials equal to a statistics pass over the output"""
+    import ctypes
+    from pdgn_amd import _lib
+    from pdgn_amd._lib import ptr, stream_of
+    L = _lib.lib()
+    L.pdgn_bn_scratch_floats.restype = ctypes.c_longlong
+    rng = np.random.default_rng(b * n + C)
+    ldy = T * C + C
+    Y = dev(rng.standard_normal((b, n, ldy)).astype(np.float32))
+    idx = dev(rng.integers(0, n, (b, n, k)).astype(np.int32))
+    bias = dev(rng.standard_normal((b, C)).astype(np.float32))
+    out0 = torch.empty((b, n, P, C), device="cuda")
+    out1 = torch.empty_like(out0)
+    assert L.pdgn_window_gather_sum(b, n, k, ldy, T, P, C, C, 0, ptr(Y), ptr(idx), ptr(bias), C, ptr(out0), stream_of(Y)) == 0
+    rows = b * n * P
+    scr = torch.empty(L.pdgn_bn_scratch_floats(ctypes.c_longlong(rows), C), device="cuda")
+    assert L.pdgn_window_gather_sum_stats(b, n, k, ldy, T, P, C, C, 0, ptr(Y), ptr(idx), ptr(bias), C, ptr(out1), ptr(scr),
+                                          stream_of(Y)) == 0
+    assert torch.equal(out0, out1)
+    g = dev(rng.uniform(0.5, 1.5, C).astype(np.float32)); be = dev(rng.uniform(-0.5, 0.5, C).astype(np.float32))
+    res = []
+    for mode in (0, 1):
+        rm = torch.zeros(C, device="cuda"); rv = torch.ones(C, device="cuda"); stats = torch.empty(4 * C, device="cuda")
+        if mode == 0:
+            scr2 = torch.empty_like(scr)
+            assert L.pdgn_bn_stats(ctypes.c_longlong(rows), C, ctypes.c_float(1e-5), ctypes.c_float(0.1), ptr(out0), ptr(g), ptr(be),
+                                   None, ptr(rm), ptr(rv), ptr(scr2), ptr(stats), stream_of(Y)) == 0
+        else:
+            assert L.pdgn_bn_stats_from_partials(ctypes.c_longlong(rows), C, ctypes.c_float(1e-5), ctypes.c_float(0.1), ptr(g),
+                                                 ptr(be), None, ptr(rm), ptr(rv), ptr(scr), ptr(stats), stream_of(Y)) == 0
+        res.append((stats, rm, rv))
+    for a, c in zip(res[0], res[1]):
+        torch.testing.assert_close(a, c, rtol=1e-5, atol=1e-6)
+
+
 def test_config_c4_four_stage_512_to_4096():
     """BASELINE.json configs[3] ("4-stage 256->4096"; SURVEY.md section 8 Note C4: base 256 points):
     the size-generic blocks run one iteration at 512/1024/2048/4096 points; outputs have the right

@@ -11,8 +11,11 @@ class EdgeGatherSumTorch:
     def apply(Y, idx, specs, *biases):
         B, N, ldy = Y.shape
         idx = idx.long()
-        outs = []
-        for (T, P, C, off, offc), bias in zip(specs, biases):
+        outs, extra = [], []
+        for spec, bias in zip(specs, biases):
+            T, P, C, off, offc = spec[:5]
+            if len(spec) > 5 and spec[5]:
+                extra.append(None)                                                  # BatchNorm partials: HIP-only
             acc = Y[:, :, offc:offc + C].unsqueeze(2).expand(B, N, P, C) if offc >= 0 else 0
             for t in range(T):
                 cols = Y[:, :, off + t * C: off + (t + 1) * C]                     # (B,N,C)
@@ -22,7 +25,7 @@ class EdgeGatherSumTorch:
             if bias is not None:
                 acc = acc + (bias if bias.dim() == 1 else bias.view(B, 1, 1, C))   # shared or per-sample
             outs.append(acc)
-        return tuple(outs)
+        return tuple(outs) + tuple(extra)
 
 
 def feature_knn_torch(x, k):
@@ -32,7 +35,7 @@ def feature_knn_torch(x, k):
     return dist.sort(dim=2, stable=True)[1][:, :, 1:k + 1].to(torch.int32).contiguous()
 
 
-def bn_act_torch(x2d, bn, training, act="leaky_relu", mul=None, pre_bias=None):
+def bn_act_torch(x2d, bn, training, act="leaky_relu", mul=None, pre_bias=None, partials=None):
     """Same contract as pdgn_amd.fused.bn_act in plain torch ops."""
     import torch.nn.functional as F
     if pre_bias is not None:
@@ -91,7 +94,8 @@ def bn_softmax_slots_permute_torch(x2d, bn, training, k, act="leaky_relu", pre_b
     return softmax_slots_permute_torch(h.view(-1, k, x2d.shape[1]))
 
 
-def bilateral_weighting_torch(x2d, bn_x, u2d, bn_u, training, k, act="leaky_relu", pre_bias_x=None, pre_bias_u=None):
+def bilateral_weighting_torch(x2d, bn_x, u2d, bn_u, training, k, act="leaky_relu", pre_bias_x=None, pre_bias_u=None,
+                              partials_u=None):
     w = bn_softmax_slots_permute_torch(x2d, bn_x, training, k, act=act, pre_bias=pre_bias_x)
     return bn_act_torch(u2d, bn_u, training, act=act, mul=w.reshape(u2d.shape), pre_bias=pre_bias_u)
 

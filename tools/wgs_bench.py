@@ -1,0 +1,27 @@
+#!/usr/bin/env python3
+"""wgs_fwd vs wgs_fwd_stats (+ the statistics pass it replaces) at the stage-4 inte shape."""
+import ctypes, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from pdgn_amd import _lib
+from pdgn_amd._lib import ptr, stream_of
+L = _lib.lib(); L.pdgn_bn_scratch_floats.restype = ctypes.c_longlong
+def t(fn, it=20):
+    for _ in range(3): fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(it): fn()
+    e.record(); torch.cuda.synchronize()
+    return s.elapsed_time(e) / it * 1e3
+b, n, k, T, P, C = 35, 1024, 10, 6, 5, 1024
+ldy = 12832
+Y = torch.randn(b, n, ldy, device="cuda"); idx = torch.randint(0, n, (b, n, k), device="cuda", dtype=torch.int32)
+bias = torch.randn(b, C, device="cuda"); out = torch.empty(b, n, P, C, device="cuda")
+rows = b * n * P
+scr = torch.empty(L.pdgn_bn_scratch_floats(ctypes.c_longlong(rows), C), device="cuda")
+g = torch.ones(C, device="cuda"); be = torch.zeros(C, device="cuda"); rm = torch.zeros(C, device="cuda"); rv = torch.ones(C, device="cuda"); st = torch.empty(4 * C, device="cuda")
+a = t(lambda: L.pdgn_window_gather_sum(b, n, k, ldy, T, P, C, 0, T * C, ptr(Y), ptr(idx), ptr(bias), C, ptr(out), stream_of(Y)))
+c = t(lambda: L.pdgn_window_gather_sum_stats(b, n, k, ldy, T, P, C, 0, T * C, ptr(Y), ptr(idx), ptr(bias), C, ptr(out), ptr(scr), stream_of(Y)))
+d = t(lambda: L.pdgn_bn_stats(ctypes.c_longlong(rows), C, ctypes.c_float(1e-5), ctypes.c_float(0.1), ptr(out), ptr(g), ptr(be), None, ptr(rm), ptr(rv), ptr(scr), ptr(st), stream_of(Y)))
+print("wgs_fwd %.1f us | wgs_fwd_stats %.1f us | bn_stats pass %.1f us  => %.1f vs %.1f" % (a, c, d, a + d, c))
