@@ -213,18 +213,29 @@ __global__ __launch_bounds__(BN_THREADS) void cl_bwd_reduce_kernel(long long R, 
         const float4 sh = *reinterpret_cast<const float4 *>(stats + C + cgi * 4);
         const float4 mu = *reinterpret_cast<const float4 *>(stats + 2 * C + cgi * 4);
         const float4 is = *reinterpret_cast<const float4 *>(stats + 3 * C + cgi * 4);
-        for (long long r = r0 + rlane; r < r1; r += rl) {
-            const float4 v = *reinterpret_cast<const float4 *>(x + r * C + cgi * 4);
-            float4 g = *reinterpret_cast<const float4 *>(dy + r * C + cgi * 4);
-            if (mul) {
-                const float4 m = *reinterpret_cast<const float4 *>(mul + r * C + cgi * 4);
-                g.x *= m.x; g.y *= m.y; g.z *= m.z; g.w *= m.w;
+        const bool has_mul = mul != nullptr;
+        for (long long rb = r0 + rlane; rb < r1; rb += 4LL * rl) {  // four rows (8-12 independent loads) in flight
+            float4 v[4], g[4], m[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const long long r = rb + (long long)u * rl;
+                if (r < r1) {
+                    v[u] = *reinterpret_cast<const float4 *>(x + r * C + cgi * 4);
+                    g[u] = *reinterpret_cast<const float4 *>(dy + r * C + cgi * 4);
+                    if (has_mul) m[u] = *reinterpret_cast<const float4 *>(mul + r * C + cgi * 4);
+                }
             }
-            float dz;
-            dz = g.x * act_grad(__fmaf_rn(v.x, sc.x, sh.x), act); s.x += dz; q.x = __fmaf_rn(dz, (v.x - mu.x) * is.x, q.x);
-            dz = g.y * act_grad(__fmaf_rn(v.y, sc.y, sh.y), act); s.y += dz; q.y = __fmaf_rn(dz, (v.y - mu.y) * is.y, q.y);
-            dz = g.z * act_grad(__fmaf_rn(v.z, sc.z, sh.z), act); s.z += dz; q.z = __fmaf_rn(dz, (v.z - mu.z) * is.z, q.z);
-            dz = g.w * act_grad(__fmaf_rn(v.w, sc.w, sh.w), act); s.w += dz; q.w = __fmaf_rn(dz, (v.w - mu.w) * is.w, q.w);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (rb + (long long)u * rl < r1) {
+                    if (has_mul) { g[u].x *= m[u].x; g[u].y *= m[u].y; g[u].z *= m[u].z; g[u].w *= m[u].w; }
+                    float dz;
+                    dz = g[u].x * act_grad(__fmaf_rn(v[u].x, sc.x, sh.x), act); s.x += dz; q.x = __fmaf_rn(dz, (v[u].x - mu.x) * is.x, q.x);
+                    dz = g[u].y * act_grad(__fmaf_rn(v[u].y, sc.y, sh.y), act); s.y += dz; q.y = __fmaf_rn(dz, (v[u].y - mu.y) * is.y, q.y);
+                    dz = g[u].z * act_grad(__fmaf_rn(v[u].z, sc.z, sh.z), act); s.z += dz; q.z = __fmaf_rn(dz, (v[u].z - mu.z) * is.z, q.z);
+                    dz = g[u].w * act_grad(__fmaf_rn(v[u].w, sc.w, sh.w), act); s.w += dz; q.w = __fmaf_rn(dz, (v[u].w - mu.w) * is.w, q.w);
+                }
+            }
         }
     }
     red[0][threadIdx.x] = s;
@@ -288,10 +299,10 @@ __global__ __launch_bounds__(BN_THREADS) void cl_bwd_apply_kernel(long long R, i
     *reinterpret_cast<float4 *>(ca) = *reinterpret_cast<const float4 *>(coef + cgi * 4);
     *reinterpret_cast<float4 *>(cb) = *reinterpret_cast<const float4 *>(coef + C + cgi * 4);
     const bool has_mul = mul != nullptr, want_dmul = dmul != nullptr;
-    for (long long r = r0 + rlane; r < r1; r += 2 * rl) {
-        float v[2][4], g[2][4], m[2][4];
+    for (long long r = r0 + rlane; r < r1; r += 4 * rl) {
+        float v[4][4], g[4][4], m[4][4];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < 4; ++u) {
             const long long rr = r + (long long)u * rl;
             if (rr < r1) {
                 *reinterpret_cast<float4 *>(v[u]) = *reinterpret_cast<const float4 *>(x + rr * C + cgi * 4);
@@ -300,7 +311,7 @@ __global__ __launch_bounds__(BN_THREADS) void cl_bwd_apply_kernel(long long R, i
             }
         }
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < 4; ++u) {
             const long long rr = r + (long long)u * rl;
             if (rr < r1) {
                 float o[4], om[4];
