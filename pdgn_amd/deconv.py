@@ -31,6 +31,15 @@ from .fused import (_zeros, bilateral_weighting, bn_act, bn_act_maxpool, bn_soft
                     has_zero_colsum, linear_cl, softmax_slots_permute)
 
 F32, I32 = torch.float32, torch.int32
+_KNN_OVERLAP = __import__("os").environ.get("PDGN_KNN_OVERLAP", "1") == "1"
+_KNN_STREAMS = {}
+
+
+def _knn_stream(device):
+    s = _KNN_STREAMS.get(device)
+    if s is None:
+        s = _KNN_STREAMS[device] = torch.cuda.Stream(device=device)
+    return s
 
 
 def _w2d(conv):
@@ -217,13 +226,25 @@ class PointDeconv(nn.Module):
         Fi, Fo, k = self.Fin, self.Fout, self.k
         Fc = Fi - Fv
         training = self.training
+        knn_side = None
         if idx is None:
             with torch.no_grad():
                 if x_cf is None:
                     x_cf = xt.transpose(1, 2)
                     if const is not None:
                         x_cf = torch.cat((const.unsqueeze(2).expand(-1, -1, N), x_cf), 1)
-                idx = feature_knn(x_cf.detach().contiguous(), k)
+                x_knn = x_cf.detach().contiguous()
+                if x_knn.is_cuda and _KNN_OVERLAP:
+                    # the graph is first needed by the gather-sum, AFTER the per-point GEMM: build it on a second stream
+                    # (its selection phase is vector-ALU work, the GEMM is matrix-core work)
+                    cur = torch.cuda.current_stream(x_knn.device)
+                    knn_side = _knn_stream(x_knn.device)
+                    knn_side.wait_stream(cur)
+                    x_knn.record_stream(knn_side)
+                    with torch.cuda.stream(knn_side):
+                        idx = feature_knn(x_knn, k)
+                else:
+                    idx = feature_knn(x_knn, k)
         elif idx.dtype != I32:
             idx = idx.to(I32)
         idx = idx.contiguous()
@@ -247,6 +268,9 @@ class PointDeconv(nn.Module):
         if Yc is not None:                                             # bias_b = bias + centre + sum of taps of Yc
             biases = [bias.unsqueeze(0) + Yc[:, sp[4]:sp[4] + sp[2]] + Yc[:, sp[3]:sp[3] + sp[0] * sp[2]].reshape(B, sp[0], sp[2]).sum(1)
                       for sp, bias in zip(specs, biases)]            # sp = (T, P, C, off, offc[, want_stats])
+        if knn_side is not None:
+            torch.cuda.current_stream(idx.device).wait_stream(knn_side)
+            idx.record_stream(torch.cuda.current_stream(idx.device))
         outs = EdgeGatherSum.apply(Y, idx, tuple(specs), *biases)
         inte_pre, a_pre = outs[0], outs[1]                             # (B,N,P,4F), (B,N,1,2Fo)
         part_i = outs[-1] if fuse_stats else None                      # BatchNorm partials of inte_pre
