@@ -202,6 +202,7 @@ _BLAS_MIN_ROWS = 4096
 
 def _timed(fn):
     fn()
+    torch.cuda.synchronize()                 # quiesce the other streams of the overlapped schedule: time in isolation
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
     for _ in range(5):

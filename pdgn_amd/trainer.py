@@ -281,11 +281,17 @@ class PDGNTrainer:
         self._side_lp.wait_stream(main)
         with torch.cuda.stream(self._side_lp):
             similar = self.similar_loss(gen)
+        # D_k(G(z2)_k): four more independent chains of small kernels, each behind D_k's own update on D_k's stream
+        # (forward here, backward wherever autograd finds the forward)
+        g_loss = []
+        for i, side in enumerate(self._side):
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                g_loss.append(F.mse_loss(self.D[i](gen[i]), st["ones"]))
         for side in self._side:
             main.wait_stream(side)
-        g_loss = [F.mse_loss(self.D[i](gen[i]), st["ones"]) for i in range(4)]
-        adv = 1.2 * g_loss[0] + 1.2 * g_loss[1] + 1.2 * g_loss[2] + g_loss[3]
         main.wait_stream(self._side_lp)
+        adv = 1.2 * g_loss[0] + 1.2 * g_loss[1] + 1.2 * g_loss[2] + g_loss[3]
         lossG = adv + 0.1 * similar
         ws = st["ws"]
         (adv + (0.1 * ws) * similar if ws > 1 else lossG).backward()
