@@ -197,6 +197,7 @@ def bn_act(x2d, bn, training, act="leaky_relu", mul=None, pre_bias=None, partial
 # timed once per (form, shape) under both back ends -- three launches each, during the first iteration -- and the
 # winner is selected before every later call (a host-side flag, no device work).
 _BLAS = {"choice": {}, "tune": os.environ.get("PDGN_BLAS_TUNE", "1") == "1", "default": None}
+warnings.filterwarnings("ignore", message=".*preferred_blas_library is an experimental feature.*")
 _BLAS_MIN_ROWS = 4096
 
 
