@@ -227,6 +227,7 @@ class PointDeconv(nn.Module):
         Fc = Fi - Fv
         training = self.training
         knn_side = None
+        want_csr = torch.is_grad_enabled() and xt.requires_grad     # a backward pass will need the transposed graph
         if idx is None:
             with torch.no_grad():
                 if x_cf is None:
@@ -243,6 +244,8 @@ class PointDeconv(nn.Module):
                     x_knn.record_stream(knn_side)
                     with torch.cuda.stream(knn_side):
                         idx = feature_knn(x_knn, k)
+                        if want_csr:
+                            transposed_graph(idx)                 # the adjoint's CSR, off the backward's critical path
                 else:
                     idx = feature_knn(x_knn, k)
         elif idx.dtype != I32:
