@@ -36,9 +36,11 @@ _KNN_STREAMS = {}
 
 
 def _knn_stream(device):
-    s = _KNN_STREAMS.get(device)
+    """One kNN side stream per (device, issuing stream): concurrent generator passes must not share one."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    s = _KNN_STREAMS.get(key)
     if s is None:
-        s = _KNN_STREAMS[device] = torch.cuda.Stream(device=device)
+        s = _KNN_STREAMS[key] = torch.cuda.Stream(device=device)
     return s
 
 
