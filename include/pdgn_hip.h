@@ -206,6 +206,15 @@ int pdgn_bn_softmax_slots_permute(long long m, int k, int c, int act, const floa
 int pdgn_bn_softmax_slots_permute_mul(long long m, int k, int c, int act, const float *x, const float *stats,
                                       int act_u, const float *u, const float *stats_u, float *w, float *y,
                                       pdgn_stream_t stream);
+/* Adjoint of pdgn_bn_softmax_slots_permute_mul in two passes over (x, u, w, dy): BatchNorm_u backward, slot-softmax
+ * backward and BatchNorm_x backward with dW / dh kept in registers.  scratch: pdgn_bilateral_scratch_floats(m,k,c)
+ * floats; bsums_x (2c) = [sum dz_x | sum dz_x*xhat] (= dbeta, dgamma of BN_x), bsums_u (4c) likewise for BN_u;
+ * training = 0: running-statistics BatchNorms (no batch terms in dx / du).  c % 4 == 0. */
+long long pdgn_bilateral_scratch_floats(long long m, int k, int c);
+int pdgn_bilateral_weighting_backward(long long m, int k, int c, int act, int training, const float *x,
+                                      const float *stats_x, const float *u, const float *stats_u, const float *w,
+                                      const float *dy, float *scratch, float *bsums_x, float *bsums_u, float *dx,
+                                      float *du, pdgn_stream_t stream);
 /* dh[m,s,c'] = w_s (dw_s - sum_s' w_s' dw_s'), w / dw in the permuted layout. */
 int pdgn_softmax_slots_permute_backward(long long m, int k, int c, const float *w, const float *dw,
                                         float *dh, pdgn_stream_t stream);

@@ -400,6 +400,170 @@ extern "C" int pdgn_bn_act_backward(long long rows, int c, int act, int training
     return pdgn_launch_status();
 }
 
+// ---------------------------------------------------------------------------- bilateral weighting, adjoint
+// y = act(BN_u(u)) * softmax_slots_permute(act(BN_x(x)))  (softmax_perm.hip: bn_softmax_perm_mul_fwd_kernel).
+// Its adjoint chains a BatchNorm backward (u), a slot-softmax backward and a second BatchNorm backward (x); done
+// separately that is 8 + 3 + 5 passes over edge-sized tensors with dW and dh materialised in between.  Here a thread
+// owns one channel pair of x (= four interleaved channels of u) and walks points: it holds all k slots of the pair,
+// so dW, the softmax dot product and dh live in registers.  Two launches (batch sums, then the gradients) read
+// x, u, w, dy twice and write dx, du once: 10 passes instead of 16, nothing intermediate in HBM.
+#define BW_MAXK 32
+
+template <int KT, bool APPLY>
+__global__ __launch_bounds__(BN_THREADS) void bilateral_bwd_kernel(
+    long long M, int k_rt, int C, int cpb, int m_per_block, int act, const float *__restrict__ x,
+    const float *__restrict__ stats_x, const float *__restrict__ u, const float *__restrict__ stats_u,
+    const float *__restrict__ w, const float *__restrict__ dy, float *__restrict__ part_x, float *__restrict__ part_u,
+    const float *__restrict__ coef_x, const float *__restrict__ coef_u, float *__restrict__ dx, float *__restrict__ du) {
+    constexpr int KM = KT ? KT : BW_MAXK;
+    __shared__ float red[12][BN_THREADS];
+    const int k = KT ? KT : k_rt, P = k / 2, C2 = C / 2, Cu = 2 * C;
+    const int cpl = threadIdx.x % cpb, rlane = threadIdx.x / cpb, rl = BN_THREADS / cpb;
+    const int cp = blockIdx.x * cpb + cpl;
+    const bool ok = cp < C2;
+    const int c = 2 * (ok ? cp : 0);
+    const long long m0 = (long long)blockIdx.y * m_per_block, m1 = min(M, m0 + m_per_block);
+    const float2 scx = *reinterpret_cast<const float2 *>(stats_x + c), shx = *reinterpret_cast<const float2 *>(stats_x + C + c);
+    const float2 mux = *reinterpret_cast<const float2 *>(stats_x + 2 * C + c), isx = *reinterpret_cast<const float2 *>(stats_x + 3 * C + c);
+    const float4 scu = *reinterpret_cast<const float4 *>(stats_u + 2 * c), shu = *reinterpret_cast<const float4 *>(stats_u + Cu + 2 * c);
+    const float4 muu = *reinterpret_cast<const float4 *>(stats_u + 2 * Cu + 2 * c), isu = *reinterpret_cast<const float4 *>(stats_u + 3 * Cu + 2 * c);
+    float2 cax = make_float2(0.f, 0.f), cbx = cax;
+    float4 cau = make_float4(0.f, 0.f, 0.f, 0.f), cbu = cau;
+    if (APPLY) {
+        cax = *reinterpret_cast<const float2 *>(coef_x + c); cbx = *reinterpret_cast<const float2 *>(coef_x + C + c);
+        cau = *reinterpret_cast<const float4 *>(coef_u + 2 * c); cbu = *reinterpret_cast<const float4 *>(coef_u + Cu + 2 * c);
+    }
+    float acc[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) acc[i] = 0.f;                  // sx[2] qx[2] su[4] qu[4]
+    if (ok)
+        for (long long m = m0 + rlane; m < m1; m += rl) {
+            const size_t ox = (size_t)m * k * C + c, ou = (size_t)m * k * C + 2 * c;
+            float2 xv[KM];
+            float4 uv[KM / 2], wv[KM / 2], gv[KM / 2];
+#pragma unroll
+            for (int s = 0; s < KM; ++s)
+                if (KT || s < k) xv[s] = *reinterpret_cast<const float2 *>(x + ox + (size_t)s * C);
+#pragma unroll
+            for (int p = 0; p < KM / 2; ++p)
+                if (KT || p < P) {
+                    uv[p] = *reinterpret_cast<const float4 *>(u + ou + (size_t)p * Cu);
+                    wv[p] = *reinterpret_cast<const float4 *>(w + ou + (size_t)p * Cu);
+                    gv[p] = *reinterpret_cast<const float4 *>(dy + ou + (size_t)p * Cu);
+                }
+            float dot0 = 0.f, dot1 = 0.f;
+#pragma unroll
+            for (int p = 0; p < KM / 2; ++p)
+                if (KT || p < P) {
+                    const float u4[4] = {uv[p].x, uv[p].y, uv[p].z, uv[p].w}, w4[4] = {wv[p].x, wv[p].y, wv[p].z, wv[p].w};
+                    const float g4[4] = {gv[p].x, gv[p].y, gv[p].z, gv[p].w};
+                    const float s4[4] = {scu.x, scu.y, scu.z, scu.w}, h4[4] = {shu.x, shu.y, shu.z, shu.w};
+                    const float m4[4] = {muu.x, muu.y, muu.z, muu.w}, i4[4] = {isu.x, isu.y, isu.z, isu.w};
+                    const float a4[4] = {cau.x, cau.y, cau.z, cau.w}, b4[4] = {cbu.x, cbu.y, cbu.z, cbu.w};
+                    float dW[4], o4[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float z = __fmaf_rn(u4[j], s4[j], h4[j]);
+                        dW[j] = g4[j] * act_fwd(z, act);
+                        const float dz = g4[j] * w4[j] * act_grad(z, act);
+                        if (APPLY) o4[j] = __fmaf_rn(s4[j], dz, -a4[j]) - b4[j] * u4[j];
+                        else { acc[4 + j] += dz; acc[8 + j] = __fmaf_rn(dz, (u4[j] - m4[j]) * i4[j], acc[8 + j]); }
+                    }
+                    if (APPLY) *reinterpret_cast<float4 *>(du + ou + (size_t)p * Cu) = make_float4(o4[0], o4[1], o4[2], o4[3]);
+                    dot0 = __fmaf_rn(w4[0], dW[0], __fmaf_rn(w4[1], dW[1], dot0));
+                    dot1 = __fmaf_rn(w4[2], dW[2], __fmaf_rn(w4[3], dW[3], dot1));
+                    gv[p] = make_float4(dW[0], dW[1], dW[2], dW[3]);          // keep dW for the softmax adjoint
+                }
+            // softmax adjoint: slot s = P*j + p of channel c (+1) sits in component j (+2) of row p
+#pragma unroll
+            for (int s = 0; s < KM; ++s)
+                if (KT || s < k) {
+                    const int p = s < P ? s : s - P;
+                    const bool hi = s >= P;
+                    const float w0 = hi ? wv[p].y : wv[p].x, g0 = hi ? gv[p].y : gv[p].x;
+                    const float w1 = hi ? wv[p].w : wv[p].z, g1 = hi ? gv[p].w : gv[p].z;
+                    const float da0 = w0 * (g0 - dot0), da1 = w1 * (g1 - dot1);
+                    const float dz0 = da0 * act_grad(__fmaf_rn(xv[s].x, scx.x, shx.x), act);
+                    const float dz1 = da1 * act_grad(__fmaf_rn(xv[s].y, scx.y, shx.y), act);
+                    if (APPLY) {
+                        float2 o;
+                        o.x = __fmaf_rn(scx.x, dz0, -cax.x) - cbx.x * xv[s].x;
+                        o.y = __fmaf_rn(scx.y, dz1, -cax.y) - cbx.y * xv[s].y;
+                        *reinterpret_cast<float2 *>(dx + ox + (size_t)s * C) = o;
+                    } else {
+                        acc[0] += dz0; acc[1] += dz1;
+                        acc[2] = __fmaf_rn(dz0, (xv[s].x - mux.x) * isx.x, acc[2]);
+                        acc[3] = __fmaf_rn(dz1, (xv[s].y - mux.y) * isx.y, acc[3]);
+                    }
+                }
+        }
+    if (APPLY) return;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) red[i][threadIdx.x] = acc[i];
+    __syncthreads();
+    if (rlane == 0 && ok) {
+        for (int j = 1; j < rl; ++j)
+#pragma unroll
+            for (int i = 0; i < 12; ++i) acc[i] += red[i][j * cpb + cpl];
+        float *px = part_x + (size_t)blockIdx.y * 2 * C, *pu = part_u + (size_t)blockIdx.y * 2 * Cu;
+        *reinterpret_cast<float2 *>(px + c) = make_float2(acc[0], acc[1]);
+        *reinterpret_cast<float2 *>(px + C + c) = make_float2(acc[2], acc[3]);
+        *reinterpret_cast<float4 *>(pu + 2 * c) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+        *reinterpret_cast<float4 *>(pu + Cu + 2 * c) = make_float4(acc[8], acc[9], acc[10], acc[11]);
+    }
+}
+
+static void bw_geometry(long long M, int C, int *cpb, int *gx, int *gy, int *mpb) {
+    const int c2 = C / 2;
+    int p = 1;
+    while (p < c2 && p < BN_THREADS) p <<= 1;
+    *cpb = p;
+    *gx = (c2 + p - 1) / p;
+    const int rl = BN_THREADS / p;
+    long long want = 1024 / *gx;
+    want = want < 1 ? 1 : want;
+    long long rows = (M + want - 1) / want;
+    rows = rows < (long long)rl * 4 ? (long long)rl * 4 : rows;
+    rows = rows > 4096 ? 4096 : rows;                       // bound the fp32 partial sums (x k slots each)
+    rows = (rows + rl - 1) / rl * rl;
+    *mpb = (int)rows;
+    *gy = (int)((M + rows - 1) / rows);
+}
+
+// floats of scratch pdgn_bilateral_weighting_backward needs for (m, k, c)
+extern "C" long long pdgn_bilateral_scratch_floats(long long m, int k, int c) {
+    if (m < 1 || k < 2 || (k & 1) || k > BW_MAXK || c < 2 || (c & 1)) return PDGN_ERR_INVALID;
+    int cpb, gx, gy, mpb;
+    bw_geometry(m, c, &cpb, &gx, &gy, &mpb);
+    return (long long)gy * 6 * c + 6 * c;                   // partials of x (2c) and u (4c) per row block + the two coefficient rows
+}
+
+// Adjoint of pdgn_bn_softmax_slots_permute_mul: x (m,k,c), u / w / dy (m,k/2,2c); bsums_x (2c) = [dbeta_x | dgamma_x],
+// bsums_u (4c) likewise for BN_u; dx (m,k,c), du (m,k/2,2c).  c even.
+extern "C" int pdgn_bilateral_weighting_backward(long long m, int k, int c, int act, int training, const float *x,
+                                                 const float *stats_x, const float *u, const float *stats_u,
+                                                 const float *w, const float *dy, float *scratch, float *bsums_x,
+                                                 float *bsums_u, float *dx, float *du, pdgn_stream_t stream) {
+    if (m < 1 || k < 2 || (k & 1) || k > BW_MAXK || c < 4 || (c % 4) || act < 0 || act > 2) return PDGN_ERR_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    int cpb, gx, gy, mpb;
+    bw_geometry(m, c, &cpb, &gx, &gy, &mpb);
+    float *part_x = scratch, *part_u = part_x + (size_t)gy * 2 * c;
+    float *coef_x = part_u + (size_t)gy * 4 * c, *coef_u = coef_x + 2 * c;
+    const dim3 grid(gx, gy), block(BN_THREADS);
+#define BW_LAUNCH(KT, AP)                                                                                              \
+    hipLaunchKernelGGL((bilateral_bwd_kernel<KT, AP>), grid, block, 0, s, m, k, c, cpb, mpb, act, x, stats_x, u, stats_u, w, \
+                       dy, part_x, part_u, coef_x, coef_u, dx, du)
+    if (k == 10) BW_LAUNCH(10, false); else if (k == 4) BW_LAUNCH(4, false); else BW_LAUNCH(0, false);
+    hipLaunchKernelGGL(cl_bwd_finalize_kernel, dim3(cdiv(c, FIN_CH)), dim3(FIN_CH * FIN_PL), 0, s, m * k, c, gy, training, part_x,
+                       stats_x, bsums_x, coef_x);
+    hipLaunchKernelGGL(cl_bwd_finalize_kernel, dim3(cdiv(2 * c, FIN_CH)), dim3(FIN_CH * FIN_PL), 0, s, m * (k / 2), 2 * c, gy,
+                       training, part_u, stats_u, bsums_u, coef_u);
+    if (k == 10) BW_LAUNCH(10, true); else if (k == 4) BW_LAUNCH(4, true); else BW_LAUNCH(0, true);
+#undef BW_LAUNCH
+    return pdgn_launch_status();
+}
+
 // ---------------------------------------------------------------------------- BN + act + max-pool
 // The PointNet-style discriminators end their per-point stack with BatchNorm1d + LeakyReLU +
 // MaxPool1d over all points (models/PDGNet_v2.py:886-911 ...).  Only the per-sample maxima leave

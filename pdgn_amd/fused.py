@@ -408,23 +408,35 @@ class BilateralWeighting(Function):
         L = _lib.lib()
         dy = dy.contiguous()
         rows_u, Cu = u.shape
-        # y = act(BN(u)) * w: adjoint wrt u, the BatchNorm parameters and w
-        scr = torch.empty(_scratch_floats(L, rows_u, Cu), dtype=F32, device=x.device)
-        bsu = torch.empty(2 * Cu, dtype=F32, device=x.device)
-        du, dw = torch.empty_like(u), torch.empty_like(u)
-        check(L.pdgn_bn_act_backward(ctypes.c_longlong(rows_u), Cu, act, int(training), ptr(u), ptr(dy), ptr(w),
-                                     ptr(stats_u), ptr(scr), ptr(bsu), ptr(du), ptr(dw), stream_of(x)),
-              "pdgn_bn_act_backward")
-        # w = softmax_slots_permute(act(BN(x)))
-        dh = torch.empty((rows, C), dtype=F32, device=x.device)
-        check(L.pdgn_softmax_slots_permute_backward(ctypes.c_longlong(rows // k), k, C, ptr(w), ptr(dw), ptr(dh),
-                                                    stream_of(x)), "pdgn_softmax_slots_permute_backward")
-        scr = torch.empty(_scratch_floats(L, rows, C), dtype=F32, device=x.device)
-        bsx = torch.empty(2 * C, dtype=F32, device=x.device)
-        dx = torch.empty_like(x)
-        check(L.pdgn_bn_act_backward(ctypes.c_longlong(rows), C, act, int(training), ptr(x), ptr(dh), ptr(None),
-                                     ptr(stats_x), ptr(scr), ptr(bsx), ptr(dx), ptr(None), stream_of(x)),
-              "pdgn_bn_act_backward")
+        if k in (4, 10):
+            # both BatchNorm adjoints and the softmax adjoint in two passes over (x, u, w, dy): dW and dh stay in registers
+            L.pdgn_bilateral_scratch_floats.restype = ctypes.c_longlong
+            scr = torch.empty(L.pdgn_bilateral_scratch_floats(ctypes.c_longlong(rows // k), k, C), dtype=F32, device=x.device)
+            bsx = torch.empty(2 * C, dtype=F32, device=x.device)
+            bsu = torch.empty(2 * Cu, dtype=F32, device=x.device)
+            dx, du = torch.empty_like(x), torch.empty_like(u)
+            check(L.pdgn_bilateral_weighting_backward(ctypes.c_longlong(rows // k), k, C, act, int(training), ptr(x),
+                                                      ptr(stats_x), ptr(u), ptr(stats_u), ptr(w), ptr(dy), ptr(scr), ptr(bsx),
+                                                      ptr(bsu), ptr(dx), ptr(du), stream_of(x)),
+                  "pdgn_bilateral_weighting_backward")
+        else:
+            # y = act(BN(u)) * w: adjoint wrt u, the BatchNorm parameters and w
+            scr = torch.empty(_scratch_floats(L, rows_u, Cu), dtype=F32, device=x.device)
+            bsu = torch.empty(2 * Cu, dtype=F32, device=x.device)
+            du, dw = torch.empty_like(u), torch.empty_like(u)
+            check(L.pdgn_bn_act_backward(ctypes.c_longlong(rows_u), Cu, act, int(training), ptr(u), ptr(dy), ptr(w),
+                                         ptr(stats_u), ptr(scr), ptr(bsu), ptr(du), ptr(dw), stream_of(x)),
+                  "pdgn_bn_act_backward")
+            # w = softmax_slots_permute(act(BN(x)))
+            dh = torch.empty((rows, C), dtype=F32, device=x.device)
+            check(L.pdgn_softmax_slots_permute_backward(ctypes.c_longlong(rows // k), k, C, ptr(w), ptr(dw), ptr(dh),
+                                                        stream_of(x)), "pdgn_softmax_slots_permute_backward")
+            scr = torch.empty(_scratch_floats(L, rows, C), dtype=F32, device=x.device)
+            bsx = torch.empty(2 * C, dtype=F32, device=x.device)
+            dx = torch.empty_like(x)
+            check(L.pdgn_bn_act_backward(ctypes.c_longlong(rows), C, act, int(training), ptr(x), ptr(dh), ptr(None),
+                                         ptr(stats_x), ptr(scr), ptr(bsx), ptr(dx), ptr(None), stream_of(x)),
+                  "pdgn_bn_act_backward")
         if training:
             mark_zero_colsum(du)
             mark_zero_colsum(dx)
