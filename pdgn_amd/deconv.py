@@ -62,6 +62,31 @@ def feature_knn(x, k):
     return idx
 
 
+def start_feature_knn(xt, const, k, x_cf=None):
+    """Launch the feature-space kNN graph of a block whose input is cat([const broadcast, xt]) (xt (B,N,Fv)
+    point-major, const (B,Fc) or None).  On a GPU it is built on a second stream -- the graph is first needed by the
+    gather-sum, AFTER the per-point GEMM; its selection phase is vector-ALU work next to the GEMM's matrix-core work --
+    together with the transposed graph a backward pass will want.  Returns (idx, stream to join | None)."""
+    want_csr = torch.is_grad_enabled() and xt.requires_grad
+    with torch.no_grad():
+        if x_cf is None:
+            x_cf = xt.transpose(1, 2)
+            if const is not None:
+                x_cf = torch.cat((const.unsqueeze(2).expand(-1, -1, xt.shape[1]), x_cf), 1)
+        x_knn = x_cf.detach().contiguous()
+        if not (x_knn.is_cuda and _KNN_OVERLAP):
+            return feature_knn(x_knn, k), None
+        cur = torch.cuda.current_stream(x_knn.device)
+        side = _knn_stream(x_knn.device)
+        side.wait_stream(cur)
+        x_knn.record_stream(side)
+        with torch.cuda.stream(side):
+            idx = feature_knn(x_knn, k)
+            if want_csr:
+                transposed_graph(idx)                         # the adjoint's CSR, off the backward's critical path
+    return idx, side
+
+
 class EdgeGatherSum(Function):
     """out_i[b,n,p,c] = bias_i[c] + Y[b,n,offc_i+c] + sum_t Y[b, idx[b,n,p+t], off_i + t*C_i + c]
     for every spec i = (T, P, C, off, offc[, want_stats]); one backward fills a single dY.  For a spec with
@@ -218,38 +243,21 @@ class PointDeconv(nn.Module):
         flush_bn_counters()
         return out.transpose(1, 2)
 
-    def forward_cl(self, xt, pct=None, idx=None, x_cf=None, const=None):
+    def forward_cl(self, xt, pct=None, idx=None, x_cf=None, const=None, idx_stream=None):
         """Point-major layout: xt (B,N,Fv) [, pct (B,N,3)] -> (B,2N,Fout) (pre bn_uc, like the
         reference block's return value).  x_cf, if given, is the full input as (B,Fin,N).
         `const` (B,Fc): the first Fc = Fin - Fv input channels when they are constant over the points
         of a sample (the broadcast global vector xs of :704-708); their contribution to every conv is a
-        per-sample vector, so they never enter the per-point GEMM (half its FLOPs at levels 2-4)."""
+        per-sample vector, so they never enter the per-point GEMM (half its FLOPs at levels 2-4).
+        `idx`, `idx_stream`: a kNN graph started earlier with start_feature_knn and the stream it is being built
+        on (joined right before the gather-sum)."""
         B, N, Fv = xt.shape
         Fi, Fo, k = self.Fin, self.Fout, self.k
         Fc = Fi - Fv
         training = self.training
-        knn_side = None
-        want_csr = torch.is_grad_enabled() and xt.requires_grad     # a backward pass will need the transposed graph
+        knn_side = idx_stream
         if idx is None:
-            with torch.no_grad():
-                if x_cf is None:
-                    x_cf = xt.transpose(1, 2)
-                    if const is not None:
-                        x_cf = torch.cat((const.unsqueeze(2).expand(-1, -1, N), x_cf), 1)
-                x_knn = x_cf.detach().contiguous()
-                if x_knn.is_cuda and _KNN_OVERLAP:
-                    # the graph is first needed by the gather-sum, AFTER the per-point GEMM: build it on a second stream
-                    # (its selection phase is vector-ALU work, the GEMM is matrix-core work)
-                    cur = torch.cuda.current_stream(x_knn.device)
-                    knn_side = _knn_stream(x_knn.device)
-                    knn_side.wait_stream(cur)
-                    x_knn.record_stream(knn_side)
-                    with torch.cuda.stream(knn_side):
-                        idx = feature_knn(x_knn, k)
-                        if want_csr:
-                            transposed_graph(idx)                 # the adjoint's CSR, off the backward's critical path
-                else:
-                    idx = feature_knn(x_knn, k)
+            idx, knn_side = start_feature_knn(xt, const, k, x_cf=x_cf)
         elif idx.dtype != I32:
             idx = idx.to(I32)
         idx = idx.contiguous()
