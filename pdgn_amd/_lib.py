@@ -36,8 +36,8 @@ def lib():
 
 
 def stream_of(t):
-    """hipStream_t of torch's current stream on t's device."""
-    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+    """hipStream_t of torch's current stream on t's device (raw handle: this runs ~3000 times per training step)."""
+    return ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(t.device.index))
 
 
 def ptr(t):
