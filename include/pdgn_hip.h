@@ -264,6 +264,16 @@ int pdgn_chamfer_gram_indexed(int npairs, int m, int n, int d, const float *x, c
                               const float *y, const int32_t *ib, float *minx, int32_t *argx,
                               float *miny, int32_t *argy, pdgn_stream_t stream);
 
+/* Weight re-association of a point-deconvolution block and its adjoint, one launch each:
+ * Wi = inte_conv_hk.0.weight (4F,2F,1,T), W2 = conv2.conv.weight (2Fo,2F,1,2k), Wf = conv_fea.0.weight (16,2F,1,1) or
+ * NULL -> the per-point GEMM operand Wcat (Mw x F) split into its first fc columns (WcatC, NULL when fc == 0) and the
+ * rest (WcatV), and conv2's dense operand Wb (2Fo, (k-T+1)*4F).  Mw = T*4F + 4F + k*2Fo + 2Fo (+ 32 with Wf).
+ * Backward: any of the three upstream gradients may be NULL (= zero); dWf NULL for blocks without conv_fea. */
+int pdgn_deconv_assemble(int F, int Fo, int k, int T, int fc, const float *Wi, const float *W2, const float *Wf,
+                         float *WcatC, float *WcatV, float *Wb, pdgn_stream_t stream);
+int pdgn_deconv_assemble_backward(int F, int Fo, int k, int T, int fc, const float *gWcatC, const float *gWcatV,
+                                  const float *gWb, float *dWi, float *dW2, float *dWf, pdgn_stream_t stream);
+
 /* ---- pointops entry points PDGN itself never calls, same argument meaning as the
  * reference launchers; index outputs int32, label statistics int32, caller allocates (and zero-fills where the
  * reference's Python does). */

@@ -187,6 +187,40 @@ def transposed_graph(idx):
     return idx._pdgn_csr
 
 
+class AssembleWeights(Function):
+    """PointDeconv._assemble on the device: (Wi, W2, Wf | None) -> (WcatC | None, WcatV, Wb) with one gather
+    kernel, and its adjoint with one more (csrc/assemble.hip) -- instead of ~15 + ~25 small torch launches."""
+
+    @staticmethod
+    def forward(ctx, Wi, W2, Wf, F_, Fo, k, T, Fc):
+        Wi, W2 = Wi.contiguous(), W2.contiguous()
+        Wf = Wf.contiguous() if Wf is not None else None
+        P = k - T + 1
+        Mw = T * 4 * F_ + 4 * F_ + k * 2 * Fo + 2 * Fo + (32 if Wf is not None else 0)
+        dev = Wi.device
+        WcatC = torch.empty((Mw, Fc), dtype=F32, device=dev) if Fc else None
+        WcatV = torch.empty((Mw, F_ - Fc), dtype=F32, device=dev)
+        Wb = torch.empty((2 * Fo, P * 4 * F_), dtype=F32, device=dev)
+        check(_lib.lib().pdgn_deconv_assemble(F_, Fo, k, T, Fc, ptr(Wi), ptr(W2), ptr(Wf), ptr(WcatC), ptr(WcatV), ptr(Wb),
+                                              stream_of(Wi)), "pdgn_deconv_assemble")
+        ctx.cfg = (F_, Fo, k, T, Fc, Wi.shape, W2.shape, None if Wf is None else Wf.shape)
+        return WcatC, WcatV, Wb
+
+    @staticmethod
+    def backward(ctx, gC, gV, gB):
+        F_, Fo, k, T, Fc, si, s2, sf = ctx.cfg
+        ref = gV if gV is not None else (gB if gB is not None else gC)
+        gC = gC.contiguous() if gC is not None else None
+        gV = gV.contiguous() if gV is not None else None
+        gB = gB.contiguous() if gB is not None else None
+        dWi = torch.empty(si, dtype=F32, device=ref.device)
+        dW2 = torch.empty(s2, dtype=F32, device=ref.device)
+        dWf = torch.empty(sf, dtype=F32, device=ref.device) if sf is not None else None
+        check(_lib.lib().pdgn_deconv_assemble_backward(F_, Fo, k, T, Fc, ptr(gC), ptr(gV), ptr(gB), ptr(dWi), ptr(dW2),
+                                                       ptr(dWf), stream_of(ref)), "pdgn_deconv_assemble_backward")
+        return dWi, dW2, dWf, None, None, None, None, None
+
+
 class _ConvBN(nn.Module):
     """Parameter container with the reference's conv2dbr keys (conv.*, bn.*) :530-545."""
 
@@ -261,13 +295,17 @@ class PointDeconv(nn.Module):
         elif idx.dtype != I32:
             idx = idx.to(I32)
         idx = idx.contiguous()
-        Wcat, Wb, T, P = self._assemble()
-        if const is None:
-            Y = linear_cl(xt.reshape(B * N, Fi), Wcat).view(B, N, -1)  # (B,N,Mw) -- per-point GEMM
-            Yc = None
-        else:
-            Y = linear_cl(xt.reshape(B * N, Fv), Wcat[:, Fc:].contiguous()).view(B, N, -1)
-            Yc = F.linear(const, Wcat[:, :Fc])                         # (B,Mw): per-sample contribution
+        if xt.is_cuda:
+            T = k // 2 + 1
+            P = k - T + 1
+            WcatC, WcatV, Wb = AssembleWeights.apply(self.inte_conv_hk[0].weight, self.conv2.conv.weight,
+                                                     self.conv_fea[0].weight if self.bilateral else None, Fi, Fo, k, T,
+                                                     Fc if const is not None else 0)
+        else:                                                          # host tests: the same algebra in torch ops
+            Wcat, Wb, T, P = self._assemble()
+            WcatC, WcatV = (Wcat[:, :Fc], Wcat[:, Fc:].contiguous()) if const is not None else (None, Wcat)
+        Y = linear_cl(xt.reshape(B * N, Fv), WcatV).view(B, N, -1)     # (B,N,Mw) -- per-point GEMM
+        Yc = F.linear(const, WcatC) if const is not None else None     # (B,Mw): per-sample contribution
         o_i, o_ci = 0, T * 4 * Fi
         o_a = o_ci + 4 * Fi
         o_ca = o_a + k * 2 * Fo

@@ -447,6 +447,37 @@ def test_window_gather_sum_with_statistics_epilogue(b, n, k, T, P, C):
         torch.testing.assert_close(a, c, rtol=1e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize("F_,Fo,k,bilateral,Fc", [(8, 8, 4, False, 0), (16, 8, 10, True, 0), (16, 24, 10, True, 8), (64, 64, 10, True, 32),
+                                                   (32, 16, 4, False, 16)])
+def test_assemble_weights_kernel_vs_torch(F_, Fo, k, bilateral, Fc):
+    """the one-launch weight re-association (and its adjoint) against PointDeconv._assemble's torch ops"""
+    from pdgn_amd.deconv import AssembleWeights, PointDeconv
+    torch.manual_seed(F_ + k)
+    m = PointDeconv(F_, Fo, k, bilateral=bilateral).cuda()
+    Wcat, Wb, T, P = m._assemble()
+    gcat = torch.randn_like(Wcat)
+    gb = torch.randn_like(Wb)
+    params = [m.inte_conv_hk[0].weight, m.conv2.conv.weight] + ([m.conv_fea[0].weight] if bilateral else [])
+    want = torch.autograd.grad([Wcat, Wb], params, [gcat, gb])
+    C, V, B2 = AssembleWeights.apply(m.inte_conv_hk[0].weight, m.conv2.conv.weight, m.conv_fea[0].weight if bilateral else None,
+                                     F_, Fo, k, T, Fc)
+    got_cat = V if Fc == 0 else torch.cat([C, V], 1)
+    assert (C is None) == (Fc == 0)
+    torch.testing.assert_close(got_cat, Wcat, rtol=1e-6, atol=1e-6)
+    assert torch.equal(B2, Wb)
+    outs = [V, B2] if Fc == 0 else [C, V, B2]
+    gouts = [gcat, gb] if Fc == 0 else [gcat[:, :Fc].contiguous(), gcat[:, Fc:].contiguous(), gb]
+    got = torch.autograd.grad(outs, params, gouts)
+    for a, b in zip(got, want):
+        torch.testing.assert_close(a, b, rtol=1e-6, atol=1e-6)
+    if Fc:                                                       # a missing upstream gradient counts as zero
+        got2 = torch.autograd.grad([V, B2], params, [gcat[:, Fc:].contiguous(), gb], allow_unused=True)
+        gz = gcat.clone(); gz[:, :Fc] = 0
+        want2 = torch.autograd.grad(m._assemble()[:2], params, [gz, gb])
+        for a, b in zip(got2, want2):
+            torch.testing.assert_close(a, b, rtol=1e-6, atol=1e-6)
+
+
 def test_config_c4_four_stage_512_to_4096():
     """BASELINE.json configs[3] ("4-stage 256->4096"; SURVEY.md section 8 Note C4: base 256 points):
     the size-generic blocks run one iteration at 512/1024/2048/4096 points; outputs have the right
