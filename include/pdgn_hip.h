@@ -274,6 +274,14 @@ int pdgn_deconv_assemble(int F, int Fo, int k, int T, int fc, const float *Wi, c
 int pdgn_deconv_assemble_backward(int F, int Fo, int k, int T, int fc, const float *gWcatC, const float *gWcatV,
                                   const float *gWb, float *dWi, float *dW2, float *dWf, pdgn_stream_t stream);
 
+/* Per-sample biases of a block's gather-sums under the constant-channel split: for spec i = (T_i, C_i, off_i, offc_i)
+ *   bb[b, o_i + c] = bias_i[c] + Yc[b, offc_i + c] + sum_{t<T_i} Yc[b, off_i + t*C_i + c],   o_i = C_0 + .. + C_{i-1},
+ * Yc (b, ldy); nspec <= 4; bias[i] may be NULL.  Adjoint: g (b, sum C_i) -> dYc (b, ldy), dbias[i] (C_i) or NULL. */
+int pdgn_sample_bias(int b, int ldy, int nspec, const int *T, const int *C, const int *off, const int *offc,
+                     const float *const *bias, const float *Yc, float *bb, pdgn_stream_t stream);
+int pdgn_sample_bias_backward(int b, int ldy, int nspec, const int *T, const int *C, const int *off, const int *offc,
+                              const float *g, float *dYc, float *const *dbias, pdgn_stream_t stream);
+
 /* ---- pointops entry points PDGN itself never calls, same argument meaning as the
  * reference launchers; index outputs int32, label statistics int32, caller allocates (and zero-fills where the
  * reference's Python does). */

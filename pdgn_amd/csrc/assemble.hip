@@ -137,3 +137,93 @@ extern "C" int pdgn_deconv_assemble_backward(int F, int Fo, int k, int T, int fc
                        gWcatC, gWcatV, gWb, dWi, dW2, dWf);
     return pdgn_launch_status();
 }
+
+// ---------------------------------------------------------------------------- per-sample bias of the gather-sums
+// With the constant-channel split every gather-sum spec i = (T_i, C_i, off_i, offc_i) gets a
+// per-sample bias   bb[b, o_i + c] = bias_i[c] + Yc[b, offc_i + c] + sum_{t < T_i} Yc[b, off_i + t*C_i + c]
+// (Yc (B, ldy) = const @ WcatC^T; o_i = packed column offset).  One launch for all specs, one for the adjoint:
+//   dYc[b, offc_i + c] = dYc[b, off_i + t*C_i + c] = g[b, o_i + c],   dbias_i[c] = sum_b g[b, o_i + c].
+#define SB_MAXSPEC 4
+struct SbSpecs {
+    int n, T[SB_MAXSPEC], C[SB_MAXSPEC], off[SB_MAXSPEC], offc[SB_MAXSPEC], o[SB_MAXSPEC];
+    const float *bias[SB_MAXSPEC];
+    float *dbias[SB_MAXSPEC];
+};
+
+__global__ void sample_bias_fwd_kernel(int B, int ldy, int ctot, SbSpecs sp, const float *__restrict__ Yc,
+                                       float *__restrict__ bb) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= B * ctot) return;
+    const int b = e / ctot, col = e % ctot;
+    int i = 0;
+    while (i + 1 < sp.n && col >= sp.o[i + 1]) ++i;
+    const int c = col - sp.o[i];
+    const float *row = Yc + (size_t)b * ldy;
+    float v = (sp.bias[i] ? sp.bias[i][c] : 0.f) + row[sp.offc[i] + c];
+    for (int t = 0; t < sp.T[i]; ++t) v += row[sp.off[i] + t * sp.C[i] + c];
+    bb[e] = v;
+}
+
+__global__ void sample_bias_bwd_kernel(int B, int ldy, int ctot, SbSpecs sp, const float *__restrict__ g,
+                                       float *__restrict__ dYc) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < B * ctot) {
+        const int b = e / ctot, col = e % ctot;
+        int i = 0;
+        while (i + 1 < sp.n && col >= sp.o[i + 1]) ++i;
+        const int c = col - sp.o[i];
+        const float v = g[e];
+        float *row = dYc + (size_t)b * ldy;
+        row[sp.offc[i] + c] = v;
+        for (int t = 0; t < sp.T[i]; ++t) row[sp.off[i] + t * sp.C[i] + c] = v;
+    } else if (e < B * ctot + ctot) {
+        const int col = e - B * ctot;
+        int i = 0;
+        while (i + 1 < sp.n && col >= sp.o[i + 1]) ++i;
+        if (sp.dbias[i]) {
+            float s = 0.f;
+            for (int b = 0; b < B; ++b) s += g[(size_t)b * ctot + col];
+            sp.dbias[i][col - sp.o[i]] = s;
+        }
+    }
+}
+
+static bool sb_fill(SbSpecs *sp, int nspec, const int *T, const int *C, const int *off, const int *offc, int *ctot) {
+    if (nspec < 1 || nspec > SB_MAXSPEC) return false;
+    sp->n = nspec;
+    int o = 0;
+    for (int i = 0; i < nspec; ++i) {
+        if (T[i] < 1 || C[i] < 1 || off[i] < 0 || offc[i] < 0) return false;
+        sp->T[i] = T[i]; sp->C[i] = C[i]; sp->off[i] = off[i]; sp->offc[i] = offc[i]; sp->o[i] = o;
+        sp->bias[i] = nullptr; sp->dbias[i] = nullptr;
+        o += C[i];
+    }
+    *ctot = o;
+    return true;
+}
+
+// bb (B, sum C_i) packed per-sample biases; bias[i] may be NULL.  The columns written / read in Yc must lie in [0, ldy).
+extern "C" int pdgn_sample_bias(int b, int ldy, int nspec, const int *T, const int *C, const int *off, const int *offc,
+                                const float *const *bias, const float *Yc, float *bb, pdgn_stream_t stream) {
+    SbSpecs sp;
+    int ctot;
+    if (b < 1 || !sb_fill(&sp, nspec, T, C, off, offc, &ctot)) return PDGN_ERR_INVALID;
+    for (int i = 0; i < nspec; ++i) sp.bias[i] = bias[i];
+    hipLaunchKernelGGL(sample_bias_fwd_kernel, dim3(cdiv((long long)b * ctot, 256)), dim3(256), 0, (hipStream_t)stream, b, ldy, ctot,
+                       sp, Yc, bb);
+    return pdgn_launch_status();
+}
+
+// g (B, sum C_i) -> dYc (B, ldy) (every column covered by the specs is written; the caller zero-fills if they do not
+// tile [0, ldy)), dbias[i] (C_i) or NULL.
+extern "C" int pdgn_sample_bias_backward(int b, int ldy, int nspec, const int *T, const int *C, const int *off,
+                                         const int *offc, const float *g, float *dYc, float *const *dbias,
+                                         pdgn_stream_t stream) {
+    SbSpecs sp;
+    int ctot;
+    if (b < 1 || !sb_fill(&sp, nspec, T, C, off, offc, &ctot)) return PDGN_ERR_INVALID;
+    for (int i = 0; i < nspec; ++i) sp.dbias[i] = dbias[i];
+    hipLaunchKernelGGL(sample_bias_bwd_kernel, dim3(cdiv((long long)b * ctot + ctot, 256)), dim3(256), 0, (hipStream_t)stream, b, ldy,
+                       ctot, sp, g, dYc);
+    return pdgn_launch_status();
+}

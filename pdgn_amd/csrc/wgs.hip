@@ -150,7 +150,8 @@ extern "C" int pdgn_window_gather_sum(int b, int n, int k, int ldy, int T, int P
     if (!wgs_ok(b, n, k, ldy, T, P, C, off, offc)) return PDGN_ERR_INVALID;
     if (b == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
-    const bool v4 = (C % 4 == 0) && (ldy % 4 == 0) && (off % 4 == 0) && (offc < 0 || offc % 4 == 0);
+    const bool v4 = (C % 4 == 0) && (ldy % 4 == 0) && (off % 4 == 0) && (offc < 0 || offc % 4 == 0) &&
+                    (!bias || (bias_bstride % 4 == 0 && ((size_t)bias & 15) == 0));
     if (v4) {
         long long total = (long long)b * n * P * (C / 4);
         hipLaunchKernelGGL(wgs_fwd_kernel<4>, dim3(cdiv(total, WGS_THREADS)), dim3(WGS_THREADS), 0, s, total,

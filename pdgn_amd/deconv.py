@@ -104,8 +104,11 @@ class EdgeGatherSum(Function):
         for spec, bias in zip(specs, biases):
             T, P, C, off, offc = spec[:5]
             out = torch.empty((b, n, P, C), dtype=F32, device=Y.device)
-            bias_c = bias.detach().contiguous() if bias is not None else None
-            bstride = C if (bias is not None and bias.dim() == 2) else 0          # (B,C): per-sample bias
+            if bias is not None and bias.dim() == 2 and bias.stride(1) == 1:       # (B,C) per-sample bias, maybe a column
+                bias_c, bstride = bias.detach(), bias.stride(0)                    # slice of a packed (B, sum C) tensor
+            else:
+                bias_c = bias.detach().contiguous() if bias is not None else None
+                bstride = C if (bias is not None and bias.dim() == 2) else 0
             if len(spec) > 5 and spec[5]:
                 # the consumer is a training-mode BatchNorm over (b*n*P, C): emit its partial statistics here
                 L.pdgn_bn_scratch_floats.restype = ctypes.c_longlong
@@ -185,6 +188,45 @@ def transposed_graph(idx):
                                               stream_of(idx)), "pdgn_knn_graph_transpose")
     idx._pdgn_csr = (rowptr, edges)
     return idx._pdgn_csr
+
+
+class SampleBias(Function):
+    """Per-sample biases of a block's gather-sums under the constant-channel split, packed as (B, sum C_i):
+    bb[b, o_i + c] = bias_i[c] + Yc[b, offc_i + c] + sum_t Yc[b, off_i + t*C_i + c]  (csrc/assemble.hip) -- one launch
+    instead of a dozen slice / reshape / sum / add launches, one more for the adjoint."""
+
+    @staticmethod
+    def _arrays(meta):
+        n = len(meta)
+        mk = lambda j: (ctypes.c_int * n)(*[m[j] for m in meta])
+        return n, mk(0), mk(1), mk(2), mk(3)
+
+    @staticmethod
+    def forward(ctx, Yc, meta, *biases):
+        Yc = Yc.contiguous()
+        B, ldy = Yc.shape
+        n, T, C, off, offc = SampleBias._arrays(meta)
+        bs = [b.detach().contiguous() if b is not None else None for b in biases]
+        bp = (ctypes.c_void_p * n)(*[b.data_ptr() if b is not None else None for b in bs])
+        bb = torch.empty((B, sum(m[1] for m in meta)), dtype=F32, device=Yc.device)
+        check(_lib.lib().pdgn_sample_bias(B, ldy, n, T, C, off, offc, bp, ptr(Yc), ptr(bb), stream_of(Yc)), "pdgn_sample_bias")
+        ctx.meta, ctx.shape = meta, (B, ldy)
+        ctx.has = [b is not None for b in biases]
+        return bb
+
+    @staticmethod
+    def backward(ctx, g):
+        meta, (B, ldy) = ctx.meta, ctx.shape
+        n, T, C, off, offc = SampleBias._arrays(meta)
+        g = g.contiguous()
+        covered = sum(m[0] * m[1] + m[1] for m in meta)
+        dYc = (torch.empty if covered == ldy else torch.zeros)((B, ldy), dtype=F32, device=g.device)
+        dbs = [torch.empty(m[1], dtype=F32, device=g.device) if h and ctx.needs_input_grad[2 + i] else None
+               for i, (m, h) in enumerate(zip(meta, ctx.has))]
+        dp = (ctypes.c_void_p * n)(*[d.data_ptr() if d is not None else None for d in dbs])
+        check(_lib.lib().pdgn_sample_bias_backward(B, ldy, n, T, C, off, offc, ptr(g), ptr(dYc), dp, stream_of(g)),
+              "pdgn_sample_bias_backward")
+        return (dYc, None) + tuple(dbs)
 
 
 class AssembleWeights(Function):
@@ -316,7 +358,10 @@ class PointDeconv(nn.Module):
         if self.bilateral:
             specs.append((1, k, 16, o_p, o_p + 16))
             biases.append(self.conv_fea[0].bias)
-        if Yc is not None:                                             # bias_b = bias + centre + sum of taps of Yc
+        if Yc is not None and Yc.is_cuda:                              # bias_b = bias + centre + sum of taps of Yc, one launch
+            bb = SampleBias.apply(Yc, tuple((sp[0], sp[2], sp[3], sp[4]) for sp in specs), *biases)
+            biases = list(torch.split(bb, [sp[2] for sp in specs], dim=1))
+        elif Yc is not None:
             biases = [bias.unsqueeze(0) + Yc[:, sp[4]:sp[4] + sp[2]] + Yc[:, sp[3]:sp[3] + sp[0] * sp[2]].reshape(B, sp[0], sp[2]).sum(1)
                       for sp, bias in zip(specs, biases)]            # sp = (T, P, C, off, offc[, want_stats])
         if knn_side is not None:
