@@ -18,4 +18,5 @@ for i in range(10):
 pr.disable()
 torch.cuda.synchronize()
 st = pstats.Stats(pr)
-st.sort_stats("tottime").print_stats(45)
+st.sort_stats("tottime").print_stats(30)
+st.sort_stats("cumulative").print_stats(45)
