@@ -282,6 +282,19 @@ int pdgn_sample_bias(int b, int ldy, int nspec, const int *T, const int *C, cons
 int pdgn_sample_bias_backward(int b, int ldy, int nspec, const int *T, const int *C, const int *off, const int *offc,
                               const float *g, float *dYc, float *const *dbias, pdgn_stream_t stream);
 
+/* nn.Sequential(Linear, [BatchNorm1d,] [LeakyReLU | ReLU]) on r <= 64 rows in one launch (the generator's per-sample
+ * global branches and first layer, models/PDGNet_v2.py:704-707, 825-828): x (r,k), W (n,k), y (r,n); k <= 1024.
+ * bn_mode 0: no BatchNorm; 1: batch statistics (running_mean / running_var updated when given); 2: running statistics.
+ * pre (r,n) and stat (2n: mean | invstd) are written for the adjoint (may be NULL).  Backward: dpre (r,n) = gradient
+ * wrt the linear output (the caller forms dx = dpre W), dgamma, dbeta, dbias (n), dW (n,k); any of those four may be NULL. */
+int pdgn_small_mlp_forward(int r, int k, int n, int act, int bn_mode, float eps, float momentum, const float *x,
+                           const float *W, const float *bias, const float *gamma, const float *beta,
+                           float *running_mean, float *running_var, float *y, float *pre, float *stat,
+                           pdgn_stream_t stream);
+int pdgn_small_mlp_backward(int r, int k, int n, int act, int bn_mode, const float *x, const float *dy, const float *pre,
+                            const float *stat, const float *gamma, const float *beta, float *dpre, float *dgamma,
+                            float *dbeta, float *dbias, float *dW, pdgn_stream_t stream);
+
 /* ---- pointops entry points PDGN itself never calls, same argument meaning as the
  * reference launchers; index outputs int32, label statistics int32, caller allocates (and zero-fills where the
  * reference's Python does). */

@@ -27,7 +27,8 @@ from torch.autograd import Function
 
 from . import _lib
 from ._lib import check, ptr, require, stream_of
-from .fused import (_zeros, bilateral_weighting, bn_act, bn_act_maxpool, bn_softmax_slots_permute, flush_bn_counters,  # noqa: F401
+from .fused import (_zeros, bilateral_weighting, bn_act,  # noqa: F401
+                    small_sequential, bn_act_maxpool, bn_softmax_slots_permute, flush_bn_counters,  # noqa: F401
                     has_zero_colsum, linear_cl, softmax_slots_permute)
 
 F32, I32 = torch.float32, torch.int32

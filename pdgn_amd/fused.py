@@ -462,6 +462,91 @@ def bilateral_weighting(x2d, bn_x, u2d, bn_u, training, k, act="leaky_relu", pre
                                     bn_x.momentum, bn_x.eps, bn_u.momentum, bn_u.eps, ACT[act], k, partials_u)
 
 
+class SmallLinearBNAct(Function):
+    """act(BatchNorm1d(x W^T + b)) for a handful of rows (x (R<=64, K<=1024)) in one launch forward and one backward
+    (+ one small GEMM for dx): the generator's per-sample layers (csrc/small_mlp.hip)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, gamma, beta, running_mean, running_var, bn_mode, momentum, eps, act):
+        x, weight = x.contiguous(), weight.contiguous()
+        R, K = x.shape
+        N = weight.shape[0]
+        dev = x.device
+        need = any(ctx.needs_input_grad)
+        y = torch.empty((R, N), dtype=F32, device=dev)
+        pre = torch.empty((R, N), dtype=F32, device=dev) if need else None
+        stat = torch.empty(2 * N, dtype=F32, device=dev) if (need and bn_mode) else None
+        g = gamma.detach().contiguous() if gamma is not None else None
+        b = beta.detach().contiguous() if beta is not None else None
+        bi = bias.detach().contiguous() if bias is not None else None
+        check(_lib.lib().pdgn_small_mlp_forward(R, K, N, act, bn_mode, ctypes.c_float(eps), ctypes.c_float(momentum), ptr(x),
+                                                ptr(weight), ptr(bi), ptr(g), ptr(b), ptr(running_mean), ptr(running_var),
+                                                ptr(y), ptr(pre), ptr(stat), stream_of(x)), "pdgn_small_mlp_forward")
+        ctx.save_for_backward(x, weight, pre, stat, g, b)
+        ctx.cfg = (R, K, N, act, bn_mode, bias is not None, gamma is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, pre, stat, g, b = ctx.saved_tensors
+        R, K, N, act, bn_mode, has_bias, has_bn = ctx.cfg
+        dy = dy.contiguous()
+        dev = dy.device
+        dpre = torch.empty((R, N), dtype=F32, device=dev)
+        dW = torch.empty((N, K), dtype=F32, device=dev) if ctx.needs_input_grad[1] else None
+        dbias = torch.empty(N, dtype=F32, device=dev) if has_bias and ctx.needs_input_grad[2] else None
+        dg = torch.empty(N, dtype=F32, device=dev) if has_bn and bn_mode else None
+        db = torch.empty(N, dtype=F32, device=dev) if has_bn and bn_mode else None
+        check(_lib.lib().pdgn_small_mlp_backward(R, K, N, act, bn_mode, ptr(x), ptr(dy), ptr(pre), ptr(stat), ptr(g), ptr(b),
+                                                 ptr(dpre), ptr(dg), ptr(db), ptr(dbias), ptr(dW), stream_of(dy)),
+              "pdgn_small_mlp_backward")
+        dx = dpre.matmul(weight) if ctx.needs_input_grad[0] else None
+        return dx, dW, dbias, dg, db, None, None, None, None, None, None
+
+
+def small_sequential(seq, x, training):
+    """nn.Sequential of (Linear [, BatchNorm1d] [, LeakyReLU | ReLU]) groups applied to x (R, K): on a GPU, with at
+    most 64 rows, every group is one fused launch (SmallLinearBNAct); otherwise the modules run as they are."""
+    mods = list(seq)
+    fusable = x.is_cuda and x.dim() == 2 and x.shape[0] <= 64 and all(
+        isinstance(m, (torch.nn.Linear, torch.nn.BatchNorm1d, torch.nn.LeakyReLU, torch.nn.ReLU)) for m in mods)
+    if fusable:
+        fusable = all(m.in_features <= 1024 and x.shape[0] * (m.in_features + 1) * 4 + 1024 <= 160 * 1024
+                      for m in mods if isinstance(m, torch.nn.Linear))
+    if not fusable:
+        return seq(x)
+    i = 0
+    while i < len(mods):
+        lin = mods[i]
+        if not isinstance(lin, torch.nn.Linear):
+            return seq(x)                                     # unexpected layout: leave it to torch
+        i += 1
+        bn = None
+        if i < len(mods) and isinstance(mods[i], torch.nn.BatchNorm1d):
+            bn = mods[i]
+            i += 1
+        act = 0
+        if i < len(mods) and isinstance(mods[i], torch.nn.LeakyReLU):
+            if mods[i].negative_slope != 0.01:
+                return seq(x)
+            act = 2
+            i += 1
+        elif i < len(mods) and isinstance(mods[i], torch.nn.ReLU):
+            act = 1
+            i += 1
+        if bn is not None:
+            use_batch = training or not bn.track_running_stats
+            if training and bn.track_running_stats:
+                _PENDING_COUNTS[bn.num_batches_tracked] = _PENDING_COUNTS.get(bn.num_batches_tracked, 0) + 1
+            x = SmallLinearBNAct.apply(x, lin.weight, lin.bias, bn.weight, bn.bias,
+                                       bn.running_mean if bn.track_running_stats else None,
+                                       bn.running_var if bn.track_running_stats else None, 1 if use_batch else 2,
+                                       bn.momentum if bn.momentum is not None else 0.1, bn.eps, act)
+        else:
+            x = SmallLinearBNAct.apply(x, lin.weight, lin.bias, None, None, None, None, 0, 0.0, 0.0, act)
+    return x
+
+
 class BNActMaxPool(Function):
     """(B*N, C) rows -> (B, C): max over the N points of each sample of act(BatchNorm(x)) -- the
     BatchNorm1d + LeakyReLU + MaxPool1d tail of the discriminators without writing the activated

