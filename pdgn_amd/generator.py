@@ -193,7 +193,7 @@ class PointDiscriminator(nn.Module):
         pooled = _deconv.bn_act_maxpool(_linear(h, _deconv._w2d(self.fc1[last])), self.fc1[last + 1], self.training, B, N,
                                         pre_bias=self.fc1[last].bias)
         _deconv.flush_bn_counters()
-        return self.mlp(pooled)
+        return _small_seq(self.mlp, pooled, self.training)            # Linear + LeakyReLU groups on B rows: one launch each
 
 
 def PointDiscriminator_1(num_point=256):
