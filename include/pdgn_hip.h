@@ -327,6 +327,13 @@ int pdgn_labelstat_and_ballquery(int b, int n, int m, float radius, int nsample,
                                  const float *xyz, const int32_t *label_stat, int32_t *idx, int32_t *new_label_stat,
                                  pdgn_stream_t stream);
 
+/* ------------------------------------------------------------------ scheduling support
+ * No reference counterpart (the reference runs on one CUDA stream).  One wavefront that occupies `stream` for
+ * `microseconds` (<= 100000) of wall time: pdgn_amd/streams.py times pairs of these to learn which HIP streams share a
+ * hardware queue -- streams on one queue serialise, and the stream-overlapped G+D schedule keeps the default stream's
+ * queue to itself. */
+int pdgn_spin(unsigned int microseconds, pdgn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -26,6 +26,7 @@ import torch.nn.functional as F
 from torch.autograd import Function
 
 from . import _lib
+from . import streams as _streams
 from ._lib import check, ptr, require, stream_of
 from .fused import (_zeros, bilateral_weighting, bn_act,  # noqa: F401
                     small_sequential, bn_act_maxpool, bn_softmax_slots_permute, flush_bn_counters,  # noqa: F401
@@ -33,16 +34,12 @@ from .fused import (_zeros, bilateral_weighting, bn_act,  # noqa: F401
 
 F32, I32 = torch.float32, torch.int32
 _KNN_OVERLAP = __import__("os").environ.get("PDGN_KNN_OVERLAP", "1") == "1"
-_KNN_STREAMS = {}
 
 
 def _knn_stream(device):
-    """One kNN side stream per (device, issuing stream): concurrent generator passes must not share one."""
-    key = (device, torch.cuda.current_stream(device).cuda_stream)
-    s = _KNN_STREAMS.get(key)
-    if s is None:
-        s = _KNN_STREAMS[key] = torch.cuda.Stream(device=device)
-    return s
+    """The kNN side stream of the issuing stream (one per (device, issuing stream): concurrent generator passes must
+    not share one), on a hardware queue other than the issuing stream's -- see streams.py."""
+    return _streams.plan(device).knn
 
 
 def _w2d(conv):

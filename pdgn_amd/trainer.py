@@ -13,6 +13,7 @@ import torch.distributed as dist
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import streams as _streams
 from .fused import clear_zero_colsum, flush_bn_counters, release_zero_arena, reset_zero_arena
 from .generator import PointDiscriminator, PointGenerator
 from .losses import LocalPairLoss
@@ -256,9 +257,8 @@ class PDGNTrainer:
         (the reference's D updates do not read each other)."""
         st = st if st is not None else self._state(reals, z1, z2)
         main = torch.cuda.current_stream(self.device)
-        if self._side is None:
-            self._side = [torch.cuda.Stream(device=self.device) for _ in range(4)]
-            self._side_lp = torch.cuda.Stream(device=self.device)
+        pl = _streams.plan(self.device)                     # streams by measured hardware queue (streams.py)
+        self._side, self._side_lp = pl.d, pl.lp
         st["fakes"] = [None] * 4
 
         def d_update(level, cloud):
@@ -329,9 +329,6 @@ class PDGNTrainer:
         groups = [[k] for k in range(6)] if self.distributed else [list(range(6))]
         self._graphs, pool = [], None
         if self.overlap and not self.distributed:
-            if self._side is None:
-                self._side = [torch.cuda.Stream(device=self.device) for _ in range(4)]
-                self._side_lp = torch.cuda.Stream(device=self.device)
             # the stream-overlapped schedule as ONE graph: the side streams fork from / join the capturing stream
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
