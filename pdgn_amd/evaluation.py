@@ -9,6 +9,7 @@ temporaries, tens of thousands of pairs per launch.  MMD / COV / 1-NNA are the r
 torch reductions over those matrices.
 """
 import torch
+import torch.distributed as dist
 
 from . import _lib
 from ._lib import check, ptr, require, stream_of
@@ -22,36 +23,63 @@ def _pair_lists(S, R, start, stop, device):
     return (p // R).to(I32).contiguous(), (p % R).to(I32).contiguous()
 
 
-def pairwise_emd_cd(sample_pcs, ref_pcs, batch_size=None):
+def shard_pairs(total, fill, group=None):
+    """Rows of the evaluation matrices are independent: rank r of the process group fills the
+    r-th contiguous slice of the flat pair index space with `fill(start, stop) -> tuple of (stop-start,) tensors`, the
+    slices are all-gathered (a few MB) and every rank returns the full-length tensors.  Every rank must call this with
+    the same `total`; without a process group it is `fill(0, total)`."""
+    world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+    if world == 1:
+        return tuple(fill(0, total))
+    rank = dist.get_rank(group)
+    chunk = -(-total // world)
+    lo, hi = min(total, rank * chunk), min(total, (rank + 1) * chunk)
+    full = []
+    for t in fill(lo, hi):
+        pad = t.new_zeros(chunk)
+        pad[:hi - lo] = t
+        parts = [torch.empty_like(pad) for _ in range(world)]
+        dist.all_gather(parts, pad, group=group)
+        full.append(torch.cat(parts)[:total])
+    return tuple(full)
+
+
+def pairwise_emd_cd(sample_pcs, ref_pcs, batch_size=None, shard_over_ranks=False, group=None):
     """_pairwise_EMD_CD_ (:85-121): all_cd, all_emd of shape (N_sample, N_ref).
     CD = mean_i min_j P + mean_j min_i P with the Gram-form P of distChamfer (:35-45);
-    EMD = match_cost / N (:26-31).  `batch_size` is accepted for signature parity and ignored."""
+    EMD = match_cost / N (:26-31).  `batch_size` is accepted for signature parity and ignored.
+    shard_over_ranks: every rank of `group` holds the same two sets and computes 1/world of the pairs (`shard_pairs`)."""
     require(sample_pcs, "sample_pcs", F32, 3)
     require(ref_pcs, "ref_pcs", F32, 3)
     S, N, _ = sample_pcs.shape
     R, M, _ = ref_pcs.shape
     dev = sample_pcs.device
-    cd = torch.empty(S * R, dtype=F32, device=dev)
-    emd = torch.empty(S * R, dtype=F32, device=dev)
     L = _lib.lib()
-    for start in range(0, S * R, _MAX_PAIRS):
-        stop = min(S * R, start + _MAX_PAIRS)
-        npairs = stop - start
-        ia, ib = _pair_lists(S, R, start, stop, dev)
-        minx = torch.empty((npairs, N), dtype=F32, device=dev)
-        miny = torch.empty((npairs, M), dtype=F32, device=dev)
-        argx = torch.empty((npairs, N), dtype=I32, device=dev)
-        argy = torch.empty((npairs, M), dtype=I32, device=dev)
-        check(L.pdgn_chamfer_gram_indexed(npairs, N, M, 3, ptr(sample_pcs), ptr(ia), ptr(ref_pcs), ptr(ib), ptr(minx),
-                                          ptr(argx), ptr(miny), ptr(argy), stream_of(sample_pcs)),
-              "pdgn_chamfer_gram_indexed")
-        # distChamfer returns (P.min(1), P.min(2)) = (per ref point, per sample point); :108 adds their means
-        cd[start:stop] = miny.mean(dim=1) + minx.mean(dim=1)
-        temp = torch.empty((npairs, 2 * (N + M)), dtype=F32, device=dev)
-        out = torch.empty((npairs,), dtype=F32, device=dev)
-        check(L.pdgn_emd_cost_indexed(npairs, N, M, ptr(sample_pcs), ptr(ia), ptr(ref_pcs), ptr(ib), ptr(temp), ptr(out),
-                                      stream_of(sample_pcs)), "pdgn_emd_cost_indexed")
-        emd[start:stop] = out / float(N)
+
+    def fill(lo, hi):
+        cd = torch.empty(hi - lo, dtype=F32, device=dev)
+        emd = torch.empty(hi - lo, dtype=F32, device=dev)
+        for start in range(lo, hi, _MAX_PAIRS):
+            stop = min(hi, start + _MAX_PAIRS)
+            npairs = stop - start
+            ia, ib = _pair_lists(S, R, start, stop, dev)
+            minx = torch.empty((npairs, N), dtype=F32, device=dev)
+            miny = torch.empty((npairs, M), dtype=F32, device=dev)
+            argx = torch.empty((npairs, N), dtype=I32, device=dev)
+            argy = torch.empty((npairs, M), dtype=I32, device=dev)
+            check(L.pdgn_chamfer_gram_indexed(npairs, N, M, 3, ptr(sample_pcs), ptr(ia), ptr(ref_pcs), ptr(ib),
+                                              ptr(minx), ptr(argx), ptr(miny), ptr(argy), stream_of(sample_pcs)),
+                  "pdgn_chamfer_gram_indexed")
+            # distChamfer returns (P.min(1), P.min(2)) = (per ref point, per sample point); :108 adds their means
+            cd[start - lo:stop - lo] = miny.mean(dim=1) + minx.mean(dim=1)
+            temp = torch.empty((npairs, 2 * (N + M)), dtype=F32, device=dev)
+            out = torch.empty((npairs,), dtype=F32, device=dev)
+            check(L.pdgn_emd_cost_indexed(npairs, N, M, ptr(sample_pcs), ptr(ia), ptr(ref_pcs), ptr(ib), ptr(temp),
+                                          ptr(out), stream_of(sample_pcs)), "pdgn_emd_cost_indexed")
+            emd[start - lo:stop - lo] = out / float(N)
+        return cd, emd
+
+    cd, emd = shard_pairs(S * R, fill, group) if shard_over_ranks else fill(0, S * R)
     return cd.view(S, R), emd.view(S, R)
 
 
@@ -99,14 +127,16 @@ def knn(Mxx, Mxy, Myy, k, sqrt=False):
     return s
 
 
-def compute_all_metrics(sample_pcs, ref_pcs, batch_size=None, accelerated_cd=False):
-    """compute_all_metrics (:172-200): MMD / COV (CD and EMD) and 1-NNA from three all-pairs passes."""
+def compute_all_metrics(sample_pcs, ref_pcs, batch_size=None, accelerated_cd=False, shard_over_ranks=False, group=None):
+    """compute_all_metrics (:172-200): MMD / COV (CD and EMD) and 1-NNA from three all-pairs passes.
+    shard_over_ranks: all ranks call with the same sets, each computes 1/world of every matrix (`shard_pairs`)."""
     results = {}
-    M_rs_cd, M_rs_emd = pairwise_emd_cd(sample_pcs, ref_pcs)
+    kw = {"shard_over_ranks": shard_over_ranks, "group": group}
+    M_rs_cd, M_rs_emd = pairwise_emd_cd(sample_pcs, ref_pcs, **kw)
     results.update({"%s-CD" % k: v for k, v in lgan_mmd_cov(M_rs_cd.t()).items()})
     results.update({"%s-EMD" % k: v for k, v in lgan_mmd_cov(M_rs_emd.t()).items()})
-    M_rr_cd, M_rr_emd = pairwise_emd_cd(ref_pcs, ref_pcs)
-    M_ss_cd, M_ss_emd = pairwise_emd_cd(sample_pcs, sample_pcs)
+    M_rr_cd, M_rr_emd = pairwise_emd_cd(ref_pcs, ref_pcs, **kw)
+    M_ss_cd, M_ss_emd = pairwise_emd_cd(sample_pcs, sample_pcs, **kw)
     results.update({"1-NN-CD-%s" % k: v for k, v in knn(M_rr_cd, M_rs_cd, M_ss_cd, 1).items() if "acc" in k})
     results.update({"1-NN-EMD-%s" % k: v for k, v in knn(M_rr_emd, M_rs_emd, M_ss_emd, 1).items() if "acc" in k})
     return results

@@ -133,3 +133,47 @@ def test_flat_grads_views_and_zero():
         assert torch.equal(p.grad, g)
         off += p.numel()
     fg.all_reduce_mean()                                                   # no process group: no-op
+
+
+def _shard_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from pdgn_amd.evaluation import shard_pairs
+    seen = []
+
+    def fill(lo, hi):                                     # stands in for the pair-list kernels: value = f(pair index)
+        seen.append((lo, hi))
+        p = torch.arange(lo, hi, dtype=torch.float32)
+        return p * 2.0 + 1.0, -p
+
+    res = {}
+    for total in (7, 8, 1):                               # uneven split, even split, an empty slice on rank 1
+        a, b = shard_pairs(total, fill)
+        res["a%d" % total], res["b%d" % total] = a.numpy(), b.numpy()
+    np.savez(os.path.join(out_dir, "shard%d.npz" % rank), seen=np.array(seen), **res)
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_evaluation_pairs_shard_over_two_ranks_gloo():
+    """SURVEY.md section 8-e, eval path: each rank fills its slice of the flat pair space, all-gather restores the
+    full matrices on every rank."""
+    world = 2
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_shard_worker, args=(world, _free_port(), d), nprocs=world, join=True)
+        r = [dict(np.load(os.path.join(d, "shard%d.npz" % i))) for i in range(world)]
+    for total in (7, 8, 1):
+        p = np.arange(total, dtype=np.float32)
+        for x in r:
+            np.testing.assert_array_equal(x["a%d" % total], p * 2 + 1)
+            np.testing.assert_array_equal(x["b%d" % total], -p)
+    assert r[0]["seen"].tolist() == [[0, 4], [0, 4], [0, 1]]
+    assert r[1]["seen"].tolist() == [[4, 7], [4, 8], [1, 1]]
+
+
+def test_shard_pairs_without_process_group_is_identity():
+    sys.path.insert(0, ROOT)
+    from pdgn_amd.evaluation import shard_pairs
+    a, = shard_pairs(5, lambda lo, hi: (torch.arange(lo, hi),))
+    assert a.tolist() == [0, 1, 2, 3, 4]

@@ -114,3 +114,27 @@ def test_generate_and_evaluate_test_phase():
     gen2, _ = ev.generate_and_evaluate(G, ref, batch_size=4, normalize="shape_bbox", rng=torch.Generator().manual_seed(5),
                                        with_jsd=False)
     assert torch.equal(gen, gen2)
+
+
+def test_pairwise_sharded_over_a_one_rank_rccl_group_equals_unsharded():
+    """The rank-sharded all-pairs path (SURVEY.md 8-e eval row) through RCCL's all-gather at world size 1."""
+    import os
+    import socket
+    import torch.distributed as dist
+    from pdgn_amd import evaluation
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    g = torch.Generator().manual_seed(5)
+    a = torch.rand(5, 256, 3, generator=g).cuda() * 2 - 1
+    b = torch.rand(7, 256, 3, generator=g).cuda() * 2 - 1
+    cd0, emd0 = evaluation.pairwise_emd_cd(a, b)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        cd1, emd1 = evaluation.pairwise_emd_cd(a, b, shard_over_ranks=True)
+        torch.cuda.synchronize()
+    finally:
+        dist.destroy_process_group()
+    assert torch.equal(cd0, cd1) and torch.equal(emd0, emd1)
