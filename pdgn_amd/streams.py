@@ -96,9 +96,12 @@ def plan(device):
         return g.pop() if len(g) > 1 else g[0]
 
     if len(groups) >= 3:
-        a, b, c = groups[:3]
-        d = [take(b), take(c), take(b), take(c)]     # D1 and D3 on b's queue, D2 and D4 on c's
-        lp, knn = take(a), take(a)
+        # D1 and D3 on one queue, D2 and D4 on another, local-pair loss + feature kNN on the third; PDGN_STREAM_LAYOUT
+        # (six letters A-C for D1 D2 D3 D4 lp knn) is the A/B switch the layouts of DESIGN.md section 10b were tried with
+        layout = os.environ.get("PDGN_STREAM_LAYOUT", "BCBCAA")
+        by = dict(zip("ABC", groups[:3]))
+        roles = [take(by[ch]) for ch in layout]
+        d, lp, knn = roles[:4], roles[4], roles[5]
     elif len(groups) == 2:
         a, b = groups
         d = [take(a), take(b), take(a), take(b)]

@@ -94,6 +94,7 @@ class PDGNTrainer:
         # stream-overlapped schedule of the eager step (see _step_overlapped); PDGN_OVERLAP=0 turns it off
         self.overlap = cap and os.environ.get("PDGN_OVERLAP", "1") == "1"
         self._side = None
+        self._lp_split = os.environ.get("PDGN_LP_SPLIT", "0") == "1"      # A/B switch, see _step_overlapped
 
     def train(self):
         self.G.train()
@@ -160,18 +161,23 @@ class PDGNTrainer:
             for p in d.parameters():
                 p.requires_grad_(not frozen)
 
-    def similar_loss(self, clouds):
-        """Sum of the 6 like_mu and the 6 like_cov terms, in the reference's order (:251-252)."""
-        mus, covs = [], []
-        own = {}                                 # stats of cloud a around itself: shared by its pairs
-        for a, b in PAIRS:
+    def similar_terms(self, clouds, pairs):
+        """{(a, b): (like_mu, like_cov)} of get_local_pair (:232-237) for the given resolution pairs."""
+        terms, own = {}, {}                      # own: stats of cloud a around itself, shared by its pairs
+        for a, b in pairs:
             if a not in own:
                 cl = clouds[a].transpose(1, 2).contiguous()
                 own[a] = self.local_pair.stats(cl, cl)
-            mu, cov = self.local_pair(clouds[a], clouds[b], self_stats=own[a])
-            mus.append(mu)
-            covs.append(cov)
-        return torch.stack(mus + covs).sum()
+            terms[(a, b)] = self.local_pair(clouds[a], clouds[b], self_stats=own[a])
+        return terms
+
+    @staticmethod
+    def _sum_terms(terms):
+        return torch.stack([terms[p][0] for p in PAIRS] + [terms[p][1] for p in PAIRS]).sum()
+
+    def similar_loss(self, clouds):
+        """Sum of the 6 like_mu and the 6 like_cov terms, in the reference's order (:251-252)."""
+        return self._sum_terms(self.similar_terms(clouds, PAIRS))
 
     # The iteration is written as six SEGMENTS separated by the five gradient all-reduces, so that
     # each segment can be captured into a hipGraph (no RCCL call inside a capture) and replayed:
@@ -275,22 +281,27 @@ class PDGNTrainer:
         self.gradG.begin()
         self._freeze_D(True)
         gen = self.G(self._z(st, "z2"))
-        # the shape-preserving loss (12 kNN + Chamfer terms) and the four D(gen) passes read the same clouds and
-        # nothing of each other: the former runs on its own stream, forward and (autograd keeps an op's
-        # backward on its forward's stream) backward
+        # The shape-preserving loss (12 kNN + Chamfer terms) and the four D(gen) passes read the same clouds and
+        # nothing of each other: the former runs on its own stream, forward and (autograd keeps an op's backward on
+        # its forward's stream) backward.  PDGN_LP_SPLIT=1 moves the five lighter pairs onto the default stream, which
+        # otherwise only waits between the end of G(z2) and the start of its backward: measured, no gain
+        # (38.5 vs 37.9 ms over 3 alternating runs each) -- the wait is not where the time goes.
+        split = self._lp_split
         self._side_lp.wait_stream(main)
         with torch.cuda.stream(self._side_lp):
-            similar = self.similar_loss(gen)
+            terms = self.similar_terms(gen, PAIRS[-1:] if split else PAIRS)
         # D_k(G(z2)_k): four more independent chains of small kernels, each behind D_k's own update on D_k's stream
-        # (forward here, backward wherever autograd finds the forward)
         g_loss = []
         for i, side in enumerate(self._side):
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 g_loss.append(F.mse_loss(self.D[i](gen[i]), st["ones"]))
+        if split:
+            terms.update(self.similar_terms(gen, PAIRS[:-1]))
         for side in self._side:
             main.wait_stream(side)
         main.wait_stream(self._side_lp)
+        similar = self._sum_terms(terms)
         adv = 1.2 * g_loss[0] + 1.2 * g_loss[1] + 1.2 * g_loss[2] + g_loss[3]
         lossG = adv + 0.1 * similar
         ws = st["ws"]
