@@ -266,6 +266,8 @@ class PDGNTrainer:
         pl = _streams.plan(self.device)                     # streams by measured hardware queue (streams.py)
         self._side, self._side_lp = pl.d, pl.lp
         st["fakes"] = [None] * 4
+        mark = st.get("mark") or (lambda name: None)        # tools/phase_events.py: HIP events on the default stream
+        mark("start")
 
         def d_update(level, cloud):
             st["fakes"][level] = cloud
@@ -278,9 +280,11 @@ class PDGNTrainer:
 
         with torch.no_grad():
             self.G(self._z(st, "z1"), stage_hook=d_update)
+        mark("G(z1) forward")
         self.gradG.begin()
         self._freeze_D(True)
         gen = self.G(self._z(st, "z2"))
+        mark("G(z2) forward")
         # The shape-preserving loss (12 kNN + Chamfer terms) and the four D(gen) passes read the same clouds and
         # nothing of each other: the former runs on its own stream, forward and (autograd keeps an op's backward on
         # its forward's stream) backward.  PDGN_LP_SPLIT=1 moves the five lighter pairs onto the default stream, which
@@ -301,15 +305,18 @@ class PDGNTrainer:
         for side in self._side:
             main.wait_stream(side)
         main.wait_stream(self._side_lp)
+        mark("wait: D(gen) + local-pair forward")
         similar = self._sum_terms(terms)
         adv = 1.2 * g_loss[0] + 1.2 * g_loss[1] + 1.2 * g_loss[2] + g_loss[3]
         lossG = adv + 0.1 * similar
         ws = st["ws"]
         (adv + (0.1 * ws) * similar if ws > 1 else lossG).backward()
+        mark("backward")
         self._freeze_D(False)
         st["out"]["g_loss"], st["out"]["similar_loss"] = lossG.detach(), similar.detach()
         self._comm(4)
         self.optG.step()
+        mark("all-reduce + Adam G")
         return st["out"]
 
     # ---------------------------------------------------------------- hipGraph replay

@@ -1,7 +1,7 @@
 """Which logical streams of the step share a hardware queue?  (rocprofv3 --kernel-trace csv -> marker kernels per queue.)
 
 HIP multiplexes streams onto GPU_MAX_HW_QUEUES (4) hardware queues; streams on one queue serialise.  The markers: the
-dense gradient GEMM of the edge convolution (generator backward: the default stream), feat_knn (kNN side stream),
+gather-sum adjoint (generator backward: the default stream), feat_knn (kNN side stream),
 chamfer (local-pair stream), the discriminators' max-pool kernels by grid size (D1..D4 streams), RCCL kernels."""
 import csv, glob, os, sys
 from collections import Counter, defaultdict
@@ -11,9 +11,9 @@ path = max(glob.glob(f"{root}/**/*kernel_trace.csv", recursive=True), key=os.pat
 rows = list(csv.DictReader(open(path)))
 marks = sorted(int(r["Start_Timestamp"]) for r in rows if "feat_knn_pc" in r["Kernel_Name"])
 t0, t1 = marks[-16], marks[-8]
-tags = (("gemm_tn_kernel<1, 4, 2>", "G backward (default stream)"), ("feat_knn_pc", "feature kNN stream"),
+tags = (("wgs_bwd_csr", "G backward (default stream)"), ("feat_knn_pc", "feature kNN stream"),
         ("chamfer_gram_grad", "local-pair stream"), ("ncclDevKernel", "RCCL"), ("rccl", "RCCL"))
-dlevel = {"8960": "D1", "17920": "D2", "35840": "D3", "71680": "D4"}
+dlevel = {"8960": "D1", "17920": "D2 or D3", "35840": "D4"}      # B x width of the layer in front of the max-pool: 256 / 512 / 512 / 1024
 q = defaultdict(Counter)
 n = Counter()
 for r in rows:
