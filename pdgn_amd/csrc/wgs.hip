@@ -9,6 +9,7 @@
 // -- this kernel.  It is a pure row gather (HBM/L2-bound): point-major rows, channels contiguous,
 // float4 per lane, the neighbour index wave-uniform.
 // Backward scatters dout rows back onto dY with contiguous 256-B wave atomics.
+#include <stdlib.h>
 #include "common.h"
 #include "bn_geom.h"
 
@@ -38,6 +39,65 @@ __global__ __launch_bounds__(WGS_THREADS) void wgs_fwd_kernel(
         acc += *reinterpret_cast<const vec_t *>(Y + row * ldy + off + t * CV * VEC + c);
     }
     *reinterpret_cast<vec_t *>(out + e * VEC) = acc;
+}
+
+// Cache-aware variant of the float4 path.  Every Y row segment (j, t) is read by each of the ~P windows that hold j
+// in slot p+t, from query points scattered over the sample: 5.3 GB of loads for 0.9 GB of Y at stage 4, and with
+// workgroups walking whole rows (C = 1024 channels = 4 KB) a sample's working set (25 MB) never fits an XCD's 4 MB L2.
+// Here a TASK is (sample, chunk of WGS_CW float4 = 64 channels): 1.5 MB of Y segments + 0.3 MB of centre columns, read
+// by n*P output rows.  Workgroups are dealt round-robin to the 8 XCDs, so block i runs on XCD i%8: all blocks of a task
+// take ids of one residue class, consecutive in launch order, and the re-reads hit that XCD's L2.
+#define WGS_CW 16          // default chunk width in float4 (64 channels); kernels are templated on it
+#define WGS_XU 4          // rows in flight per thread: all their index loads, then all their row loads
+template <int TT, int CW>   // compile-time tap count (0 = runtime T <= 8), chunk width in float4
+__global__ __launch_bounds__(WGS_THREADS) void wgs_fwd_xcd_kernel(
+    int ntasks, int bpt, int n, int k, int ldy, int T, int P, int CV, int nchunk, int off, int offc,
+    const float *__restrict__ Y, const int32_t *__restrict__ idx, const float *__restrict__ bias,
+    int bias_bstride, float *__restrict__ out) {
+    typedef float vec_t __attribute__((ext_vector_type(4)));
+    constexpr int MAXT = TT ? TT : 8, RL = WGS_THREADS / CW;
+    const int seq = blockIdx.x >> 3;
+    const int task = (seq / bpt) * 8 + (blockIdx.x & 7);
+    if (task >= ntasks) return;
+    const int b = task / nchunk, chunk = task - b * nchunk;
+    const int cv = chunk * CW + (threadIdx.x % CW);
+    if (cv >= CV) return;
+    const int c = cv * 4, R = n * P;
+    const int r0 = (seq % bpt) * (RL * WGS_XU) + threadIdx.x / CW;      // output rows r0 + u*RL of this sample
+    const long long b0 = (long long)b * n;
+    int pt[WGS_XU], nb[WGS_XU][MAXT];
+    bool live[WGS_XU];
+#pragma unroll
+    for (int u = 0; u < WGS_XU; ++u) {
+        const int r = r0 + u * RL;
+        live[u] = r < R;
+        const int rr = live[u] ? r : r0 < R ? r0 : 0;
+        pt[u] = rr / P;
+        const int32_t *I = idx + (b0 + pt[u]) * k + (rr - pt[u] * P);
+#pragma unroll
+        for (int t = 0; t < MAXT; ++t)
+            if (TT || t < T) nb[u][t] = I[t];
+    }
+    vec_t acc[WGS_XU], ctr[WGS_XU], tap[WGS_XU][MAXT];
+    const vec_t zero = {0.f, 0.f, 0.f, 0.f};
+    const vec_t bv = bias ? *reinterpret_cast<const vec_t *>(bias + (long long)b * bias_bstride + c) : zero;
+    const float *Yt = Y + off + c;
+#pragma unroll
+    for (int u = 0; u < WGS_XU; ++u) {
+        ctr[u] = offc >= 0 ? *reinterpret_cast<const vec_t *>(Y + (b0 + pt[u]) * ldy + offc + c) : zero;
+#pragma unroll
+        for (int t = 0; t < MAXT; ++t)
+            if (TT || t < T) tap[u][t] = *reinterpret_cast<const vec_t *>(Yt + (b0 + nb[u][t]) * ldy + t * CV * 4);
+    }
+#pragma unroll
+    for (int u = 0; u < WGS_XU; ++u) {
+        acc[u] = bv + ctr[u];
+#pragma unroll
+        for (int t = 0; t < MAXT; ++t)
+            if (TT || t < T) acc[u] += tap[u][t];
+        if (live[u])
+            __builtin_nontemporal_store(acc[u], reinterpret_cast<vec_t *>(out + ((b0 * P + r0 + u * RL) * CV + cv) * 4));
+    }
 }
 
 // The same gather-sum in the geometry of the BatchNorm reductions (bn_geom.h): a thread owns one float4 column group
@@ -117,6 +177,90 @@ __global__ __launch_bounds__(WGS_THREADS) void wgs_fwd_stats_kernel(
     }
 }
 
+// wgs_fwd_stats in the task mapping of wgs_fwd_xcd_kernel: a block owns `rpb` output rows of one (sample, 64-channel
+// chunk) task, keeps WGS_XU rows in flight per thread, and writes one partial row (row block `b*bpt + blk`) of the
+// statistics; blocks past the tasks zero the partial rows the BatchNorm geometry has beyond b*bpt.
+template <int TT, int CW>
+__global__ __launch_bounds__(WGS_THREADS) void wgs_fwd_stats_xcd_kernel(
+    int ntasks, int bpt, int rpb, int main_blocks, int gy_used, int n, int k, int ldy, int T, int P, int CV, int nchunk,
+    int off, int offc, const float *__restrict__ Y, const int32_t *__restrict__ idx, const float *__restrict__ bias,
+    int bias_bstride, float *__restrict__ out, float *__restrict__ part) {
+    typedef float vec_t __attribute__((ext_vector_type(4)));
+    constexpr int MAXT = TT ? TT : 8, RL = WGS_THREADS / CW;
+    __shared__ vec_t red[2][WGS_THREADS];
+    const int C = CV * 4;
+    if ((int)blockIdx.x >= main_blocks) {                      // unused partial rows of the BatchNorm geometry: zeros
+        float *Z = part + (size_t)(gy_used + (blockIdx.x - main_blocks)) * 2 * C;
+        for (int i = threadIdx.x; i < 2 * C; i += WGS_THREADS) Z[i] = 0.f;
+        return;
+    }
+    const int seq = blockIdx.x >> 3;
+    const int task = (seq / bpt) * 8 + (blockIdx.x & 7);
+    if (task >= ntasks) return;
+    const int blk = seq % bpt;
+    const int b = task / nchunk, chunk = task - b * nchunk;
+    const int cvl = threadIdx.x % CW, rlane = threadIdx.x / CW;
+    const int cv = chunk * CW + cvl;
+    const bool cok = cv < CV;
+    const int c = cv * 4, R = n * P;
+    const long long b0 = (long long)b * n;
+    const vec_t zero = {0.f, 0.f, 0.f, 0.f};
+    vec_t s = zero, q = zero;
+    if (cok) {
+        const vec_t bv = bias ? *reinterpret_cast<const vec_t *>(bias + (long long)b * bias_bstride + c) : zero;
+        const float *Yt = Y + off + c;
+        const int rend = min(R, (blk + 1) * rpb);
+        for (int r0 = blk * rpb + rlane; r0 < rend; r0 += RL * WGS_XU) {
+            int pt[WGS_XU], nb[WGS_XU][MAXT];
+            bool live[WGS_XU];
+#pragma unroll
+            for (int u = 0; u < WGS_XU; ++u) {
+                const int r = r0 + u * RL;
+                live[u] = r < rend;
+                const int rr = live[u] ? r : r0;
+                pt[u] = rr / P;
+                const int32_t *I = idx + (b0 + pt[u]) * k + (rr - pt[u] * P);
+#pragma unroll
+                for (int t = 0; t < MAXT; ++t)
+                    if (TT || t < T) nb[u][t] = I[t];
+            }
+            vec_t ctr[WGS_XU], tap[WGS_XU][MAXT];
+#pragma unroll
+            for (int u = 0; u < WGS_XU; ++u) {
+                ctr[u] = offc >= 0 ? *reinterpret_cast<const vec_t *>(Y + (b0 + pt[u]) * ldy + offc + c) : zero;
+#pragma unroll
+                for (int t = 0; t < MAXT; ++t)
+                    if (TT || t < T) tap[u][t] = *reinterpret_cast<const vec_t *>(Yt + (b0 + nb[u][t]) * ldy + t * C);
+            }
+#pragma unroll
+            for (int u = 0; u < WGS_XU; ++u) {
+                vec_t a = bv + ctr[u];
+#pragma unroll
+                for (int t = 0; t < MAXT; ++t)
+                    if (TT || t < T) a += tap[u][t];
+                if (live[u]) {
+                    *reinterpret_cast<vec_t *>(out + ((b0 * P + r0 + u * RL) * CV + cv) * 4) = a;
+                    s += a;
+                    q.x = __fmaf_rn(a.x, a.x, q.x); q.y = __fmaf_rn(a.y, a.y, q.y);
+                    q.z = __fmaf_rn(a.z, a.z, q.z); q.w = __fmaf_rn(a.w, a.w, q.w);
+                }
+            }
+        }
+    }
+    red[0][threadIdx.x] = s;
+    red[1][threadIdx.x] = q;
+    __syncthreads();
+    if (rlane == 0 && cok) {
+        for (int j = 1; j < RL; ++j) {
+            s += red[0][j * CW + cvl];
+            q += red[1][j * CW + cvl];
+        }
+        float *Pp = part + (size_t)(b * bpt + blk) * 2 * C;
+        *reinterpret_cast<vec_t *>(Pp + c) = s;
+        *reinterpret_cast<vec_t *>(Pp + C + c) = q;
+    }
+}
+
 __global__ __launch_bounds__(WGS_THREADS) void wgs_bwd_kernel(
     long long total, int n, int k, int ldy, int T, int P, int C, int off, int offc,
     const float *__restrict__ dout, const int32_t *__restrict__ idx, float *__restrict__ dY) {
@@ -138,6 +282,17 @@ __global__ __launch_bounds__(WGS_THREADS) void wgs_bwd_kernel(
     }
 }
 
+// chunk width (float4 per row segment) of the task mapping; PDGN_WGS_CW / PDGN_WGS_BCW override for experiments
+static int wgs_cw(const char *env, int dflt) {
+    const char *v = getenv(env);
+    const int w = v ? atoi(v) : dflt;
+    return (w == 8 || w == 16 || w == 32 || w == 64) ? w : dflt;
+}
+#define WGS_DISPATCH_CW(cw, CALL)   \
+    do {                            \
+        if ((cw) == 8) { CALL(8); } else if ((cw) == 32) { CALL(32); } else if ((cw) == 64) { CALL(64); } else { CALL(16); } \
+    } while (0)
+
 static bool wgs_ok(int b, int n, int k, int ldy, int T, int P, int C, int off, int offc) {
     return b >= 0 && n >= 1 && k >= 1 && T >= 1 && P >= 1 && C >= 1 && T + P - 1 <= k && off >= 0 &&
            off + T * C <= ldy && (offc < 0 || offc + C <= ldy);
@@ -152,7 +307,23 @@ extern "C" int pdgn_window_gather_sum(int b, int n, int k, int ldy, int T, int P
     hipStream_t s = (hipStream_t)stream;
     const bool v4 = (C % 4 == 0) && (ldy % 4 == 0) && (off % 4 == 0) && (offc < 0 || offc % 4 == 0) &&
                     (!bias || (bias_bstride % 4 == 0 && ((size_t)bias & 15) == 0));
-    if (v4) {
+    static const int xcd = getenv("PDGN_WGS_XCD") ? atoi(getenv("PDGN_WGS_XCD")) : 1;
+    if (v4 && xcd && T <= 8 && (long long)n * P * (C / 4) >= 65536) {   // enough re-read volume for the L2 mapping to matter
+        static const int cw = wgs_cw("PDGN_WGS_CW", 32);
+        const int CV = C / 4, nchunk = cdiv(CV, cw), ntasks = b * nchunk;
+        const int bpt = cdiv((long long)n * P, WGS_THREADS / cw * WGS_XU);
+        const long long blocks = (long long)cdiv(ntasks, 8) * 8 * bpt;
+        if (blocks > 0x7fffffffLL) return PDGN_ERR_INVALID;
+#define WGS_CALL(W)                                                                                                        \
+    if (T == 6)                                                                                                            \
+        hipLaunchKernelGGL((wgs_fwd_xcd_kernel<6, W>), dim3((unsigned)blocks), dim3(WGS_THREADS), 0, s, ntasks, bpt, n, k, \
+                           ldy, T, P, CV, nchunk, off, offc, Y, idx, bias, bias_bstride, out);                             \
+    else                                                                                                                   \
+        hipLaunchKernelGGL((wgs_fwd_xcd_kernel<0, W>), dim3((unsigned)blocks), dim3(WGS_THREADS), 0, s, ntasks, bpt, n, k, \
+                           ldy, T, P, CV, nchunk, off, offc, Y, idx, bias, bias_bstride, out)
+        WGS_DISPATCH_CW(cw, WGS_CALL);
+#undef WGS_CALL
+    } else if (v4) {
         long long total = (long long)b * n * P * (C / 4);
         hipLaunchKernelGGL(wgs_fwd_kernel<4>, dim3(cdiv(total, WGS_THREADS)), dim3(WGS_THREADS), 0, s, total,
                            n, k, ldy, T, P, C / 4, off, offc, Y, idx, bias, bias_bstride, out);
@@ -175,6 +346,32 @@ extern "C" int pdgn_window_gather_sum_stats(int b, int n, int k, int ldy, int T,
     const long long R = (long long)b * n * P;
     int cgb, gx, gy, rpb;
     cl_geometry(R, C, &cgb, &gx, &gy, &rpb);
+    static const int xcd = getenv("PDGN_WGS_XCD") ? atoi(getenv("PDGN_WGS_XCD")) : 1;
+    if (xcd && (long long)n * P * (C / 4) >= 65536 && gy >= b) {
+        // partial rows: one per (sample, row block); the BatchNorm geometry's gy bounds them, the rest are zeroed
+        static const int cw = wgs_cw("PDGN_WGS_SCW", 16);
+        const int RLU = WGS_THREADS / cw * WGS_XU;
+        int bpt = gy / b;
+        int rows = cdiv((long long)n * P, bpt);
+        rows = cdiv(rows, RLU) * RLU;
+        bpt = cdiv((long long)n * P, rows);
+        const int CV = C / 4, nchunk = cdiv(CV, cw), ntasks = b * nchunk;
+        const long long main_blocks = (long long)cdiv(ntasks, 8) * 8 * bpt, blocks = main_blocks + (gy - b * bpt);
+        if (blocks <= 0x7fffffffLL && rows <= 65536) {
+#define WGS_CALL(W)                                                                                                             \
+    if (T == 6)                                                                                                                 \
+        hipLaunchKernelGGL((wgs_fwd_stats_xcd_kernel<6, W>), dim3((unsigned)blocks), dim3(WGS_THREADS), 0, (hipStream_t)stream, \
+                           ntasks, bpt, rows, (int)main_blocks, b * bpt, n, k, ldy, T, P, CV, nchunk, off, offc, Y, idx, bias,  \
+                           bias_bstride, out, scratch);                                                                         \
+    else                                                                                                                        \
+        hipLaunchKernelGGL((wgs_fwd_stats_xcd_kernel<0, W>), dim3((unsigned)blocks), dim3(WGS_THREADS), 0, (hipStream_t)stream, \
+                           ntasks, bpt, rows, (int)main_blocks, b * bpt, n, k, ldy, T, P, CV, nchunk, off, offc, Y, idx, bias,  \
+                           bias_bstride, out, scratch)
+            WGS_DISPATCH_CW(cw, WGS_CALL);
+#undef WGS_CALL
+            return pdgn_launch_status();
+        }
+    }
     if (T == 6)
         hipLaunchKernelGGL(wgs_fwd_stats_kernel<6>, dim3(gx, gy), dim3(WGS_THREADS), 0, (hipStream_t)stream, R, n, k, ldy, T, P,
                            C, cgb, rpb, off, offc, Y, idx, bias, bias_bstride, out, scratch);
@@ -283,6 +480,82 @@ __global__ __launch_bounds__(WGS_THREADS) void wgs_bwd_csr_kernel(
     *reinterpret_cast<vec_t *>(dY + bj * ldy + off + t * C + c) = acc;
 }
 
+// The adjoint in the task mapping of wgs_fwd_xcd_kernel.  A WAVE owns one source point j of a (sample, 64-channel
+// chunk) task: lane = (float4 column, edge lane); the four edge lanes of a column split j's in-edges between them (the
+// in-degree of a kNN graph is skewed: a hub no longer holds up three neighbours' lanes), an in-edge (n', s) is decoded
+// once and feeds dout[n', s-t] to accumulator t for every valid t -- up to 2P independent loads in flight -- and the
+// four partial sums meet in two cross-lane exchanges.  The task's dout chunk (n*P rows x 256 B = 1.3 MB at stage 4, each
+// row wanted by ~T/2 taps of k sources) stays in one XCD's L2.
+template <int TT, int CW>
+__global__ __launch_bounds__(WGS_THREADS) void wgs_bwd_csr_xcd_kernel(
+    int ntasks, int bpt, int n, int k, int ldy, int T, int P, int CV, int nchunk, int off, int offc,
+    const float *__restrict__ dout, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ edges,
+    float *__restrict__ dY) {
+    typedef float vec_t __attribute__((ext_vector_type(4)));
+    constexpr int MAXT = TT ? TT : 8, JB = WGS_THREADS / 64, WGS_EL = 64 / CW;   // source points per block; edge lanes per column
+    const int seq = blockIdx.x >> 3;
+    const int task = (seq / bpt) * 8 + (blockIdx.x & 7);
+    if (task >= ntasks) return;
+    const int b = task / nchunk, chunk = task - b * nchunk;
+    const int lane = threadIdx.x & 63, cvl = lane % CW, el = lane / CW;
+    const int cv = chunk * CW + cvl;
+    const int j = (seq % bpt) * JB + (threadIdx.x >> 6);
+    if (j >= n) return;                                        // wave-uniform
+    const bool cok = cv < CV;
+    const int C = CV * 4, c = (cok ? cv : 0) * 4;
+    const long long b0 = (long long)b * n;
+    const vec_t zero = {0.f, 0.f, 0.f, 0.f};
+    vec_t acc[MAXT];
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t) acc[t] = zero;
+    const int32_t *E = edges + b0 * k;
+    const int e0 = rowptr[(long long)b * (n + 1) + j], e1 = rowptr[(long long)b * (n + 1) + j + 1];
+    const float *D = dout + b0 * P * C + c;
+    for (int q = e0 + el; q < e1; q += 2 * WGS_EL) {           // this lane's edges, two at a time
+        const bool two = q + WGS_EL < e1;
+        const int ra = E[q], rb = two ? E[q + WGS_EL] : 0;
+        const float *Da = D + (long long)(ra >> 5) * P * C, *Db = D + (long long)(rb >> 5) * P * C;
+        const int sa = ra & 31, sb = two ? (rb & 31) : -64;
+        vec_t va[MAXT], vb[MAXT];
+#pragma unroll
+        for (int t = 0; t < MAXT; ++t) {
+            const int pa = sa - t, pb = sb - t;
+            va[t] = ((TT || t < T) && pa >= 0 && pa < P) ? *reinterpret_cast<const vec_t *>(Da + pa * C) : zero;
+            vb[t] = ((TT || t < T) && pb >= 0 && pb < P) ? *reinterpret_cast<const vec_t *>(Db + pb * C) : zero;
+        }
+#pragma unroll
+        for (int t = 0; t < MAXT; ++t) acc[t] += va[t] + vb[t];
+    }
+    vec_t ctr = zero;
+    if (offc >= 0)                                             // centre columns: the point's own P windows, split too
+        for (int p = el; p < P; p += WGS_EL) ctr += *reinterpret_cast<const vec_t *>(D + ((long long)j * P + p) * C);
+    // sum over the four edge lanes (lanes l, l+16, l+32, l+48): afterwards every lane holds the totals
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t)
+        if (TT || t < T) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float v = acc[t][i];
+#pragma unroll
+                for (int m = CW; m < 64; m <<= 1) v += __shfl_xor(v, m);
+                acc[t][i] = v;
+            }
+        }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float v = ctr[i];
+#pragma unroll
+        for (int m = CW; m < 64; m <<= 1) v += __shfl_xor(v, m);
+        ctr[i] = v;
+    }
+    if (!cok) return;
+    float *O = dY + (b0 + j) * ldy + c;
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t)                             // the stores are dealt out over the edge lanes as well
+        if ((TT || t < T) && (t % WGS_EL) == el) *reinterpret_cast<vec_t *>(O + off + t * C) = acc[t];
+    if (offc >= 0 && el == WGS_EL - 1) *reinterpret_cast<vec_t *>(O + offc) = ctr;
+}
+
 extern "C" int pdgn_knn_graph_transpose(int b, int n, int k, const int32_t *idx, int32_t *rowptr,
                                         int32_t *edges, int32_t *scratch, pdgn_stream_t stream) {
     if (b < 0 || n < 1 || k < 1 || k > 31 || (long long)n * 32 > 0x7fffffffLL) return PDGN_ERR_INVALID;
@@ -305,6 +578,24 @@ extern "C" int pdgn_window_gather_sum_backward_csr(int b, int n, int k, int ldy,
     if (!wgs_ok(b, n, k, ldy, T, P, C, off, offc) || C % 4 || ldy % 4 || off % 4 || (offc >= 0 && offc % 4) || k > 31)
         return PDGN_ERR_INVALID;
     if (b == 0) return 0;
+    static const int xcd = getenv("PDGN_WGS_XCD") ? atoi(getenv("PDGN_WGS_XCD")) : 1;
+    if (xcd && T <= 8 && (long long)n * P * (C / 4) >= 65536) {
+        static const int cw = wgs_cw("PDGN_WGS_BCW", 64);
+        const int CV = C / 4, nchunk = cdiv(CV, cw), ntasks = b * nchunk, bpt = cdiv(n, WGS_THREADS / 64);
+        const long long blocks = (long long)cdiv(ntasks, 8) * 8 * bpt;
+        if (blocks <= 0x7fffffffLL) {
+#define WGS_CALL(W)                                                                                                           \
+    if (T == 6)                                                                                                               \
+        hipLaunchKernelGGL((wgs_bwd_csr_xcd_kernel<6, W>), dim3((unsigned)blocks), dim3(WGS_THREADS), 0, (hipStream_t)stream, \
+                           ntasks, bpt, n, k, ldy, T, P, CV, nchunk, off, offc, dout, rowptr, edges, dY);                     \
+    else                                                                                                                      \
+        hipLaunchKernelGGL((wgs_bwd_csr_xcd_kernel<0, W>), dim3((unsigned)blocks), dim3(WGS_THREADS), 0, (hipStream_t)stream, \
+                           ntasks, bpt, n, k, ldy, T, P, CV, nchunk, off, offc, dout, rowptr, edges, dY)
+            WGS_DISPATCH_CW(cw, WGS_CALL);
+#undef WGS_CALL
+            return pdgn_launch_status();
+        }
+    }
     const int TT = offc >= 0 ? T + 1 : T;
     const long long total = (long long)b * n * TT * (C / 4);
     hipLaunchKernelGGL(wgs_bwd_csr_kernel, dim3(cdiv(total, WGS_THREADS)), dim3(WGS_THREADS), 0, (hipStream_t)stream,

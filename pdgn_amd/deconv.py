@@ -64,7 +64,7 @@ def start_feature_knn(xt, const, k, x_cf=None):
     """Launch the feature-space kNN graph of a block whose input is cat([const broadcast, xt]) (xt (B,N,Fv)
     point-major, const (B,Fc) or None).  On a GPU it is built on a second stream -- the graph is first needed by the
     gather-sum, AFTER the per-point GEMM; its selection phase is vector-ALU work next to the GEMM's matrix-core work --
-    together with the transposed graph a backward pass will want.  Returns (idx, stream to join | None)."""
+    together with the transposed graph a backward pass will want.  Returns (idx, event to wait for | None)."""
     want_csr = torch.is_grad_enabled() and xt.requires_grad
     with torch.no_grad():
         if x_cf is None:
@@ -80,9 +80,13 @@ def start_feature_knn(xt, const, k, x_cf=None):
         x_knn.record_stream(side)
         with torch.cuda.stream(side):
             idx = feature_knn(x_knn, k)
+            ready = torch.cuda.Event()
+            ready.record(side)                                # the consumer waits for the graph only ...
             if want_csr:
-                transposed_graph(idx)                         # the adjoint's CSR, off the backward's critical path
-    return idx, side
+                transposed_graph(idx)                         # ... the adjoint's CSR keeps building behind it, off
+                idx._pdgn_csr_ready = torch.cuda.Event()      # both critical paths; the backward waits for this event
+                idx._pdgn_csr_ready.record(side)
+    return idx, ready
 
 
 class EdgeGatherSum(Function):
@@ -177,6 +181,9 @@ def transposed_graph(idx):
     gather-sums of a block -- features and xyz -- share one graph)."""
     cached = getattr(idx, "_pdgn_csr", None)
     if cached is not None:
+        ev = getattr(idx, "_pdgn_csr_ready", None)           # built on the kNN side stream (start_feature_knn)
+        if ev is not None:
+            torch.cuda.current_stream(idx.device).wait_event(ev)
         return cached
     b, n, k = idx.shape
     rowptr = torch.empty((b, n + 1), dtype=I32, device=idx.device)
@@ -317,19 +324,19 @@ class PointDeconv(nn.Module):
         flush_bn_counters()
         return out.transpose(1, 2)
 
-    def forward_cl(self, xt, pct=None, idx=None, x_cf=None, const=None, idx_stream=None):
+    def forward_cl(self, xt, pct=None, idx=None, x_cf=None, const=None, idx_ready=None):
         """Point-major layout: xt (B,N,Fv) [, pct (B,N,3)] -> (B,2N,Fout) (pre bn_uc, like the
         reference block's return value).  x_cf, if given, is the full input as (B,Fin,N).
         `const` (B,Fc): the first Fc = Fin - Fv input channels when they are constant over the points
         of a sample (the broadcast global vector xs of :704-708); their contribution to every conv is a
         per-sample vector, so they never enter the per-point GEMM (half its FLOPs at levels 2-4).
-        `idx`, `idx_stream`: a kNN graph started earlier with start_feature_knn and the stream it is being built
-        on (joined right before the gather-sum)."""
+        `idx`, `idx_ready`: a kNN graph started earlier with start_feature_knn and the event that marks it complete
+        (waited for right before the gather-sum)."""
         B, N, Fv = xt.shape
         Fi, Fo, k = self.Fin, self.Fout, self.k
         Fc = Fi - Fv
         training = self.training
-        knn_side = idx_stream
+        knn_side = idx_ready
         if idx is None:
             idx, knn_side = start_feature_knn(xt, const, k, x_cf=x_cf)
         elif idx.dtype != I32:
@@ -363,7 +370,7 @@ class PointDeconv(nn.Module):
             biases = [bias.unsqueeze(0) + Yc[:, sp[4]:sp[4] + sp[2]] + Yc[:, sp[3]:sp[3] + sp[0] * sp[2]].reshape(B, sp[0], sp[2]).sum(1)
                       for sp, bias in zip(specs, biases)]            # sp = (T, P, C, off, offc[, want_stats])
         if knn_side is not None:
-            torch.cuda.current_stream(idx.device).wait_stream(knn_side)
+            torch.cuda.current_stream(idx.device).wait_event(knn_side)
             idx.record_stream(torch.cuda.current_stream(idx.device))
         outs = EdgeGatherSum.apply(Y, idx, tuple(specs), *biases)
         inte_pre, a_pre = outs[0], outs[1]                             # (B,N,P,4F), (B,N,1,2Fo)

@@ -71,7 +71,7 @@ class BilateralBlock(nn.Module):
         if level < 4:
             self.g_fc = nn.Sequential(nn.Linear(Fout, 512), nn.BatchNorm1d(512), nn.LeakyReLU(inplace=True))
 
-    def forward_cl(self, xt, pct=None, idx=None, const=None, idx_stream=None):
+    def forward_cl(self, xt, pct=None, idx=None, const=None, idx_ready=None):
         """xt (B,N,Fv) [, pct (B,N,3)] -> xs (B,Fout), x_ec (B,2N,Fout), g (B,512)|None.  The block's
         input is cat([const broadcast over the points (B,Fc), xt]) along channels (:708) -- passed in two
         pieces so that the broadcast half is never materialised per point."""
@@ -84,7 +84,7 @@ class BilateralBlock(nn.Module):
             dec, bn = self.upsample_cov[0], self.upsample_cov[1]
         else:
             dec, bn = self.upsample_cov, self.bn_uc
-        x_ec = dec.forward_cl(xt, pct, idx=idx, const=const, idx_stream=idx_stream)    # (B,2N,Fout)
+        x_ec = dec.forward_cl(xt, pct, idx=idx, const=const, idx_ready=idx_ready)    # (B,2N,Fout)
         x_ec = _bn_act(x_ec.reshape(B * 2 * N, -1), bn, self.training).view(B, 2 * N, -1)
         g = _small_seq(self.g_fc, xs, self.training) if self.level < 4 else None
         return xs, x_ec, g
@@ -136,8 +136,8 @@ class PointGenerator(nn.Module):
         heads = (self.mlp1, self.mlp2, self.mlp3, self.mlp4)
         pending = (None, None)
         for lvl in range(4):
-            lvl_idx, lvl_stream = (idx[lvl], None) if idx[lvl] is not None else pending
-            xs, x_ec, g = blocks[lvl].forward_cl(xt, pct, idx=lvl_idx, const=const, idx_stream=lvl_stream)
+            lvl_idx, lvl_ready = (idx[lvl], None) if idx[lvl] is not None else pending
+            xs, x_ec, g = blocks[lvl].forward_cl(xt, pct, idx=lvl_idx, const=const, idx_ready=lvl_ready)
             pending = (None, None)
             if lvl < 3 and idx[lvl + 1] is None and x_ec.is_cuda:
                 # the next block's kNN graph only needs this block's outputs: start it now, underneath this level's

@@ -93,9 +93,11 @@ def bn_act_backward_stage4(B, base_points, device):
 
 
 def window_gather_sum_stage4(B, base_points, device):
-    """inte_conv_hk's gather half at the last stage: N = 8*base points, F = 256, k = 10,
-    T = 6 taps, P = 5 positions, C = 4F.  Algorithmic bytes per point: 30 gathered rows + 1 centre
-    row + 5 written rows of C floats, + 10 indices."""
+    """inte_conv_hk's gather half at the last stage: N = 8*base points, F = 256, k = 10, T = 6 taps, P = 5 positions,
+    C = 4F.  Algorithmic (compulsory) bytes per point: the T + 1 segments of its Y row read ONCE, P written rows of C
+    floats, k indices.  The kernel issues T*P + 1 row loads per point (`gathered_bytes_per_launch`): each Y segment
+    is wanted by ~P windows of other points; the task mapping of wgs_fwd_xcd_kernel serves those re-reads from one
+    XCD's L2 (before it they were L2 misses: 5.4 GB of fabric traffic per launch, 704 us)."""
     N, F, k, T, P = 8 * base_points, 256, 10, 6, 5
     C = 4 * F
     ldy = T * C + C
@@ -108,8 +110,9 @@ def window_gather_sum_stage4(B, base_points, device):
         check(L.pdgn_window_gather_sum(B, N, k, ldy, T, P, C, 0, T * C, ptr(Y), ptr(idx), None, 0, ptr(out),
                                        stream_of(Y)), "pdgn_window_gather_sum")
     us = _time_us(run)
-    return _entry("wgs_fwd_kernel<4> (inte_conv_hk gather, stage 4)", "hbm",
-                  float(B * N * ((T * P + 1 + P) * C * 4 + k * 4)), us)
+    return _entry("wgs_fwd_xcd_kernel<6, 32> (inte_conv_hk gather, stage 4)", "hbm",
+                  float(B * N * ((T + 1 + P) * C * 4 + k * 4)), us,
+                  gathered_bytes_per_launch=float(B * N * ((T * P + 1 + P) * C * 4 + k * 4)))
 
 
 def feature_knn_stage4(B, base_points, device):

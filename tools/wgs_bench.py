@@ -25,3 +25,10 @@ a = t(lambda: L.pdgn_window_gather_sum(b, n, k, ldy, T, P, C, 0, T * C, ptr(Y), 
 c = t(lambda: L.pdgn_window_gather_sum_stats(b, n, k, ldy, T, P, C, 0, T * C, ptr(Y), ptr(idx), ptr(bias), C, ptr(out), ptr(scr), stream_of(Y)))
 d = t(lambda: L.pdgn_bn_stats(ctypes.c_longlong(rows), C, ctypes.c_float(1e-5), ctypes.c_float(0.1), ptr(out), ptr(g), ptr(be), None, ptr(rm), ptr(rv), ptr(scr), ptr(st), stream_of(Y)))
 print("wgs_fwd %.1f us | wgs_fwd_stats %.1f us | bn_stats pass %.1f us  => %.1f vs %.1f" % (a, c, d, a + d, c))
+# adjoint through the transposed graph (stage-4 inte shape)
+rowptr = torch.empty(b, n + 1, dtype=torch.int32, device="cuda"); edges = torch.empty(b, n * k, dtype=torch.int32, device="cuda")
+scr2 = torch.empty(2 * b * n, dtype=torch.int32, device="cuda")
+L.pdgn_knn_graph_transpose(b, n, k, ptr(idx), ptr(rowptr), ptr(edges), ptr(scr2), stream_of(Y))
+dout = torch.randn(b, n, P, C, device="cuda"); dY = torch.empty(b, n, ldy, device="cuda")
+e = t(lambda: L.pdgn_window_gather_sum_backward_csr(b, n, k, ldy, T, P, C, 0, T * C, ptr(dout), ptr(rowptr), ptr(edges), ptr(dY), stream_of(Y)))
+print("wgs_bwd_csr %.1f us" % e)
