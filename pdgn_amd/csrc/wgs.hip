@@ -579,7 +579,7 @@ extern "C" int pdgn_window_gather_sum_backward_csr(int b, int n, int k, int ldy,
         return PDGN_ERR_INVALID;
     if (b == 0) return 0;
     static const int xcd = getenv("PDGN_WGS_XCD") ? atoi(getenv("PDGN_WGS_XCD")) : 1;
-    if (xcd && T <= 8 && (long long)n * P * (C / 4) >= 65536) {
+    if (xcd && (T <= 8 || T == 10) && (long long)n * T * (C / 4) >= 65536) {
         static const int cw = wgs_cw("PDGN_WGS_BCW", 64);
         const int CV = C / 4, nchunk = cdiv(CV, cw), ntasks = b * nchunk, bpt = cdiv(n, WGS_THREADS / 64);
         const long long blocks = (long long)cdiv(ntasks, 8) * 8 * bpt;
@@ -587,6 +587,9 @@ extern "C" int pdgn_window_gather_sum_backward_csr(int b, int n, int k, int ldy,
 #define WGS_CALL(W)                                                                                                           \
     if (T == 6)                                                                                                               \
         hipLaunchKernelGGL((wgs_bwd_csr_xcd_kernel<6, W>), dim3((unsigned)blocks), dim3(WGS_THREADS), 0, (hipStream_t)stream, \
+                           ntasks, bpt, n, k, ldy, T, P, CV, nchunk, off, offc, dout, rowptr, edges, dY);                     \
+    else if (T == 10)                                                                                                         \
+        hipLaunchKernelGGL((wgs_bwd_csr_xcd_kernel<10, W>), dim3((unsigned)blocks), dim3(WGS_THREADS), 0, (hipStream_t)stream,\
                            ntasks, bpt, n, k, ldy, T, P, CV, nchunk, off, offc, dout, rowptr, edges, dY);                     \
     else                                                                                                                      \
         hipLaunchKernelGGL((wgs_bwd_csr_xcd_kernel<0, W>), dim3((unsigned)blocks), dim3(WGS_THREADS), 0, (hipStream_t)stream, \

@@ -1,5 +1,6 @@
 """The stream-overlapped schedule of the eager step (PDGNTrainer._step_overlapped) against the sequential
-segments: same losses, same parameters after two iterations (float atomics' order is the only difference)."""
+segments: same losses and same parameters after each of two iterations started from identical state (float atomics' order is
+the only difference)."""
 import copy
 
 import pytest
@@ -28,17 +29,23 @@ def test_overlapped_schedule_equals_sequential():
         assert set(la) == set(lb) == {"d_loss1", "d_loss2", "d_loss3", "d_loss4", "g_loss", "similar_loss"}
         for k in la:
             va, vb = float(la[k]), float(lb[k])
-            # iteration 0 starts from identical weights; after an update the two runs differ by atomics' rounding,
-            # which the feature-kNN graphs amplify (a flipped neighbour is a discontinuity): few-% band, as for
-            # the HIP-graph vs fp64-graph step test
-            tol = 2e-3 if it == 0 else 5e-2
-            assert abs(va - vb) <= tol * max(1.0, abs(vb)), (it, k, va, vb)
-    for (na, pa), (nb, pb) in zip(a.G.named_parameters(), b.G.named_parameters()):
-        assert na == nb
-        assert (pa - pb).abs().max().item() <= 5e-4, na       # two Adam steps of lr 1e-4
+            assert abs(va - vb) <= 2e-3 * max(1.0, abs(vb)), (it, k, va, vb)
+        for (na, pa), (nb, pb) in zip(a.G.named_parameters(), b.G.named_parameters()):
+            assert na == nb
+            assert (pa - pb).abs().max().item() <= 3e-4, (it, na)   # one Adam step of lr 1e-4 on rounding-level gradient noise
+        for da, db in zip(a.D, b.D):
+            for pa, pb in zip(da.parameters(), db.parameters()):
+                assert (pa - pb).abs().max().item() <= 3e-4, it
+        # Every iteration is compared FROM IDENTICAL STATE: the two schedules differ by the order of float atomics, the
+        # updated weights by that rounding, and a feature-kNN graph built from them may flip a neighbour -- a
+        # discontinuity that made a free-running second iteration differ by anything up to several % (and, once in a
+        # dozen runs, more than any fixed band).  The schedule is what is under test, not the map's sensitivity.
+        b.G.load_state_dict(a.G.state_dict())
+        b.optG.load_state_dict(copy.deepcopy(a.optG.state_dict()))     # deepcopy: load_state_dict keeps same-device tensors
+        for da, db, oa, ob in zip(a.D, b.D, a.optD, b.optD):
+            db.load_state_dict(da.state_dict())
+            ob.load_state_dict(copy.deepcopy(oa.state_dict()))
     for da, db in zip(a.D, b.D):
-        for pa, pb in zip(da.parameters(), db.parameters()):
-            assert (pa - pb).abs().max().item() <= 5e-4
         for (ka, va), (kb, vb) in zip(da.state_dict().items(), db.state_dict().items()):
             if "num_batches_tracked" in ka:
                 assert int(va) == int(vb) == 6, ka              # 2 iterations x (real, fake, gen)
