@@ -92,6 +92,26 @@ __device__ __forceinline__ float sq3(float ax, float ay, float az, float bx, flo
     return __fmaf_rn(dz, dz, __fmaf_rn(dy, dy, __fmul_rn(dx, dx)));
 }
 
+// Packed-fp32 forms of the inner loops: two points of a thread ride in one VGPR pair, so the subtract / multiply /
+// fused-multiply-add chain of every (point, opposite point) element issues as v_pk_* instructions at half the
+// per-element cost; only the transcendentals (v_exp_f32, v_sqrt_f32: quarter rate) stay scalar.  Same operations in the
+// same order as sq3 / __expf, so the results are bit-identical to the scalar form.
+typedef float f2 __attribute__((ext_vector_type(2)));
+#define AM_LOG2E 0x1.715476p+0f
+__device__ __forceinline__ f2 sq3_pk(float qx, float qy, float qz, f2 px, f2 py, f2 pz, bool q_first) {
+    const f2 vx = {qx, qx}, vy = {qy, qy}, vz = {qz, qz};
+    const f2 dx = q_first ? vx - px : px - vx, dy = q_first ? vy - py : py - vy, dz = q_first ? vz - pz : pz - vz;
+    return __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
+}
+__device__ __forceinline__ f2 exp_pk(float level, f2 d2) {              // __expf(level * d2) per lane
+    const f2 lv = {level, level}, k = {AM_LOG2E, AM_LOG2E};
+    const f2 a = (lv * d2) * k;
+    f2 r;
+    r.x = __builtin_amdgcn_exp2f(a.x);
+    r.y = __builtin_amdgcn_exp2f(a.y);
+    return r;
+}
+
 // FUSED = false: writes match (b,m,n) like approxmatchkernel (approxmatch.cu:3-182).
 // FUSED = true : accumulates sum match*sqrt(d2) instead (matchcostkernel :184-224 folded in).
 template <bool FUSED>
@@ -136,12 +156,21 @@ __global__ __launch_bounds__(AM_THREADS) void approxmatch_kernel(
                 for (int l = tid; l < lend; l += AM_THREADS)
                     buf[l] = make_float4(B[(l0 + l) * 3], B[(l0 + l) * 3 + 1], B[(l0 + l) * 3 + 2], remainR[l0 + l]);
                 __syncthreads();
-                for (int l = 0; l < lend; ++l) {
-                    float4 q = buf[l];
+                f2 ax[AM_PPT / 2], ay[AM_PPT / 2], az[AM_PPT / 2], ac[AM_PPT / 2];
 #pragma unroll
-                    for (int i = 0; i < AM_PPT; ++i)
-                        acc[i] = __fmaf_rn(__expf(level * sq3(q.x, q.y, q.z, px[i], py[i], pz[i])), q.w, acc[i]);
+                for (int i = 0; i < AM_PPT / 2; ++i) {
+                    ax[i] = f2{px[2 * i], px[2 * i + 1]}; ay[i] = f2{py[2 * i], py[2 * i + 1]};
+                    az[i] = f2{pz[2 * i], pz[2 * i + 1]}; ac[i] = f2{acc[2 * i], acc[2 * i + 1]};
                 }
+                for (int l = 0; l < lend; ++l) {
+                    const float4 q = buf[l];
+                    const f2 qw = {q.w, q.w};
+#pragma unroll
+                    for (int i = 0; i < AM_PPT / 2; ++i)
+                        ac[i] = __builtin_elementwise_fma(exp_pk(level, sq3_pk(q.x, q.y, q.z, ax[i], ay[i], az[i], true)), qw, ac[i]);
+                }
+#pragma unroll
+                for (int i = 0; i < AM_PPT / 2; ++i) { acc[2 * i] = ac[i].x; acc[2 * i + 1] = ac[i].y; }
             }
 #pragma unroll
             for (int i = 0; i < AM_PPT; ++i) {
@@ -166,12 +195,21 @@ __global__ __launch_bounds__(AM_THREADS) void approxmatch_kernel(
                 for (int k = tid; k < kend; k += AM_THREADS)
                     buf[k] = make_float4(A[(k0 + k) * 3], A[(k0 + k) * 3 + 1], A[(k0 + k) * 3 + 2], ratioL[k0 + k]);
                 __syncthreads();
-                for (int k = 0; k < kend; ++k) {
-                    float4 q = buf[k];
+                f2 ax[AM_PPT / 2], ay[AM_PPT / 2], az[AM_PPT / 2], ac[AM_PPT / 2];
 #pragma unroll
-                    for (int i = 0; i < AM_PPT; ++i)
-                        acc[i] = __fmaf_rn(__expf(level * sq3(px[i], py[i], pz[i], q.x, q.y, q.z)), q.w, acc[i]);
+                for (int i = 0; i < AM_PPT / 2; ++i) {
+                    ax[i] = f2{px[2 * i], px[2 * i + 1]}; ay[i] = f2{py[2 * i], py[2 * i + 1]};
+                    az[i] = f2{pz[2 * i], pz[2 * i + 1]}; ac[i] = f2{acc[2 * i], acc[2 * i + 1]};
                 }
+                for (int k = 0; k < kend; ++k) {
+                    const float4 q = buf[k];
+                    const f2 qw = {q.w, q.w};
+#pragma unroll
+                    for (int i = 0; i < AM_PPT / 2; ++i)
+                        ac[i] = __builtin_elementwise_fma(exp_pk(level, sq3_pk(q.x, q.y, q.z, ax[i], ay[i], az[i], false)), qw, ac[i]);
+                }
+#pragma unroll
+                for (int i = 0; i < AM_PPT / 2; ++i) { acc[2 * i] = ac[i].x; acc[2 * i + 1] = ac[i].y; }
             }
 #pragma unroll
             for (int i = 0; i < AM_PPT; ++i) {
@@ -203,6 +241,36 @@ __global__ __launch_bounds__(AM_THREADS) void approxmatch_kernel(
                 for (int l = tid; l < lend; l += AM_THREADS)
                     buf[l] = make_float4(B[(l0 + l) * 3], B[(l0 + l) * 3 + 1], B[(l0 + l) * 3 + 2], ratioR[l0 + l]);
                 __syncthreads();
+                if (FUSED) {
+                    // cost-only form: packed arithmetic, and v_sqrt_f32 itself (<= 1 ulp) instead of sqrtf's correctly
+                    // rounded expansion (16 instructions per element -- half of this loop); the sum of 4M such terms
+                    // is compared at 1e-4
+                    f2 ax[AM_PPT / 2], ay[AM_PPT / 2], az[AM_PPT / 2], ar[AM_PPT / 2], ac[AM_PPT / 2], cs[AM_PPT / 2];
+#pragma unroll
+                    for (int i = 0; i < AM_PPT / 2; ++i) {
+                        ax[i] = f2{px[2 * i], px[2 * i + 1]}; ay[i] = f2{py[2 * i], py[2 * i + 1]};
+                        az[i] = f2{pz[2 * i], pz[2 * i + 1]}; ar[i] = f2{rl[2 * i], rl[2 * i + 1]};
+                        ac[i] = f2{acc[2 * i], acc[2 * i + 1]}; cs[i] = f2{0.f, 0.f};
+                    }
+                    for (int l = 0; l < lend; ++l) {
+                        const float4 q = buf[l];
+                        const f2 qw = {q.w, q.w};
+#pragma unroll
+                        for (int i = 0; i < AM_PPT / 2; ++i) {
+                            const f2 d2 = sq3_pk(q.x, q.y, q.z, ax[i], ay[i], az[i], true);
+                            const f2 w = (exp_pk(level, d2) * ar[i]) * qw;
+                            const f2 r = {__builtin_amdgcn_sqrtf(d2.x), __builtin_amdgcn_sqrtf(d2.y)};
+                            cs[i] = __builtin_elementwise_fma(w, r, cs[i]);
+                            ac[i] += w;
+                        }
+                    }
+#pragma unroll
+                    for (int i = 0; i < AM_PPT / 2; ++i) {
+                        acc[2 * i] = ac[i].x; acc[2 * i + 1] = ac[i].y;
+                        cost += cs[i].x + cs[i].y;
+                    }
+                    continue;
+                }
                 for (int l = 0; l < lend; ++l) {
                     float4 q = buf[l];
 #pragma unroll
