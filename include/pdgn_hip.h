@@ -327,6 +327,17 @@ int pdgn_labelstat_and_ballquery(int b, int n, int m, float radius, int nsample,
                                  const float *xyz, const int32_t *label_stat, int32_t *idx, int32_t *new_label_stat,
                                  pdgn_stream_t stream);
 
+/* ------------------------------------------------------------------ max-pool over the points
+ * nn.MaxPool2d((1, N)) at the head of every generator block (models/PDGNet_v2.py:675/:699, :716/:736, :754/:777,
+ * :794/:810) on the point-major layout: x (b,n,c) -> out (b,c) and the point index of each maximum (lowest index on
+ * ties), which is all the adjoint needs: grad_x[b,r,ch] = (r == arg[b,ch]) ? grad_out[b,ch] : 0 (c % 4 == 0).
+ * scratch_val / scratch_arg hold pdgn_point_max_scratch(b,n,c) floats / int32 each. */
+long long pdgn_point_max_scratch(int b, int n, int c);
+int pdgn_point_max(int b, int n, int c, const float *x, float *scratch_val, int32_t *scratch_arg, float *out, int32_t *arg,
+                   pdgn_stream_t stream);
+int pdgn_point_max_backward(int b, int n, int c, const float *grad_out, const int32_t *arg, float *grad_x,
+                            pdgn_stream_t stream);
+
 /* ------------------------------------------------------------------ scheduling support
  * No reference counterpart (the reference runs on one CUDA stream).  One wavefront that occupies `stream` for
  * `microseconds` (<= 100000) of wall time: pdgn_amd/streams.py times pairs of these to learn which HIP streams share a

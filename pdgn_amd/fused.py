@@ -8,7 +8,7 @@ import torch
 from torch.autograd import Function
 
 from . import _lib
-from ._lib import check, ptr, stream_of
+from ._lib import check, ptr, require, stream_of
 
 F32 = torch.float32
 ACT = {"none": 0, "relu": 1, "leaky_relu": 2}
@@ -597,3 +597,43 @@ def bn_act_maxpool(x2d, bn, training, B, N, act="leaky_relu", pre_bias=None):
         _PENDING_COUNTS[bn.num_batches_tracked] = _PENDING_COUNTS.get(bn.num_batches_tracked, 0) + 1
     return BNActMaxPool.apply(x2d, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, bn.momentum, bn.eps,
                               ACT[act], B, N, pre_bias)
+
+
+class PointMax(Function):
+    """nn.MaxPool2d((1, N)) over the points of a point-major (B, N, C) tensor (models/PDGNet_v2.py:699/:736/:777/:810):
+    values (B, C); the adjoint writes the dense gradient in one pass from the saved argmax (csrc/pointmax.hip)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        require(x, "x", F32, 3)
+        b, n, c = x.shape
+        L = _lib.lib()
+        L.pdgn_point_max_scratch.restype = ctypes.c_longlong
+        ns = int(L.pdgn_point_max_scratch(b, n, c))
+        sval = torch.empty(ns, dtype=F32, device=x.device)
+        sarg = torch.empty(ns, dtype=torch.int32, device=x.device)
+        out = torch.empty((b, c), dtype=F32, device=x.device)
+        arg = torch.empty((b, c), dtype=torch.int32, device=x.device)
+        check(L.pdgn_point_max(b, n, c, ptr(x), ptr(sval), ptr(sarg), ptr(out), ptr(arg), stream_of(x)), "pdgn_point_max")
+        ctx.save_for_backward(arg)
+        ctx.n = n
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        arg, = ctx.saved_tensors
+        b, c = arg.shape
+        g = g.contiguous()
+        if c % 4:
+            dx = torch.zeros((b, ctx.n, c), dtype=F32, device=g.device)
+            return dx.scatter_(1, arg.long().unsqueeze(1), g.unsqueeze(1))
+        dx = torch.empty((b, ctx.n, c), dtype=F32, device=g.device)
+        check(_lib.lib().pdgn_point_max_backward(b, ctx.n, c, ptr(g), ptr(arg), ptr(dx), stream_of(g)),
+              "pdgn_point_max_backward")
+        return dx
+
+
+def point_max(x):
+    """Max over the points (dim 1) of (B, N, C): the HIP kernel pair on a GPU, torch on the CPU (host tests only)."""
+    return PointMax.apply(x) if x.is_cuda else x.max(dim=1)[0]

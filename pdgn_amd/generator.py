@@ -26,6 +26,11 @@ def _small_seq(seq, x, training):
     return _deconv.small_sequential(seq, x, training)      # looked up late: tests patch deconv.small_sequential
 
 
+def _point_max(x):
+    from .fused import point_max
+    return point_max(x)
+
+
 def _linear(rows, weight, bias=None):
     return _deconv.linear_cl(rows, weight, bias)              # looked up late: tests patch deconv.linear_cl
 
@@ -76,7 +81,7 @@ class BilateralBlock(nn.Module):
         input is cat([const broadcast over the points (B,Fc), xt]) along channels (:708) -- passed in two
         pieces so that the broadcast half is never materialised per point."""
         B, N, _ = xt.shape
-        pooled = xt.max(dim=1)[0]                               # MaxPool2d((1,N)) over the points
+        pooled = _point_max(xt)                                 # MaxPool2d((1,N)) over the points
         if const is not None:
             pooled = torch.cat((const, pooled), 1)              # max of a broadcast channel is itself
         xs = _small_seq(self.fc, pooled, self.training)

@@ -678,3 +678,24 @@ def test_small_sequential_vs_torch(R, dims, training):
         assert (p1.grad - p2.grad).abs().max().item() <= 2e-3 * scale + 1e-6, n1
     for (n1, b1), (n2, b2) in zip(mine.named_buffers(), ref.named_buffers()):
         torch.testing.assert_close(b1.float(), b2.float(), rtol=1e-5, atol=1e-6, msg=n1)
+
+
+@pytest.mark.parametrize("B,N,C", [(3, 128, 32), (35, 1024, 128), (2, 300, 20), (4, 129, 6)])
+def test_point_max_forward_backward(B, N, C):
+    """MaxPool2d((1,N)) over the points (models/PDGNet_v2.py:699): values, and the gradient routed to the argmax."""
+    from pdgn_amd.fused import point_max
+    rng = np.random.default_rng(B * N + C)
+    x = torch.from_numpy(rng.standard_normal((B, N, C)).astype(np.float32))
+    x[0, 5, 0] = x[0, 77 % N, 0] = 9.0                       # a tie: the lowest point index takes the gradient
+    g = torch.from_numpy(rng.standard_normal((B, C)).astype(np.float32))
+    xg = dev(x).requires_grad_(True)
+    out = point_max(xg)
+    out.backward(dev(g))
+    ref = x.max(dim=1)[0]
+    assert torch.equal(out.detach().cpu(), ref)
+    arg = torch.zeros(B, C, dtype=torch.long)
+    for b in range(B):
+        for c in range(C):
+            arg[b, c] = int(torch.nonzero(x[b, :, c] == ref[b, c])[0])
+    want = torch.zeros_like(x).scatter_(1, arg.unsqueeze(1), g.unsqueeze(1))
+    assert torch.equal(xg.grad.cpu(), want)
