@@ -97,7 +97,8 @@ class PDGNTrainer:
         self._lw = {}
         for ws in {1, world_size() if self.distributed else 1}:
             self._loss_weights(ws)
-        self._lp_split = os.environ.get("PDGN_LP_SPLIT", "0") == "1"      # A/B switch, see _step_overlapped
+        self._lp_split = os.environ.get("PDGN_LP_SPLIT", "0") == "1"      # A/B switches, see _step_overlapped
+        self._early_tail = os.environ.get("PDGN_EARLY_TAIL", "1") == "1"
 
     def train(self):
         self.G.train()
@@ -172,9 +173,10 @@ class PDGNTrainer:
             for p in d.parameters():
                 p.requires_grad_(not frozen)
 
-    def similar_terms(self, clouds, pairs):
-        """{(a, b): (like_mu, like_cov)} of get_local_pair (:232-237) for the given resolution pairs."""
-        terms, own = {}, {}                      # own: stats of cloud a around itself, shared by its pairs
+    def similar_terms(self, clouds, pairs, own=None):
+        """{(a, b): (like_mu, like_cov)} of get_local_pair (:232-237) for the given resolution pairs.  `own` caches
+        the statistics of cloud a around itself across calls (they are shared by all pairs (a, .))."""
+        terms, own = {}, ({} if own is None else own)
         for a, b in pairs:
             if a not in own:
                 cl = clouds[a].transpose(1, 2).contiguous()
@@ -294,25 +296,40 @@ class PDGNTrainer:
         mark("G(z1) forward")
         self.gradG.begin()
         self._freeze_D(True)
-        gen = self.G(self._z(st, "z2"))
-        mark("G(z2) forward")
-        # The shape-preserving loss (12 kNN + Chamfer terms) and the four D(gen) passes read the same clouds and
-        # nothing of each other: the former runs on its own stream, forward and (autograd keeps an op's backward on
-        # its forward's stream) backward.  PDGN_LP_SPLIT=1 moves the five lighter pairs onto the default stream, which
-        # otherwise only waits between the end of G(z2) and the start of its backward: measured, no gain
-        # (38.5 vs 37.9 ms over 3 alternating runs each) -- the wait is not where the time goes.
-        split = self._lp_split
-        self._side_lp.wait_stream(main)
-        with torch.cuda.stream(self._side_lp):
-            terms = self.similar_terms(gen, PAIRS[-1:] if split else PAIRS)
-        # D_k(G(z2)_k): four more independent chains of small kernels, each behind D_k's own update on D_k's stream
-        g_loss = []
-        for i, side in enumerate(self._side):
+        # The shape-preserving loss (12 kNN + Chamfer terms) and the four D(gen) passes read the clouds and nothing of
+        # each other: they run on their own streams, forward and (autograd keeps an op's backward on its forward's
+        # stream) backward.  They also do not need the whole forward: pair (a, k) and D_k(gen_k) only need level k, so
+        # they are enqueued from the generator's stage hook and run underneath the deeper blocks; after the forward
+        # only D4(gen) and the three pairs with the 2048-point cloud are left to wait for.  Being created last, those
+        # are also the first adjoints autograd issues -- the ones block 4's backward waits for.
+        # (PDGN_LP_SPLIT=1, the lighter pairs on the default stream instead: measured, no gain.)
+        terms, own, g_loss, gen_so_far = {}, {}, [None] * 4, []
+        early = self._early_tail
+
+        def tail(level, cloud):
+            gen_so_far.append(cloud)
+            if level >= 1:
+                self._side_lp.wait_stream(main)
+                with torch.cuda.stream(self._side_lp):
+                    terms.update(self.similar_terms(gen_so_far, [(a, level) for a in range(level)], own))
+            side = self._side[level]
             side.wait_stream(main)
             with torch.cuda.stream(side):
-                g_loss.append(F.mse_loss(self.D[i](gen[i]), st["ones"]))
-        if split:
-            terms.update(self.similar_terms(gen, PAIRS[:-1]))
+                g_loss[level] = F.mse_loss(self.D[level](cloud), st["ones"])
+
+        gen = self.G(self._z(st, "z2"), stage_hook=tail if early else None)
+        mark("G(z2) forward")
+        if not early:
+            split = self._lp_split
+            self._side_lp.wait_stream(main)
+            with torch.cuda.stream(self._side_lp):
+                terms = self.similar_terms(gen, PAIRS[-1:] if split else PAIRS)
+            for i, side in enumerate(self._side):
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    g_loss[i] = F.mse_loss(self.D[i](gen[i]), st["ones"])
+            if split:
+                terms.update(self.similar_terms(gen, PAIRS[:-1]))
         for side in self._side:
             main.wait_stream(side)
         main.wait_stream(self._side_lp)
