@@ -61,7 +61,9 @@ def test_feature_knn_duplicates_drop_rank0():
 
 @pytest.mark.parametrize("B,N,k,ldy,spec", [(2, 50, 10, 64, (6, 5, 8, 0, 48)), (2, 33, 10, 40, (10, 1, 3, 1, 31)),
                                             (3, 64, 10, 32, (1, 10, 16, 0, 16)), (2, 40, 4, 24, (3, 2, 4, 4, -1)),
-                                            (2, 512, 10, 7200, (6, 5, 1024, 0, 6144))])
+                                            (2, 512, 10, 7200, (6, 5, 1024, 0, 6144)),
+                                            # ragged for the cache-aware task mapping: rows not a multiple of the block's, a partial last chunk
+                                            (3, 1000, 10, 1912, (6, 5, 160, 0, 960)), (3, 1000, 10, 1912, (10, 1, 72, 1120, 1840))])
 def test_window_gather_sum_forward_backward(B, N, k, ldy, spec):
     from pdgn_amd.deconv import EdgeGatherSum
     rng = np.random.default_rng(N)
@@ -268,7 +270,8 @@ def test_graphed_step_equals_eager_step():
 
 @pytest.mark.parametrize("B,N,k,specs", [(2, 50, 10, ((6, 5, 8, 0, 48),)),                       # ldy = 56, one spec tiles it
                                          (3, 300, 10, ((6, 5, 16, 0, 96), (10, 1, 8, 112, 192), (1, 10, 4, 200, 204))),
-                                         (2, 1024, 10, ((6, 5, 128, 0, 768), (10, 1, 64, 896, 1536)))])
+                                         (2, 1024, 10, ((6, 5, 128, 0, 768), (10, 1, 64, 896, 1536))),
+                                         (3, 1000, 10, ((6, 5, 160, 0, 960), (10, 1, 72, 1120, 1840)))])
 def test_window_gather_sum_backward_csr_path(B, N, k, specs):
     """Specs that tile dY completely take the atomic-free transposed-graph adjoint."""
     from pdgn_amd.deconv import EdgeGatherSum
@@ -416,7 +419,8 @@ def test_bilateral_weighting(M, k, C, training):
     np.testing.assert_allclose(y2.cpu().numpy(), yr2.numpy(), rtol=1e-4, atol=1e-6)
 
 
-@pytest.mark.parametrize("b,n,k,T,P,C", [(3, 64, 10, 6, 5, 64), (2, 128, 10, 6, 5, 1024), (2, 50, 4, 3, 2, 8)])
+@pytest.mark.parametrize("b,n,k,T,P,C", [(3, 64, 10, 6, 5, 64), (2, 128, 10, 6, 5, 1024), (2, 50, 4, 3, 2, 8), (3, 1000, 10, 6, 5, 160),
+                                         (5, 700, 8, 4, 5, 96)])
 def test_window_gather_sum_with_statistics_epilogue(b, n, k, T, P, C):
     """pdgn_window_gather_sum_stats: the same output bit for bit, and BatchNorm statistics (incl. running buffers)
     finished from its partials equal to a statistics pass over the output"""
