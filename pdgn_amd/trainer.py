@@ -271,9 +271,10 @@ class PDGNTrainer:
         and of everything the generator does after emitting their resolution, and they are chains of small
         kernels (D1-D3 see 256-1024 points) that leave most CUs idle.  D_k's update (forward real + fake,
         backward, all-reduce, Adam) is enqueued on its own HIP stream the moment G(z1) has produced level k,
-        so it runs underneath the deeper levels' GEMMs / gather-sums; D4's runs underneath G(z2).  The
-        default stream joins the four streams before D(G(z2)).  Results are those of the sequential order
-        (the reference's D updates do not read each other)."""
+        so it runs underneath the deeper levels' GEMMs / gather-sums; D4's runs underneath G(z2).  In the same
+        way D_k(G(z2)_k) (behind D_k's update, on D_k's stream) and the loss pairs that end at level k start from
+        G(z2)'s stage hook; the default stream joins all of them before the backward.  Results are those of the
+        sequential order (the reference's D updates do not read each other)."""
         st = st if st is not None else self._state(reals, z1, z2)
         main = torch.cuda.current_stream(self.device)
         pl = _streams.plan(self.device)                     # streams by measured hardware queue (streams.py)
