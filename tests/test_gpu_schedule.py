@@ -52,3 +52,42 @@ def test_overlapped_schedule_equals_sequential():
     for (ka, va), (kb, vb) in zip(a.G.state_dict().items(), b.G.state_dict().items()):
         if "num_batches_tracked" in ka:
             assert int(va) == int(vb) == 4, ka                  # 2 iterations x 2 generator passes
+
+
+def test_rccl_path_at_world_size_one_equals_single_process():
+    """distributed=True under a one-rank RCCL group: flat-buffer pack + all-reduce (mean over 1 rank) + Adam on the views
+    must reproduce the single-process iteration (same schedule, same kernels)."""
+    import os
+    import socket
+    import torch.distributed as dist
+    from pdgn_amd.trainer import PDGNTrainer, noise, synthetic_batch
+    dev = torch.device("cuda:0")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.manual_seed(5)
+    a = PDGNTrainer(device=dev, distributed=False)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        b = PDGNTrainer(device=dev, distributed=True, generator=copy.deepcopy(a.G),
+                        discriminators=[copy.deepcopy(d) for d in a.D])
+        a.train(), b.train()
+        B = 4
+        reals = synthetic_batch(B, dev)
+        g = torch.Generator().manual_seed(11)
+        z1, z2 = noise(B, dev, g), noise(B, dev, g)
+        la, lb = a.step(reals, z1, z2), b.step(reals, z1, z2)
+        torch.cuda.synchronize()
+        for k in la:
+            va, vb = float(la[k]), float(lb[k])
+            assert abs(va - vb) <= 2e-3 * max(1.0, abs(vb)), (k, va, vb)
+        for (na, pa), (nb, pb) in zip(a.G.named_parameters(), b.G.named_parameters()):
+            assert (pa - pb).abs().max().item() <= 3e-4, na
+            assert pb.grad.data_ptr() >= b.gradG.buf.data_ptr()          # .grad is a view of the flat buffer
+        for da, db in zip(a.D, b.D):
+            for pa, pb in zip(da.parameters(), db.parameters()):
+                assert (pa - pb).abs().max().item() <= 3e-4
+    finally:
+        dist.destroy_process_group()
