@@ -34,5 +34,8 @@ for k, n in enumerate(names):
     tot += ms
     print("  %-40s %7.2f ms" % (n, ms))
 print("  %-40s %7.2f ms" % ("sum (event to event, one step)", tot))
+if os.environ.get("PDGN_X_PERSTEP") == "1":
+    for k, n in enumerate(names):
+        print("  per step %-28s" % n, " ".join("%.1f" % r[k][1].elapsed_time(r[k + 1][1]) for r in runs))
 gap = sum(runs[i][-1][1].elapsed_time(runs[i + 1][0][1]) for i in range(STEPS - 1)) / (STEPS - 1)
 print("  %-40s %7.2f ms" % ("between steps", gap))
