@@ -99,6 +99,7 @@ class PDGNTrainer:
             self._loss_weights(ws)
         self._lp_split = os.environ.get("PDGN_LP_SPLIT", "0") == "1"      # A/B switches, see _step_overlapped
         self._early_tail = os.environ.get("PDGN_EARLY_TAIL", "1") == "1"
+        self._defer_d = os.environ.get("PDGN_DEFER_D", "1") == "1"
 
     def train(self):
         self.G.train()
@@ -283,17 +284,36 @@ class PDGNTrainer:
         mark = st.get("mark") or (lambda name: None)        # tools/phase_events.py: HIP events on the default stream
         mark("start")
 
-        def d_update(level, cloud):
+        # D_k's update starts on the DEVICE when level k exists (an event recorded in the stage hook), but its ~150
+        # launches are issued by the host only after the whole generator pass has been issued: with a host that runs
+        # ahead (steady state) the device sees the same schedule, and right after a synchronise -- the first timed step
+        # of a benchmark, the first step after a checkpoint -- the default stream is not left idle while the host
+        # works through three discriminator updates between the generator's blocks (G(z1) forward of such a step:
+        # 15-25 ms before).
+        levels = []
+
+        def d_mark(level, cloud):
             st["fakes"][level] = cloud
+            ev = torch.cuda.Event()
+            ev.record(main)
+            levels.append((level, ev))
+
+        def d_update(level, ev):
             side = self._side[level]
-            side.wait_stream(main)
+            side.wait_event(ev)
             with torch.cuda.stream(side), torch.enable_grad():
                 self._seg_d(st, level)
                 self._comm(level)
                 self.optD[level].step()
 
+        def d_now(level, cloud):
+            d_mark(level, cloud)
+            d_update(*levels.pop())
+
         with torch.no_grad():
-            self.G(self._z(st, "z1"), stage_hook=d_update)
+            self.G(self._z(st, "z1"), stage_hook=d_mark if self._defer_d else d_now)
+        for level, ev in levels:
+            d_update(level, ev)
         mark("G(z1) forward")
         self.gradG.begin()
         self._freeze_D(True)
