@@ -400,8 +400,12 @@ class PDGNTrainer:
         if self.overlap and not self.distributed:
             # the stream-overlapped schedule as ONE graph: the side streams fork from / join the capturing stream
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                self._step_overlapped(None, None, None, st=self._static)
+            defer, self._defer_d = self._defer_d, False       # capture order = node order of the replay: keep D_k's
+            try:                                              # nodes next to the level that feeds them
+                with torch.cuda.graph(g):
+                    self._step_overlapped(None, None, None, st=self._static)
+            finally:
+                self._defer_d = defer
             self._graphs.append((g, 5))
             return self
         for group in groups:
