@@ -297,6 +297,8 @@ class PDGNTrainer:
             ev = torch.cuda.Event()
             ev.record(main)
             levels.append((level, ev))
+            if level < 3:
+                mark("G(z1) level %d" % (level + 1))
 
         def d_update(level, ev):
             side = self._side[level]
