@@ -316,7 +316,7 @@ class PDGNTrainer:
             self.G(self._z(st, "z1"), stage_hook=d_mark if self._defer_d else d_now)
         for level, ev in levels:
             d_update(level, ev)
-        mark("G(z1) forward")
+        mark("G(z1) level 4")
         self.gradG.begin()
         self._freeze_D(True)
         # The shape-preserving loss (12 kNN + Chamfer terms) and the four D(gen) passes read the clouds and nothing of
