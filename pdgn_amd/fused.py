@@ -223,7 +223,7 @@ def _timed(fn):
 # checks its validators (torch / ROCm / hipBLASLt versions, gfx arch) and ignores a table from another build, in which
 # case this candidate is the heuristic pick again and never wins.  TunableOp is switched on around the calls it won.
 _TUNED = "tuned"
-_TUNABLE = {"state": None, "min_flops": 1e9}
+_TUNABLE = {"state": None, "min_flops": 0.0}
 _TUNABLE_TABLE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tunableop_gfx950.csv")
 
 
