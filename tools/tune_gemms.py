@@ -17,11 +17,15 @@ tn.set_max_tuning_duration(int(os.environ.get("PDGN_TUNE_MS", "15")))
 tn.set_max_tuning_iterations(20)
 from pdgn_amd.trainer import PDGNTrainer, noise, synthetic_batch
 B = 35
-tr = PDGNTrainer(device="cuda"); tr.train()
-reals = synthetic_batch(B, "cuda")
 t0 = time.time()
-tr.step(reals, noise(B, "cuda"), noise(B, "cuda"))       # first iteration: fused._library_gemm searches every large shape
-torch.cuda.synchronize()
+for base in (128, 256):                                  # the reference's 256->2048 configuration and the 512->4096 one (C4)
+    res_pts = tuple((2 * base) << i for i in range(4))
+    tr = PDGNTrainer(device="cuda", base_points=base); tr.train()
+    reals = synthetic_batch(B, "cuda", n_points=res_pts[3], resolutions=res_pts)
+    tr.step(reals, noise(B, "cuda"), noise(B, "cuda"))   # first iteration: fused._library_gemm searches every shape it meets
+    torch.cuda.synchronize()
+    del tr, reals
+    torch.cuda.empty_cache()
 print("search took %.0f s" % (time.time() - t0))
 res = tn.get_results()
 print("%d tuned entries" % len(res))
