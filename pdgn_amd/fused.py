@@ -296,6 +296,41 @@ def _library_gemm(form, a, b, bias=None):
     return out
 
 
+_TN_CHOICE = {}
+_TN_MIN_FLOPS = 4e9
+
+
+def _weight_grad_pick(dy, x):
+    """pdgn_gemm_tn or a searched library solution for dW = dy^T x?  Decided once per shape, for the large shapes the
+    committed TunableOp table covers (the library's HEURISTIC picks for this form run at 22-89 TFLOP/s -- the reason
+    pdgn_gemm_tn exists; its best solution for conv2's dense half reaches 145 TFLOP/s against pdgn_gemm_tn's 125)."""
+    m, n = dy.shape
+    k = x.shape[1]
+    key = (m, n, k, x.is_contiguous())
+    pick = _TN_CHOICE.get(key)
+    if pick is None:
+        if torch.cuda.is_current_stream_capturing():
+            return "own"
+        pick = "own"
+        tn = _tunable() if (2.0 * m * n * k >= _TN_MIN_FLOPS and n % 4 == 0 and k % 4 == 0 and x.is_contiguous()) else None
+        if tn is not None:
+            out = torch.zeros((n, k), dtype=F32, device=dy.device)
+            L = _lib.lib()
+            with torch.no_grad():
+                t_own = _timed(lambda: check(L.pdgn_gemm_tn(ctypes.c_longlong(m), n, k, ptr(dy), ptr(x), ptr(out), stream_of(dy)),
+                                             "pdgn_gemm_tn"))
+                tn.enable(True)
+                t_lib = _timed(lambda: dy.t().matmul(x))
+                tn.enable(False)
+            if t_lib < 0.95 * t_own:
+                pick = _TUNED
+            if os.environ.get("PDGN_BLAS_LOG") == "1":
+                print("blas tn (%d, %d)^T x (%d, %d): pdgn_gemm_tn %.3f ms searched library %.3f ms -> %s" % (
+                    m, n, m, k, t_own / 5, t_lib / 5, pick), flush=True)
+        _TN_CHOICE[key] = pick
+    return pick
+
+
 class LinearCL(Function):
     """y = x @ W^T (+ b) for point-major rows x (M, C_in).  Forward and the input gradient are
     library GEMMs (they already run at 105-140 TFLOP/s on these shapes); the weight gradient
@@ -318,7 +353,12 @@ class LinearCL(Function):
         if ctx.needs_input_grad[1]:
             m, n = dy.shape
             k = x.shape[1]
-            if m >= 1024:
+            if m >= 1024 and _weight_grad_pick(dy, x) is _TUNED:
+                tn = _TUNABLE["state"]                             # a searched library solution wins on this shape
+                tn.enable(True)
+                dw = dy.t().matmul(x)
+                tn.enable(False)
+            elif m >= 1024:
                 # pdgn_gemm_tn wants channel counts in multiples of 4: the xyz input layers (k = 3) and the MLP heads'
                 # last conv (n = 3) are zero-padded to 4 (a 3-row output handed to the library is a 3-workgroup
                 # GEMM over 10^4..10^5 rows: ~250 us)

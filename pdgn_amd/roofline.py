@@ -48,10 +48,41 @@ def _entry(name, bound, work, us, **extra):
     return d
 
 
-def gemm_tn_stage4(B, base_points, device):
-    """Largest weight-gradient GEMM of the step: conv2's dense half at stage 4, dW (512 x 5120) = dY^T (inte*w)
-    over M = B * 8*base rows (N = 2*Fout, K = 5 positions * 4F).  Algorithmic flops 2*M*N*K; algorithmic bytes
-    (M*N + M*K + N*K) * 4."""
+def weight_grad_stage4(B, base_points, device):
+    """The largest single contraction of the step's backward: conv2's dense half at stage 4, dW (512 x 5120) = dY^T (inte*w)
+    over M = B * 8*base rows (N = 2*Fout, K = 5 positions * 4F), launched the way the step launches it
+    (fused._weight_grad_pick: the hand-written pdgn_gemm_tn, or the searched rocBLAS / hipBLASLt solution of the
+    committed TunableOp table where that is faster on this box).  Algorithmic flops 2*M*N*K; bytes (M*N + M*K + N*K) * 4."""
+    from . import fused
+    M, N, K = B * 8 * base_points, 512, 5120
+    dy = torch.randn(M, N, device=device)
+    x = torch.randn(M, K, device=device)
+    L = _lib.lib()
+    if fused._weight_grad_pick(dy, x) is fused._TUNED:
+        tn = fused._TUNABLE["state"]
+
+        def run():
+            tn.enable(True)
+            dy.t().matmul(x)
+            tn.enable(False)
+        us = _time_us(run)
+        name = "searched library GEMM (dW of conv2's dense half, stage 4, M=%d N=%d K=%d; pdgn_gemm_tn: see others)" % (M, N, K)
+    else:
+        dw = torch.zeros(N, K, device=device)
+
+        def run():
+            dw.zero_()
+            check(L.pdgn_gemm_tn(ctypes.c_longlong(M), N, K, ptr(dy), ptr(x), ptr(dw), stream_of(dy)), "pdgn_gemm_tn")
+        us = _time_us(run) - _time_us(lambda: dw.zero_())
+        name = "gemm_tn_kernel (dW of conv2's dense half, stage 4, M=%d N=%d K=%d)" % (M, N, K)
+    e = _entry(name, "mfma", 2.0 * M * N * K, us, shape=[M, N, K])
+    e["algorithmic_bytes_per_launch"] = 4.0 * (M * N + M * K + N * K)
+    return e
+
+
+def gemm_tn_own(B, base_points, device):
+    """pdgn_gemm_tn itself at the same problem (the hand-written split-reduction kernel, whichever launcher the step
+    picked for it) -- the number to beat is the searched library solution's."""
     M, N, K = B * 8 * base_points, 512, 5120
     dy = torch.randn(M, N, device=device)
     x = torch.randn(M, K, device=device)
@@ -61,10 +92,8 @@ def gemm_tn_stage4(B, base_points, device):
     def run():
         dw.zero_()
         check(L.pdgn_gemm_tn(ctypes.c_longlong(M), N, K, ptr(dy), ptr(x), ptr(dw), stream_of(dy)), "pdgn_gemm_tn")
-    us = _time_us(run)
-    z = _time_us(lambda: dw.zero_())
-    e = _entry("gemm_tn_kernel (dW of conv2's dense half, stage 4, M=%d N=%d K=%d)" % (M, N, K), "mfma",
-               2.0 * M * N * K, us - z, shape=[M, N, K])
+    us = _time_us(run) - _time_us(lambda: dw.zero_())
+    e = _entry("pdgn_gemm_tn, hand-written (same problem, M=%d N=%d K=%d)" % (M, N, K), "mfma", 2.0 * M * N * K, us, shape=[M, N, K])
     e["algorithmic_bytes_per_launch"] = 4.0 * (M * N + M * K + N * K)
     return e
 
@@ -148,12 +177,12 @@ def knn3_largest(B, base_points, device):
     return e
 
 
-ENTRIES = (gemm_tn_stage4, bn_act_backward_stage4, window_gather_sum_stage4, feature_knn_stage4, knn3_largest)
+ENTRIES = (weight_grad_stage4, gemm_tn_own, bn_act_backward_stage4, window_gather_sum_stage4, feature_knn_stage4, knn3_largest)
 
 
 def measure(B, base_points, device):
-    """Roofline object of the dominant hand-written kernel of the step (largest share of the
-    step's kernel time in profiles/: gemm_tn_kernel) with the runners-up under "others"."""
+    """Roofline object of the dominant kernel of the step -- its largest single contraction, the stage-4 weight gradient
+    of conv2's dense half, as the step launches it -- with the hand-written kernels under "others"."""
     entries = [f(B, base_points, device) for f in ENTRIES]
     try:
         with open(_TRAFFIC) as f:

@@ -13,6 +13,8 @@ import csv, glob, json, os, sys
 
 KERNELS = {   # roofline entry prefix -> (kernel-name substrings, FETCH_SIZE correction)
     "gemm_tn_kernel": (["gemm_tn_kernel"], 2.0),
+    "pdgn_gemm_tn, hand-written": (["gemm_tn_kernel"], 2.0),
+    "searched library GEMM": (["Cijk_"], 2.0),
     "cl_bwd_reduce + cl_bwd_apply": (["cl_bwd_reduce_kernel", "cl_bwd_apply_kernel"], 2.0),
     "wgs_fwd_xcd_kernel": (["wgs_fwd_xcd_kernel"], 2.0),
     "feat_knn_pc_kernel<128>": (["feat_knn_pc_kernel"], 2.0),
