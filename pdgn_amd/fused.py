@@ -333,9 +333,10 @@ def _weight_grad_pick(dy, x):
 
 class LinearCL(Function):
     """y = x @ W^T (+ b) for point-major rows x (M, C_in).  Forward and the input gradient are
-    library GEMMs (they already run at 105-140 TFLOP/s on these shapes); the weight gradient
-    dW = dy^T x -- a reduction over 10^4..10^5.5 rows with a small output, which the library does
-    not split -- runs on the hand-written split-reduction MFMA kernel pdgn_gemm_tn."""
+    library GEMMs (105-147 TFLOP/s on the large shapes, see _library_gemm); the weight gradient
+    dW = dy^T x -- a reduction over 10^4..10^5.5 rows with a small output, which the library's
+    heuristics do not split -- runs on the hand-written split-reduction MFMA kernel pdgn_gemm_tn,
+    or on a searched library solution where the committed table holds a faster one (_weight_grad_pick)."""
 
     @staticmethod
     def forward(ctx, x, weight, bias):
