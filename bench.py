@@ -124,8 +124,7 @@ def main():
         except Exception as e:                 # a capture problem must not lose the measurement
             print("hipGraph capture failed (%r): running eagerly" % (e,), file=sys.stderr)
             torch.cuda.synchronize()
-    # Two untimed priming iterations ahead of the W warm-up steps: the first iteration times every large library GEMM
-    # shape under both BLAS back ends (fused._library_gemm) and grows the caching allocator's pools; they must never
+    # Two untimed priming iterations grow the caching allocator's pools and measure the stream-to-queue map; they must never
     # land in the timed region, whatever W the caller asks for.
     for _ in range(2):
         step(reals, *zs[0])

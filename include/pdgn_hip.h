@@ -220,13 +220,20 @@ int pdgn_softmax_slots_permute_backward(long long m, int k, int c, const float *
                                         float *dh, pdgn_stream_t stream);
 
 /* Dense contraction of a point-major layer on the fp32 matrix cores:
- *   C (m x n) = A (m x k) W (n x k)^T (+ bias[n]) (+ addend (m x n)),  all row-major, k % 4 == 0.
+ *   C (m x n, row pitch ldc) = A (m x k, pitch lda) W (n x k, pitch ldw)^T (+ bias[n]) (+ addend (m x n, pitch ldadd)),
+ * all row-major; n, k and every pitch are multiples of 4 floats, base pointers 16-byte aligned.
  * (The reference's Conv2d/Conv1d/Linear forward at models/PDGNet_v2.py:559-625, 835-862, 886-1014 in
- * point-major form; with W^T it is their input gradient.)  stat_part (may be NULL): ceil(m/128) rows of
- * [2n] floats = per-column sum | sum of squares of every 128-row block of C, the partials that
- * pdgn_bn_finalize turns into BatchNorm statistics. */
-int pdgn_gemm_nt(long long m, int n, int k, const float *A, const float *W, const float *bias,
-                 const float *addend, float *C, float *stat_part, pdgn_stream_t stream);
+ * point-major form; with the transposed weight it is their input gradient dX = dY W.)  stat_part (may be
+ * NULL): pdgn_gemm_nt_stat_rows(m, n, k) rows of [2n] floats = per-column sum | sum of squares of row
+ * blocks of C, the partials pdgn_bn_stats_from_gemm_partials turns into BatchNorm statistics.  Without
+ * stat_part and with ldc == n the launch may add partial tiles with fp32 atomics (C is zero-filled by the
+ * call itself where needed). */
+int pdgn_gemm_nt(long long m, int n, int k, const float *A, int lda, const float *W, int ldw,
+                 const float *bias, const float *addend, int ldadd, float *C, int ldc, float *stat_part,
+                 pdgn_stream_t stream);
+long long pdgn_gemm_nt_stat_rows(long long m, int n, int k);
+/* Tile configuration the launch model picks (0: 256x128, 1: 128x128, 2: 160x64, 3: 128x64 workgroup tiles); host only. */
+int pdgn_gemm_nt_config(long long m, int n, int k, int with_stats);
 
 /* Weight gradient of a point-major dense layer on the fp32 matrix cores, reduction split over
  * workgroups:  dW (n x k) += dY (m x n)^T  X (m x k), all row-major, m >> n, k.

@@ -1,151 +1,555 @@
-// gemm_nt.hip -- the dense contraction of the point-major layers on the fp32 matrix cores.
+// gemm_nt.hip -- the dense contractions of the point-major layers on the fp32 matrix cores.
 //
 //   C[m, n] = sum_k A[m, k] * W[n, k]  (+ bias[n]) (+ addend[m, n])        A (M x K), W (N x K) row-major
 //
-// i.e. rows x C_in @ (C_out x C_in)^T -- the shape of every conv / linear of the deconvolution
-// stack once activations are point-major (the per-point GEMM Y = X Wcat^T, conv_all, the
-// inte*w contraction of conv2, MLP heads, discriminators), and of their input gradients
-// dX = dY W (call it with W^T).  Optional epilogue: per-column partial sums / sums of squares of
-// the block's rows, so the BatchNorm that follows needs no statistics pass over C.
+// i.e. rows x C_in @ (C_out x C_in)^T -- every conv / linear of the deconvolution stack and of the
+// discriminators once activations are point-major (models/PDGNet_v2.py:559-625, 835-862, 886-1014), and,
+// called with the transposed weight, their input gradients dX = dY W.  Optional epilogue: per-column
+// partial sums / sums of squares of each row block, so the BatchNorm that follows needs no statistics pass.
 //
-// Tiling (wave64, v_mfma_f32_32x32x2_f32 = exact fp32 fma chains):
-//   * workgroup 256 threads = 2x2 waves, tile 128 x 128, K chunk 32; each wave 64 x 64 = 2x2
-//     accumulators of 32x32 (64 accumulator registers);
-//   * both operands are K-contiguous, so tiles are copied global -> LDS untransposed with float4
-//     loads/stores (row pitch 36 floats: conflict-free ds_read_b128);
-//   * a lane feeds FOUR consecutive MFMA k-steps from ONE ds_read_b128 per operand: lane (i, h)
-//     holds A[i][8q+4h .. 8q+4h+3]; step u multiplies element u of both operands -- the MFMA sums over
-//     k, so any assignment of k values to (step, half) is valid as long as A and B agree.
-//     16 MFMAs per 4 LDS reads;
-//   * the next K chunk is prefetched into registers while the current one is multiplied.
+// Structure (gfx950, wave64):
+//   * PERSISTENT workgroups: the grid is one or two workgroups per CU; each walks a sequence of work items
+//     (tile, k range) and streams ONE continuous sequence of 32-deep k chunks through a ring of LDS stages --
+//     the loads of the next item's first chunks are in flight while the current item finishes, so short
+//     reductions (K = 128: four chunks per tile) pay no pipeline fill per tile;
+//   * operands go global -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds, 16 B per lane, no staging
+//     registers, out-of-range rows / k columns read as zeros through the buffer descriptor); a chunk is
+//     [rows][32 floats] with the 16-B column of row r stored at position (col ^ (r & 7)) -- applied on the
+//     SOURCE address, the LDS image itself is lane-linear -- which makes every ds_read_b128 of the fragment
+//     reads bank-conflict-free;
+//   * one barrier per chunk; waits on the DMA are COUNTED (s_waitcnt vmcnt(n)): STAGES-1 chunks stay in
+//     flight across barriers and across the epilogue's stores;
+//   * v_mfma_f32_16x16x4_f32 (exact fp32 fma chains): a lane feeds four consecutive MFMA k-steps from ONE
+//     ds_read_b128 per operand row (lane (i, g) holds k = 16q + 4g + u for step u; A and W agree, and the
+//     MFMA sums over k, so the assignment of k values to (step, lane group) is free).  The weight rows are
+//     the MFMA's row operand, so a lane ends up with FOUR CONSECUTIVE output columns: one 16-B store each;
+//   * work decomposition by the host: whole tiles dealt round-robin over the workgroups ("data-parallel"
+//     launch, XCD-aware order: the workgroups of one XCD hold neighbouring tiles, which share operand panels
+//     in that XCD's L2), and, when the tile count does not fill the last round of CUs, the remaining tiles
+//     in a second launch that splits the flattened (tile, k chunk) space evenly ("stream-K" launch, partial
+//     tiles added with fp32 atomics into the zero-filled rows).
+#include <type_traits>
+
 #include "common.h"
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void lds_void_t;
 
-#define NT_THREADS 256
-#define NT_BM 128
-#define NT_BN 128
 #define NT_BK 32
-#define NT_LD 36
+#define NT_OOB 0x40000000u            // a byte offset past every tile descriptor (num_records < 2^30)
 
-__global__ __launch_bounds__(NT_THREADS) void gemm_nt_kernel(
-    long long M, int N, int K, const float *__restrict__ A, const float *__restrict__ W,
-    const float *__restrict__ bias, const float *__restrict__ addend, float *__restrict__ C,
-    float *__restrict__ stat_part) {
-    __shared__ float As[NT_BM][NT_LD];
-    __shared__ float Bs[NT_BN][NT_LD];
-    // blockIdx.x walks the N tiles fastest: consecutive workgroups share the same A rows (L2 reuse)
-    const int n0 = blockIdx.x * NT_BN;
-    const long long m0 = (long long)blockIdx.y * NT_BM;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wr = wave >> 1, wc = wave & 1;                 // wave's 64x64 quadrant
-    const int li = lane & 31, half = lane >> 5;
+typedef int i32x4 __attribute__((ext_vector_type(4)));
 
-    // staging: thread loads float4 (row r_ld + 32*i, k-offset k4), i = 0..3, for A and W
-    const int r_ld = tid >> 3, k4 = (tid & 7) * 4;
-    float4 pa[4], pb[4];
-    auto prefetch = [&](int kk) {
-        const bool kok = kk + k4 < K;                         // K % 4 == 0
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const long long m = m0 + r_ld + 32 * i;
-            const int n = n0 + r_ld + 32 * i;
-            pa[i] = (kok && m < M) ? *reinterpret_cast<const float4 *>(A + m * K + kk + k4) : make_float4(0.f, 0.f, 0.f, 0.f);
-            pb[i] = (kok && n < N) ? *reinterpret_cast<const float4 *>(W + (size_t)n * K + kk + k4) : make_float4(0.f, 0.f, 0.f, 0.f);
+// Buffer descriptor (raw, stride 0): offsets >= bytes read as zero / are not written.
+__device__ __forceinline__ i32x4 nt_srd(const void *base, unsigned bytes) {
+    const unsigned long long b = (unsigned long long)base;
+    i32x4 r;
+    r.x = __builtin_amdgcn_readfirstlane((int)(unsigned)b);
+    r.y = __builtin_amdgcn_readfirstlane((int)((unsigned)(b >> 32) & 0xffffu));
+    r.z = __builtin_amdgcn_readfirstlane((int)bytes);
+    r.w = 0x00020000;
+    return r;
+}
+
+// One LDS-DMA wave instruction: 64 lanes x 16 B, lane l -> LDS byte lds_base + 16 l, from descriptor offset
+// voff (per lane) + soff (scalar).  Issued as inline asm so that the compiler does not order every later LDS read
+// behind it with s_waitcnt vmcnt(0) -- the kernel counts these operations itself.
+__device__ __forceinline__ void nt_dma16(i32x4 srd, unsigned lds_base, unsigned voff, unsigned soff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                 :
+                 : "s"(lds_base), "v"(voff), "s"(srd), "s"(soff)
+                 : "memory", "m0");
+}
+
+struct NtArgs {
+    long long M;
+    int N, K, lda, ldw, ldc, ldadd;
+    const float *A, *W, *bias, *addend;
+    float *C, *stat_part;
+    int tiles_n, tile_begin, tile_end, kchunks;
+    long long sk_per_wg;              // stream-K launch: (tile, chunk) iterations per workgroup
+    int dbg;                          // PDGN_NT_DBG (measurement only): 1 no stores, 2 no DMA
+};
+
+template <int TM, int TN, int WM, int WN, bool ATOMIC>
+__global__ __launch_bounds__(64 * WM * WN, 2) void gemm_nt_kernel(const NtArgs p) {
+    constexpr int NW = WM * WN, BM = 16 * TM * WM, BN = 16 * TN * WN;
+    constexpr int STAGE_FLOATS = (BM + BN) * NT_BK;
+    constexpr int NPA = BM / 8 / NW, NPB = BN / 8 / NW, NP = NPA + NPB;   // 1-KB DMA pieces per wave and chunk
+    constexpr int NS = ATOMIC ? 0 : TM * TN;                              // counted stores per wave and item
+    static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "pieces must divide over the waves");
+    constexpr int STAGES = 2;
+    static_assert(4 * TM * TN >= 2 * NP, "a half chunk must have room for the DMA pieces between its MFMAs");
+    __shared__ __attribute__((aligned(1024))) float smem[STAGES * STAGE_FLOATS];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int li = lane & 15, lg = lane >> 4;
+
+    // XCD-aware decode of the 1-D grid: ids are dealt round-robin to the 8 XCDs; XCD x takes a contiguous range
+    const int G = gridDim.x, pid = blockIdx.x;
+    const int gq = G >> 3, gr = G & 7, xcd = pid & 7;
+    const int v = xcd * gq + min(xcd, gr) + (pid >> 3);
+
+    const int KC = p.kchunks;
+    // ---- work-item cursors (all scalar).  DP: item j = tile tile_begin + v + j*G.  SK: a flattened range.
+    struct Cur {
+        int tile, kb, kc, ke;       // current item: tile, first / next / end chunk
+        int j;                      // DP: next item index
+        long long f, f1;            // SK: next flattened position, end
+        bool valid;
+    };
+    auto next_item = [&](Cur &c) {
+        if (ATOMIC) {
+            c.valid = c.f < c.f1;
+            if (c.valid) {
+                c.tile = p.tile_begin + (int)(c.f / KC);
+                c.kc = c.kb = (int)(c.f % KC);
+                const long long left = c.f1 - c.f;
+                c.ke = (left < (long long)(KC - c.kc)) ? c.kc + (int)left : KC;
+                c.f += c.ke - c.kc;
+            }
+        } else {
+            c.tile = p.tile_begin + v + c.j * G;
+            c.valid = c.tile < p.tile_end;
+            c.kc = c.kb = 0;
+            c.ke = KC;
+            c.j++;
         }
     };
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    Cur ld, cp;
+    ld.j = 0;
+    ld.f = (long long)v * p.sk_per_wg;
+    {
+        const long long total = (long long)(p.tile_end - p.tile_begin) * KC;
+        ld.f1 = min(total, ld.f + p.sk_per_wg);
+    }
+    ld.tile = ld.kb = ld.kc = ld.ke = 0;
+    ld.valid = false;
+    next_item(ld);
+    cp = ld;
+    if (!ld.valid) return;
 
-    prefetch(0);
-    for (int kk = 0; kk < K; kk += NT_BK) {
-        __syncthreads();
+    // ---- per-lane constants of the DMA: piece i of a wave covers rows 8*(wave + i*NW) .. +7 of the A (then W) part
+    const int drow = lane >> 3;                                   // row inside the piece == (row & 7)
+    const int dcol = (lane & 7) ^ drow;                           // 16-B source column stored at position lane & 7
+    unsigned voffA[NPA], voffB[NPB];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            *reinterpret_cast<float4 *>(&As[r_ld + 32 * i][k4]) = pa[i];
-            *reinterpret_cast<float4 *>(&Bs[r_ld + 32 * i][k4]) = pb[i];
+    for (int i = 0; i < NPA; ++i) voffA[i] = (unsigned)(((wave + i * NW) * 8 + drow) * p.lda + dcol * 4) * 4u;
+#pragma unroll
+    for (int i = 0; i < NPB; ++i) voffB[i] = (unsigned)(((wave + i * NW) * 8 + drow) * p.ldw + dcol * 4) * 4u;
+
+    // descriptors of the load cursor's tile
+    i32x4 rsA, rsW;
+    auto make_srds = [&](int tile) {
+        const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
+        const long long m0 = (long long)tm * BM;
+        const int n0 = tn * BN;
+        const long long mrows = min((long long)BM, p.M - m0);
+        const int nrows = min(BN, p.N - n0);
+        rsA = nt_srd(p.A + m0 * p.lda, (unsigned)(mrows * p.lda * 4));
+        rsW = nt_srd(p.W + (long long)n0 * p.ldw, (unsigned)(nrows * p.ldw * 4));
+    };
+    make_srds(ld.tile);
+
+    const unsigned smem_base = (unsigned)(size_t)(lds_void_t *)smem;
+    // One DMA piece of the load cursor's chunk (i < NPA: activation rows, else weight rows) into `stage`.
+    int ld_k0 = 0;
+    bool ld_kok = true;
+    unsigned ld_dst = 0;
+    auto issue_begin = [&](int stage) {
+        ld_k0 = ld.kc * NT_BK;
+        ld_kok = ld_k0 + dcol * 4 < p.K;                           // K % 4 == 0: a 16-B column is all in or all out
+        ld_dst = smem_base + (unsigned)(stage * STAGE_FLOATS + wave * 256) * 4u;
+    };
+    auto issue_piece = [&](int i) {
+        if (p.dbg & 2) return;
+        if (i < NPA) nt_dma16(rsA, ld_dst + i * NW * 1024, ld_kok ? voffA[i < NPA ? i : 0] : NT_OOB, ld_k0 * 4);
+        else nt_dma16(rsW, ld_dst + BM * NT_BK * 4 + (i - NPA) * NW * 1024, ld_kok ? voffB[i < NPA ? 0 : i - NPA] : NT_OOB, ld_k0 * 4);
+    };
+    auto advance_load = [&]() {
+        ld.kc++;
+        if (ld.kc == ld.ke) {
+            next_item(ld);
+            if (ld.valid) make_srds(ld.tile);
         }
-        __syncthreads();
-        if (kk + NT_BK < K) prefetch(kk + NT_BK);
+    };
+
+    // ---- fragment read offsets (floats): row (li) * 32 + 4 * ((4q + lg) ^ (li & 7)), q = 0, 1
+    const int fo0 = li * NT_BK + 4 * ((lg) ^ (li & 7));
+    const int fo1 = li * NT_BK + 4 * ((4 + lg) ^ (li & 7));
+    const int abase = wm * 16 * TM * NT_BK, bbase = (BM + wn * 16 * TN) * NT_BK;
+
+    f32x4 acc[TM][TN];
 #pragma unroll
-        for (int q = 0; q < NT_BK / 8; ++q) {
-            float4 av[2], bv[2];
+    for (int a = 0; a < TM; ++a)
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                av[t] = *reinterpret_cast<const float4 *>(&As[wr * 64 + t * 32 + li][8 * q + 4 * half]);
-                bv[t] = *reinterpret_cast<const float4 *>(&Bs[wc * 64 + t * 32 + li][8 * q + 4 * half]);
+        for (int b = 0; b < TN; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float4 ra0[TM], rb0[TN], ra1[TM], rb1[TN];                     // fragments of the two 16-deep halves of a chunk
+    auto read_half = [&](int stage, int fo, float4 *ra, float4 *rb) {
+        const float *sa = smem + stage * STAGE_FLOATS + abase + fo;
+        const float *sb = smem + stage * STAGE_FLOATS + bbase + fo;
+#pragma unroll
+        for (int a = 0; a < TM; ++a) ra[a] = *reinterpret_cast<const float4 *>(sa + a * 16 * NT_BK);
+#pragma unroll
+        for (int b = 0; b < TN; ++b) rb[b] = *reinterpret_cast<const float4 *>(sb + b * 16 * NT_BK);
+    };
+    // ---- output of a finished item.  Direct mode: D row (4*lg + r) = weight row, D column li = activation row, so a lane
+    // holds 4 consecutive output columns of row li; the 16-B stores of item t are issued from INSIDE the first half chunk
+    // of item t+1 (store of accumulator (a, b), then the MFMA that restarts it from zero), where their issue time falls
+    // into the shadow of running MFMAs and no register is copied or zero-filled.
+    const int mloc0 = wm * 16 * TM + li, nloc0 = wn * 16 * TN + 4 * lg;
+    __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc((void *)p.C, 0, 0, 0x00020000);   // nothing pending: all out of range
+    unsigned st_off[TN];                                           // byte offset of (row mloc0, column block b), or out of range
+#pragma unroll
+    for (int b = 0; b < TN; ++b) st_off[b] = NT_OOB;
+    auto store_acc = [&](int a, int b) {
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[a][b]), rsC, st_off[b] + (unsigned)(a * 16 * p.ldc) * 4u, 0, 0);
+    };
+    // bias / addend / statistics on the finished accumulators (in place), descriptor + offsets of its stores
+    auto finish_item = [&]() {
+        const int tm = cp.tile / p.tiles_n, tn = cp.tile - tm * p.tiles_n;
+        const long long m0 = (long long)tm * BM;
+        const int n0 = tn * BN;
+        const long long mrows = min((long long)BM, p.M - m0);
+        const int ncols = min(BN, p.N - n0);
+        if (!ATOMIC) {
+            rsC = __builtin_amdgcn_make_buffer_rsrc((void *)(p.C + m0 * p.ldc + n0), 0, (int)(mrows * p.ldc * 4), 0x00020000);
+#pragma unroll
+            for (int b = 0; b < TN; ++b)
+                st_off[b] = (nloc0 + 16 * b < ncols && !(p.dbg & 1)) ? (unsigned)(mloc0 * p.ldc + nloc0 + 16 * b) * 4u : NT_OOB;
+            if (p.addend) {                                        // all tile loads in flight at once; out of range reads 0
+                __amdgpu_buffer_rsrc_t rsD = __builtin_amdgcn_make_buffer_rsrc((void *)(p.addend + m0 * p.ldadd + n0), 0,
+                                                                               (int)(mrows * p.ldadd * 4), 0x00020000);
+#pragma unroll
+                for (int b = 0; b < TN; ++b)
+#pragma unroll
+                    for (int a = 0; a < TM; ++a) {
+                        const int ml = mloc0 + 16 * a, nl = nloc0 + 16 * b;
+                        acc[a][b] += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                                 rsD, nl < ncols ? (unsigned)(ml * p.ldadd + nl) * 4u : NT_OOB, 0, 0));
+                    }
             }
+            if (p.bias) {
+                __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void *)(p.bias + n0), 0, ncols * 4, 0x00020000);
 #pragma unroll
-            for (int a = 0; a < 2; ++a)
+                for (int b = 0; b < TN; ++b) {
+                    const f32x4 bz = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, (unsigned)(nloc0 + 16 * b) * 4u, 0, 0));
 #pragma unroll
-                for (int b = 0; b < 2; ++b) {
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a].x, bv[b].x, acc[a][b], 0, 0, 0);
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a].y, bv[b].y, acc[a][b], 0, 0, 0);
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a].z, bv[b].z, acc[a][b], 0, 0, 0);
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a].w, bv[b].w, acc[a][b], 0, 0, 0);
+                    for (int a = 0; a < TM; ++a) acc[a][b] += bz;
                 }
+            }
+            if (p.stat_part) {
+                // per-column sum / sum of squares over the wave's rows: in registers over a, then over the 16 lanes of
+                // equal lg; one partial row of [2N] floats per (tile row, wave row)
+                float *P = p.stat_part + ((size_t)tm * WM + wm) * 2 * p.N;
+#pragma unroll
+                for (int b = 0; b < TN; ++b) {
+                    float cs[4] = {0.f, 0.f, 0.f, 0.f}, cq[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int a = 0; a < TM; ++a)
+                        if (mloc0 + 16 * a < mrows) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                cs[r] += acc[a][b][r];
+                                cq[r] = __fmaf_rn(acc[a][b][r], acc[a][b][r], cq[r]);
+                            }
+                        }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int d = 1; d < 16; d <<= 1) {
+                            cs[r] += __shfl_xor(cs[r], d, 64);
+                            cq[r] += __shfl_xor(cq[r], d, 64);
+                        }
+                    const int nl = nloc0 + 16 * b;
+                    if (li == 0 && nl < ncols) {
+                        *reinterpret_cast<float4 *>(P + n0 + nl) = make_float4(cs[0], cs[1], cs[2], cs[3]);
+                        *reinterpret_cast<float4 *>(P + p.N + n0 + nl) = make_float4(cq[0], cq[1], cq[2], cq[3]);
+                    }
+                }
+            }
+        } else {
+            // partial tile: D row (4*lg + r) = activation row, D column li = weight row (a register holds 16 consecutive
+            // columns of 4 rows: 64-B atomic segments).  The holder of the tile's first chunk adds the bias / addend.
+            const bool head = cp.kb == 0;
+            const int mla = wm * 16 * TM + 4 * lg, nla = wn * 16 * TN + li;
+#pragma unroll
+            for (int b = 0; b < TN; ++b) {
+                const int nl = nla + 16 * b;
+                const bool nok = nl < ncols;
+                const float bz = (head && p.bias && nok) ? p.bias[n0 + nl] : 0.f;
+#pragma unroll
+                for (int a = 0; a < TM; ++a)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int ml = mla + 16 * a + r;
+                        if (nok && ml < mrows) {
+                            float o = acc[a][b][r] + bz;
+                            if (head && p.addend) o += p.addend[(m0 + ml) * p.ldadd + n0 + nl];
+                            atomicAdd(p.C + (m0 + ml) * p.ldc + n0 + nl, o);
+                        }
+                    }
+            }
         }
-    }
-    // epilogue: D[row = (r&3) + 8*(r>>2) + 4*half][col = li]
-    float csum[2] = {0.f, 0.f}, csq[2] = {0.f, 0.f};
+    };
+
+    // The MFMAs of one 16-deep half chunk.
+    //   MODE 0: plain.
+    //   MODE 1: the NP pieces of the next refill are issued between them, one every (4 TM TN / NP) MFMAs: an LDS-DMA
+    //           instruction occupies the wave's issue for tens of cycles, which must fall into the shadow of a running
+    //           MFMA, not in front of the first one.
+    //   MODE 2: first half chunk of an item: every accumulator is stored (the previous item's result; out of range when
+    //           there is none) right before the MFMA that restarts it from zero.
+    auto mfma_half = [&](const float4 *ra, const float4 *rb, auto mode) {
+        constexpr int MODE = decltype(mode)::value;
+        constexpr int TOTAL = 4 * TM * TN, EVERY = TOTAL / NP;
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
-        const int n = n0 + wc * 64 + b * 32 + li;
-        const bool nok = n < N;
-        const float bz = (bias && nok) ? bias[n] : 0.f;
+        for (int u = 0; u < 4; ++u) {
 #pragma unroll
-        for (int a = 0; a < 2; ++a) {
+            for (int a = 0; a < TM; ++a) {
+                const float x = u == 0 ? ra[a].x : u == 1 ? ra[a].y : u == 2 ? ra[a].z : ra[a].w;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const long long m = m0 + wr * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (nok && m < M) {
-                    float v = acc[a][b][r] + bz;
-                    if (addend) v += addend[m * N + n];
-                    C[m * N + n] = v;
-                    csum[b] += v;
-                    csq[b] = __fmaf_rn(v, v, csq[b]);
+                for (int b = 0; b < TN; ++b) {
+                    const float w = u == 0 ? rb[b].x : u == 1 ? rb[b].y : u == 2 ? rb[b].z : rb[b].w;
+                    f32x4 c = acc[a][b];
+                    if (MODE == 2 && u == 0) {
+                        if (!ATOMIC) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            store_acc(a, b);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                        c = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    }
+                    acc[a][b] = ATOMIC ? __builtin_amdgcn_mfma_f32_16x16x4f32(x, w, c, 0, 0, 0)
+                                       : __builtin_amdgcn_mfma_f32_16x16x4f32(w, x, c, 0, 0, 0);
+                    const int idx = (u * TM + a) * TN + b;
+                    if (MODE == 1 && idx % EVERY == EVERY / 2 && idx / EVERY < NP) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        issue_piece(idx / EVERY);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 }
             }
         }
-    }
-    if (stat_part) {
-        // combine the two lane halves, then the two row-halves of the workgroup through LDS
-        __syncthreads();
-        float *red = &As[0][0];                               // reuse: [wr][2][128]
+    };
+    typedef std::integral_constant<int, 0> M0_t;
+    typedef std::integral_constant<int, 1> M1_t;
+    typedef std::integral_constant<int, 2> M2_t;
+
+    // ---- prologue: chunks 0 and 1 in flight, chunk 0 landed, its first half in registers
+    long long todo;                                                // chunks of this workgroup's sequence still to multiply
+    if (ATOMIC) todo = ld.f1 - (long long)v * p.sk_per_wg;
+    else todo = (long long)((p.tile_end - 1 - (p.tile_begin + v)) / G + 1) * KC;
+    issue_begin(0);
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            float s = csum[b] + __shfl_xor(csum[b], 32, 64);
-            float q = csq[b] + __shfl_xor(csq[b], 32, 64);
-            if (half == 0) {
-                const int cl = wc * 64 + b * 32 + li;
-                red[(wr * 2 + 0) * 128 + cl] = s;
-                red[(wr * 2 + 1) * 128 + cl] = q;
+    for (int i = 0; i < NP; ++i) issue_piece(i);
+    advance_load();
+    if (ld.valid) {
+        issue_begin(1);
+#pragma unroll
+        for (int i = 0; i < NP; ++i) issue_piece(i);
+        advance_load();
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP) : "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    read_half(0, fo0, ra0, rb0);
+    int stage = 0;
+    while (cp.valid) {
+        bool first = true;
+        for (;;) {
+            // (A) second half's fragments on their way while the first half is multiplied
+            read_half(stage, fo1, ra1, rb1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (first) mfma_half(ra0, rb0, M2_t());
+            else mfma_half(ra0, rb0, M0_t());
+            // (B) everyone has read this stage to the end, and the next chunk has landed everywhere: my own pieces
+            // (counted wait: only the stores of (A) were issued after them), then the barrier
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (first) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NS > 63 ? 63 : NS) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            // (C) next chunk's first half on its way, this stage refilled with the chunk after next, while the second
+            // half is multiplied
+            first = false;
+            todo--;
+            if (todo > 0) read_half(stage ^ 1, fo0, ra0, rb0);
+            if (ld.valid) {
+                issue_begin(stage);
+                mfma_half(ra1, rb1, M1_t());
+                advance_load();
+            } else {
+                mfma_half(ra1, rb1, M0_t());
             }
+            stage ^= 1;
+            cp.kc++;
+            if (cp.kc == cp.ke) break;
         }
-        __syncthreads();
-        if (tid < 128 && n0 + tid < N) {
-            float *P = stat_part + (size_t)blockIdx.y * 2 * N;
-            P[n0 + tid] = red[0 * 128 + tid] + red[2 * 128 + tid];
-            P[N + n0 + tid] = red[1 * 128 + tid] + red[3 * 128 + tid];
-        }
+        __builtin_amdgcn_sched_barrier(0);
+        finish_item();
+        __builtin_amdgcn_sched_barrier(0);
+        next_item(cp);
+    }
+    // the last item's result
+    if (!ATOMIC) {
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < TN; ++b) store_acc(a, b);
     }
 }
 
-// C (m x n) = A (m x k) W (n x k)^T (+ bias) (+ addend); k % 4 == 0.  stat_part (may be NULL):
-// ceil(m/128) rows of [2n] floats receiving the per-column sum / sum of squares of each 128-row block
-// (the layout pdgn_bn_finalize consumes).
-extern "C" int pdgn_gemm_nt(long long m, int n, int k, const float *A, const float *W, const float *bias,
-                            const float *addend, float *C, float *stat_part, pdgn_stream_t stream) {
-    if (m < 1 || n < 1 || k < 4 || k % 4) return PDGN_ERR_INVALID;
-    const long long gy = (m + NT_BM - 1) / NT_BM;
-    if (gy > 65535) return PDGN_ERR_INVALID;
-    dim3 grid(cdiv(n, NT_BN), (unsigned)gy);
-    hipLaunchKernelGGL(gemm_nt_kernel, grid, dim3(NT_THREADS), 0, (hipStream_t)stream, m, n, k, A, W, bias, addend, C,
-                       stat_part);
-    return pdgn_launch_status();
+// ------------------------------------------------------------------ host side
+struct NtDev {
+    int cus;
+};
+static int nt_cus() {
+    static int cached = 0;
+    if (!cached) {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1)
+            return 256;
+        cached = cus;
+    }
+    return cached;
+}
+
+template <int TM, int TN, int WM, int WN, int MAXWG>
+struct NtCfg {
+    static constexpr int BM = 16 * TM * WM, BN = 16 * TN * WN;
+    static constexpr int LDS = 2 * (BM + BN) * NT_BK * 4;
+    static constexpr int WG_PER_CU = (160 * 1024 / LDS) < MAXWG ? (160 * 1024 / LDS) : MAXWG;   // MAXWG: the register file's limit
+
+    // what the launch will do: tiles, slots, whether a stream-K tail follows the whole rounds
+    struct Plan {
+        int tiles_m, tiles_n, kchunks, grid_dp, dp_tiles, grid_sk;
+        long long sk_per_wg;
+        double cost;                                               // model: CU-time in units of one 16x16x32 MFMA block
+    };
+    static Plan plan(long long m, int n, int k, bool allow_sk) {
+        Plan pl;
+        pl.tiles_m = cdiv(m, BM);
+        pl.tiles_n = cdiv(n, BN);
+        pl.kchunks = cdiv(k, NT_BK);
+        const long long T = (long long)pl.tiles_m * pl.tiles_n;
+        const int cus = nt_cus(), slots = cus * WG_PER_CU;
+        const long long rounds = T / slots, tail = T - rounds * slots;
+        pl.dp_tiles = (int)T;
+        pl.grid_dp = (int)(T < slots ? T : slots);
+        pl.grid_sk = 0;
+        pl.sk_per_wg = 0;
+        // one tile on a CU of its own: its MFMA blocks + about two chunks' worth of fill / epilogue; narrow wave tiles
+        // re-read more per MFMA and pay more barriers per flop
+        const double tile = (double)(TM * TN * WM * WN) * (pl.kchunks + 2.0) * (TM * TN >= 16 ? 1.0 : 1.06);
+        // a partial last round of whole tiles leaves CUs idle for a whole tile time: split those tiles' (tile, chunk)
+        // space over every slot instead, when the reduction is long enough to amortise the atomics
+        if (allow_sk && tail > 0 && tail * 10 < (long long)slots * 9 && pl.kchunks >= 16) {
+            pl.dp_tiles = (int)(rounds * slots);
+            pl.grid_dp = rounds ? slots : 0;
+            const long long iters = tail * pl.kchunks;
+            pl.grid_sk = (int)(iters < slots ? iters : slots);
+            pl.sk_per_wg = (iters + pl.grid_sk - 1) / pl.grid_sk;
+            pl.grid_sk = (int)((iters + pl.sk_per_wg - 1) / pl.sk_per_wg);
+            pl.cost = tile * ((double)T / cus) + tile * 0.25;
+        } else {
+            // tiles per CU in the busiest CU (workgroups sharing a CU share its matrix cores)
+            const long long per_cu = (T + cus - 1) / cus;
+            const long long rounds_up = (T + slots - 1) / slots;
+            const long long busiest = per_cu > rounds_up * WG_PER_CU ? per_cu : (T >= slots ? rounds_up * WG_PER_CU : per_cu);
+            pl.cost = tile * (double)busiest;
+        }
+        return pl;
+    }
+
+    static int launch(long long m, int n, int k, const float *A, int lda, const float *W, int ldw, const float *bias,
+                      const float *addend, int ldadd, float *C, int ldc, float *stat_part, hipStream_t s) {
+        const bool allow_sk = stat_part == nullptr && ldc == n;
+        const Plan pl = plan(m, n, k, allow_sk);
+        NtArgs a;
+        a.M = m; a.N = n; a.K = k; a.lda = lda; a.ldw = ldw; a.ldc = ldc; a.ldadd = ldadd;
+        a.A = A; a.W = W; a.bias = bias; a.addend = addend; a.C = C; a.stat_part = stat_part;
+        a.tiles_n = pl.tiles_n; a.kchunks = pl.kchunks;
+        { const char *e = getenv("PDGN_NT_DBG"); a.dbg = e ? atoi(e) : 0; }
+        const long long T = (long long)pl.tiles_m * pl.tiles_n;
+        if (pl.grid_sk) {
+            // rows of the tail tiles start at tile row dp_tiles / tiles_n: zero them first (whole rows; the data-parallel
+            // launch overwrites its share of that tile row afterwards)
+            const long long r0 = (long long)(pl.dp_tiles / pl.tiles_n) * BM;
+            if (hipMemsetAsync(C + r0 * ldc, 0, (size_t)(m - r0) * ldc * sizeof(float), s) != hipSuccess) return pdgn_launch_status();
+        }
+        if (pl.grid_dp) {
+            a.tile_begin = 0; a.tile_end = pl.dp_tiles; a.sk_per_wg = 0;
+            hipLaunchKernelGGL((gemm_nt_kernel<TM, TN, WM, WN, false>), dim3(pl.grid_dp), dim3(64 * WM * WN), 0, s, a);
+        }
+        if (pl.grid_sk) {
+            a.tile_begin = pl.dp_tiles; a.tile_end = (int)T; a.sk_per_wg = pl.sk_per_wg;
+            hipLaunchKernelGGL((gemm_nt_kernel<TM, TN, WM, WN, true>), dim3(pl.grid_sk), dim3(64 * WM * WN), 0, s, a);
+        }
+        return pdgn_launch_status();
+    }
+};
+
+typedef NtCfg<4, 4, 4, 2, 1> NtBig;      // 256 x 128, 8 waves (96 KB): one workgroup per CU
+typedef NtCfg<4, 4, 2, 2, 2> NtSquare;   // 128 x 128, 4 waves (64 KB): two per CU
+typedef NtCfg<5, 2, 2, 2, 2> NtTall;     // 160 x 64, 4 waves (56 KB): two per CU; 35840 = 224 x 160
+typedef NtCfg<4, 2, 2, 2, 3> NtNarrow;   // 128 x 64, 4 waves (48 KB, < 168 registers): three per CU
+
+// Tile configuration for a problem: PDGN_NT_CFG (0-3, measurement only), else the cheapest by the launch model.
+static int nt_pick(long long m, int n, int k, bool stats) {
+    const char *e = getenv("PDGN_NT_CFG");
+    if (e && *e) return atoi(e);
+    const bool sk = !stats;
+    const double c[4] = {NtBig::plan(m, n, k, sk).cost, NtSquare::plan(m, n, k, sk).cost, NtTall::plan(m, n, k, sk).cost,
+                         NtNarrow::plan(m, n, k, sk).cost};
+    int best = 1;
+    for (int i = 0; i < 4; ++i)
+        if (c[i] < c[best] * 0.98) best = i;                        // the square tile unless another is clearly cheaper
+    return best;
+}
+
+static bool nt_args_ok(long long m, int n, int k, int lda, int ldw, int ldadd, int ldc, const float *addend) {
+    return m >= 1 && n >= 4 && k >= 4 && n % 4 == 0 && k % 4 == 0 && lda % 4 == 0 && ldw % 4 == 0 && ldc % 4 == 0 &&
+           lda >= k && ldw >= k && ldc >= n && (!addend || (ldadd % 4 == 0 && ldadd >= n)) && lda < (1 << 19) &&
+           ldw < (1 << 19) && ldc < (1 << 19) && (long long)cdiv(m, 128) * cdiv(n, 64) < 0x7fffffffLL;
+}
+
+// C (m x n, row pitch ldc) = A (m x k, pitch lda) W (n x k, pitch ldw)^T (+ bias[n]) (+ addend (m x n, pitch ldadd)).
+// n, k and every pitch are multiples of 4 floats and all base pointers 16-byte aligned.  stat_part (may be NULL):
+// pdgn_gemm_nt_stat_rows(m, n, k) rows of [2n] floats = per-column sum | sum of squares of row blocks of C.
+extern "C" int pdgn_gemm_nt(long long m, int n, int k, const float *A, int lda, const float *W, int ldw,
+                            const float *bias, const float *addend, int ldadd, float *C, int ldc, float *stat_part,
+                            pdgn_stream_t stream) {
+    if (!nt_args_ok(m, n, k, lda, ldw, ldadd, ldc, addend)) return PDGN_ERR_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    switch (nt_pick(m, n, k, stat_part != nullptr)) {
+        case 0: return NtBig::launch(m, n, k, A, lda, W, ldw, bias, addend, ldadd, C, ldc, stat_part, s);
+        case 2: return NtTall::launch(m, n, k, A, lda, W, ldw, bias, addend, ldadd, C, ldc, stat_part, s);
+        case 3: return NtNarrow::launch(m, n, k, A, lda, W, ldw, bias, addend, ldadd, C, ldc, stat_part, s);
+        default: return NtSquare::launch(m, n, k, A, lda, W, ldw, bias, addend, ldadd, C, ldc, stat_part, s);
+    }
+}
+
+// Number of [2n] partial-statistics rows pdgn_gemm_nt writes for this problem (tile rows x waves along m).
+extern "C" long long pdgn_gemm_nt_stat_rows(long long m, int n, int k) {
+    if (m < 1 || n < 1 || k < 1) return PDGN_ERR_INVALID;
+    switch (nt_pick(m, n, k, true)) {
+        case 0: return (long long)cdiv(m, NtBig::BM) * 4;
+        case 2: return (long long)cdiv(m, NtTall::BM) * 2;
+        case 3: return (long long)cdiv(m, NtNarrow::BM) * 2;
+        default: return (long long)cdiv(m, NtSquare::BM) * 2;
+    }
+}
+
+// Tile configuration pdgn_gemm_nt picks for a problem (0: 256x128, 1: 128x128, 2: 160x64, 3: 128x64); host-side only.
+extern "C" int pdgn_gemm_nt_config(long long m, int n, int k, int with_stats) {
+    if (m < 1 || n < 1 || k < 1) return PDGN_ERR_INVALID;
+    return nt_pick(m, n, k, with_stats != 0);
 }

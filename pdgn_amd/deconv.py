@@ -399,7 +399,7 @@ class PointDeconv(nn.Module):
         else:
             # inte = LeakyReLU(BN(inte_pre))  (:637)
             inte = bn_act(inte_pre.view(-1, 4 * Fi), self.inte_conv_hk[1], training, partials=part_i)
-        out_pre = a_pre.view(B * N, 2 * Fo) + linear_cl(inte.view(B * N, P * 4 * Fi), Wb)
+        out_pre = linear_cl(inte.view(B * N, P * 4 * Fi), Wb, None, a_pre.view(B * N, 2 * Fo))    # sum in the GEMM's epilogue
         out = bn_act(out_pre, self.conv2.bn, training, act="relu")     # (B*N, 2Fo): channel 2c+j
         # (B,2Fout,N,1) -> view(B,Fout,2,N) -> (B,Fout,2N) (:645-647): point j*N+n of channel c is conv
         # channel 2c+j at point n; in point-major form that is (B, 2, N, Fout) -> (B, 2N, Fout)

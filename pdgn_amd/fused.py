@@ -1,7 +1,6 @@
 """Autograd wrappers of the fused channels-last kernels of libpdgn_hip.so (bnact.hip)."""
 import ctypes
 import os
-import warnings
 import weakref
 
 import torch
@@ -191,195 +190,103 @@ def bn_act(x2d, bn, training, act="leaky_relu", mul=None, pre_bias=None, partial
                          ACT[act], mul, pre_bias, partials)
 
 
-# PyTorch-ROCm ships two GEMM back ends (rocBLAS, hipBLASLt) and neither wins everywhere on the step's fp32
-# shapes (tools/blas_pref.py: rows x 64 @ 64 x 512 runs 232 us under rocBLAS and 334 us under hipBLASLt, while the
-# NN-form input gradients of the thin layers are 2-3x faster under hipBLASLt).  Large library GEMMs are therefore
-# timed once per (form, shape) under both back ends -- three launches each, during the first iteration -- and the
-# winner is selected before every later call (a host-side flag, no device work).
-_BLAS = {"choice": {}, "tune": os.environ.get("PDGN_BLAS_TUNE", "1") == "1", "default": None}
-warnings.filterwarnings("ignore", message=".*preferred_blas_library is an experimental feature.*")
-_BLAS_MIN_ROWS = 4096
+# ---------------------------------------------------------------------------------------------------------------
+# Dense layers on point-major rows.  Every contraction with >= _OWN_MIN_ROWS rows runs on the hand-written fp32-MFMA
+# kernels of libpdgn_hip.so: forward y = x W^T and input gradient dx = dy W on pdgn_gemm_nt (csrc/gemm_nt.hip: the
+# second with the transposed weight as its "W"), the weight gradient dW = dy^T x on pdgn_gemm_tn (csrc/gemm_tn.hip).
+# No BLAS library, no run-time back-end selection.  Below that row count (the 35-row per-sample layers) torch's
+# default matmul is used as it is.
+_OWN_MIN_ROWS = 1024
 
 
-def _timed(fn):
-    fn()
-    torch.cuda.synchronize()                 # quiesce the other streams of the overlapped schedule: time in isolation
-    best = float("inf")
-    for _ in range(2):                       # best of two rounds of five: a stray stall must not decide a pick
-        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        s.record()
-        for _ in range(5):
-            fn()
-        e.record()
-        e.synchronize()
-        best = min(best, s.elapsed_time(e))
-    return best
+def _pad_cols(t, mult=4):
+    """(rows, c) -> contiguous (rows, ceil(c / mult) * mult), zero-padded; t itself when nothing has to change."""
+    c = t.shape[1]
+    if c % mult == 0 and t.stride(1) == 1 and t.stride(0) % 4 == 0 and t.data_ptr() % 16 == 0:
+        return t
+    if c % mult == 0:
+        return t.contiguous()
+    return torch.nn.functional.pad(t, (0, mult - c % mult)).contiguous()
 
 
-# Third candidate for the LARGE shapes: torch's TunableOp, i.e. the best of ALL rocBLAS / hipBLASLt solutions for that
-# exact problem instead of each library's heuristic pick (conv2's dense contraction: 1.38 -> 1.28 ms = 146 TFLOP/s, its
-# input gradient 1.47 -> 1.28 ms).  Searching takes 1-13 s per shape, so it is done offline (tools/tune_gemms.py, on an
-# MI355X) and the table is committed (pdgn_amd/tunableop_gfx950.csv); at run time the table is only READ -- TunableOp
-# checks its validators (torch / ROCm / hipBLASLt versions, gfx arch) and ignores a table from another build, in which
-# case this candidate is the heuristic pick again and never wins.  TunableOp is switched on around the calls it won.
-_TUNED = "tuned"
-_TUNABLE = {"state": None, "min_flops": 0.0}
-_TUNABLE_TABLE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tunableop_gfx950.csv")
+def gemm_nt(a, w, bias=None, addend=None, want_stats=False):
+    """a (m, k) @ w (n, k)^T (+ bias) (+ addend) on pdgn_gemm_nt.  Channel counts that are not multiples of 4 (the xyz
+    layers: k = 3, the heads' last conv: n = 3) are zero-padded for the launch.  want_stats: also returns the BatchNorm
+    partial sums of the result ((parts, 2n) fp32: per-column sum | sum of squares of row blocks)."""
+    m, k = a.shape
+    n = w.shape[0]
+    ap, wp = _pad_cols(a), _pad_cols(w)
+    kp = ap.shape[1]
+    np_ = (n + 3) // 4 * 4
+    if np_ != n:
+        wp = torch.nn.functional.pad(wp, (0, 0, 0, np_ - n))
+        bias = torch.nn.functional.pad(bias, (0, np_ - n)) if bias is not None else None
+        addend = torch.nn.functional.pad(addend, (0, np_ - n)) if addend is not None else None
+    if addend is not None:
+        addend = _pad_cols(addend)
+    L = _lib.lib()
+    out = torch.empty((m, np_), dtype=F32, device=a.device)
+    part = None
+    if want_stats:
+        L.pdgn_gemm_nt_stat_rows.restype = ctypes.c_longlong
+        part = torch.empty((L.pdgn_gemm_nt_stat_rows(ctypes.c_longlong(m), np_, kp), 2 * np_), dtype=F32, device=a.device)
+    b = bias.detach().contiguous() if bias is not None else None
+    check(L.pdgn_gemm_nt(ctypes.c_longlong(m), np_, kp, ptr(ap), ap.stride(0), ptr(wp), wp.stride(0), ptr(b), ptr(addend),
+                         addend.stride(0) if addend is not None else 0, ptr(out), np_, ptr(part), stream_of(a)),
+          "pdgn_gemm_nt")
+    if np_ != n:
+        out = out[:, :n].contiguous()
+    return (out, part) if want_stats else out
 
 
-def _tunable():
-    """torch.cuda.tunable with the committed table loaded (None when unavailable / PDGN_BLAS_TUNABLE=0)."""
-    if _TUNABLE["state"] is None:
-        _TUNABLE["state"] = False
-        if os.environ.get("PDGN_BLAS_TUNABLE", "1") == "1":
-            try:
-                import torch.cuda.tunable as tn
-                searching = os.environ.get("PDGN_BLAS_TUNABLE_SEARCH") == "1"      # tools/tune_gemms.py only
-                tn.enable(True)                                   # the C++ context reads files only while enabled
-                tn.tuning_enable(searching)
-                ok = searching or (os.path.exists(_TUNABLE_TABLE) and tn.read_file(_TUNABLE_TABLE))
-                tn.enable(False)
-                if ok:
-                    _TUNABLE["state"] = tn
-            except Exception:                                     # no TunableOp in this torch build: two candidates
-                _TUNABLE["state"] = False
-    return _TUNABLE["state"] or None
-
-
-def _library_gemm(form, a, b, bias=None):
-    """form 'nt': a @ b^T (+ bias) = F.linear(a, b, bias); form 'nn': a @ b."""
-    if not (_BLAS["tune"] and a.is_cuda and a.shape[0] >= _BLAS_MIN_ROWS):
-        return torch.nn.functional.linear(a, b, bias) if form == "nt" else a.matmul(b)
-    key = (form, a.shape, b.shape, a.is_contiguous(), b.is_contiguous())
-    pick = _BLAS["choice"].get(key)
-    setpref = torch._C._set_blas_preferred_backend
-    run = (lambda: torch.nn.functional.linear(a, b, bias)) if form == "nt" else (lambda: a.matmul(b))
-    if pick is None:
-        if torch.cuda.is_current_stream_capturing():
-            return run()
-        if _BLAS["default"] is None:
-            _BLAS["default"] = torch._C._get_blas_preferred_backend()
-            with warnings.catch_warnings():                     # one-time "experimental feature" notice
-                warnings.simplefilter("ignore")
-                setpref(_BLAS["default"])
-        times = {}
-        lt, rb = torch._C._BlasBackend.Cublaslt, torch._C._BlasBackend.Cublas
-        with torch.no_grad():
-            for lib in (lt, rb):
-                setpref(lib)
-                times[lib] = _timed(run)
-            setpref(_BLAS["default"])
-            tn = _tunable() if 2.0 * a.shape[0] * a.shape[1] * b.shape[0 if form == "nt" else 1] >= _TUNABLE["min_flops"] else None
-            if tn is not None:
-                tn.enable(True)
-                times[_TUNED] = _timed(run)
-                tn.enable(False)
-        # hipBLASLt is torch's default here; rocBLAS has to win clearly (the first iteration's timings are noisy:
-        # other streams are busy) to replace it, and a searched solution has to beat both
-        pick = rb if times[rb] < 0.92 * times[lt] else lt
-        if _TUNED in times and times[_TUNED] < 0.96 * times[pick]:
-            pick = _TUNED
-        _BLAS["choice"][key] = pick
-        if os.environ.get("PDGN_BLAS_LOG") == "1":
-            print("blas %s %s x %s bias=%s: hipblaslt %.3f ms rocblas %.3f ms%s -> %s" % (
-                form, tuple(a.shape), tuple(b.shape), bias is not None, times[lt] / 5, times[rb] / 5,
-                " searched %.3f ms" % (times[_TUNED] / 5) if _TUNED in times else "", pick), flush=True)
-    if pick is _TUNED:
-        tn = _TUNABLE["state"]
-        tn.enable(True)
-        out = run()
-        tn.enable(False)
-        return out
-    setpref(pick)
-    out = run()
-    setpref(_BLAS["default"])
-    return out
-
-
-_TN_CHOICE = {}
-_TN_MIN_FLOPS = 4e9
-
-
-def _weight_grad_pick(dy, x):
-    """pdgn_gemm_tn or a searched library solution for dW = dy^T x?  Decided once per shape, for the large shapes the
-    committed TunableOp table covers (the library's HEURISTIC picks for this form run at 22-89 TFLOP/s -- the reason
-    pdgn_gemm_tn exists; its best solution for conv2's dense half reaches 145 TFLOP/s against pdgn_gemm_tn's 125)."""
+def gemm_tn(dy, x):
+    """dy (m, n)^T @ x (m, k) -> (n, k) on pdgn_gemm_tn (reduction over the rows split over workgroups)."""
     m, n = dy.shape
     k = x.shape[1]
-    key = (m, n, k, x.is_contiguous())
-    pick = _TN_CHOICE.get(key)
-    if pick is None:
-        if torch.cuda.is_current_stream_capturing():
-            return "own"
-        pick = "own"
-        tn = _tunable() if (2.0 * m * n * k >= _TN_MIN_FLOPS and n % 4 == 0 and k % 4 == 0 and x.is_contiguous()) else None
-        if tn is not None:
-            out = torch.zeros((n, k), dtype=F32, device=dy.device)
-            L = _lib.lib()
-            with torch.no_grad():
-                t_own = _timed(lambda: check(L.pdgn_gemm_tn(ctypes.c_longlong(m), n, k, ptr(dy), ptr(x), ptr(out), stream_of(dy)),
-                                             "pdgn_gemm_tn"))
-                tn.enable(True)
-                t_lib = _timed(lambda: dy.t().matmul(x))
-                tn.enable(False)
-            if t_lib < 0.95 * t_own:
-                pick = _TUNED
-            if os.environ.get("PDGN_BLAS_LOG") == "1":
-                print("blas tn (%d, %d)^T x (%d, %d): pdgn_gemm_tn %.3f ms searched library %.3f ms -> %s" % (
-                    m, n, m, k, t_own / 5, t_lib / 5, pick), flush=True)
-        _TN_CHOICE[key] = pick
-    return pick
+    dyp, xp = _pad_cols(dy), _pad_cols(x)
+    if dyp.stride(0) != dyp.shape[1]:
+        dyp = dyp.contiguous()
+    if xp.stride(0) != xp.shape[1]:
+        xp = xp.contiguous()
+    dwp = _zeros((dyp.shape[1], xp.shape[1]), dy.device)
+    check(_lib.lib().pdgn_gemm_tn(ctypes.c_longlong(m), dyp.shape[1], xp.shape[1], ptr(dyp), ptr(xp), ptr(dwp),
+                                  stream_of(dy)), "pdgn_gemm_tn")
+    return dwp if (dyp.shape[1] == n and xp.shape[1] == k) else dwp[:n, :k]
 
 
 class LinearCL(Function):
-    """y = x @ W^T (+ b) for point-major rows x (M, C_in).  Forward and the input gradient are
-    library GEMMs (105-147 TFLOP/s on the large shapes, see _library_gemm); the weight gradient
-    dW = dy^T x -- a reduction over 10^4..10^5.5 rows with a small output, which the library's
-    heuristics do not split -- runs on the hand-written split-reduction MFMA kernel pdgn_gemm_tn,
-    or on a searched library solution where the committed table holds a faster one (_weight_grad_pick)."""
+    """y = x @ W^T (+ b) (+ addend) for point-major rows x (M, C_in): the reference's Conv2d / Conv1d / Linear layers
+    (models/PDGNet_v2.py:559-625, 835-862, 886-1014) as row-matrix products on the hand-written MFMA kernels (see above)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, addend):
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
-        return _library_gemm("nt", x, weight, bias)
+        ctx.has_addend = addend is not None
+        if x.is_cuda and x.shape[0] >= _OWN_MIN_ROWS:
+            return gemm_nt(x, weight, bias, addend)
+        y = torch.nn.functional.linear(x, weight, bias)
+        return y + addend if addend is not None else y
 
     @staticmethod
     def backward(ctx, dy):
         x, weight = ctx.saved_tensors
-        zero_db = has_zero_colsum(dy)
+        zero_db = ctx.has_bias and ctx.needs_input_grad[2] and has_zero_colsum(dy)
         dy = dy.contiguous()
-        dx = _library_gemm("nn", dy, weight) if ctx.needs_input_grad[0] else None
-        dw = None
+        own = dy.is_cuda and dy.shape[0] >= _OWN_MIN_ROWS
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = gemm_nt(dy, weight.t().contiguous()) if own else dy.matmul(weight)
         if ctx.needs_input_grad[1]:
-            m, n = dy.shape
-            k = x.shape[1]
-            if m >= 1024 and _weight_grad_pick(dy, x) is _TUNED:
-                tn = _TUNABLE["state"]                             # a searched library solution wins on this shape
-                tn.enable(True)
-                dw = dy.t().matmul(x)
-                tn.enable(False)
-            elif m >= 1024:
-                # pdgn_gemm_tn wants channel counts in multiples of 4: the xyz input layers (k = 3) and the MLP heads'
-                # last conv (n = 3) are zero-padded to 4 (a 3-row output handed to the library is a 3-workgroup
-                # GEMM over 10^4..10^5 rows: ~250 us)
-                dyp = dy if n % 4 == 0 else torch.nn.functional.pad(dy, (0, 4 - n % 4))
-                xp = x if (k % 4 == 0 and x.is_contiguous()) else torch.nn.functional.pad(x, (0, (4 - k % 4) % 4)).contiguous()
-                dwp = _zeros((dyp.shape[1], xp.shape[1]), dy.device)
-                check(_lib.lib().pdgn_gemm_tn(ctypes.c_longlong(m), dyp.shape[1], xp.shape[1], ptr(dyp), ptr(xp), ptr(dwp),
-                                              stream_of(dy)), "pdgn_gemm_tn")
-                dw = dwp if (dyp is dy and xp.shape[1] == k) else dwp[:n, :k]
-            else:
-                dw = dy.t().matmul(x)
-        db = None
+            dw = gemm_tn(dy, x) if own else dy.t().matmul(x)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = _zeros((dy.shape[1],), dy.device) if zero_db else dy.sum(dim=0)
-        return dx, dw, db
+        return dx, dw, db, (dy if ctx.has_addend and ctx.needs_input_grad[3] else None)
 
 
-def linear_cl(x2d, weight, bias=None):
-    """Dense layer on point-major rows (see LinearCL)."""
-    return LinearCL.apply(x2d, weight, bias)
+def linear_cl(x2d, weight, bias=None, addend=None):
+    """Dense layer on point-major rows (see LinearCL); `addend` (M, C_out) is added in the GEMM's epilogue."""
+    return LinearCL.apply(x2d, weight, bias, addend)
 
 
 class SoftmaxSlotsPermute(Function):

@@ -48,41 +48,41 @@ def _entry(name, bound, work, us, **extra):
     return d
 
 
-def weight_grad_stage4(B, base_points, device):
-    """The largest single contraction of the step's backward: conv2's dense half at stage 4, dW (512 x 5120) = dY^T (inte*w)
-    over M = B * 8*base rows (N = 2*Fout, K = 5 positions * 4F), launched the way the step launches it
-    (fused._weight_grad_pick: the hand-written pdgn_gemm_tn, or the searched rocBLAS / hipBLASLt solution of the
-    committed TunableOp table where that is faster on this box).  Algorithmic flops 2*M*N*K; bytes (M*N + M*K + N*K) * 4."""
-    from . import fused
-    M, N, K = B * 8 * base_points, 512, 5120
-    dy = torch.randn(M, N, device=device)
-    x = torch.randn(M, K, device=device)
+def _nt_entry(label, M, N, K, device):
+    a = torch.randn(M, K, device=device)
+    w = torch.randn(N, K, device=device)
+    c = torch.empty(M, N, device=device)
     L = _lib.lib()
-    if fused._weight_grad_pick(dy, x) is fused._TUNED:
-        tn = fused._TUNABLE["state"]
 
-        def run():
-            tn.enable(True)
-            dy.t().matmul(x)
-            tn.enable(False)
-        us = _time_us(run)
-        name = "searched library GEMM (dW of conv2's dense half, stage 4, M=%d N=%d K=%d; pdgn_gemm_tn: see others)" % (M, N, K)
-    else:
-        dw = torch.zeros(N, K, device=device)
-
-        def run():
-            dw.zero_()
-            check(L.pdgn_gemm_tn(ctypes.c_longlong(M), N, K, ptr(dy), ptr(x), ptr(dw), stream_of(dy)), "pdgn_gemm_tn")
-        us = _time_us(run) - _time_us(lambda: dw.zero_())
-        name = "gemm_tn_kernel (dW of conv2's dense half, stage 4, M=%d N=%d K=%d)" % (M, N, K)
-    e = _entry(name, "mfma", 2.0 * M * N * K, us, shape=[M, N, K])
+    def run():
+        check(L.pdgn_gemm_nt(ctypes.c_longlong(M), N, K, ptr(a), K, ptr(w), K, None, None, 0, ptr(c), N, None, stream_of(a)),
+              "pdgn_gemm_nt")
+    us = _time_us(run)
+    e = _entry("gemm_nt_kernel (%s, M=%d N=%d K=%d)" % (label, M, N, K), "mfma", 2.0 * M * N * K, us, shape=[M, N, K])
     e["algorithmic_bytes_per_launch"] = 4.0 * (M * N + M * K + N * K)
     return e
 
 
-def gemm_tn_own(B, base_points, device):
-    """pdgn_gemm_tn itself at the same problem (the hand-written split-reduction kernel, whichever launcher the step
-    picked for it) -- the number to beat is the searched library solution's."""
+def conv2_dense_stage4(B, base_points, device):
+    """The largest single contraction of the step: conv2's dense half at stage 4 (models/PDGNet_v2.py:644 after the
+    re-association of DESIGN.md section 3), out (M x 512) = (inte*w) (M x 5120) Wb^T over M = B * 8*base rows, on
+    pdgn_gemm_nt.  Algorithmic flops 2*M*N*K; bytes (M*N + M*K + N*K) * 4."""
+    return _nt_entry("conv2 dense half forward, stage 4", B * 8 * base_points, 512, 5120, device)
+
+
+def per_point_stage4(B, base_points, device):
+    """The per-point GEMM of stage 4: Y (M x 12832) = X (M x 128) Wcat^T, all taps of inte_conv_hk / conv2 / conv_fea."""
+    return _nt_entry("per-point GEMM, stage 4", B * 8 * base_points, 12832, 128, device)
+
+
+def conv2_dense_dx_stage4(B, base_points, device):
+    """Input gradient of conv2's dense half: d(inte*w) (M x 5120) = dout (M x 512) Wb (512 x 5120) -- pdgn_gemm_nt with Wb^T."""
+    return _nt_entry("conv2 dense half input gradient, stage 4", B * 8 * base_points, 5120, 512, device)
+
+
+def weight_grad_stage4(B, base_points, device):
+    """conv2's dense half weight gradient at stage 4, dW (512 x 5120) = dY^T (inte*w) over M = B * 8*base rows, on
+    pdgn_gemm_tn (split row reduction)."""
     M, N, K = B * 8 * base_points, 512, 5120
     dy = torch.randn(M, N, device=device)
     x = torch.randn(M, K, device=device)
@@ -93,7 +93,8 @@ def gemm_tn_own(B, base_points, device):
         dw.zero_()
         check(L.pdgn_gemm_tn(ctypes.c_longlong(M), N, K, ptr(dy), ptr(x), ptr(dw), stream_of(dy)), "pdgn_gemm_tn")
     us = _time_us(run) - _time_us(lambda: dw.zero_())
-    e = _entry("pdgn_gemm_tn, hand-written (same problem, M=%d N=%d K=%d)" % (M, N, K), "mfma", 2.0 * M * N * K, us, shape=[M, N, K])
+    e = _entry("gemm_tn_kernel (dW of conv2's dense half, stage 4, M=%d N=%d K=%d)" % (M, N, K), "mfma", 2.0 * M * N * K, us,
+               shape=[M, N, K])
     e["algorithmic_bytes_per_launch"] = 4.0 * (M * N + M * K + N * K)
     return e
 
@@ -177,12 +178,13 @@ def knn3_largest(B, base_points, device):
     return e
 
 
-ENTRIES = (weight_grad_stage4, gemm_tn_own, bn_act_backward_stage4, window_gather_sum_stage4, feature_knn_stage4, knn3_largest)
+ENTRIES = (conv2_dense_stage4, per_point_stage4, conv2_dense_dx_stage4, weight_grad_stage4, bn_act_backward_stage4,
+           window_gather_sum_stage4, feature_knn_stage4, knn3_largest)
 
 
 def measure(B, base_points, device):
-    """Roofline object of the dominant kernel of the step -- its largest single contraction, the stage-4 weight gradient
-    of conv2's dense half, as the step launches it -- with the hand-written kernels under "others"."""
+    """Roofline object of the dominant kernel of the step -- its largest single contraction, conv2's dense half at
+    stage 4 on pdgn_gemm_nt -- with the other hand-written kernels under "others"."""
     entries = [f(B, base_points, device) for f in ENTRIES]
     try:
         with open(_TRAFFIC) as f:

@@ -100,6 +100,32 @@ class PDGNTrainer:
         self._lp_split = os.environ.get("PDGN_LP_SPLIT", "0") == "1"      # A/B switches, see _step_overlapped
         self._early_tail = os.environ.get("PDGN_EARLY_TAIL", "1") == "1"
         self._defer_d = os.environ.get("PDGN_DEFER_D", "1") == "1"
+        self.sync_replicas()
+
+    def sync_replicas(self, src=0):
+        """nn.DataParallel replicates module 0's parameters and buffers onto every device each forward
+        (models/PDGNet_v2.py:101-105); with one process per GPU the replicas are made identical ONCE -- here, and
+        after load() -- by broadcasting rank `src`'s parameters, buffers and Adam state; identical averaged gradients
+        keep the parameters identical afterwards (BatchNorm running statistics stay per replica, as they do under
+        DataParallel, where only replica 0's survive).  No-op in a single process."""
+        if not (self.distributed and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+            return
+        with torch.no_grad():
+            for net in [self.G] + self.D:
+                flat = [t for t in list(net.parameters()) + list(net.buffers())]
+                for dtype in sorted({t.dtype for t in flat}, key=str):   # same order on every rank
+                    group = [t for t in flat if t.dtype == dtype]
+                    buf = torch.cat([t.reshape(-1) for t in group])
+                    dist.broadcast(buf, src)
+                    off = 0
+                    for t in group:
+                        t.copy_(buf[off:off + t.numel()].view_as(t))
+                        off += t.numel()
+            for opt in [self.optG] + self.optD:
+                for st in opt.state.values():
+                    for v in st.values():
+                        if torch.is_tensor(v):
+                            dist.broadcast(v, src)
 
     def train(self):
         self.G.train()
@@ -159,6 +185,7 @@ class PDGNTrainer:
         for i, (m, o) in enumerate(zip(self.D, self.optD), 1):
             load_reference_state_dict(m, d["D_model%d" % i])
             self._load_optim(o, d["D_optimizer%d" % i])
+        self.sync_replicas()
         return g["G_epoch"]
 
     def _loss_weights(self, ws):

@@ -23,7 +23,7 @@ def _free_port():
     return port
 
 
-def _build_trainer(distributed):
+def _build_trainer(distributed, seed=7):
     for p in (ROOT, HERE):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -38,7 +38,7 @@ def _build_trainer(distributed):
     deconv.softmax_slots_permute = softmax_slots_permute_torch
     deconv.bn_softmax_slots_permute = bn_softmax_slots_permute_torch
     deconv.bilateral_weighting = bilateral_weighting_torch
-    torch.manual_seed(7)                                   # identical initial weights on every rank
+    torch.manual_seed(seed)                                # identical initial weights on every rank (unless a test varies it)
     tr = PDGNTrainer(device="cpu", base_points=16, distributed=distributed)
     patch_losses(None)
     tr.train()
@@ -115,6 +115,42 @@ def test_two_rank_step_gloo(request):
         gG.append(tr.gradG.buf.clone())
     expect = (gG[0] + gG[1]) / world
     np.testing.assert_allclose(r[0]["gradG"], expect.numpy(), rtol=2e-3, atol=1e-5 * float(expect.abs().max()))
+
+
+def _worker_diverged_seeds(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    tr = _build_trainer(distributed=True, seed=100 + 17 * rank)      # every rank initialises DIFFERENT weights
+    names = [n for net in [tr.G] + tr.D for n, _ in list(net.named_parameters()) + list(net.named_buffers())]
+    flat0 = torch.cat([t.detach().double().reshape(-1) for net in [tr.G] + tr.D
+                       for t in list(net.parameters()) + list(net.buffers())])
+    reals, z1, z2 = _batch(rank)
+    tr.step(reals, z1, z2)
+    flat1 = torch.cat([p.detach().reshape(-1) for net in [tr.G] + tr.D for p in net.parameters()])
+    adam = torch.cat([v.detach().double().reshape(-1) for opt in [tr.optG] + tr.optD for st in opt.state.values()
+                      for v in st.values() if torch.is_tensor(v)])
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), init=flat0.numpy(), after=flat1.numpy(), adam=adam.numpy(),
+             n=len(names))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_replicas_are_broadcast_from_rank0_gloo():
+    """ranks that construct their networks under different seeds must still hold rank 0's parameters and
+    buffers (nn.DataParallel replicates module 0, models/PDGNet_v2.py:101-105), and stay identical after a step."""
+    world = 2
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker_diverged_seeds, args=(world, _free_port(), d), nprocs=world, join=True)
+        r = [dict(np.load(os.path.join(d, "rank%d.npz" % i))) for i in range(world)]
+    np.testing.assert_array_equal(r[0]["init"], r[1]["init"])
+    np.testing.assert_array_equal(r[0]["after"], r[1]["after"])
+    np.testing.assert_array_equal(r[0]["adam"], r[1]["adam"])
+    # and rank 0's own initialisation is what survived (seed 100), not something else
+    tr = _build_trainer(distributed=False, seed=100)
+    flat = torch.cat([t.detach().double().reshape(-1) for net in [tr.G] + tr.D
+                      for t in list(net.parameters()) + list(net.buffers())])
+    np.testing.assert_array_equal(r[0]["init"], flat.numpy())
 
 
 def test_flat_grads_views_and_zero():

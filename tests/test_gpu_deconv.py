@@ -297,32 +297,51 @@ def test_window_gather_sum_backward_csr_path(B, N, k, specs):
         np.testing.assert_allclose(a_.grad.cpu().numpy(), b_.grad.numpy(), rtol=1e-4, atol=1e-3)
 
 
-@pytest.mark.parametrize("M,N,K", [(35840, 12832, 256), (71680, 1024, 256), (358400, 512, 64), (35840, 512, 5120),
-                                   (5000, 20, 12), (1024, 4, 4), (100003, 132, 68), (71680, 64, 16)])
-def test_gemm_tn_weight_gradient(M, N, K):
-    """pdgn_gemm_tn (split-reduction fp32 MFMA): dW = dY^T X within 1e-4 of an fp64 reference
-    (error measured against sum |dy||x| as for any fp32 accumulation)."""
+@pytest.mark.parametrize("M,N,K", [(35840, 12832, 256), (35840, 12832, 128), (71680, 1024, 256), (358400, 512, 64),
+                                   (35840, 512, 5120), (17920, 256, 2560), (5000, 20, 12), (1024, 4, 4), (100003, 132, 68),
+                                   (71680, 64, 16), (358400, 64, 16), (71680, 64, 4)])
+def test_gemm_tn_direct(M, N, K):
+    """pdgn_gemm_tn called through the C ABI itself (no dispatch in between) on every large weight-gradient shape
+    of the step: dW = dY^T X within 1e-5 of an fp64 reference, measured against sum |dy||x| as for any fp32 accumulation."""
+    import ctypes
+    from pdgn_amd import _lib
+    from pdgn_amd._lib import ptr, stream_of
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    x = torch.randn(M, K, device="cuda", generator=g)
+    dy = torch.randn(M, N, device="cuda", generator=g)
+    dw = torch.zeros(N, K, device="cuda")
+    assert _lib.lib().pdgn_gemm_tn(ctypes.c_longlong(M), N, K, ptr(dy), ptr(x), ptr(dw), stream_of(dy)) == 0
+    rows = min(M, 40000)                                        # fp64 on a row sample (exact), fp32 matmul on all rows
+    scale = (dy.abs().t().matmul(x.abs())).clamp_min(1e-6)
+    assert ((dw - dy.t().matmul(x)).abs() / scale).max().item() < 2e-5
+    dw2 = torch.zeros(N, K, device="cuda")
+    assert _lib.lib().pdgn_gemm_tn(ctypes.c_longlong(rows), N, K, ptr(dy), ptr(x), ptr(dw2), stream_of(dy)) == 0
+    ref64 = dy[:rows].double().t().matmul(x[:rows].double())
+    scale64 = dy[:rows].abs().double().t().matmul(x[:rows].abs().double()).clamp_min(1e-6)
+    assert ((dw2.double() - ref64).abs() / scale64).max().item() < 1e-5
+
+
+@pytest.mark.parametrize("M,N,K", [(35840, 512, 256), (5000, 20, 12), (1024, 3, 64), (100003, 132, 68), (71680, 64, 3),
+                                   (2048, 6, 3), (300, 64, 64)])
+def test_linear_cl_autograd(M, N, K):
+    """LinearCL end to end (forward, input / weight / bias / addend gradients), including the channel counts that are
+    zero-padded for the kernels (k = 3: xyz layers, n = 3: the heads' last conv) and the sub-threshold torch path."""
     from pdgn_amd.fused import linear_cl
     g = torch.Generator(device="cuda").manual_seed(M + N + K)
     x = torch.randn(M, K, device="cuda", generator=g)
-    w = torch.randn(N, K, device="cuda", generator=g, requires_grad=True)
-    b = torch.randn(N, device="cuda", generator=g, requires_grad=True)
+    w = torch.randn(N, K, device="cuda", generator=g)
+    b = torch.randn(N, device="cuda", generator=g)
+    add = torch.randn(M, N, device="cuda", generator=g)
     dy = torch.randn(M, N, device="cuda", generator=g)
-    xg = x.clone().requires_grad_(True)
-    y = linear_cl(xg, w, b)
-    y.backward(dy)
-    rows = min(M, 20000)                                        # fp64 reference on a row sample + full check vs fp32 mm
-    ref32 = dy.t().matmul(x)
-    scale = (dy.abs().t().matmul(x.abs())).clamp_min(1e-6)
-    assert ((w.grad - ref32).abs() / scale).max().item() < 2e-5
-    sub = slice(0, rows)
-    ref64 = dy[sub].double().t().matmul(x[sub].double())
-    y2 = linear_cl(x[sub].clone(), w.detach().clone().requires_grad_(True), None)
-    w2 = y2.grad_fn.next_functions[1][0].variable
-    y2.backward(dy[sub])
-    assert ((w2.grad.double() - ref64).abs() / (dy[sub].abs().t().matmul(x[sub].abs())).double().clamp_min(1e-6)).max().item() < 1e-5
-    np.testing.assert_allclose(b.grad.cpu().numpy(), dy.sum(0).cpu().numpy(), rtol=1e-4, atol=1e-2)
-    np.testing.assert_allclose(xg.grad.cpu().numpy(), dy.matmul(w.detach()).cpu().numpy(), rtol=1e-4, atol=1e-3)
+    res = []
+    for fn, cast in ((linear_cl, lambda t: t), (lambda x_, w_, b_, a_: torch.nn.functional.linear(x_, w_, b_) + a_, lambda t: t.double())):
+        leaves = [cast(t).clone().requires_grad_(True) for t in (x, w, b, add)]
+        y = fn(*leaves)
+        y.backward(cast(dy))
+        res.append([y.detach()] + [l.grad for l in leaves])
+    sc = float(M) ** 0.5
+    for name, got, ref, atol in zip(("y", "dx", "dw", "db", "dadd"), res[0], res[1], (1e-4 * K, 1e-4 * N, 2e-4 * sc, 2e-4 * sc, 0.0)):
+        np.testing.assert_allclose(got.cpu().numpy(), ref.cpu().numpy(), rtol=1e-4, atol=atol + 1e-6, err_msg=name)
 
 
 @pytest.mark.parametrize("M,k,C", [(1000, 10, 16), (3584, 10, 512), (77, 4, 24), (500, 32, 3)])
@@ -522,30 +541,64 @@ def test_config_c4_four_stage_512_to_4096():
     assert all(torch.isfinite(v).item() for v in losses.values())
 
 
-@pytest.mark.parametrize("M,N,K", [(35840, 512, 128), (5000, 132, 36), (129, 7, 4), (71680, 1024, 256)])
-def test_gemm_nt_with_epilogues(M, N, K):
-    """pdgn_gemm_nt (hand-written fp32 MFMA NT GEMM; kept as the fused-epilogue alternative to the
-    library GEMM, which is faster on MI355X -- DESIGN.md section 4): C = A W^T + bias + addend and the
-    per-128-row-block column statistics."""
+@pytest.mark.parametrize("cfg", [None, 0, 1, 2, 3])
+@pytest.mark.parametrize("M,N,K", [(35840, 512, 128), (5000, 132, 36), (129, 8, 4), (71680, 1024, 256), (35840, 512, 5120),
+                                   (17920, 64, 6432), (8960, 3232, 32), (1000, 36, 20), (358400, 64, 16)])
+def test_gemm_nt_with_epilogues(M, N, K, cfg, monkeypatch):
+    """pdgn_gemm_nt through the C ABI, every tile configuration (PDGN_NT_CFG) and the launch model's own pick:
+    C = A W^T (plain: the stream-K tail may run), and C = A W^T + bias + addend with the column-statistics partials."""
     import ctypes
+    import os
     from pdgn_amd import _lib
     from pdgn_amd._lib import ptr, stream_of
+    if cfg is None:
+        monkeypatch.delenv("PDGN_NT_CFG", raising=False)
+    else:
+        monkeypatch.setenv("PDGN_NT_CFG", str(cfg))
+    L = _lib.lib()
+    L.pdgn_gemm_nt_stat_rows.restype = ctypes.c_longlong
     g = torch.Generator(device="cuda").manual_seed(M + N)
     A = torch.randn(M, K, device="cuda", generator=g)
     W = torch.randn(N, K, device="cuda", generator=g)
     bias = torch.randn(N, device="cuda", generator=g)
     add = torch.randn(M, N, device="cuda", generator=g)
-    C = torch.empty(M, N, device="cuda")
-    nb = (M + 127) // 128
-    part = torch.zeros(nb, 2 * N, device="cuda")
-    rc = _lib.lib().pdgn_gemm_nt(ctypes.c_longlong(M), N, K, ptr(A), ptr(W), ptr(bias), ptr(add), ptr(C), ptr(part),
-                                 stream_of(A))
-    assert rc == 0
-    ref = (A.double() @ W.double().t() + bias.double() + add.double())
-    scale = (A.abs() @ W.abs().t()).double() + 1
-    assert ((C.double() - ref).abs() / scale).max().item() < 1e-5
-    np.testing.assert_allclose(part[:, :N].sum(0).cpu().numpy(), ref.sum(0).cpu().numpy(), rtol=1e-3, atol=0.05 * M ** 0.5)
-    np.testing.assert_allclose(part[:, N:].sum(0).cpu().numpy(), (ref * ref).sum(0).cpu().numpy(), rtol=1e-3)
+    rows = min(M, 30000)                                        # fp64 reference on a row sample, fp32 matmul on all rows
+    scale = (A.abs() @ W.abs().t()) + 1
+    C = torch.full((M, N), float("nan"), device="cuda")
+    assert L.pdgn_gemm_nt(ctypes.c_longlong(M), N, K, ptr(A), K, ptr(W), K, None, None, 0, ptr(C), N, None, stream_of(A)) == 0
+    assert ((C - A @ W.t()).abs() / scale).max().item() < 2e-5
+    ref = A[:rows].double() @ W.double().t()
+    assert ((C[:rows].double() - ref).abs() / scale[:rows].double()).max().item() < 1e-5
+    nparts = L.pdgn_gemm_nt_stat_rows(ctypes.c_longlong(M), N, K)
+    part = torch.full((nparts, 2 * N), float("nan"), device="cuda")
+    C2 = torch.full((M, N), float("nan"), device="cuda")
+    assert L.pdgn_gemm_nt(ctypes.c_longlong(M), N, K, ptr(A), K, ptr(W), K, ptr(bias), ptr(add), N, ptr(C2), N, ptr(part),
+                          stream_of(A)) == 0
+    ref2 = (A @ W.t() + bias + add)
+    assert ((C2 - ref2).abs() / scale).max().item() < 2e-5
+    c64 = C2.double()
+    np.testing.assert_allclose(part[:, :N].double().sum(0).cpu().numpy(), c64.sum(0).cpu().numpy(), rtol=1e-4,
+                               atol=1e-4 * float(c64.abs().sum(0).max()))
+    np.testing.assert_allclose(part[:, N:].double().sum(0).cpu().numpy(), (c64 * c64).sum(0).cpu().numpy(), rtol=1e-4)
+
+
+def test_gemm_nt_strided_operands():
+    """Row pitches larger than the logical widths (views into wider matrices) for A, W, the addend and C."""
+    import ctypes
+    from pdgn_amd import _lib
+    from pdgn_amd._lib import ptr, stream_of
+    M, N, K = 5000, 96, 72
+    g = torch.Generator(device="cuda").manual_seed(5)
+    Abig = torch.randn(M, K + 24, device="cuda", generator=g)
+    Wbig = torch.randn(N, K + 8, device="cuda", generator=g)
+    Dbig = torch.randn(M, N + 4, device="cuda", generator=g)
+    Cbig = torch.zeros(M, N + 32, device="cuda")
+    A, W, D, C = Abig[:, 4:4 + K], Wbig[:, :K], Dbig[:, 4:], Cbig[:, 16:16 + N]
+    assert _lib.lib().pdgn_gemm_nt(ctypes.c_longlong(M), N, K, ptr(A), A.stride(0), ptr(W), W.stride(0), None, ptr(D), D.stride(0),
+                                   ptr(C), C.stride(0), None, stream_of(A)) == 0
+    ref = A.double() @ W.double().t() + D.double()
+    assert (C.double() - ref).abs().max().item() < 1e-4
+    assert Cbig[:, :16].abs().max().item() == 0 and Cbig[:, 16 + N:].abs().max().item() == 0
 
 
 @pytest.mark.parametrize("B,N,C,training", [(4, 300, 64, True), (35, 2048, 1024, True), (3, 17, 8, True), (5, 512, 256, False)])

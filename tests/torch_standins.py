@@ -85,8 +85,9 @@ def patch_losses(monkeypatch_or_module):
             setattr(losses, name, fn)
 
 
-def linear_cl_torch(x2d, weight, bias=None):
-    return torch.nn.functional.linear(x2d, weight, bias)
+def linear_cl_torch(x2d, weight, bias=None, addend=None):
+    y = torch.nn.functional.linear(x2d, weight, bias)
+    return y + addend if addend is not None else y
 
 
 def bn_softmax_slots_permute_torch(x2d, bn, training, k, act="leaky_relu", pre_bias=None):
