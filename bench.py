@@ -1,29 +1,35 @@
 #!/usr/bin/env python3
 """bench.py -- generator+D step throughput of the PDGN hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch 35] [--no-cpu-baseline]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch 35] [--no-cpu-baseline] [--eval]
 
 A "step" is one complete training iteration of models/PDGNet_v2.py:171-256 (generator forward
 x2, four discriminator updates, six local-pair shape losses, generator backward, five Adam
 steps) on a synthetic ShapeNet-shaped batch that is already resident in HBM.  Metric (BASELINE.json):
 final-resolution points per second = n_gpus * B * 2048 / t_step, B = 35 per GPU (weak scaling).
-N > 1 is launched by the driver through torch.distributed.run, one rank per GPU over RCCL.
-Rank 0 prints ONE JSON line.
+
+N > 1: one rank per GPU over RCCL.  Launched through torch.distributed.run (the driver's way) the ranks
+are already there; launched as plain `python bench.py --gpus N`, this process starts
+`python -m torch.distributed.run --nproc-per-node N bench.py ...` as a CHILD -- before anything here has
+touched a GPU -- relays rank 0's JSON line and exits with the child's code.  Rank 0 prints ONE JSON line.
+
+--eval times configuration C5 instead (evaluation path: Chamfer + approximate EMD on 512 pairs of
+2048-point clouds, evaluation/evaluation_metrics.py:26-45, 85-121) and prints its own JSON line.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
-
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 matrix peak (v_mfma_f32_32x32x2_f32)
+MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 matrix peak (v_mfma_f32_32x32x2_f32 / 16x16x4_f32)
+# SURVEY.md section 8-d / BASELINE.md section 2: the reference's direct form costs ~222 GFLOP per sample and G+D step
+DIRECT_FORM_FLOPS_PER_SAMPLE = 222e9
 
 
 def parse():
@@ -34,49 +40,84 @@ def parse():
     ap.add_argument("--batch", type=int, default=35, help="per-GPU batch (BASELINE.json: 35)")
     ap.add_argument("--base-points", type=int, default=128, help="128: 256->2048 (reference); 256: 512->4096")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-batch", type=int, default=35)
+    ap.add_argument("--cpu-sample-batch", type=int, default=12,
+                    help="batch of one CPU-baseline sample (three samples are timed; 12 keeps them at ~20 s in all)")
     ap.add_argument("--graph", action="store_true",
-                    help="replay the iteration as hipGraphs (trainer.capture).  Off by default: with the fused "
-                         "kernels the eager step is within 0.5%% of the replay on MI355X, and on ROCm 7.2 graph "
-                         "launches are not reliably ordered against RCCL / eager kernels on the same stream")
+                    help="replay the iteration as hipGraphs (trainer.capture).  Off by default: the eager step is "
+                         "faster on MI355X (DESIGN.md section 6), and on ROCm 7.2 graph launches are not reliably "
+                         "ordered against RCCL / eager kernels on the same stream")
     ap.add_argument("--no-graph", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-roofline", action="store_true", help="skip the roofline kernels (for clean rocprof traces)")
+    ap.add_argument("--eval", action="store_true", help="time config C5 (Chamfer + EMD, 512 pairs of 2048 points)")
+    ap.add_argument("--eval-pairs", type=int, default=512)
+    ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo-stub"),
+                    help="gloo-stub: CPU-only plumbing check of the N-rank launch path (tests), no HIP work")
+    ap.add_argument("--master-port", type=int, default=0)
     return ap.parse_args()
 
 
-def init_dist(args):
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    force = os.environ.get("PDGN_FORCE_DIST") == "1"        # exercise the RCCL path on a single GPU
-    if world > 1 or force:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local))
-    else:
-        torch.cuda.set_device(0)
-    if args.gpus != world and rank == 0 and world > 1:
-        print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
-    return world, rank, local
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as a child job and relay its result.  Nothing in
+    this process has initialised a GPU (torch is not even imported yet), and the child is a fresh process."""
+    import socket
+    port = args.master_port
+    if not port:
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if proc.returncode != 0 or line is None:
+        print("bench.py: the %d-rank child job failed (exit code %d)" % (args.gpus, proc.returncode), file=sys.stderr)
+        sys.exit(proc.returncode or 1)
+    got = json.loads(line).get("n_gpus")
+    if got != args.gpus:
+        print("bench.py: asked for %d GPUs, the job reports n_gpus = %r" % (args.gpus, got), file=sys.stderr)
+        sys.exit(1)
+    print(line, flush=True)
+    sys.exit(0)
 
 
-def barrier(world):
-    if dist.is_initialized():
-        dist.barrier()
-    torch.cuda.synchronize()
+def host_cpu():
+    """CPU model, sockets and physical cores of this host (from /proc/cpuinfo)."""
+    model, phys, cores = "unknown", set(), set()
+    try:
+        pid = cid = None
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.startswith("model name") and model == "unknown":
+                    model = ln.split(":", 1)[1].strip()
+                elif ln.startswith("physical id"):
+                    pid = ln.split(":", 1)[1].strip()
+                    phys.add(pid)
+                elif ln.startswith("core id"):
+                    cid = ln.split(":", 1)[1].strip()
+                    cores.add((pid, cid))
+    except OSError:
+        pass
+    return {"model": model, "sockets": len(phys) or None, "physical_cores": len(cores) or None,
+            "logical_cpus": os.cpu_count()}
 
 
-def cpu_baseline(sample_batch):
-    """The oracle's torch-CPU/C restatement of the same iteration (oracle/pdgnet_ref.TrainerRef),
-    timed on this box's host cores on a bounded sample (one step at a small batch)."""
+def cpu_baseline(sample_batch, samples=3):
+    """The oracle's torch-CPU/C restatement of the same iteration (oracle/pdgnet_ref.TrainerRef), timed on this box's
+    host cores on a bounded sample: `samples` full G+D iterations at a reduced batch, median reported per point."""
+    import torch
     from oracle import cref, pdgnet_ref
     from pdgn_amd.trainer import synthetic_batch
     cref.build()
-    # 16 threads is the fastest setting measured on the 2x EPYC 9575F GPU-box host (16 thr: 17.7 s,
-    # 32: 20.9 s, 64: 26.3 s, 256: minutes per B=35 iteration -- torch's intra-op pool oversubscribes).
+    # 16 threads is the fastest setting measured on the 2x EPYC 9575F GPU-box host (16 thr: 17.7 s, 32: 20.9 s,
+    # 64: 26.3 s, 256: minutes per B=35 iteration -- torch's intra-op pool oversubscribes).
     cores = min(16, os.cpu_count() or 1)
     torch.set_num_threads(cores)
     torch.manual_seed(9999)
@@ -85,29 +126,168 @@ def cpu_baseline(sample_batch):
     z = lambda b: torch.randn(b, 128, generator=g) * 0.2
     tr.step(synthetic_batch(2, "cpu"), z(2), z(2))                 # warm-up (thread pools, allocator)
     reals = synthetic_batch(sample_batch, "cpu")
+    times = []
+    for _ in range(samples):
+        t0 = time.perf_counter()
+        tr.step(reals, z(sample_batch), z(sample_batch))
+        times.append(time.perf_counter() - t0)
+    times.sort()
+    med = times[len(times) // 2]
+    return {"value": sample_batch * 2048 / med, "unit": "points/s", "cores": torch.get_num_threads(), "kind": "port",
+            "samples_s": [round(t, 3) for t in times], "host": host_cpu(),
+            "sample": "%d full G+D iterations (oracle/pdgnet_ref.TrainerRef: torch-CPU fp32 + C pointops) at B=%d, "
+                      "256->2048 pts, after a B=2 warm-up; median %.1f s on %d threads (the fastest thread count "
+                      "measured on this host class)" % (samples, sample_batch, med, cores)}
+
+
+def stub_main(args):
+    """CPU-only plumbing of the N-rank path (tests/test_bench_launch.py): gloo, a toy step with one all-reduce."""
+    import torch
+    import torch.distributed as dist
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    if args.gpus != world:
+        sys.exit(2)
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    x = torch.ones(1024)
     t0 = time.perf_counter()
-    tr.step(reals, z(sample_batch), z(sample_batch))
+    for _ in range(args.steps):
+        y = (x * 2).sum()
+        if world > 1:
+            dist.all_reduce(y)
     dt = time.perf_counter() - t0
-    return {"value": sample_batch * 2048 / dt, "unit": "points/s", "cores": torch.get_num_threads(),
-            "kind": "port",
-            "sample": "1 full G+D iteration (oracle/pdgnet_ref.TrainerRef: torch-CPU fp32 + C pointops) at "
-                      "B=%d, 256->2048 pts, after a B=2 warm-up; %.1f s on %d threads" % (sample_batch, dt, cores)}
+    ts = [torch.tensor([dt], dtype=torch.float64) for _ in range(world)]
+    if world > 1:
+        dist.all_gather(ts, torch.tensor([dt], dtype=torch.float64))
+    if rank == 0:
+        ms = [t.item() / args.steps * 1e3 for t in ts]
+        print(json.dumps({"metric": "plumbing stub (no HIP work)", "value": world * 1024 / max(ms) * 1e3, "unit": "elements/s",
+                          "n_gpus": world, "rccl_ranks": dist.get_world_size() if world > 1 else 1, "steps": args.steps,
+                          "warmup": args.warmup, "ms_per_step": max(ms), "ms_per_step_min_rank": min(ms),
+                          "ms_per_step_max_rank": max(ms), "stub": True, "allreduce_check": float(y)}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
-def dominant_kernel_roofline(args, device):
-    """Live HIP-event timing of the dominant hand-written kernel at the step's launch shape."""
-    from pdgn_amd import roofline
-    return roofline.measure(args.batch, args.base_points, device)
+def init_dist(args):
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    force = os.environ.get("PDGN_FORCE_DIST") == "1"        # exercise the RCCL path on a single GPU
+    if args.gpus != world:
+        # never print a line whose n_gpus differs from what was asked for
+        if rank == 0:
+            print("bench.py: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+        sys.exit(2)
+    if world > 1 or force:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    else:
+        torch.cuda.set_device(0)
+    return world, rank, local
+
+
+def barrier():
+    import torch
+    import torch.distributed as dist
+    if dist.is_initialized():
+        dist.barrier()
+    torch.cuda.synchronize()
+
+
+def executed_flops(trainer, reals, z1, z2):
+    """Dense-contraction flops ONE iteration really launches: every pdgn_gemm_nt / _nn / _tn problem (2 m n k) plus the
+    feature-space kNN Gram products (2 N^2 F per sample), logged by the wrappers during one extra untimed step."""
+    import torch
+    from pdgn_amd import deconv, fused
+    fused.GEMM_LOG, deconv.KNN_LOG = [], []
+    trainer.step(reals, z1, z2)
+    torch.cuda.synchronize()
+    gemm, knn = fused.GEMM_LOG, deconv.KNN_LOG
+    fused.GEMM_LOG = deconv.KNN_LOG = None
+    f_gemm = sum(2.0 * m * n * k for (_, m, n, k) in gemm)
+    f_knn = sum(2.0 * b * n * n * f for (b, f, n) in knn)
+    return {"gemm": f_gemm, "feature_knn_gram": f_knn, "gemm_launches": len(gemm), "knn_launches": len(knn)}
+
+
+def _event_ms(fn, iters=5):
+    import torch
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters
+
+
+def eval_main(args):
+    """Config C5: Chamfer (nn_distance) + approximate EMD (fused pdgn_emd_cost) on `pairs` pairs of 2048 x 2048 points."""
+    import torch
+    from pdgn_amd.structural_losses import emd_cost, nn_distance
+    torch.cuda.set_device(0)
+    P, N = args.eval_pairs, 2048
+    g = torch.Generator().manual_seed(9999)
+    a = (torch.rand(P, N, 3, generator=g) * 2 - 1).cuda()
+    b = (torch.rand(P, N, 3, generator=g) * 2 - 1).cuda()
+
+    def step():
+        d1, d2 = nn_distance(a, b)
+        return d1.mean(1) + d2.mean(1), emd_cost(a, b)
+
+    for _ in range(max(args.warmup, 1)):
+        cd, emd = step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        cd, emd = step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.steps
+    ms_emd, ms_cd = _event_ms(lambda: emd_cost(a, b)), _event_ms(lambda: nn_distance(a, b))
+    # approxmatch_kernel<true>: 9 levels x 3 phases, one v_exp_f32 per (point, point) pair and phase (SURVEY.md 8-d);
+    # transcendental issue: 8 cycles per wave64 instruction (MI355X_MICROARCH.md, cycle constants) = 8 lanes/clk/SIMD
+    exp_peak = 8 * 4 * 256 * 2.4e9
+    exps = P * 27.0 * N * N
+    line = {"metric": "Chamfer + approx-EMD structural losses, pairs/sec (2048-pt pairs, B=%d)" % P,
+            "value": P / dt, "unit": "pairs/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "eval path C5: nn_distance (Chamfer) + fused approximate EMD cost on %d pairs of 2048 x 2048 "
+                                   "uniform points in [-1, 1]^3 (evaluation_metrics.py:26-45, 85-121)" % P,
+                       "finite": bool(torch.isfinite(cd).all() and torch.isfinite(emd).all())},
+            "roofline": {"kernel": "approxmatch_kernel<true> (fused EMD cost)", "bound": "valu-transcendental",
+                         "achieved": exps / (ms_emd * 1e-3) / 1e9, "peak": exp_peak / 1e9, "unit": "G exp/s",
+                         "frac": exps / (ms_emd * 1e-3) / exp_peak, "traffic": None, "us_per_launch": ms_emd * 1e3,
+                         "algorithmic_bytes_per_launch": P * 2.0 * N * 12,
+                         "others": [{"kernel": "nndist_kernel (both Chamfer directions)", "bound": "valu",
+                                     "achieved": 2.0 * P * N * N / (ms_cd * 1e-3) / 1e9, "unit": "G pair evaluations/s",
+                                     "us_per_launch": ms_cd * 1e3, "algorithmic_bytes_per_launch": P * (2.0 * N) * 20}]}}
+    print(json.dumps(line), flush=True)
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)                                        # does not return
+    if args.backend == "gloo-stub":
+        return stub_main(args)
+    if args.eval:
+        return eval_main(args)
+    import torch
+    import torch.distributed as dist
     world, rank, local = init_dist(args)
     device = torch.device("cuda", local)
     from pdgn_amd.trainer import PDGNTrainer, noise, synthetic_batch
 
-    torch.manual_seed(9999 + rank)
-    res = tuple((2 * args.base_points) << i for i in range(4))
+    torch.manual_seed(9999)                                      # the same initial weights on every rank (they are
+    res = tuple((2 * args.base_points) << i for i in range(4))   # broadcast from rank 0 as well); data differs per rank
     trainer = PDGNTrainer(device=device, base_points=args.base_points,
                           distributed=True if os.environ.get("PDGN_FORCE_DIST") == "1" else None)
     trainer.train()
@@ -124,22 +304,25 @@ def main():
         except Exception as e:                 # a capture problem must not lose the measurement
             print("hipGraph capture failed (%r): running eagerly" % (e,), file=sys.stderr)
             torch.cuda.synchronize()
-    # Two untimed priming iterations grow the caching allocator's pools and measure the stream-to-queue map; they must never
-    # land in the timed region, whatever W the caller asks for.
+    # Two untimed priming iterations grow the caching allocator's pools and measure the stream-to-queue map; they must
+    # never land in the timed region, whatever W the caller asks for.
     for _ in range(2):
         step(reals, *zs[0])
     for i in range(args.warmup):
         step(reals, *zs[i])
-    barrier(world)
+    barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
         out = step(reals, *zs[args.warmup + i])
-    barrier(world)
-    dt = time.perf_counter() - t0
+    barrier()
+    dt_local = time.perf_counter() - t0
+    dt, dts = dt_local, [dt_local]
     if world > 1:
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = t.item()
+        t = torch.tensor([dt_local], device=device, dtype=torch.float64)
+        all_t = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(all_t, t)
+        dts = [x.item() for x in all_t]
+        dt = max(dts)
     finite = all(torch.isfinite(v).item() for v in out.values())
 
     if rank == 0:
@@ -148,8 +331,10 @@ def main():
             "metric": "generator+D step points/sec (B=35, 256->2048 pts)",
             "value": world * B * res[3] / (dt / args.steps),
             "unit": "points/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
+            "n_gpus": world, "rccl_ranks": dist.get_world_size() if dist.is_initialized() else 1,
+            "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms, "ms_per_step_min_rank": min(dts) / args.steps * 1e3, "ms_per_step_max_rank": ms,
+            "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "PDGNet_v2 G+D iteration (models/PDGNet_v2.py:171-256), chair-shaped "
                                    "synthetic batch, per-GPU batch %d, %d->%d pts, random-init weights"
@@ -157,9 +342,21 @@ def main():
                        "global_batch": world * B, "points_all_resolutions_per_s": world * B * sum(res) / (dt / args.steps),
                        "parallelism": "dp%d" % world, "losses_finite": finite, "hipgraph": graphed},
         }
+        if not graphed:
+            try:
+                fl = executed_flops(trainer, reals, *zs[0])
+                total = fl["gemm"] + fl["feature_knn_gram"]
+                line["executed_flops_per_step"] = total
+                line["executed_flops_detail"] = fl
+                line["step_mfma_frac"] = total / (ms * 1e-3) / (MFMA_F32_PEAK_TFLOPS * 1e12)
+                line["direct_form_flops_per_step"] = DIRECT_FORM_FLOPS_PER_SAMPLE * B
+                line["algebraic_saving"] = DIRECT_FORM_FLOPS_PER_SAMPLE * B / total
+            except Exception as e:
+                line["executed_flops_per_step"] = {"error": repr(e)}
         if not args.no_roofline:
             try:
-                line["roofline"] = dominant_kernel_roofline(args, device)
+                from pdgn_amd import roofline
+                line["roofline"] = roofline.measure(args.batch, args.base_points, device)
             except Exception as e:                               # never lose the headline number
                 line["roofline"] = {"error": repr(e)}
         if not args.no_cpu_baseline and world == 1:          # host baseline: rank 0, N = 1 only

@@ -168,6 +168,12 @@ int pdgn_bn_eval_stats(int c, float eps, const float *gamma, const float *beta, 
 int pdgn_bn_stats_from_partials(long long rows, int c, float eps, float momentum, const float *gamma,
                                 const float *beta, const float *pre_bias, float *running_mean, float *running_var,
                                 const float *scratch, float *stats, pdgn_stream_t stream);
+/* The same second stage over an explicit number of partial rows: the per-row-block column sums pdgn_gemm_nt /
+ * pdgn_gemm_nn write from their epilogue (pdgn_gemm_nt_stat_rows(m, n, k) rows of [2c] floats). */
+int pdgn_bn_stats_from_gemm_partials(long long rows, int c, long long nparts, float eps, float momentum,
+                                     const float *gamma, const float *beta, const float *pre_bias,
+                                     float *running_mean, float *running_var, const float *partials,
+                                     float *stats, pdgn_stream_t stream);
 /* y = act(x*scale + shift) [* mul]   (mul may be NULL; same shape as x) */
 int pdgn_bn_act_forward(long long rows, int c, int act, const float *x, const float *stats,
                         const float *mul, float *y, pdgn_stream_t stream);
@@ -229,6 +235,11 @@ int pdgn_softmax_slots_permute_backward(long long m, int k, int c, const float *
  * stat_part and with ldc == n the launch may add partial tiles with fp32 atomics (C is zero-filled by the
  * call itself where needed). */
 int pdgn_gemm_nt(long long m, int n, int k, const float *A, int lda, const float *W, int ldw,
+                 const float *bias, const float *addend, int ldadd, float *C, int ldc, float *stat_part,
+                 pdgn_stream_t stream);
+/* The same product with the second operand given transposed, C = A Wt with Wt (k x n, row pitch ldw): the input
+ * gradient dX = dY W of a dense layer straight from its (C_out x C_in) weight (models/PDGNet_v2.py conv / linear backward). */
+int pdgn_gemm_nn(long long m, int n, int k, const float *A, int lda, const float *Wt, int ldw,
                  const float *bias, const float *addend, int ldadd, float *C, int ldc, float *stat_part,
                  pdgn_stream_t stream);
 long long pdgn_gemm_nt_stat_rows(long long m, int n, int k);

@@ -364,6 +364,18 @@ extern "C" int pdgn_bn_stats_from_partials(long long rows, int c, float eps, flo
     return pdgn_launch_status();
 }
 
+// The same second stage over an explicit number of partial rows ([2c] floats each: per-column sum | sum of squares of a
+// row block): the partials pdgn_gemm_nt / pdgn_gemm_nn write from their epilogue (pdgn_gemm_nt_stat_rows of them).
+extern "C" int pdgn_bn_stats_from_gemm_partials(long long rows, int c, long long nparts, float eps, float momentum,
+                                                const float *gamma, const float *beta, const float *pre_bias,
+                                                float *running_mean, float *running_var, const float *partials,
+                                                float *stats, pdgn_stream_t stream) {
+    if (rows < 1 || c < 4 || c % 4 || nparts < 1 || nparts > 0x7fffffffLL) return PDGN_ERR_INVALID;
+    hipLaunchKernelGGL(cl_finalize_kernel, dim3(cdiv(c, FIN_CH)), dim3(FIN_CH * FIN_PL), 0, (hipStream_t)stream, rows, c,
+                       (int)nparts, eps, momentum, partials, gamma, beta, pre_bias, running_mean, running_var, stats);
+    return pdgn_launch_status();
+}
+
 extern "C" int pdgn_bn_eval_stats(int c, float eps, const float *gamma, const float *beta, const float *pre_bias,
                                   const float *running_mean, const float *running_var, float *stats,
                                   pdgn_stream_t stream) {

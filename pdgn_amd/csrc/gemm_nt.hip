@@ -72,10 +72,14 @@ struct NtArgs {
     int dbg;                          // PDGN_NT_DBG (measurement only): 1 no stores, 2 no DMA
 };
 
-template <int TM, int TN, int WM, int WN, bool ATOMIC>
+template <int TM, int TN, int WM, int WN, bool ATOMIC, bool WT>
 __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_nt_kernel(const NtArgs p) {
     constexpr int NW = WM * WN, BM = 16 * TM * WM, BN = 16 * TN * WN;
-    constexpr int STAGE_FLOATS = (BM + BN) * NT_BK;
+    // WT: the weight operand is given TRANSPOSED, W^T (K x N) row-major (the input gradient dX = dY W uses the layer's own
+    // (C_out x C_in) weight as it is): its chunk is [32 k][BN] in LDS, 1-KB pieces padded apart so that the b32 fragment
+    // reads of rows k and k + 4 fall on different banks
+    constexpr int WROWS = 256 / BN, WPAD = WT ? 4 * WROWS : 0;      // k rows per 1-KB piece, pad floats after each piece
+    constexpr int STAGE_FLOATS = (BM + BN) * NT_BK + (BN / 8) * WPAD;
     constexpr int NPA = BM / 8 / NW, NPB = BN / 8 / NW, NP = NPA + NPB;   // 1-KB DMA pieces per wave and chunk
     constexpr int NS = ATOMIC ? 0 : TM * TN;                              // counted stores per wave and item
     static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "pieces must divide over the waves");
@@ -139,7 +143,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_nt_kernel(const NtArgs p
 #pragma unroll
     for (int i = 0; i < NPA; ++i) voffA[i] = (unsigned)(((wave + i * NW) * 8 + drow) * p.lda + dcol * 4) * 4u;
 #pragma unroll
-    for (int i = 0; i < NPB; ++i) voffB[i] = (unsigned)(((wave + i * NW) * 8 + drow) * p.ldw + dcol * 4) * 4u;
+    for (int i = 0; i < NPB; ++i)
+        voffB[i] = WT ? (unsigned)(((wave + i * NW) * WROWS + lane / (BN / 4)) * p.ldw + (lane % (BN / 4)) * 4) * 4u
+                      : (unsigned)(((wave + i * NW) * 8 + drow) * p.ldw + dcol * 4) * 4u;
 
     // descriptors of the load cursor's tile
     i32x4 rsA, rsW;
@@ -150,7 +156,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_nt_kernel(const NtArgs p
         const long long mrows = min((long long)BM, p.M - m0);
         const int nrows = min(BN, p.N - n0);
         rsA = nt_srd(p.A + m0 * p.lda, (unsigned)(mrows * p.lda * 4));
-        rsW = nt_srd(p.W + (long long)n0 * p.ldw, (unsigned)(nrows * p.ldw * 4));
+        rsW = WT ? nt_srd(p.W + n0, (unsigned)(((long long)(p.K - 1) * p.ldw + nrows) * 4))
+                 : nt_srd(p.W + (long long)n0 * p.ldw, (unsigned)(nrows * p.ldw * 4));
     };
     make_srds(ld.tile);
 
@@ -158,16 +165,22 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_nt_kernel(const NtArgs p
     // One DMA piece of the load cursor's chunk (i < NPA: activation rows, else weight rows) into `stage`.
     int ld_k0 = 0;
     bool ld_kok = true;
-    unsigned ld_dst = 0;
+    unsigned ld_dst = 0, ld_dst_w = 0;
     auto issue_begin = [&](int stage) {
         ld_k0 = ld.kc * NT_BK;
         ld_kok = ld_k0 + dcol * 4 < p.K;                           // K % 4 == 0: a 16-B column is all in or all out
         ld_dst = smem_base + (unsigned)(stage * STAGE_FLOATS + wave * 256) * 4u;
+        ld_dst_w = smem_base + (unsigned)(stage * STAGE_FLOATS + BM * NT_BK + wave * (256 + WPAD)) * 4u;
     };
     auto issue_piece = [&](int i) {
         if (p.dbg & 2) return;
         if (i < NPA) nt_dma16(rsA, ld_dst + i * NW * 1024, ld_kok ? voffA[i < NPA ? i : 0] : NT_OOB, ld_k0 * 4);
-        else nt_dma16(rsW, ld_dst + BM * NT_BK * 4 + (i - NPA) * NW * 1024, ld_kok ? voffB[i < NPA ? 0 : i - NPA] : NT_OOB, ld_k0 * 4);
+        else if (!WT) nt_dma16(rsW, ld_dst + BM * NT_BK * 4 + (i - NPA) * NW * 1024, ld_kok ? voffB[i < NPA ? 0 : i - NPA] : NT_OOB, ld_k0 * 4);
+        else {
+            const int j = i < NPA ? 0 : i - NPA;                     // piece wave + j*NW: k rows (wave + j*NW)*WROWS + lane / (BN/4)
+            const bool rok = ld_k0 + (wave + j * NW) * WROWS + lane / (BN / 4) < p.K;
+            nt_dma16(rsW, ld_dst_w + j * NW * (1024 + WPAD * 4), rok ? voffB[j] + (unsigned)(ld_k0 * p.ldw) * 4u : NT_OOB, 0);
+        }
     };
     auto advance_load = [&]() {
         ld.kc++;
@@ -188,13 +201,30 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_nt_kernel(const NtArgs p
 #pragma unroll
         for (int b = 0; b < TN; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float4 ra0[TM], rb0[TN], ra1[TM], rb1[TN];                     // fragments of the two 16-deep halves of a chunk
-    auto read_half = [&](int stage, int fo, float4 *ra, float4 *rb) {
-        const float *sa = smem + stage * STAGE_FLOATS + abase + fo;
-        const float *sb = smem + stage * STAGE_FLOATS + bbase + fo;
+    // WT: k row r of the W^T chunk sits at float (r / WROWS) * (256 + WPAD) + (r % WROWS) * BN; a lane's fragment element u
+    // of column block b is row 16q + 4*lg + u, column wn*16*TN + 16b + li
+    const int wt_lane = ((4 * lg) / WROWS) * (256 + WPAD) + ((4 * lg) % WROWS) * BN + wn * 16 * TN + li;
+    auto read_half = [&](int stage, int q, float4 *ra, float4 *rb) {
+        const float *sa = smem + stage * STAGE_FLOATS + abase + (q ? fo1 : fo0);
 #pragma unroll
         for (int a = 0; a < TM; ++a) ra[a] = *reinterpret_cast<const float4 *>(sa + a * 16 * NT_BK);
+        if (!WT) {
+            const float *sb = smem + stage * STAGE_FLOATS + bbase + (q ? fo1 : fo0);
 #pragma unroll
-        for (int b = 0; b < TN; ++b) rb[b] = *reinterpret_cast<const float4 *>(sb + b * 16 * NT_BK);
+            for (int b = 0; b < TN; ++b) rb[b] = *reinterpret_cast<const float4 *>(sb + b * 16 * NT_BK);
+        } else {
+            const float *sb = smem + stage * STAGE_FLOATS + BM * NT_BK + wt_lane;
+#pragma unroll
+            for (int b = 0; b < TN; ++b) {
+                float e[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int r = 16 * q + u;                      // + 4*lg, folded into wt_lane (4*lg and r never carry across a piece: WROWS | 4)
+                    e[u] = sb[(r / WROWS) * (256 + WPAD) + (r % WROWS) * BN + 16 * b];
+                }
+                rb[b] = make_float4(e[0], e[1], e[2], e[3]);
+            }
+        }
     };
     // ---- output of a finished item.  Direct mode: D row (4*lg + r) = weight row, D column li = activation row, so a lane
     // holds 4 consecutive output columns of row li; the 16-B stores of item t are issued from INSIDE the first half chunk
@@ -358,13 +388,13 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_nt_kernel(const NtArgs p
     }
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    read_half(0, fo0, ra0, rb0);
+    read_half(0, 0, ra0, rb0);
     int stage = 0;
     while (cp.valid) {
         bool first = true;
         for (;;) {
             // (A) second half's fragments on their way while the first half is multiplied
-            read_half(stage, fo1, ra1, rb1);
+            read_half(stage, 1, ra1, rb1);
             __builtin_amdgcn_sched_barrier(0);
             if (first) mfma_half(ra0, rb0, M2_t());
             else mfma_half(ra0, rb0, M0_t());
@@ -380,7 +410,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_nt_kernel(const NtArgs p
             // half is multiplied
             first = false;
             todo--;
-            if (todo > 0) read_half(stage ^ 1, fo0, ra0, rb0);
+            if (todo > 0) read_half(stage ^ 1, 0, ra0, rb0);
             if (ld.valid) {
                 issue_begin(stage);
                 mfma_half(ra1, rb1, M1_t());
@@ -432,43 +462,67 @@ struct NtCfg {
     struct Plan {
         int tiles_m, tiles_n, kchunks, grid_dp, dp_tiles, grid_sk;
         long long sk_per_wg;
-        double cost;                                               // model: CU-time in units of one 16x16x32 MFMA block
+        double cost;                                               // launch model, microseconds
     };
+    // Launch model (calibrated on MI355X, tools/gemm_shapes.py): a CU multiplies ~0.56 Mflop/us on this loop; the w
+    // workgroups sharing a CU share that; a tile costs ~2.5 chunks on top of its own (ring fill, output); the atomics of
+    // a partial tile are added at ~1.3 TB/s chip-wide.
+    // Workgroups of the data-parallel launch: at least one per slot, and more -- each then walks fewer tiles -- so that
+    // the hardware hands them out as CUs come free (this kernel shares the chip with the step's other streams; a static
+    // assignment over exactly `slots` workgroups lets one delayed workgroup hold up the launch): enough tiles per
+    // workgroup to keep ~32 chunks of work behind one ring fill.
+    static int dp_grid(long long tiles, int slots, int kc) {
+        static int tpw_env = -1;
+        if (tpw_env < 0) { const char *e = getenv("PDGN_NT_TPW"); tpw_env = e ? atoi(e) : 0; }
+        int tpw = tpw_env > 0 ? tpw_env : (32 + kc - 1) / kc;
+        tpw = tpw < 1 ? 1 : (tpw > 8 ? 8 : tpw);
+        if (tpw_env >= 1000) return (int)(tiles < slots ? tiles : slots);          // measurement: one workgroup per slot
+        const long long g = (tiles + tpw - 1) / tpw;
+        const long long lo = tiles < slots ? tiles : slots;
+        return (int)(g < lo ? lo : g);
+    }
+    static double chunk_us(int w) { return 2.0 * BM * BN * NT_BK * w / (0.56e6 * (TM * TN >= 16 ? 1.0 : 0.95)); }
     static Plan plan(long long m, int n, int k, bool allow_sk) {
         Plan pl;
         pl.tiles_m = cdiv(m, BM);
         pl.tiles_n = cdiv(n, BN);
         pl.kchunks = cdiv(k, NT_BK);
         const long long T = (long long)pl.tiles_m * pl.tiles_n;
-        const int cus = nt_cus(), slots = cus * WG_PER_CU;
+        const int cus = nt_cus(), slots = cus * WG_PER_CU, KC = pl.kchunks;
         const long long rounds = T / slots, tail = T - rounds * slots;
+        const double ov = 2.5;
+        const double full = (double)rounds * (KC + ov) * chunk_us(WG_PER_CU);
+        // data-parallel only: the last, partial round runs ceil(tail / cus) workgroups on its busiest CU
         pl.dp_tiles = (int)T;
-        pl.grid_dp = (int)(T < slots ? T : slots);
+        pl.grid_dp = dp_grid(T, slots, KC);
         pl.grid_sk = 0;
         pl.sk_per_wg = 0;
-        // one tile on a CU of its own: its MFMA blocks + about two chunks' worth of fill / epilogue; narrow wave tiles
-        // re-read more per MFMA and pay more barriers per flop
-        const double tile = (double)(TM * TN * WM * WN) * (pl.kchunks + 2.0) * (TM * TN >= 16 ? 1.0 : 1.06);
-        // a partial last round of whole tiles leaves CUs idle for a whole tile time: split those tiles' (tile, chunk)
-        // space over every slot instead, when the reduction is long enough to amortise the atomics
-        if (allow_sk && tail > 0 && tail * 10 < (long long)slots * 9 && pl.kchunks >= 16) {
-            pl.dp_tiles = (int)(rounds * slots);
-            pl.grid_dp = rounds ? slots : 0;
-            const long long iters = tail * pl.kchunks;
-            pl.grid_sk = (int)(iters < slots ? iters : slots);
-            pl.sk_per_wg = (iters + pl.grid_sk - 1) / pl.grid_sk;
-            pl.grid_sk = (int)((iters + pl.sk_per_wg - 1) / pl.sk_per_wg);
-            pl.cost = tile * ((double)T / cus) + tile * 0.25;
-        } else {
-            // tiles per CU in the busiest CU (workgroups sharing a CU share its matrix cores)
-            const long long per_cu = (T + cus - 1) / cus;
-            const long long rounds_up = (T + slots - 1) / slots;
-            const long long busiest = per_cu > rounds_up * WG_PER_CU ? per_cu : (T >= slots ? rounds_up * WG_PER_CU : per_cu);
-            pl.cost = tile * (double)busiest;
+        pl.cost = full + (tail ? (KC + ov) * chunk_us((int)((tail + cus - 1) / cus)) : 0.0);
+        if (allow_sk && tail > 0) {
+            // stream-K tail over g workgroups: g = every slot, or one per CU
+            for (int w = WG_PER_CU; w >= 1; w -= (WG_PER_CU > 1 ? WG_PER_CU - 1 : 1)) {
+                const long long iters = tail * KC;
+                long long g = (long long)cus * w < iters ? (long long)cus * w : iters;
+                const long long per = (iters + g - 1) / g;
+                if (per < 8) continue;                             // short ranges: the atomics cost more than they balance
+                g = (iters + per - 1) / per;
+                const double zero_rows = (double)(m - (long long)((rounds * slots) / pl.tiles_n) * BM);
+                const double c = full + (per + ov) * chunk_us((int)((g + cus - 1) / cus)) + (double)(g + tail) * BM * BN * 4 / 1.3e6 +
+                                 zero_rows * n * 4 / 3.0e6 + 4.0;
+                if (c < pl.cost) {
+                    pl.cost = c;
+                    pl.dp_tiles = (int)(rounds * slots);
+                    pl.grid_dp = rounds ? dp_grid(rounds * slots, slots, KC) : 0;
+                    pl.grid_sk = (int)g;
+                    pl.sk_per_wg = per;
+                }
+                if (WG_PER_CU == 1) break;
+            }
         }
         return pl;
     }
 
+    template <bool WT>
     static int launch(long long m, int n, int k, const float *A, int lda, const float *W, int ldw, const float *bias,
                       const float *addend, int ldadd, float *C, int ldc, float *stat_part, hipStream_t s) {
         const bool allow_sk = stat_part == nullptr && ldc == n;
@@ -487,11 +541,11 @@ struct NtCfg {
         }
         if (pl.grid_dp) {
             a.tile_begin = 0; a.tile_end = pl.dp_tiles; a.sk_per_wg = 0;
-            hipLaunchKernelGGL((gemm_nt_kernel<TM, TN, WM, WN, false>), dim3(pl.grid_dp), dim3(64 * WM * WN), 0, s, a);
+            hipLaunchKernelGGL((gemm_nt_kernel<TM, TN, WM, WN, false, WT>), dim3(pl.grid_dp), dim3(64 * WM * WN), 0, s, a);
         }
         if (pl.grid_sk) {
             a.tile_begin = pl.dp_tiles; a.tile_end = (int)T; a.sk_per_wg = pl.sk_per_wg;
-            hipLaunchKernelGGL((gemm_nt_kernel<TM, TN, WM, WN, true>), dim3(pl.grid_sk), dim3(64 * WM * WN), 0, s, a);
+            hipLaunchKernelGGL((gemm_nt_kernel<TM, TN, WM, WN, true, WT>), dim3(pl.grid_sk), dim3(64 * WM * WN), 0, s, a);
         }
         return pdgn_launch_status();
     }
@@ -511,14 +565,26 @@ static int nt_pick(long long m, int n, int k, bool stats) {
                          NtNarrow::plan(m, n, k, sk).cost};
     int best = 1;
     for (int i = 0; i < 4; ++i)
-        if (c[i] < c[best] * 0.98) best = i;                        // the square tile unless another is clearly cheaper
+        if (c[i] < c[best] * 0.97) best = i;                        // the square tile unless another is clearly cheaper
     return best;
 }
 
-static bool nt_args_ok(long long m, int n, int k, int lda, int ldw, int ldadd, int ldc, const float *addend) {
+static bool nt_args_ok(long long m, int n, int k, int lda, int ldw, int ldadd, int ldc, const float *addend, bool wt) {
     return m >= 1 && n >= 4 && k >= 4 && n % 4 == 0 && k % 4 == 0 && lda % 4 == 0 && ldw % 4 == 0 && ldc % 4 == 0 &&
-           lda >= k && ldw >= k && ldc >= n && (!addend || (ldadd % 4 == 0 && ldadd >= n)) && lda < (1 << 19) &&
-           ldw < (1 << 19) && ldc < (1 << 19) && (long long)cdiv(m, 128) * cdiv(n, 64) < 0x7fffffffLL;
+           lda >= k && ldw >= (wt ? n : k) && ldc >= n && (!addend || (ldadd % 4 == 0 && ldadd >= n)) && lda < (1 << 19) &&
+           ldw < (1 << 19) && ldc < (1 << 19) && (long long)cdiv(m, 128) * cdiv(n, 64) < 0x7fffffffLL &&
+           (!wt || (long long)k * ldw < (1LL << 27));
+}
+
+template <bool WT>
+static int nt_dispatch(long long m, int n, int k, const float *A, int lda, const float *W, int ldw, const float *bias,
+                       const float *addend, int ldadd, float *C, int ldc, float *stat_part, hipStream_t s) {
+    switch (nt_pick(m, n, k, stat_part != nullptr)) {
+        case 0: return NtBig::launch<WT>(m, n, k, A, lda, W, ldw, bias, addend, ldadd, C, ldc, stat_part, s);
+        case 2: return NtTall::launch<WT>(m, n, k, A, lda, W, ldw, bias, addend, ldadd, C, ldc, stat_part, s);
+        case 3: return NtNarrow::launch<WT>(m, n, k, A, lda, W, ldw, bias, addend, ldadd, C, ldc, stat_part, s);
+        default: return NtSquare::launch<WT>(m, n, k, A, lda, W, ldw, bias, addend, ldadd, C, ldc, stat_part, s);
+    }
 }
 
 // C (m x n, row pitch ldc) = A (m x k, pitch lda) W (n x k, pitch ldw)^T (+ bias[n]) (+ addend (m x n, pitch ldadd)).
@@ -527,14 +593,17 @@ static bool nt_args_ok(long long m, int n, int k, int lda, int ldw, int ldadd, i
 extern "C" int pdgn_gemm_nt(long long m, int n, int k, const float *A, int lda, const float *W, int ldw,
                             const float *bias, const float *addend, int ldadd, float *C, int ldc, float *stat_part,
                             pdgn_stream_t stream) {
-    if (!nt_args_ok(m, n, k, lda, ldw, ldadd, ldc, addend)) return PDGN_ERR_INVALID;
-    hipStream_t s = (hipStream_t)stream;
-    switch (nt_pick(m, n, k, stat_part != nullptr)) {
-        case 0: return NtBig::launch(m, n, k, A, lda, W, ldw, bias, addend, ldadd, C, ldc, stat_part, s);
-        case 2: return NtTall::launch(m, n, k, A, lda, W, ldw, bias, addend, ldadd, C, ldc, stat_part, s);
-        case 3: return NtNarrow::launch(m, n, k, A, lda, W, ldw, bias, addend, ldadd, C, ldc, stat_part, s);
-        default: return NtSquare::launch(m, n, k, A, lda, W, ldw, bias, addend, ldadd, C, ldc, stat_part, s);
-    }
+    if (!nt_args_ok(m, n, k, lda, ldw, ldadd, ldc, addend, false)) return PDGN_ERR_INVALID;
+    return nt_dispatch<false>(m, n, k, A, lda, W, ldw, bias, addend, ldadd, C, ldc, stat_part, (hipStream_t)stream);
+}
+
+// The same product with the second operand given transposed: C (m x n) = A (m x k) Wt (k x n, row pitch ldw) -- the
+// input gradient dX = dY W of a dense layer straight from its (C_out x C_in) weight.
+extern "C" int pdgn_gemm_nn(long long m, int n, int k, const float *A, int lda, const float *Wt, int ldw,
+                            const float *bias, const float *addend, int ldadd, float *C, int ldc, float *stat_part,
+                            pdgn_stream_t stream) {
+    if (!nt_args_ok(m, n, k, lda, ldw, ldadd, ldc, addend, true)) return PDGN_ERR_INVALID;
+    return nt_dispatch<true>(m, n, k, A, lda, Wt, ldw, bias, addend, ldadd, C, ldc, stat_part, (hipStream_t)stream);
 }
 
 // Number of [2n] partial-statistics rows pdgn_gemm_nt writes for this problem (tile rows x waves along m).
@@ -548,8 +617,13 @@ extern "C" long long pdgn_gemm_nt_stat_rows(long long m, int n, int k) {
     }
 }
 
-// Tile configuration pdgn_gemm_nt picks for a problem (0: 256x128, 1: 128x128, 2: 160x64, 3: 128x64); host-side only.
+// Tile configuration pdgn_gemm_nt picks for a problem (0: 256x128, 1: 128x128, 2: 160x64, 3: 128x64), + 16 when a
+// stream-K launch follows the data-parallel one; host-side only.
 extern "C" int pdgn_gemm_nt_config(long long m, int n, int k, int with_stats) {
     if (m < 1 || n < 1 || k < 1) return PDGN_ERR_INVALID;
-    return nt_pick(m, n, k, with_stats != 0);
+    const int c = nt_pick(m, n, k, with_stats != 0);
+    const bool sk = !with_stats;
+    const int g = c == 0 ? NtBig::plan(m, n, k, sk).grid_sk : c == 1 ? NtSquare::plan(m, n, k, sk).grid_sk
+                : c == 2 ? NtTall::plan(m, n, k, sk).grid_sk : NtNarrow::plan(m, n, k, sk).grid_sk;
+    return c + (g ? 16 : 0);
 }

@@ -49,10 +49,15 @@ def _w2d(conv):
     return w.view(w.shape[0], w.shape[1])
 
 
+KNN_LOG = None             # bench.py sets this to a list: every (b, f, n) Gram problem launched is appended
+
+
 def feature_knn(x, k):
     """models/PDGNet_v2.py:447-458.  x (B,F,N) fp32 -> idx (B,N,k) int32 (ranks 1..k)."""
     require(x, "x", F32, 3)
     b, f, n = x.shape
+    if KNN_LOG is not None:
+        KNN_LOG.append((b, f, n))
     idx = torch.empty((b, n, k), dtype=I32, device=x.device)
     sq = torch.empty((b, n), dtype=F32, device=x.device)
     check(_lib.lib().pdgn_feature_knn(b, f, n, int(k), ptr(x), ptr(sq), ptr(idx), stream_of(x)),
@@ -384,16 +389,17 @@ class PointDeconv(nn.Module):
             h = bn_act(outs[2].view(-1, 16), self.conv_fea[1], training, mul=xyzf)   # w_fea * w_xyz :632
             # conv biases in front of a BatchNorm are not added by the GEMM (no bias epilogue / broadcast pass):
             # they cancel in the normalisation and reach only the running mean (bn_act's pre_bias)
-            h = linear_cl(h, _w2d(self.conv_all[0]))
-            h = bn_act(h, self.conv_all[1], training, pre_bias=self.conv_all[0].bias)
-            h = linear_cl(h, _w2d(self.conv_all[3]))
+            # in training the GEMMs' epilogues emit the BatchNorm statistics of their outputs: no statistics pass
+            h, ph = linear_cl(h, _w2d(self.conv_all[0]), None, None, training)
+            h = bn_act(h, self.conv_all[1], training, pre_bias=self.conv_all[0].bias, partials=ph)
+            h, ph = linear_cl(h, _w2d(self.conv_all[3]), None, None, training)
             if self.softmax:
                 # conv_all.4 + LeakyReLU + softmax over the k slots + interleave w[b,n,s=P*j+p,c'] -> [b,n,p,o=2c'+j]
                 # (:623-625, :634-641) AND inte = LeakyReLU(BN(inte_pre)) * w (:637, :642): one pass over both raw tensors
                 inte = bilateral_weighting(h, self.conv_all[4], inte_pre.view(-1, 4 * Fi), self.inte_conv_hk[1], training, k,
-                                           pre_bias_x=self.conv_all[3].bias, partials_u=part_i)
+                                           pre_bias_x=self.conv_all[3].bias, partials_u=part_i, partials_x=ph)
             else:
-                h = bn_act(h, self.conv_all[4], training, pre_bias=self.conv_all[3].bias)
+                h = bn_act(h, self.conv_all[4], training, pre_bias=self.conv_all[3].bias, partials=ph)
                 w = h.view(B, N, 2, P, 2 * Fi).permute(0, 1, 3, 4, 2).reshape(B * N * P, 4 * Fi)
                 inte = bn_act(inte_pre.view(-1, 4 * Fi), self.inte_conv_hk[1], training, mul=w, partials=part_i)
         else:

@@ -87,7 +87,12 @@ def _bn_stats(L, x, rows, C, g, b, pre_bias, running_mean, running_var, training
     training, running statistics in eval.  pre_bias: see include/pdgn_hip.h (the producer's bias, left out of x)."""
     stats = torch.empty(4 * C, dtype=F32, device=x.device)
     pb = pre_bias.detach().contiguous() if pre_bias is not None else None
-    if training and partials is not None:                       # first stage done by x's producer (its epilogue)
+    if training and partials is not None and partials.dim() == 2:   # (nparts, 2C) rows from a GEMM's epilogue
+        check(L.pdgn_bn_stats_from_gemm_partials(ctypes.c_longlong(rows), C, ctypes.c_longlong(partials.shape[0]),
+                                                 ctypes.c_float(eps), ctypes.c_float(momentum), ptr(g), ptr(b), ptr(pb),
+                                                 ptr(running_mean), ptr(running_var), ptr(partials), ptr(stats), stream_of(x)),
+              "pdgn_bn_stats_from_gemm_partials")
+    elif training and partials is not None:                     # first stage done by x's producer (its epilogue)
         check(L.pdgn_bn_stats_from_partials(ctypes.c_longlong(rows), C, ctypes.c_float(eps), ctypes.c_float(momentum),
                                             ptr(g), ptr(b), ptr(pb), ptr(running_mean), ptr(running_var), ptr(partials),
                                             ptr(stats), stream_of(x)), "pdgn_bn_stats_from_partials")
@@ -209,17 +214,30 @@ def _pad_cols(t, mult=4):
     return torch.nn.functional.pad(t, (0, mult - c % mult)).contiguous()
 
 
-def gemm_nt(a, w, bias=None, addend=None, want_stats=False):
-    """a (m, k) @ w (n, k)^T (+ bias) (+ addend) on pdgn_gemm_nt.  Channel counts that are not multiples of 4 (the xyz
-    layers: k = 3, the heads' last conv: n = 3) are zero-padded for the launch.  want_stats: also returns the BatchNorm
-    partial sums of the result ((parts, 2n) fp32: per-column sum | sum of squares of row blocks)."""
+GEMM_LOG = None            # tools/gemm_shapes.py sets this to a list: every (kind, m, n, k) launched is appended
+
+
+def gemm_nt(a, w, bias=None, addend=None, want_stats=False, w_transposed=False):
+    """a (m, k) @ w (n, k)^T (+ bias) (+ addend) on pdgn_gemm_nt -- or, with w_transposed, a (m, k) @ w (k, n) on
+    pdgn_gemm_nn (the input gradient dy @ W straight from the layer's weight).  Channel counts that are not multiples
+    of 4 (the xyz layers: k = 3, the heads' last conv: n = 3) are zero-padded for the launch.  want_stats: also returns
+    the BatchNorm partial sums of the result ((parts, 2n) fp32: per-column sum | sum of squares of row blocks)."""
     m, k = a.shape
-    n = w.shape[0]
-    ap, wp = _pad_cols(a), _pad_cols(w)
+    n = w.shape[1] if w_transposed else w.shape[0]
+    if GEMM_LOG is not None:
+        GEMM_LOG.append(("nn" if w_transposed else "nt", m, n, k))
+    ap = _pad_cols(a)
     kp = ap.shape[1]
     np_ = (n + 3) // 4 * 4
-    if np_ != n:
+    if w_transposed:
+        wp = _pad_cols(w)                                          # (k, n) -> (k, np_)
+        if kp != k:
+            wp = torch.nn.functional.pad(wp, (0, 0, 0, kp - k))
+    else:
+        wp = _pad_cols(w)
+    if np_ != n and not w_transposed:
         wp = torch.nn.functional.pad(wp, (0, 0, 0, np_ - n))
+    if np_ != n:
         bias = torch.nn.functional.pad(bias, (0, np_ - n)) if bias is not None else None
         addend = torch.nn.functional.pad(addend, (0, np_ - n)) if addend is not None else None
     if addend is not None:
@@ -231,9 +249,10 @@ def gemm_nt(a, w, bias=None, addend=None, want_stats=False):
         L.pdgn_gemm_nt_stat_rows.restype = ctypes.c_longlong
         part = torch.empty((L.pdgn_gemm_nt_stat_rows(ctypes.c_longlong(m), np_, kp), 2 * np_), dtype=F32, device=a.device)
     b = bias.detach().contiguous() if bias is not None else None
-    check(L.pdgn_gemm_nt(ctypes.c_longlong(m), np_, kp, ptr(ap), ap.stride(0), ptr(wp), wp.stride(0), ptr(b), ptr(addend),
-                         addend.stride(0) if addend is not None else 0, ptr(out), np_, ptr(part), stream_of(a)),
-          "pdgn_gemm_nt")
+    fn = L.pdgn_gemm_nn if w_transposed else L.pdgn_gemm_nt
+    check(fn(ctypes.c_longlong(m), np_, kp, ptr(ap), ap.stride(0), ptr(wp), wp.stride(0), ptr(b), ptr(addend),
+             addend.stride(0) if addend is not None else 0, ptr(out), np_, ptr(part), stream_of(a)),
+          "pdgn_gemm_nn" if w_transposed else "pdgn_gemm_nt")
     if np_ != n:
         out = out[:, :n].contiguous()
     return (out, part) if want_stats else out
@@ -243,6 +262,8 @@ def gemm_tn(dy, x):
     """dy (m, n)^T @ x (m, k) -> (n, k) on pdgn_gemm_tn (reduction over the rows split over workgroups)."""
     m, n = dy.shape
     k = x.shape[1]
+    if GEMM_LOG is not None:
+        GEMM_LOG.append(("tn", m, n, k))
     dyp, xp = _pad_cols(dy), _pad_cols(x)
     if dyp.stride(0) != dyp.shape[1]:
         dyp = dyp.contiguous()
@@ -259,34 +280,47 @@ class LinearCL(Function):
     (models/PDGNet_v2.py:559-625, 835-862, 886-1014) as row-matrix products on the hand-written MFMA kernels (see above)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, addend):
+    def forward(ctx, x, weight, bias, addend, want_stats=False):
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
         ctx.has_addend = addend is not None
         if x.is_cuda and x.shape[0] >= _OWN_MIN_ROWS:
-            return gemm_nt(x, weight, bias, addend)
+            if want_stats and weight.shape[0] % 4 == 0:
+                y, part = gemm_nt(x, weight, bias, addend, want_stats=True)
+                ctx.mark_non_differentiable(part)
+                return y, part
+            y = gemm_nt(x, weight, bias, addend)
+            return (y, None) if want_stats else y
         y = torch.nn.functional.linear(x, weight, bias)
-        return y + addend if addend is not None else y
+        y = y + addend if addend is not None else y
+        return (y, None) if want_stats else y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, *unused):
         x, weight = ctx.saved_tensors
         zero_db = ctx.has_bias and ctx.needs_input_grad[2] and has_zero_colsum(dy)
         dy = dy.contiguous()
         own = dy.is_cuda and dy.shape[0] >= _OWN_MIN_ROWS
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = gemm_nt(dy, weight.t().contiguous()) if own else dy.matmul(weight)
+            dx = gemm_nt(dy, weight, w_transposed=True) if own else dy.matmul(weight)
         if ctx.needs_input_grad[1]:
             dw = gemm_tn(dy, x) if own else dy.t().matmul(x)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = _zeros((dy.shape[1],), dy.device) if zero_db else dy.sum(dim=0)
-        return dx, dw, db, (dy if ctx.has_addend and ctx.needs_input_grad[3] else None)
+        return dx, dw, db, (dy if ctx.has_addend and ctx.needs_input_grad[3] else None), None
 
 
-def linear_cl(x2d, weight, bias=None, addend=None):
-    """Dense layer on point-major rows (see LinearCL); `addend` (M, C_out) is added in the GEMM's epilogue."""
-    return LinearCL.apply(x2d, weight, bias, addend)
+def linear_cl(x2d, weight, bias=None, addend=None, want_stats=None):
+    """Dense layer on point-major rows (see LinearCL); `addend` (M, C_out) is added in the GEMM's epilogue.
+    want_stats (True / False, not None): returns the PAIR (y, partials) -- with True the BatchNorm partial sums of y from
+    the GEMM's epilogue, for bn_act / bilateral_weighting's `partials` argument (no statistics pass over y); None when
+    this call did not produce them."""
+    if want_stats is None:
+        return LinearCL.apply(x2d, weight, bias, addend)
+    if want_stats:
+        return LinearCL.apply(x2d, weight, bias, addend, True)
+    return LinearCL.apply(x2d, weight, bias, addend), None
 
 
 class SoftmaxSlotsPermute(Function):
@@ -379,13 +413,13 @@ class BilateralWeighting(Function):
 
     @staticmethod
     def forward(ctx, x, u, gx, bx, rmx, rvx, pbx, gu, bu, rmu, rvu, pbu, training, momentum_x, eps_x, momentum_u, eps_u,
-                act, k, partials_u=None):
+                act, k, partials_u=None, partials_x=None):
         rows, C = x.shape
         m = rows // k
         x, u = x.contiguous(), u.contiguous()
         L = _lib.lib()
         stats_x = _bn_stats(L, x, rows, C, gx.detach().contiguous(), bx.detach().contiguous(), pbx, rmx, rvx, training,
-                            momentum_x, eps_x)
+                            momentum_x, eps_x, partials_x)
         stats_u = _bn_stats(L, u, u.shape[0], 2 * C, gu.detach().contiguous(), bu.detach().contiguous(), pbu, rmu, rvu,
                             training, momentum_u, eps_u, partials_u)
         need_w = any(ctx.needs_input_grad)
@@ -438,11 +472,11 @@ class BilateralWeighting(Function):
             mark_zero_colsum(du)
             mark_zero_colsum(dx)
         return (dx, du, bsx[C:], bsx[:C], None, None, _pre_bias_grad(has_pbx, C, x.device), bsu[Cu:], bsu[:Cu], None, None,
-                _pre_bias_grad(has_pbu, Cu, x.device), None, None, None, None, None, None, None, None)
+                _pre_bias_grad(has_pbu, Cu, x.device), None, None, None, None, None, None, None, None, None)
 
 
 def bilateral_weighting(x2d, bn_x, u2d, bn_u, training, k, act="leaky_relu", pre_bias_x=None, pre_bias_u=None,
-                        partials_u=None):
+                        partials_u=None, partials_x=None):
     """x2d (M*k, C) raw conv_all.3 output, u2d (M*k/2, 2C) raw inte_conv_hk output ->
     act(bn_u(u2d)) * softmax_slots_permute(act(bn_x(x2d))), shape of u2d."""
     x2d, pre_bias_x = _fold_pre_bias(x2d, pre_bias_x, training)
@@ -456,7 +490,7 @@ def bilateral_weighting(x2d, bn_x, u2d, bn_u, training, k, act="leaky_relu", pre
                 _PENDING_COUNTS[bn.num_batches_tracked] = _PENDING_COUNTS.get(bn.num_batches_tracked, 0) + 1
     return BilateralWeighting.apply(x2d, u2d, bn_x.weight, bn_x.bias, bn_x.running_mean, bn_x.running_var, pre_bias_x,
                                     bn_u.weight, bn_u.bias, bn_u.running_mean, bn_u.running_var, pre_bias_u, training,
-                                    bn_x.momentum, bn_x.eps, bn_u.momentum, bn_u.eps, ACT[act], k, partials_u)
+                                    bn_x.momentum, bn_x.eps, bn_u.momentum, bn_u.eps, ACT[act], k, partials_u, partials_x)
 
 
 class SmallLinearBNAct(Function):
@@ -550,13 +584,14 @@ class BNActMaxPool(Function):
     tensor; the backward is one streaming pass."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, act, B, N, pre_bias=None):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, act, B, N, pre_bias=None,
+                partials=None):
         x = x.contiguous()
         rows, C = x.shape
         dev = x.device
         L = _lib.lib()
         g, b = gamma.detach().contiguous(), beta.detach().contiguous()
-        stats = _bn_stats(L, x, rows, C, g, b, pre_bias, running_mean, running_var, training, momentum, eps)
+        stats = _bn_stats(L, x, rows, C, g, b, pre_bias, running_mean, running_var, training, momentum, eps, partials)
         ctx.has_pre_bias = pre_bias is not None
         L.pdgn_bn_maxpool_scratch_floats.restype = ctypes.c_longlong
         scr = torch.empty(L.pdgn_bn_maxpool_scratch_floats(B, C), dtype=F32, device=dev)
@@ -582,10 +617,10 @@ class BNActMaxPool(Function):
         if training:
             mark_zero_colsum(dx)
         return (dx, bs[C:], bs[:C], None, None, None, None, None, None, None, None,
-                _pre_bias_grad(ctx.has_pre_bias, C, x.device))
+                _pre_bias_grad(ctx.has_pre_bias, C, x.device), None)
 
 
-def bn_act_maxpool(x2d, bn, training, B, N, act="leaky_relu", pre_bias=None):
+def bn_act_maxpool(x2d, bn, training, B, N, act="leaky_relu", pre_bias=None, partials=None):
     """max over the N points of every sample of act(BN(x2d)); x2d (B*N, C) -> (B, C)."""
     x2d, pre_bias = _fold_pre_bias(x2d, pre_bias, training)
     if x2d.shape[1] % 4:
@@ -593,7 +628,7 @@ def bn_act_maxpool(x2d, bn, training, B, N, act="leaky_relu", pre_bias=None):
     if training and bn.track_running_stats:
         _PENDING_COUNTS[bn.num_batches_tracked] = _PENDING_COUNTS.get(bn.num_batches_tracked, 0) + 1
     return BNActMaxPool.apply(x2d, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, bn.momentum, bn.eps,
-                              ACT[act], B, N, pre_bias)
+                              ACT[act], B, N, pre_bias, partials)
 
 
 class PointMax(Function):

@@ -35,6 +35,11 @@ def _linear(rows, weight, bias=None):
     return _deconv.linear_cl(rows, weight, bias)              # looked up late: tests patch deconv.linear_cl
 
 
+def _linear_stats(rows, weight, training):
+    """(y, BatchNorm partials of y | None): in training the GEMM's epilogue emits the statistics the BatchNorm behind it needs."""
+    return _deconv.linear_cl(rows, weight, None, None, bool(training))
+
+
 def _conv1x1_rows(rows, conv):
     """Conv1d(kernel 1) applied to a (rows, C_in) matrix."""
     return _linear(rows, _deconv._w2d(conv), conv.bias)
@@ -193,10 +198,11 @@ class PointDiscriminator(nn.Module):
         last = len(self.fc1) - 3
         for i in range(0, last, 3):                             # Conv1d(k=1) + BatchNorm1d + LeakyReLU
             # the conv bias is folded into the BatchNorm (pre_bias): the GEMM runs without a bias epilogue
-            h = _bn_act(_linear(h, _deconv._w2d(self.fc1[i])), self.fc1[i + 1], self.training, pre_bias=self.fc1[i].bias)
+            y, part = _linear_stats(h, _deconv._w2d(self.fc1[i]), self.training)
+            h = _deconv.bn_act(y, self.fc1[i + 1], self.training, pre_bias=self.fc1[i].bias, partials=part)
         # last layer: BatchNorm1d + LeakyReLU + MaxPool1d(num_point) fused (the activated tensor is not written)
-        pooled = _deconv.bn_act_maxpool(_linear(h, _deconv._w2d(self.fc1[last])), self.fc1[last + 1], self.training, B, N,
-                                        pre_bias=self.fc1[last].bias)
+        y, part = _linear_stats(h, _deconv._w2d(self.fc1[last]), self.training)
+        pooled = _deconv.bn_act_maxpool(y, self.fc1[last + 1], self.training, B, N, pre_bias=self.fc1[last].bias, partials=part)
         _deconv.flush_bn_counters()
         return _small_seq(self.mlp, pooled, self.training)            # Linear + LeakyReLU groups on B rows: one launch each
 

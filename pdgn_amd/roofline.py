@@ -186,13 +186,19 @@ def measure(B, base_points, device):
     """Roofline object of the dominant kernel of the step -- its largest single contraction, conv2's dense half at
     stage 4 on pdgn_gemm_nt -- with the other hand-written kernels under "others"."""
     entries = [f(B, base_points, device) for f in ENTRIES]
+    # `traffic` is NOT measured by this run: it is the PMC figure (FETCH_SIZE + WRITE_SIZE, separate rocprofv3 passes,
+    # corrected as the guide prescribes) committed in profiles/traffic.json by tools/pmc_traffic.py, attached only when
+    # that file was recorded at this batch / resolution
     try:
         with open(_TRAFFIC) as f:
             traffic = json.load(f)
-        for e in entries:
-            for key, val in traffic.items():
-                if e["kernel"].startswith(key):
-                    e["traffic"] = val
+        meta = traffic.get("_meta", {})
+        if meta.get("batch", 35) == B and meta.get("base_points", 128) == base_points:
+            for e in entries:
+                for key, val in traffic.items():
+                    if key != "_meta" and e["kernel"].startswith(key):
+                        e["traffic"] = val
+                        e["traffic_source"] = "profiles/traffic.json (%s)" % meta.get("recorded", "round 1 PMC passes")
     except (OSError, ValueError):
         pass
     top = dict(entries[0])

@@ -299,6 +299,56 @@ def gen_checkpoint_manifest():
     print("wrote checkpoint_manifest.json")
 
 
+# ------------------------------------------------------------------ 5b. config C4: base 256 points, 512 -> 4096
+def gen_c4():
+    """SURVEY.md section 8, Note (C4): the reference PointGenerator hard-codes 128 base points (:825-833, :867), but
+    its BLOCK classes are size-generic.  A reference PointGenerator whose fc1 / bilateral1..4 are swapped for base-256
+    instances of the reference's own classes (maxpool sizes 256/512/1024/2048), driven through the reference forward's
+    op sequence with view(B, 32, 256), emits 512 / 1024 / 2048 / 4096 points.  Every value stored is computed by
+    reference modules; the kNN graphs they picked are stored for margin-free float parity."""
+    base, k = 256, 20
+    G = ref.PointGenerator(2048, k)
+    G.fc1 = torch.nn.Sequential(torch.nn.Linear(128, 32 * base), torch.nn.BatchNorm1d(32 * base),
+                                torch.nn.LeakyReLU(inplace=True))
+    G.bilateral1 = ref.bilateral_block_l1(32, 32, base, num_k=k)
+    G.bilateral2 = ref.bilateral_block_l2(64, 64, 2 * base, num_k=k, softmax=True)
+    G.bilateral3 = ref.bilateral_block_l3(128, 128, 4 * base, num_k=k, softmax=True)
+    G.bilateral4 = ref.bilateral_block_l4(256, 256, 8 * base, num_k=k, softmax=True)
+    fill_module(G, salt=21)
+    G.train()
+    B = 4
+    z = hash_tensor("c4_z", (B, 128), 0.2)
+    idxs, margins = [], []
+
+    def grab(mod, inp):
+        i, d = pdgnet_ref.feature_knn(inp[0], mod.k)
+        ds = d.sort(dim=2)[0]
+        margins.append((ds[:, :, 1:mod.k + 2] - ds[:, :, 0:mod.k + 1]).min().item())
+        idxs.append(i)
+    hooks = [blk.register_forward_pre_hook(grab) for blk in
+             (G.bilateral1.upsample_cov[0], G.bilateral2.upsample_cov, G.bilateral3.upsample_cov, G.bilateral4.upsample_cov)]
+    with torch.no_grad():
+        x = G.fc1(z).view(B, 32, base)                          # :866-867 with the base-256 view
+        x1, g_x1 = G.bilateral1(x)
+        x1s = G.mlp1(g_x1)
+        x2, g_x2 = G.bilateral2(x1, x1s)
+        x2s = G.mlp2(g_x2)
+        x3, g_x3 = G.bilateral3(x2, x2s)
+        x3s = G.mlp3(g_x3)
+        x4 = G.bilateral4(x3, x3s)
+        x4s = G.mlp4(x4)
+    for h in hooks:
+        h.remove()
+    D4 = ref.PointDiscriminator_4(16 * base)
+    fill_module(D4, salt=13)
+    D4.train()
+    with torch.no_grad():
+        d4 = D4(x4s)
+    assert [t.shape[2] for t in (x1s, x2s, x3s, x4s)] == [512, 1024, 2048, 4096]
+    save("generator_c4_b4.npz", z=z, p1=x1s, p2=x2s, p3=x3s, p4=x4s, d4=d4, knn_margins=np.array(margins),
+         **{"idx%d" % (i + 1): t.to(torch.int16) for i, t in enumerate(idxs)})
+
+
 # ------------------------------------------------------------------ 6. one G+D iteration (composed)
 def gen_step(G, Ds, B):
     """COMPOSED: reference torch modules / ChamferLoss / compute_mean_covariance / Adam with
@@ -356,6 +406,12 @@ def gen_step(G, Ds, B):
 
 if __name__ == "__main__":
     cref.build()
+    if "--c4" in sys.argv:                      # only the round-2 additions (the other fixtures are unchanged)
+        gen_c4()
+        G = ref.PointGenerator(2048, 20)
+        Ds = [ref.PointDiscriminator_1(), ref.PointDiscriminator_2(), ref.PointDiscriminator_3(), ref.PointDiscriminator_4()]
+        gen_step(G, Ds, 16)
+        sys.exit(0)
     gen_knn()
     gen_edges()
     gen_deconv()
@@ -364,6 +420,10 @@ if __name__ == "__main__":
     gen_checkpoint_manifest()
     gen_data_and_jsd()
     G, Ds, z, outs = gen_networks()
+    gen_c4()
     if "--no-step" not in sys.argv:
         gen_step(G, Ds, 2)      # BASELINE.json configs[0] batch size (ill-conditioned BN: loose tolerance)
         gen_step(G, Ds, 4)
+        gen_step(G, Ds, 16)     # well-conditioned BatchNorm: the tight whole-iteration fixture
+    if "--only-new" in sys.argv:
+        pass

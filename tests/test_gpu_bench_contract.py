@@ -38,3 +38,20 @@ def test_bench_prints_one_json_line_with_roofline_and_cpu_baseline():
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
     assert c["kind"] in ("port", "reference") and c["unit"] == "points/s" and c["value"] > 0 and c["cores"] >= 1
+    assert "host" in c and "samples_s" in c and len(c["samples_s"]) >= 3
+    assert d["rccl_ranks"] == 1 and d["ms_per_step_min_rank"] <= d["ms_per_step_max_rank"]
+    assert d["executed_flops_per_step"] > 1e12 and 0.0 < d["step_mfma_frac"] < 1.0 and d["algebraic_saving"] > 1.0
+    assert r["kernel"].startswith("gemm_nt_kernel") and "Cijk" not in json.dumps(r)      # the roofline names own kernels only
+
+
+@pytest.mark.timeout(600)
+def test_bench_eval_mode_c5_line():
+    """bench.py --eval: config C5 (Chamfer + EMD on 2048-point pairs) at a reduced pair count."""
+    env = dict(os.environ)
+    env.pop("RANK", None), env.pop("WORLD_SIZE", None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--eval", "--eval-pairs", "64", "--steps", "2",
+                        "--warmup", "1"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=550)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
+    assert d["unit"] == "pairs/s" and d["value"] > 0 and d["config"]["finite"] is True
+    assert d["roofline"]["kernel"].startswith("approxmatch_kernel") and 0 < d["roofline"]["frac"] < 1

@@ -85,9 +85,10 @@ def patch_losses(monkeypatch_or_module):
             setattr(losses, name, fn)
 
 
-def linear_cl_torch(x2d, weight, bias=None, addend=None):
+def linear_cl_torch(x2d, weight, bias=None, addend=None, want_stats=None):
     y = torch.nn.functional.linear(x2d, weight, bias)
-    return y + addend if addend is not None else y
+    y = y + addend if addend is not None else y
+    return y if want_stats is None else (y, None)
 
 
 def bn_softmax_slots_permute_torch(x2d, bn, training, k, act="leaky_relu", pre_bias=None):
@@ -96,7 +97,7 @@ def bn_softmax_slots_permute_torch(x2d, bn, training, k, act="leaky_relu", pre_b
 
 
 def bilateral_weighting_torch(x2d, bn_x, u2d, bn_u, training, k, act="leaky_relu", pre_bias_x=None, pre_bias_u=None,
-                              partials_u=None):
+                              partials_u=None, partials_x=None):
     w = bn_softmax_slots_permute_torch(x2d, bn_x, training, k, act=act, pre_bias=pre_bias_x)
     return bn_act_torch(u2d, bn_u, training, act=act, mul=w.reshape(u2d.shape), pre_bias=pre_bias_u)
 
@@ -112,5 +113,5 @@ def flush_bn_counters_noop():
     pass
 
 
-def bn_act_maxpool_torch(x2d, bn, training, B, N, act="leaky_relu", pre_bias=None):
+def bn_act_maxpool_torch(x2d, bn, training, B, N, act="leaky_relu", pre_bias=None, partials=None):
     return bn_act_torch(x2d, bn, training, act=act, pre_bias=pre_bias).view(B, N, -1).max(dim=1)[0]
