@@ -350,11 +350,29 @@ def gen_c4():
 
 
 # ------------------------------------------------------------------ 6. one G+D iteration (composed)
-def gen_step(G, Ds, B):
+def _ref_graph(x, k):
+    """The kNN graph get_edge_features / get_edge_features_xyz pick for input x (:449-458, :489-498) -- the same
+    expression on the same tensor in the same process, hence bit for bit the reference's own idx."""
+    xt = x.permute(0, 2, 1)
+    xi = -2 * torch.bmm(xt, x)
+    xs = torch.sum(xt ** 2, dim=2, keepdim=True)
+    dist = xi + xs + xs.permute(0, 2, 1)
+    return torch.sort(dist, dim=2)[1][:, :, 1:k + 1].contiguous()
+
+
+def gen_step(G, Ds, B, record_graphs=False):
     """COMPOSED: reference torch modules / ChamferLoss / compute_mean_covariance / Adam with
     the C oracle standing in for the CUDA knnquery+grouping (models/PDGNet_v2.py:171-256).
     BASELINE.json configs[0] uses 256->512; the full 4-stage net is used here because
-    the reference generator cannot stop at 512."""
+    the reference generator cannot stop at 512.
+    record_graphs: also stores the eight feature-space kNN graphs the reference picked (four blocks x two generator
+    passes, in call order) so that a test can force the same graphs and compare pure arithmetic."""
+    graphs = []
+    hooks = []
+    if record_graphs:
+        for blk in (G.bilateral1.upsample_cov[0], G.bilateral2.upsample_cov, G.bilateral3.upsample_cov,
+                    G.bilateral4.upsample_cov):
+            hooks.append(blk.register_forward_pre_hook(lambda mod, inp: graphs.append(_ref_graph(inp[0].detach(), mod.k))))
     fill_module(G, salt=1)
     for i, d in enumerate(Ds):
         fill_module(d, salt=10 + i)
@@ -401,16 +419,29 @@ def gen_step(G, Ds, B):
     optG.step()
     res.update(g_loss=lossG.item(), similar_loss=sim.item(), g_grad_norm=gnorm,
                g_fc1_w_after=G.fc1[0].weight.detach()[:4, :8].clone())
-    save("step_b%d.npz" % B, **res)
+    for h in hooks:
+        h.remove()
+    if record_graphs:
+        assert len(graphs) == 8
+        res.update({"graph%d" % i: t.to(torch.int16) for i, t in enumerate(graphs)})
+        save("step_b%d_graphs.npz" % B, **res)
+    else:
+        save("step_b%d.npz" % B, **res)
 
 
 if __name__ == "__main__":
     cref.build()
+    if "--graphs" in sys.argv:
+        G = ref.PointGenerator(2048, 20)
+        Ds = [ref.PointDiscriminator_1(), ref.PointDiscriminator_2(), ref.PointDiscriminator_3(), ref.PointDiscriminator_4()]
+        gen_step(G, Ds, 8, record_graphs=True)
+        sys.exit(0)
     if "--c4" in sys.argv:                      # only the round-2 additions (the other fixtures are unchanged)
         gen_c4()
         G = ref.PointGenerator(2048, 20)
         Ds = [ref.PointDiscriminator_1(), ref.PointDiscriminator_2(), ref.PointDiscriminator_3(), ref.PointDiscriminator_4()]
         gen_step(G, Ds, 16)
+        gen_step(G, Ds, 8, record_graphs=True)
         sys.exit(0)
     gen_knn()
     gen_edges()
@@ -424,6 +455,7 @@ if __name__ == "__main__":
     if "--no-step" not in sys.argv:
         gen_step(G, Ds, 2)      # BASELINE.json configs[0] batch size (ill-conditioned BN: loose tolerance)
         gen_step(G, Ds, 4)
-        gen_step(G, Ds, 16)     # well-conditioned BatchNorm: the tight whole-iteration fixture
+        gen_step(G, Ds, 16)     # well-conditioned BatchNorm, losses only
+        gen_step(G, Ds, 8, record_graphs=True)   # + the reference's own kNN graphs: the tight whole-iteration fixture
     if "--only-new" in sys.argv:
         pass

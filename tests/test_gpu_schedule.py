@@ -62,14 +62,20 @@ def test_rccl_path_at_world_size_one_equals_single_process():
     import torch.distributed as dist
     from pdgn_amd.trainer import PDGNTrainer, noise, synthetic_batch
     dev = torch.device("cuda:0")
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     torch.manual_seed(5)
     a = PDGNTrainer(device=dev, distributed=False)
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    for attempt in range(5):                                  # a just-released port can still be taken: pick another
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        try:
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+            break
+        except Exception:
+            if attempt == 4:
+                raise
     try:
         b = PDGNTrainer(device=dev, distributed=True, generator=copy.deepcopy(a.G),
                         discriminators=[copy.deepcopy(d) for d in a.D])
