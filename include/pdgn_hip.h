@@ -242,6 +242,11 @@ int pdgn_gemm_nt(long long m, int n, int k, const float *A, int lda, const float
 int pdgn_gemm_nn(long long m, int n, int k, const float *A, int lda, const float *Wt, int ldw,
                  const float *bias, const float *addend, int ldadd, float *C, int ldc, float *stat_part,
                  pdgn_stream_t stream);
+/* Weight gradient on the same kernel (both operands transposed, reduction over the m rows split over the workgroups):
+ * dW (n x k) = dY (m x n, pitch ldy)^T X (m x k, pitch ldx); dW is zero-filled by the call.  Meant for outputs of at
+ * least one 128 x 64 tile (pdgn_gemm_tn keeps the small ones). */
+int pdgn_gemm_tn_big(long long m, int n, int k, const float *dY, int ldy, const float *X, int ldx, float *dW,
+                     pdgn_stream_t stream);
 long long pdgn_gemm_nt_stat_rows(long long m, int n, int k);
 /* Tile configuration the launch model picks (0: 256x128, 1: 128x128, 2: 160x64, 3: 128x64 workgroup tiles); host only. */
 int pdgn_gemm_nt_config(long long m, int n, int k, int with_stats);

@@ -72,14 +72,20 @@ struct NtArgs {
     int dbg;                          // PDGN_NT_DBG (measurement only): 1 no stores, 2 no DMA
 };
 
-template <int TM, int TN, int WM, int WN, bool ATOMIC, bool WT>
+template <int TM, int TN, int WM, int WN, bool ATOMIC, bool WT, bool AT>
 __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_nt_kernel(const NtArgs p) {
     constexpr int NW = WM * WN, BM = 16 * TM * WM, BN = 16 * TN * WN;
     // WT: the weight operand is given TRANSPOSED, W^T (K x N) row-major (the input gradient dX = dY W uses the layer's own
     // (C_out x C_in) weight as it is): its chunk is [32 k][BN] in LDS, 1-KB pieces padded apart so that the b32 fragment
     // reads of rows k and k + 4 fall on different banks
+    // AT: likewise the FIRST operand, A^T (K x M) row-major: with both, C = At^T Wt is the weight gradient dW = dY^T X of a
+    // dense layer, the reduction running over the (10^4 .. 10^5.5) rows and split over the workgroups by the stream-K launch.
     constexpr int WROWS = 256 / BN, WPAD = WT ? 4 * WROWS : 0;      // k rows per 1-KB piece, pad floats after each piece
-    constexpr int STAGE_FLOATS = (BM + BN) * NT_BK + (BN / 8) * WPAD;
+    constexpr int AROWS = 256 / BM, APAD = AT ? 4 * AROWS : 0;
+    static_assert(!AT || (BM <= 256 && 256 % BM == 0 && 4 % AROWS == 0), "A^T pieces: whole rows, a divisor of 4 per piece");
+    static_assert(!WT || (BN <= 256 && 256 % BN == 0 && 4 % WROWS == 0), "W^T pieces: whole rows, a divisor of 4 per piece");
+    constexpr int A_FLOATS = BM * NT_BK + (BM / 8) * APAD;          // A part of a stage
+    constexpr int STAGE_FLOATS = A_FLOATS + BN * NT_BK + (BN / 8) * WPAD;
     constexpr int NPA = BM / 8 / NW, NPB = BN / 8 / NW, NP = NPA + NPB;   // 1-KB DMA pieces per wave and chunk
     constexpr int NS = ATOMIC ? 0 : TM * TN;                              // counted stores per wave and item
     static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "pieces must divide over the waves");
@@ -141,23 +147,27 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_nt_kernel(const NtArgs p
     const int dcol = (lane & 7) ^ drow;                           // 16-B source column stored at position lane & 7
     unsigned voffA[NPA], voffB[NPB];
 #pragma unroll
-    for (int i = 0; i < NPA; ++i) voffA[i] = (unsigned)(((wave + i * NW) * 8 + drow) * p.lda + dcol * 4) * 4u;
+    for (int i = 0; i < NPA; ++i)
+        voffA[i] = AT ? (unsigned)(((wave + i * NW) * AROWS + lane / (BM / 4)) * p.lda + (lane % (BM / 4)) * 4) * 4u
+                      : (unsigned)(((wave + i * NW) * 8 + drow) * p.lda + dcol * 4) * 4u;
 #pragma unroll
     for (int i = 0; i < NPB; ++i)
         voffB[i] = WT ? (unsigned)(((wave + i * NW) * WROWS + lane / (BN / 4)) * p.ldw + (lane % (BN / 4)) * 4) * 4u
                       : (unsigned)(((wave + i * NW) * 8 + drow) * p.ldw + dcol * 4) * 4u;
 
-    // descriptors of the load cursor's tile
+    // descriptors of the load cursor's tile (a transposed operand: of its current chunk -- the rows of a chunk start
+    // k0 * pitch floats into the matrix, which a 32-bit offset from the tile's origin could not always reach)
     i32x4 rsA, rsW;
+    long long ld_m0 = 0;
+    int ld_n0 = 0, ld_mrows = 0, ld_nrows = 0;
     auto make_srds = [&](int tile) {
         const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
-        const long long m0 = (long long)tm * BM;
-        const int n0 = tn * BN;
-        const long long mrows = min((long long)BM, p.M - m0);
-        const int nrows = min(BN, p.N - n0);
-        rsA = nt_srd(p.A + m0 * p.lda, (unsigned)(mrows * p.lda * 4));
-        rsW = WT ? nt_srd(p.W + n0, (unsigned)(((long long)(p.K - 1) * p.ldw + nrows) * 4))
-                 : nt_srd(p.W + (long long)n0 * p.ldw, (unsigned)(nrows * p.ldw * 4));
+        ld_m0 = (long long)tm * BM;
+        ld_n0 = tn * BN;
+        ld_mrows = (int)min((long long)BM, p.M - ld_m0);
+        ld_nrows = min(BN, p.N - ld_n0);
+        if (!AT) rsA = nt_srd(p.A + ld_m0 * p.lda, (unsigned)((long long)ld_mrows * p.lda * 4));
+        if (!WT) rsW = nt_srd(p.W + (long long)ld_n0 * p.ldw, (unsigned)(ld_nrows * p.ldw * 4));
     };
     make_srds(ld.tile);
 
@@ -165,21 +175,27 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_nt_kernel(const NtArgs p
     // One DMA piece of the load cursor's chunk (i < NPA: activation rows, else weight rows) into `stage`.
     int ld_k0 = 0;
     bool ld_kok = true;
-    unsigned ld_dst = 0, ld_dst_w = 0;
+    unsigned ld_dst = 0, ld_dst_w = 0, ld_dst_a = 0;
     auto issue_begin = [&](int stage) {
         ld_k0 = ld.kc * NT_BK;
         ld_kok = ld_k0 + dcol * 4 < p.K;                           // K % 4 == 0: a 16-B column is all in or all out
         ld_dst = smem_base + (unsigned)(stage * STAGE_FLOATS + wave * 256) * 4u;
-        ld_dst_w = smem_base + (unsigned)(stage * STAGE_FLOATS + BM * NT_BK + wave * (256 + WPAD)) * 4u;
+        ld_dst_w = smem_base + (unsigned)(stage * STAGE_FLOATS + A_FLOATS + wave * (256 + WPAD)) * 4u;
+        ld_dst_a = smem_base + (unsigned)(stage * STAGE_FLOATS + wave * (256 + APAD)) * 4u;
+        const int krows = min(NT_BK, p.K - ld_k0);                 // reduction rows of this chunk: the rest reads as zero
+        if (AT) rsA = nt_srd(p.A + (long long)ld_k0 * p.lda + ld_m0, (unsigned)(((long long)(krows - 1) * p.lda + ld_mrows) * 4));
+        if (WT) rsW = nt_srd(p.W + (long long)ld_k0 * p.ldw + ld_n0, (unsigned)(((long long)(krows - 1) * p.ldw + ld_nrows) * 4));
     };
     auto issue_piece = [&](int i) {
         if (p.dbg & 2) return;
-        if (i < NPA) nt_dma16(rsA, ld_dst + i * NW * 1024, ld_kok ? voffA[i < NPA ? i : 0] : NT_OOB, ld_k0 * 4);
-        else if (!WT) nt_dma16(rsW, ld_dst + BM * NT_BK * 4 + (i - NPA) * NW * 1024, ld_kok ? voffB[i < NPA ? 0 : i - NPA] : NT_OOB, ld_k0 * 4);
-        else {
-            const int j = i < NPA ? 0 : i - NPA;                     // piece wave + j*NW: k rows (wave + j*NW)*WROWS + lane / (BN/4)
-            const bool rok = ld_k0 + (wave + j * NW) * WROWS + lane / (BN / 4) < p.K;
-            nt_dma16(rsW, ld_dst_w + j * NW * (1024 + WPAD * 4), rok ? voffB[j] + (unsigned)(ld_k0 * p.ldw) * 4u : NT_OOB, 0);
+        if (i < NPA) {
+            const int j = i < NPA ? i : 0;
+            if (!AT) nt_dma16(rsA, ld_dst + j * NW * 1024, ld_kok ? voffA[j] : NT_OOB, ld_k0 * 4);
+            else nt_dma16(rsA, ld_dst_a + j * NW * (1024 + APAD * 4), voffA[j], 0);
+        } else {
+            const int j = i < NPA ? 0 : i - NPA;
+            if (!WT) nt_dma16(rsW, ld_dst + A_FLOATS * 4 + j * NW * 1024, ld_kok ? voffB[j] : NT_OOB, ld_k0 * 4);
+            else nt_dma16(rsW, ld_dst_w + j * NW * (1024 + WPAD * 4), voffB[j], 0);
         }
     };
     auto advance_load = [&]() {
@@ -193,7 +209,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_nt_kernel(const NtArgs p
     // ---- fragment read offsets (floats): row (li) * 32 + 4 * ((4q + lg) ^ (li & 7)), q = 0, 1
     const int fo0 = li * NT_BK + 4 * ((lg) ^ (li & 7));
     const int fo1 = li * NT_BK + 4 * ((4 + lg) ^ (li & 7));
-    const int abase = wm * 16 * TM * NT_BK, bbase = (BM + wn * 16 * TN) * NT_BK;
+    const int abase = wm * 16 * TM * NT_BK, bbase = A_FLOATS + wn * 16 * TN * NT_BK;
 
     f32x4 acc[TM][TN];
 #pragma unroll
@@ -204,16 +220,31 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_nt_kernel(const NtArgs p
     // WT: k row r of the W^T chunk sits at float (r / WROWS) * (256 + WPAD) + (r % WROWS) * BN; a lane's fragment element u
     // of column block b is row 16q + 4*lg + u, column wn*16*TN + 16b + li
     const int wt_lane = ((4 * lg) / WROWS) * (256 + WPAD) + ((4 * lg) % WROWS) * BN + wn * 16 * TN + li;
+    const int at_lane = ((4 * lg) / AROWS) * (256 + APAD) + ((4 * lg) % AROWS) * BM + wm * 16 * TM + li;
     auto read_half = [&](int stage, int q, float4 *ra, float4 *rb) {
-        const float *sa = smem + stage * STAGE_FLOATS + abase + (q ? fo1 : fo0);
+        if (!AT) {
+            const float *sa = smem + stage * STAGE_FLOATS + abase + (q ? fo1 : fo0);
 #pragma unroll
-        for (int a = 0; a < TM; ++a) ra[a] = *reinterpret_cast<const float4 *>(sa + a * 16 * NT_BK);
+            for (int a = 0; a < TM; ++a) ra[a] = *reinterpret_cast<const float4 *>(sa + a * 16 * NT_BK);
+        } else {
+            const float *sa = smem + stage * STAGE_FLOATS + at_lane;
+#pragma unroll
+            for (int a = 0; a < TM; ++a) {
+                float e[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int r = 16 * q + u;
+                    e[u] = sa[(r / AROWS) * (256 + APAD) + (r % AROWS) * BM + 16 * a];
+                }
+                ra[a] = make_float4(e[0], e[1], e[2], e[3]);
+            }
+        }
         if (!WT) {
             const float *sb = smem + stage * STAGE_FLOATS + bbase + (q ? fo1 : fo0);
 #pragma unroll
             for (int b = 0; b < TN; ++b) rb[b] = *reinterpret_cast<const float4 *>(sb + b * 16 * NT_BK);
         } else {
-            const float *sb = smem + stage * STAGE_FLOATS + BM * NT_BK + wt_lane;
+            const float *sb = smem + stage * STAGE_FLOATS + A_FLOATS + wt_lane;
 #pragma unroll
             for (int b = 0; b < TN; ++b) {
                 float e[4];
@@ -499,12 +530,14 @@ struct NtCfg {
         pl.sk_per_wg = 0;
         pl.cost = full + (tail ? (KC + ov) * chunk_us((int)((tail + cus - 1) / cus)) : 0.0);
         if (allow_sk && tail > 0) {
-            // stream-K tail over g workgroups: g = every slot, or one per CU
-            for (int w = WG_PER_CU; w >= 1; w -= (WG_PER_CU > 1 ? WG_PER_CU - 1 : 1)) {
-                const long long iters = tail * KC;
-                long long g = (long long)cus * w < iters ? (long long)cus * w : iters;
+            // stream-K tail over g workgroups: every slot, one per CU, or fewer with at least 16 chunks each
+            const long long iters = tail * KC;
+            const long long cand[3] = {(long long)slots, (long long)cus, iters / 16};
+            for (int ci = 0; ci < 3; ++ci) {
+                long long g = cand[ci] < 1 ? 1 : (cand[ci] > slots ? slots : cand[ci]);
+                g = g < iters ? g : iters;
                 const long long per = (iters + g - 1) / g;
-                if (per < 8) continue;                             // short ranges: the atomics cost more than they balance
+                if (per < 8 && g > 1) continue;                    // short ranges: the atomics cost more than they balance
                 g = (iters + per - 1) / per;
                 const double zero_rows = (double)(m - (long long)((rounds * slots) / pl.tiles_n) * BM);
                 const double c = full + (per + ov) * chunk_us((int)((g + cus - 1) / cus)) + (double)(g + tail) * BM * BN * 4 / 1.3e6 +
@@ -516,13 +549,12 @@ struct NtCfg {
                     pl.grid_sk = (int)g;
                     pl.sk_per_wg = per;
                 }
-                if (WG_PER_CU == 1) break;
             }
         }
         return pl;
     }
 
-    template <bool WT>
+    template <bool WT, bool AT = false>
     static int launch(long long m, int n, int k, const float *A, int lda, const float *W, int ldw, const float *bias,
                       const float *addend, int ldadd, float *C, int ldc, float *stat_part, hipStream_t s) {
         const bool allow_sk = stat_part == nullptr && ldc == n;
@@ -541,11 +573,11 @@ struct NtCfg {
         }
         if (pl.grid_dp) {
             a.tile_begin = 0; a.tile_end = pl.dp_tiles; a.sk_per_wg = 0;
-            hipLaunchKernelGGL((gemm_nt_kernel<TM, TN, WM, WN, false, WT>), dim3(pl.grid_dp), dim3(64 * WM * WN), 0, s, a);
+            hipLaunchKernelGGL((gemm_nt_kernel<TM, TN, WM, WN, false, WT, AT>), dim3(pl.grid_dp), dim3(64 * WM * WN), 0, s, a);
         }
         if (pl.grid_sk) {
             a.tile_begin = pl.dp_tiles; a.tile_end = (int)T; a.sk_per_wg = pl.sk_per_wg;
-            hipLaunchKernelGGL((gemm_nt_kernel<TM, TN, WM, WN, true, WT>), dim3(pl.grid_sk), dim3(64 * WM * WN), 0, s, a);
+            hipLaunchKernelGGL((gemm_nt_kernel<TM, TN, WM, WN, true, WT, AT>), dim3(pl.grid_sk), dim3(64 * WM * WN), 0, s, a);
         }
         return pdgn_launch_status();
     }
@@ -557,15 +589,15 @@ typedef NtCfg<5, 2, 2, 2, 2> NtTall;     // 160 x 64, 4 waves (56 KB): two per C
 typedef NtCfg<4, 2, 2, 2, 3> NtNarrow;   // 128 x 64, 4 waves (48 KB, < 168 registers): three per CU
 
 // Tile configuration for a problem: PDGN_NT_CFG (0-3, measurement only), else the cheapest by the launch model.
-static int nt_pick(long long m, int n, int k, bool stats) {
+static int nt_pick(long long m, int n, int k, bool stats, bool no_tall = false) {
     const char *e = getenv("PDGN_NT_CFG");
-    if (e && *e) return atoi(e);
+    if (e && *e) return (no_tall && atoi(e) == 2) ? 1 : atoi(e);
     const bool sk = !stats;
     const double c[4] = {NtBig::plan(m, n, k, sk).cost, NtSquare::plan(m, n, k, sk).cost, NtTall::plan(m, n, k, sk).cost,
                          NtNarrow::plan(m, n, k, sk).cost};
     int best = 1;
     for (int i = 0; i < 4; ++i)
-        if (c[i] < c[best] * 0.97) best = i;                        // the square tile unless another is clearly cheaper
+        if (c[i] < c[best] * 0.97 && !(no_tall && i == 2)) best = i;    // the square tile unless another is clearly cheaper
     return best;
 }
 
@@ -604,6 +636,24 @@ extern "C" int pdgn_gemm_nn(long long m, int n, int k, const float *A, int lda, 
                             pdgn_stream_t stream) {
     if (!nt_args_ok(m, n, k, lda, ldw, ldadd, ldc, addend, true)) return PDGN_ERR_INVALID;
     return nt_dispatch<true>(m, n, k, A, lda, Wt, ldw, bias, addend, ldadd, C, ldc, stat_part, (hipStream_t)stream);
+}
+
+// Weight gradient of a point-major dense layer, dW (n x k) = dY (m x n)^T X (m x k): the same kernel with BOTH operands
+// given transposed, the reduction over the m rows split over the workgroups (stream-K launch, fp32 atomics into dW,
+// which the launch zero-fills itself).  For outputs of at least one 128 x 64 tile; pdgn_gemm_tn (gemm_tn.hip) keeps the
+// small ones.
+extern "C" int pdgn_gemm_tn_big(long long m, int n, int k, const float *dY, int ldy, const float *X, int ldx, float *dW,
+                                pdgn_stream_t stream) {
+    if (m < 1 || n < 4 || k < 4 || n % 4 || k % 4 || ldy % 4 || ldx % 4 || ldy < n || ldx < k || ldy >= (1 << 19) ||
+        ldx >= (1 << 19) || m > 0x7fffffffLL * 16)
+        return PDGN_ERR_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    // kernel roles: output rows = n (columns of dY), output columns = k (columns of X), reduction = m
+    switch (nt_pick(n, k, (int)(m > 0x7fffffff ? 0x7fffffff : m), false, true)) {
+        case 0: return NtBig::launch<true, true>(n, k, (int)m, dY, ldy, X, ldx, nullptr, nullptr, 0, dW, k, nullptr, s);
+        case 3: return NtNarrow::launch<true, true>(n, k, (int)m, dY, ldy, X, ldx, nullptr, nullptr, 0, dW, k, nullptr, s);
+        default: return NtSquare::launch<true, true>(n, k, (int)m, dY, ldy, X, ldx, nullptr, nullptr, 0, dW, k, nullptr, s);
+    }
 }
 
 // Number of [2n] partial-statistics rows pdgn_gemm_nt writes for this problem (tile rows x waves along m).

@@ -202,6 +202,7 @@ def bn_act(x2d, bn, training, act="leaky_relu", mul=None, pre_bias=None, partial
 # No BLAS library, no run-time back-end selection.  Below that row count (the 35-row per-sample layers) torch's
 # default matmul is used as it is.
 _OWN_MIN_ROWS = 1024
+_TN_BIG = os.environ.get("PDGN_TN_BIG", "1") == "1"            # A/B switch: weight gradients of >= 128 x 64 outputs on pdgn_gemm_tn_big
 
 
 def _pad_cols(t, mult=4):
@@ -265,6 +266,14 @@ def gemm_tn(dy, x):
     if GEMM_LOG is not None:
         GEMM_LOG.append(("tn", m, n, k))
     dyp, xp = _pad_cols(dy), _pad_cols(x)
+    if _TN_BIG and dyp.shape[1] >= 64 and xp.shape[1] >= 64 and 65536 <= dyp.shape[1] * xp.shape[1] <= (1 << 20):
+        # mid-sized outputs (4 .. 64 tiles of 128 x 128): the stream-K launch of the pdgn_gemm_nt kernel with both operands
+        # transposed balances them better than pdgn_gemm_tn's split (measured, tools/gemm_shapes.py: 0.70-0.94x its time);
+        # smaller outputs and the two largest ones (conv2's dense half, the per-point GEMM) stay on pdgn_gemm_tn
+        dwp = torch.empty((dyp.shape[1], xp.shape[1]), dtype=F32, device=dy.device)
+        check(_lib.lib().pdgn_gemm_tn_big(ctypes.c_longlong(m), dyp.shape[1], xp.shape[1], ptr(dyp), dyp.stride(0), ptr(xp),
+                                          xp.stride(0), ptr(dwp), stream_of(dy)), "pdgn_gemm_tn_big")
+        return dwp if (dyp.shape[1] == n and xp.shape[1] == k) else dwp[:n, :k]
     if dyp.stride(0) != dyp.shape[1]:
         dyp = dyp.contiguous()
     if xp.stride(0) != xp.shape[1]:

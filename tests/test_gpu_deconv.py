@@ -374,6 +374,35 @@ def test_gemm_tn_direct(M, N, K):
     assert ((dw2.double() - ref64).abs() / scale64).max().item() < 1e-5
 
 
+@pytest.mark.parametrize("cfg", [None, 0, 1, 3])
+@pytest.mark.parametrize("M,N,K", [(35840, 12832, 128), (71680, 1024, 256), (358400, 512, 64), (35840, 512, 5120),
+                                   (17920, 256, 2560), (100003, 132, 68), (5000, 64, 128), (40, 128, 64), (8960, 3232, 32)])
+def test_gemm_tn_big_direct(M, N, K, cfg, monkeypatch):
+    """pdgn_gemm_tn_big through the C ABI (weight gradient on the pdgn_gemm_nt kernel with both operands transposed and
+    the row reduction split stream-K): dW = dY^T X against fp32 matmul on all rows and fp64 on a row sample, every
+    configuration the entry point can pick; dW needs no zero-fill by the caller (poisoned with NaN here)."""
+    import ctypes
+    from pdgn_amd import _lib
+    from pdgn_amd._lib import ptr, stream_of
+    if cfg is None:
+        monkeypatch.delenv("PDGN_NT_CFG", raising=False)
+    else:
+        monkeypatch.setenv("PDGN_NT_CFG", str(cfg))
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    x = torch.randn(M, K, device="cuda", generator=g)
+    dy = torch.randn(M, N, device="cuda", generator=g)
+    dw = torch.full((N, K), float("nan"), device="cuda")
+    assert _lib.lib().pdgn_gemm_tn_big(ctypes.c_longlong(M), N, K, ptr(dy), N, ptr(x), K, ptr(dw), stream_of(dy)) == 0
+    scale = (dy.abs().t().matmul(x.abs())).clamp_min(1e-6)
+    assert ((dw - dy.t().matmul(x)).abs() / scale).max().item() < 2e-5
+    rows = min(M, 40000)
+    dw2 = torch.full((N, K), float("nan"), device="cuda")
+    assert _lib.lib().pdgn_gemm_tn_big(ctypes.c_longlong(rows), N, K, ptr(dy), N, ptr(x), K, ptr(dw2), stream_of(dy)) == 0
+    ref64 = dy[:rows].double().t().matmul(x[:rows].double())
+    scale64 = dy[:rows].abs().double().t().matmul(x[:rows].abs().double()).clamp_min(1e-6)
+    assert ((dw2.double() - ref64).abs() / scale64).max().item() < 1e-5
+
+
 @pytest.mark.parametrize("M,N,K", [(35840, 512, 256), (5000, 20, 12), (1024, 3, 64), (100003, 132, 68), (71680, 64, 3),
                                    (2048, 6, 3), (300, 64, 64)])
 def test_linear_cl_autograd(M, N, K):

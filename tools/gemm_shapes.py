@@ -62,6 +62,9 @@ for (kind, m, n, k), cnt in log.items():
         own = t(lambda: L.pdgn_gemm_tn(ctypes.c_longlong(m), pad(n), pad(k), ptr(dy), ptr(x), ptr(dw), stream_of(dy)))
         lib = t(lambda: dy.t().matmul(x))
         cfg = -1
+        if pad(n) >= 64 and pad(k) >= 64:
+            big = t(lambda: L.pdgn_gemm_tn_big(ctypes.c_longlong(m), pad(n), pad(k), ptr(dy), pad(n), ptr(x), pad(k), ptr(dw), stream_of(dy)))
+            extra[(kind, m, n, k)] = " | tn_big %8.1f us %6.1f TF (x%.2f of gemm_tn)" % (big, 2.0 * m * n * k / big / 1e6, big / own)
     rows.append((own * cnt, kind, m, n, k, cnt, cfg, own, lib))
     tot_own += own * cnt; tot_lib += lib * cnt
 rows.sort(reverse=True)
