@@ -72,6 +72,157 @@ __global__ __launch_bounds__(KNN_THREADS) void knn3_wave_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Several queries per wave (round 2; KNN4_Q = 2 measured fastest: 4 halves the occupancy, 1 the reuse).  The one-query kernel above spends most of a query's ~5000 cycles in dependent chains
+// (32 ballot-bisection steps for the threshold, a 21-stage bitonic sort over ds_bpermute for the merge) at two waves
+// per SIMD.  Here a wave owns KNN4_Q consecutive queries: one ds_read_b128 of a candidate feeds their distance chains, the
+// threshold searches / survivor queues / merges are independent instruction streams the scheduler interleaves, the
+// threshold search stops after 16 bits (an upper bound within 0.8 % of the exact K-th lane minimum is as good a filter),
+// the merge is the rank-based one of wave_select.h (broadcast LDS reads, no cross-lane chain), the candidate tile is
+// staged 4 points = three float4 per thread, and the workgroup is sized for six waves per SIMD (48 KB of LDS).
+// Results are bit-identical: same sqdist3 chain, same strict (distance, index) order.
+#define KNN4_THREADS 512
+#define KNN4_WAVES (KNN4_THREADS / PDGN_WAVE)
+#define KNN4_Q 2
+#define KNN4_TILE 2048       // candidates staged per pass: 32 KiB of float4
+#define KNN4_QCAP 64         // survivor queue entries per query (+ room for the running list in a merge)
+
+// Upper bound of the K-th smallest (1-based) of the 64 lane values (all >= 0 or +inf): bisection over the top 16 bits of
+// the order-preserving integer image, the rest rounded up.
+__device__ __forceinline__ float wave_kth_smallest_ub16(float v, int K) {
+    const unsigned key = __float_as_uint(v) | 0x80000000u;       // v >= +0: image = bits ^ 0x80000000
+    unsigned prefix = 0x80000000u;
+#pragma unroll
+    for (int bit = 30; bit >= 15; --bit) {
+        const unsigned cand = prefix | (1u << bit);
+        const int below = __popcll(__ballot(key < cand));
+        prefix = below < K ? cand : prefix;
+    }
+    const unsigned ub = min(prefix | 0x7fffu, 0xff800000u);      // never past +inf (a NaN pattern would filter everything)
+    return __uint_as_float(ub & 0x7fffffffu);
+}
+
+__global__ __launch_bounds__(KNN4_THREADS) void knn3_wave4_kernel(
+    int n, int m, int K, int qpw, const float *__restrict__ xyz, const float *__restrict__ new_xyz,
+    int32_t *__restrict__ idx, float *__restrict__ dist2) {
+    __shared__ float4 cand[KNN4_TILE];
+    __shared__ DI queue[KNN4_WAVES][KNN4_Q][KNN4_QCAP + KNN_FAST_MAX_K];
+    __shared__ DI win[KNN4_WAVES][KNN4_Q][KNN_FAST_MAX_K];
+
+    const int bs = blockIdx.y;
+    const int lane = lane_id();
+    const int wave = threadIdx.x / PDGN_WAVE;
+    const float *P = xyz + (size_t)bs * n * 3;
+    // qpw groups of KNN4_Q queries per wave, one after the other on the same staged tile (qpw > 1 only when the whole
+    // candidate set is one tile: the running lists of a group live in registers across tiles)
+  for (int grp = 0; grp < qpw; ++grp) {
+    const int q0 = ((blockIdx.x * KNN4_WAVES + wave) * qpw + grp) * KNN4_Q;
+
+    float qx[KNN4_Q], qy[KNN4_Q], qz[KNN4_Q], rd[KNN4_Q];
+    int ri[KNN4_Q], cnt[KNN4_Q];
+#pragma unroll
+    for (int q = 0; q < KNN4_Q; ++q) {
+        const int query = min(q0 + q, m - 1);                    // queries past m: computed, never stored
+        const float *Qp = new_xyz + ((size_t)bs * m + query) * 3;
+        qx[q] = Qp[0]; qy[q] = Qp[1]; qz[q] = Qp[2];
+        rd[q] = INFINITY;
+        ri[q] = 0x7fffffff;
+        cnt[q] = 0;
+    }
+    const bool vec_ok = (n % 4 == 0) && ((reinterpret_cast<uintptr_t>(xyz) & 15) == 0);
+    for (int t0 = 0; t0 < n; t0 += KNN4_TILE) {
+        const int tn = min(KNN4_TILE, n - t0);
+        const int tp = (tn + 255) & ~255;
+      if (grp == 0 || n > KNN4_TILE) {
+        __syncthreads();                                         // previous tile fully consumed
+        if (vec_ok) {
+            // 4 points = 12 floats = three float4 per thread (t0 and tn are multiples of 4 here)
+            const float4 *src = reinterpret_cast<const float4 *>(P + (size_t)t0 * 3);
+            for (int g = threadIdx.x; g < tn / 4; g += KNN4_THREADS) {
+                const float4 a = src[3 * g], b = src[3 * g + 1], c = src[3 * g + 2];
+                cand[4 * g] = make_float4(a.x, a.y, a.z, 0.f);
+                cand[4 * g + 1] = make_float4(a.w, b.x, b.y, 0.f);
+                cand[4 * g + 2] = make_float4(b.z, b.w, c.x, 0.f);
+                cand[4 * g + 3] = make_float4(c.y, c.z, c.w, 0.f);
+            }
+        } else {
+            for (int c = threadIdx.x; c < tn; c += KNN4_THREADS) {
+                const float *pp = P + (size_t)(t0 + c) * 3;
+                cand[c] = make_float4(pp[0], pp[1], pp[2], 0.f);
+            }
+        }
+        // pad the tile to a multiple of 256 candidates with points at infinity (distance +inf: never a minimum, never
+        // kept), so that the scans below run without per-candidate guards, four LDS reads in flight per lane
+        for (int c = tn + threadIdx.x; c < tp; c += KNN4_THREADS) cand[c] = make_float4(INFINITY, INFINITY, INFINITY, 0.f);
+        __syncthreads();
+      }
+        // pass A: per-lane minimum for each of the four queries -> thresholds
+        float lmin[KNN4_Q];
+#pragma unroll
+        for (int q = 0; q < KNN4_Q; ++q) lmin[q] = INFINITY;
+        for (int c = lane; c < tp; c += 256) {
+            float4 p[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) p[j] = cand[c + 64 * j];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int q = 0; q < KNN4_Q; ++q) {
+                    const float d = sqdist3(qx[q], qy[q], qz[q], p[j].x, p[j].y, p[j].z);
+                    lmin[q] = d < lmin[q] ? d : lmin[q];
+                }
+        }
+        float tau[KNN4_Q];
+#pragma unroll
+        for (int q = 0; q < KNN4_Q; ++q) tau[q] = fminf(wave_kth_smallest_ub16(lmin[q], K), __shfl(rd[q], K - 1, 64));
+        // pass B: survivors into the per-query queues
+        for (int c0 = 0; c0 < tp; c0 += 128) {
+            float4 p[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) p[j] = cand[c0 + 64 * j + lane];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int c = c0 + 64 * j + lane;
+#pragma unroll
+                for (int q = 0; q < KNN4_Q; ++q) {
+                    const float d = sqdist3(qx[q], qy[q], qz[q], p[j].x, p[j].y, p[j].z);
+                    bool keep = d <= tau[q] && d < INFINITY;
+                    unsigned long long mask = __ballot(keep);
+                    if (mask) {
+                        DI *qq = queue[wave][q];
+                        if (cnt[q] + __popcll(mask) > KNN4_QCAP) {   // rare (duplicates, > 64 ties): merge, tighten, re-filter
+                            knn_flush_ranked(qq, cnt[q], K, rd[q], ri[q], lane, win[wave][q]);
+                            cnt[q] = 0;
+                            tau[q] = fminf(tau[q], __shfl(rd[q], K - 1, 64));
+                            keep = keep && d <= tau[q];
+                            mask = __ballot(keep);
+                        }
+                        const int pos = cnt[q] + __popcll(mask & ((1ull << lane) - 1ull));
+                        if (keep) { qq[pos].d = d; qq[pos].i = t0 + c; }
+                        cnt[q] += __popcll(mask);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < KNN4_Q; ++q) {
+            knn_flush_ranked(queue[wave][q], cnt[q], K, rd[q], ri[q], lane, win[wave][q]);
+            cnt[q] = 0;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < KNN4_Q; ++q) {
+        const int query = q0 + q;
+        if (query < m && lane < K) {
+            const size_t o = ((size_t)bs * m + query) * K + lane;
+            const bool valid = rd[q] < INFINITY;
+            idx[o] = valid ? ri[q] : 0;                          // reference tail: idx 0 / dist 1e40 -> +inf
+            if (dist2) dist2[o] = rd[q];
+        }
+    }
+  }
+}
+
 // Generic fallback for 32 < nsample <= 200: one thread per query, sorted insertion in
 // per-thread scratch (the reference's own shape; not used by PDGN, which has nsample = 20).
 __global__ __launch_bounds__(KNN_THREADS) void knn3_generic_kernel(
@@ -147,7 +298,21 @@ extern "C" int pdgn_knnquery(int b, int n, int m, int nsample, const float *xyz,
     if (b == 0 || m == 0) return 0;
     if (b > 65535) return PDGN_ERR_INVALID;
     hipStream_t s = (hipStream_t)stream;
-    if (nsample <= KNN_FAST_MAX_K) {
+    static int use4 = -1;
+    if (use4 < 0) { const char *e = getenv("PDGN_KNN3_WAVE4"); use4 = e ? atoi(e) : 1; }
+    if (nsample <= KNN_FAST_MAX_K && use4) {
+        // groups per wave: amortise the staging of the tile while keeping several rounds of workgroups on the chip
+        static int qpw_env = -1;
+        if (qpw_env < 0) { const char *e = getenv("PDGN_KNN3_QPW"); qpw_env = e ? atoi(e) : 0; }
+        int qpw = 1;
+        if (n <= KNN4_TILE) {
+            const long long wgs1 = (long long)b * cdiv(m, KNN4_WAVES * KNN4_Q);
+            qpw = qpw_env > 0 ? qpw_env : 1;            // measured (tools/knn3_bench.py): 1 is fastest at the step's shapes
+            (void)wgs1;
+        }
+        dim3 grid(cdiv(m, KNN4_WAVES * KNN4_Q * qpw), b);
+        hipLaunchKernelGGL(knn3_wave4_kernel, grid, dim3(KNN4_THREADS), 0, s, n, m, nsample, qpw, xyz, new_xyz, idx, dist2);
+    } else if (nsample <= KNN_FAST_MAX_K) {
         // queries per wave: enough workgroups to cover 256 CUs several times over, while
         // amortising the LDS staging of the candidate set when there are many queries.
         long long waves = (long long)b * m;
