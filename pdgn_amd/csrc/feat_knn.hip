@@ -39,7 +39,15 @@ __global__ __launch_bounds__(256) void sqnorm_kernel(int f, int n, const float *
     if (i >= n) return;
     const float *X = x + (size_t)bs * f * n;
     float s = 0.f;
-    for (int c = 0; c < f; ++c) s = __fmaf_rn(X[(size_t)c * n + i], X[(size_t)c * n + i], s);
+    int c = 0;
+    for (; c + 8 <= f; c += 8) {                             // eight loads in flight; the fma chain keeps its channel order
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = X[(size_t)(c + j) * n + i];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s = __fmaf_rn(v[j], v[j], s);
+    }
+    for (; c < f; ++c) s = __fmaf_rn(X[(size_t)c * n + i], X[(size_t)c * n + i], s);
     sq[(size_t)bs * n + i] = s;
 }
 
@@ -188,7 +196,9 @@ __global__ __launch_bounds__(FK_THREADS) void feat_knn_kernel(
 // dist tiles alternate in LDS and one workgroup barrier per chunk hands them over.  Matrix and vector
 // work of different waves of a SIMD issue side by side, so the selection hides behind the MFMAs.
 // Both operands are fed from global memory (L2-resident) through 8-deep register rings.
-#define FKP_THREADS 512
+#define FKP_CW 8                 // consumer waves (the selection is latency-bound: two per SIMD next to one producer)
+#define FKP_THREADS (256 + 64 * FKP_CW)
+#define FKP_QPW (FK_QB / FKP_CW)  // queries per consumer wave
 #define FKP_QCAP 64
 
 template <int FH>
@@ -198,44 +208,51 @@ __global__ __launch_bounds__(FKP_THREADS) void feat_knn_pc_kernel(
     constexpr int f = 2 * FH;
     __shared__ float dist[2][FK_QB][NCP];
     __shared__ DI queue[FK_QB][FKP_QCAP + 32];       // + room for the running list during a ranked merge
-    __shared__ DI win[4][32];                          // per consumer wave
+    __shared__ DI win[FKP_CW][32];                     // per consumer wave
 
-    // XCD-aware decode: workgroup ids go round-robin over the 8 XCDs; every query tile of a sample streams
-    // that sample's whole feature matrix, so all tiles of sample s are given ids = s (mod 8): one L2
-    // fetches the sample once instead of each of the 8 L2s fetching every sample.
+    // PERSISTENT workgroups, one per CU: workgroup ids go round-robin over the 8 XCDs; XCD x owns the samples x, x+8, ...
+    // (every query tile of a sample streams that sample's whole feature matrix: one L2 fetches it once), and its
+    // workgroups deal those samples' query tiles among themselves.  A workgroup walks its tiles as ONE stream of
+    // 512-candidate chunks: while the consumer waves select from chunk i, the producer waves already build chunk i+1
+    // -- of the same tile or the next one -- so the matrix cores idle only in the very first and last step.
     const int tiles = n / FK_QB, pid = blockIdx.x;
-    const int bs = ((pid >> 3) / tiles) * 8 + (pid & 7);
-    if (bs >= b) return;
-    const int q0 = ((pid >> 3) % tiles) * FK_QB;
+    const int xcd = pid & 7, slot = pid >> 3, wpx = gridDim.x >> 3;
+    const int ns = (b - xcd + 7) / 8;                        // samples of this XCD
+    const int T = ns > 0 ? ns * tiles : 0;                   // its query tiles
+    const int mine = slot < T ? (T - slot + wpx - 1) / wpx : 0;
+    if (mine == 0) return;
     const int lane = lane_id();
     const int wave = threadIdx.x / PDGN_WAVE;
     const bool producer = wave < 4;
     const int col = lane & 31, half = lane >> 5;
-    const float *X = x + (size_t)bs * f * n;
-    const float *SQ = sq + (size_t)bs * n;
     const int K = k + 1;
     const int nchunks = (n + FK_NC - 1) / FK_NC;
+    const int total = mine * nchunks;
 
-    float rd[FK_QPW];
-    int ri[FK_QPW], cnt[FK_QPW];
+    float rd[FKP_QPW];
+    int ri[FKP_QPW], cnt[FKP_QPW];
 #pragma unroll
-    for (int t = 0; t < FK_QPW; ++t) { rd[t] = INFINITY; ri[t] = 0x7fffffff; cnt[t] = 0; }
-    const float sq_q = SQ[q0 + col];
+    for (int t = 0; t < FKP_QPW; ++t) { rd[t] = INFINITY; ri[t] = 0x7fffffff; cnt[t] = 0; }
 
-    for (int it = 0; it <= nchunks; ++it) {
+    for (int it = 0; it <= total; ++it) {
         if (producer) {
-            const int t0 = it * FK_NC;
+            const int j = slot + (it / nchunks) * wpx;            // tile index within the XCD
+            const int bs = xcd + 8 * (j / tiles), q0 = (j % tiles) * FK_QB;
+            const int t0 = (it % nchunks) * FK_NC;
             const int strip = 128 * wave;
-            if (it < nchunks && t0 + strip < n) {
+            if (it < total && t0 + strip < n) {
+                const float *X = x + (size_t)bs * f * n;
+                const float *SQ = sq + (size_t)bs * n;
+                const float sq_q = SQ[q0 + col];
                 const int a4 = ((lane >> 3) & 3) * 32 + (lane & 7) * 4;
                 const int cand = t0 + strip + a4;
                 const float *Af = X + (size_t)half * n + cand;
                 const float *Bf = X + (size_t)half * n + q0 + col;
                 f32x16 acc[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+                    for (int r = 0; r < 16; ++r) acc[jj][r] = 0.f;
                 constexpr int PF = FH >= 128 ? 8 : 4;
                 float4 ring[PF];
                 float bring[PF];
@@ -276,29 +293,50 @@ __global__ __launch_bounds__(FKP_THREADS) void feat_knn_pc_kernel(
                 }
             }
         } else if (it >= 1) {
-            const int t0 = (it - 1) * FK_NC;
+            const int jt = (it - 1) / nchunks, ch = (it - 1) % nchunks;
+            const int t0 = ch * FK_NC;
             const int tn = min(FK_NC, n - t0);
 #pragma unroll
-            for (int t = 0; t < FK_QPW; ++t) {
-                const int ql = (wave - 4) * FK_QPW + t;
+            for (int t = 0; t < FKP_QPW; ++t) {
+                const int ql = (wave - 4) * FKP_QPW + t;
                 const float *row = dist[(it - 1) & 1][ql];
 #ifndef FK_ABLATE_SELECT
                 wave_topk_append_cap([&](int c) { return row[c]; }, tn, t0, queue[ql], cnt[t], FKP_QCAP, K, rd[t], ri[t],
                                      lane);
 #endif
             }
+            if (ch == nchunks - 1) {                           // the tile's last chunk: merge, emit its rows, start afresh
+                const int j = slot + jt * wpx;
+                const int bs = xcd + 8 * (j / tiles), q0 = (j % tiles) * FK_QB;
+#pragma unroll
+                for (int t = 0; t < FKP_QPW; ++t) {
+                    const int ql = (wave - 4) * FKP_QPW + t;
+                    knn_flush_ranked(queue[ql], cnt[t], K, rd[t], ri[t], lane, win[wave - 4]);
+                    if (lane >= 1 && lane <= k)
+                        idx[((size_t)bs * n + q0 + ql) * k + lane - 1] = rd[t] < INFINITY ? ri[t] : 0;
+                    rd[t] = INFINITY;
+                    ri[t] = 0x7fffffff;
+                    cnt[t] = 0;
+                }
+            }
         }
         __syncthreads();
     }
-    if (!producer) {
-#pragma unroll
-        for (int t = 0; t < FK_QPW; ++t) {
-            const int ql = (wave - 4) * FK_QPW + t;
-            knn_flush_ranked(queue[ql], cnt[t], K, rd[t], ri[t], lane, win[wave - 4]);
-            if (lane >= 1 && lane <= k)
-                idx[((size_t)bs * n + q0 + ql) * k + lane - 1] = rd[t] < INFINITY ? ri[t] : 0;
-        }
+}
+
+// Persistent grid of the producer / consumer kernel: one workgroup per CU (its 157 KB of LDS allow no more), a
+// multiple of 8, no more per XCD than the busiest XCD has tiles.
+static int fk_persistent_grid(int b, int tiles) {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 8)
+            cus = 256;
     }
+    const int per_xcd_tiles = ((b + 7) / 8) * tiles;
+    int wpx = cus / 8;
+    if (wpx > per_xcd_tiles) wpx = per_xcd_tiles;
+    return 8 * wpx;
 }
 
 template <int FH>
@@ -306,7 +344,7 @@ static int launch_fk(int b, int f, int n, int k, const float *x, const float *sq
                      hipStream_t s) {
     dim3 grid(cdiv(n, FK_QB), b);
     if (f == 2 * FH && n % 128 == 0)
-        hipLaunchKernelGGL((feat_knn_pc_kernel<FH>), dim3((unsigned)((b + 7) / 8 * 8 * (n / FK_QB))), dim3(FKP_THREADS), 0, s, b,
+        hipLaunchKernelGGL((feat_knn_pc_kernel<FH>), dim3((unsigned)fk_persistent_grid(b, n / FK_QB)), dim3(FKP_THREADS), 0, s, b,
                            n, k, x, sq, idx);
     else
         hipLaunchKernelGGL((feat_knn_kernel<FH>), grid, dim3(FK_THREADS), 0, s, f, n, k, x, sq, idx);

@@ -117,6 +117,23 @@ __device__ __forceinline__ float wave_kth_smallest(float v, int K) {
     return __uint_as_float(b);
 }
 
+// Upper bound of the K-th smallest lane value: the bisection stops after the top 16 bits of the order-preserving
+// image and rounds the rest up (within 0.8 % of the exact value for the distances selected here -- as good a filter
+// threshold as the exact one at half the dependent steps).  Any sign; never past +inf.
+__device__ __forceinline__ float wave_kth_smallest_ub16_any(float v, int K) {
+    const unsigned bits = __float_as_uint(v);
+    const unsigned key = bits ^ ((bits >> 31) ? 0xffffffffu : 0x80000000u);
+    unsigned prefix = 0;
+#pragma unroll
+    for (int bit = 31; bit >= 16; --bit) {
+        const unsigned cand = prefix | (1u << bit);
+        const int below = __popcll(__ballot(key < cand));
+        prefix = below < K ? cand : prefix;
+    }
+    const unsigned ub = min(prefix | 0xffffu, 0xff800000u);
+    return __uint_as_float((ub & 0x80000000u) ? (ub ^ 0x80000000u) : ~ub);
+}
+
 // Variant of wave_topk_scan with a per-query survivor queue that persists across candidate
 // chunks: survivors are only appended here (threshold from this chunk's lane minima and the
 // running list); the (distance, index) sort runs when the queue is half full or at the end.
@@ -152,7 +169,7 @@ __device__ __forceinline__ void wave_topk_append_cap(DistFn dist, int tn, int t0
                                                      float &rd, int &ri, int lane) {
     float lmin = INFINITY;
     for (int c = lane; c < tn; c += 64) lmin = fminf(lmin, dist(c));
-    float tau = fminf(wave_kth_smallest(lmin, K), __shfl(rd, K - 1, 64));
+    float tau = fminf(wave_kth_smallest_ub16_any(lmin, K), __shfl(rd, K - 1, 64));
     for (int c0 = 0; c0 < tn; c0 += 64) {
         int c = c0 + lane;
         float d = c < tn ? dist(c) : INFINITY;
