@@ -1,0 +1,23 @@
+#!/bin/bash
+# Everything under profiles/ for one round, on one MI355X box (run through gpurun from the repo root):
+#   bash tools/collect_profiles.sh gpurun_out/prof r02
+set -u
+OUT=${1:-gpurun_out/prof}; TAG=${2:-r02}
+mkdir -p $OUT
+python3 bench.py --steps 30 --warmup 5 > $OUT/${TAG}_bench_full.json 2> $OUT/bench.err
+python3 bench.py --eval --steps 10 --warmup 2 > $OUT/${TAG}_eval_c5.json 2>> $OUT/bench.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_bench -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline > $OUT/kt_bench.log 2>&1
+cp $(find $OUT/kt_bench -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_bench_kernel_stats.csv
+python3 tools/step_kernels.py $OUT/kt_bench 8 > $OUT/${TAG}_step_kernels.txt
+MS=$(python3 -c "import json,sys; print(json.load(open(sys.argv[1]))[\"ms_per_step\"])" $OUT/${TAG}_bench_full.json)
+python3 tools/queue_timeline.py $OUT/kt_bench $MS > $OUT/${TAG}_queue_timeline.txt 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_roof -- python3 tools/roofline_only.py > $OUT/${TAG}_roofline_only.json 2> $OUT/kt_roof.log
+cp $(find $OUT/kt_roof -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_roofline_kernel_stats.csv
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_eval -- python3 bench.py --eval --steps 5 --warmup 1 > $OUT/kt_eval.log 2>&1
+cp $(find $OUT/kt_eval -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_eval_kernel_stats.csv
+bash tools/run_pmc_roofline.sh $OUT/pmc > /dev/null 2>&1
+python3 tools/pmc_roofline.py $OUT/pmc $OUT/${TAG}_pmc_mfma.csv $OUT/traffic.json > $OUT/${TAG}_pmc_summary.txt
+python3 tools/gemm_shapes.py > $OUT/${TAG}_gemm_shapes.txt 2>&1
+python3 tools/host_time.py > $OUT/${TAG}_host_time.txt 2>&1
+rm -rf $OUT/kt_bench $OUT/kt_roof $OUT/kt_eval $OUT/pmc $OUT/pmc.*.log
+ls -la $OUT
