@@ -117,7 +117,7 @@ def bn_act_backward_stage4(B, base_points, device):
     def run():
         check(L.pdgn_bn_act_backward(ctypes.c_longlong(rows), C, 2, 1, ptr(x), ptr(dy), ptr(mul), ptr(stats),
                                      ptr(scratch), ptr(bs), ptr(dx), ptr(dmul), stream_of(x)), "pdgn_bn_act_backward")
-    us = _time_us(run, iters=10)
+    us = _time_us(run)
     return _entry("cl_bwd_reduce + cl_bwd_apply (BN+LeakyReLU*w backward, rows=%d C=%d)" % (rows, C), "hbm",
                   8.0 * rows * C * 4, us)
 
