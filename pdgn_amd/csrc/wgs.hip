@@ -294,7 +294,8 @@ static int wgs_cw(const char *env, int dflt) {
     } while (0)
 
 static bool wgs_ok(int b, int n, int k, int ldy, int T, int P, int C, int off, int offc) {
-    return b >= 0 && n >= 1 && k >= 1 && T >= 1 && P >= 1 && C >= 1 && T + P - 1 <= k && off >= 0 &&
+    // T == 0: no taps, the centre column block (+ bias) alone -- out[b,n,p,c] = bias + Y[b,n,offc+c]
+    return b >= 0 && n >= 1 && k >= 1 && T >= 0 && (T >= 1 || offc >= 0) && P >= 1 && C >= 1 && T + P - 1 <= k && off >= 0 &&
            off + T * C <= ldy && (offc < 0 || offc + C <= ldy);
 }
 
