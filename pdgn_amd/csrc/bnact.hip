@@ -111,16 +111,49 @@ __device__ __forceinline__ double fin_reduce(const float *__restrict__ part, int
     return red[0][cl];
 }
 
+// Both column sums of a channel (slots c and C + c) in ONE pass: the loads of the two reductions are in flight together
+// and the LDS tree carries both values -- these finalize kernels are ~150 launches per step, each a pure latency chain.
+__device__ __forceinline__ void fin_reduce2(const float *__restrict__ part, int nparts, size_t ld, int c, int C, bool ok,
+                                            double (*red)[FIN_CH], double (*red2)[FIN_CH], double &s1, double &s2) {
+    const int cl = threadIdx.x % FIN_CH, pl = threadIdx.x / FIN_CH;
+    double a = 0, b = 0;
+    if (ok) {
+        int p = pl;
+        for (; p + 3 * FIN_PL < nparts; p += 4 * FIN_PL) {          // eight independent loads in flight
+            const float *q = part + (size_t)p * ld + c;
+            const float a0 = q[0], a1 = q[(size_t)FIN_PL * ld], a2 = q[(size_t)2 * FIN_PL * ld], a3 = q[(size_t)3 * FIN_PL * ld];
+            const float b0 = q[C], b1 = q[(size_t)FIN_PL * ld + C], b2 = q[(size_t)2 * FIN_PL * ld + C], b3 = q[(size_t)3 * FIN_PL * ld + C];
+            a += ((double)a0 + (double)a1) + ((double)a2 + (double)a3);
+            b += ((double)b0 + (double)b1) + ((double)b2 + (double)b3);
+        }
+        for (; p < nparts; p += FIN_PL) {
+            a += (double)part[(size_t)p * ld + c];
+            b += (double)part[(size_t)p * ld + C + c];
+        }
+    }
+    red[pl][cl] = a;
+    red2[pl][cl] = b;
+    __syncthreads();
+    for (int h = FIN_PL / 2; h > 0; h >>= 1) {
+        if (pl < h) {
+            red[pl][cl] += red[pl + h][cl];
+            red2[pl][cl] += red2[pl + h][cl];
+        }
+        __syncthreads();
+    }
+    s1 = red[0][cl];
+    s2 = red2[0][cl];
+}
+
 __global__ __launch_bounds__(FIN_CH * FIN_PL) void cl_finalize_kernel(
     long long R, int C, int nparts, float eps, float momentum, const float *__restrict__ part,
     const float *__restrict__ gamma, const float *__restrict__ beta, const float *__restrict__ pre_bias,
     float *__restrict__ running_mean, float *__restrict__ running_var, float *__restrict__ stats) {
-    __shared__ double red[FIN_PL][FIN_CH];
+    __shared__ double red[FIN_PL][FIN_CH], red2[FIN_PL][FIN_CH];
     const int c = blockIdx.x * FIN_CH + threadIdx.x % FIN_CH;
     const bool ok = c < C;
-    const double s1 = fin_reduce(part, nparts, (size_t)2 * C, c, ok, red);
-    __syncthreads();
-    const double s2 = fin_reduce(part, nparts, (size_t)2 * C, C + c, ok, red);
+    double s1, s2;
+    fin_reduce2(part, nparts, (size_t)2 * C, c, C, ok, red, red2, s1, s2);
     if (!ok || threadIdx.x >= FIN_CH) return;
     const double mean = s1 / (double)R;
     double var = s2 / (double)R - mean * mean;
@@ -261,12 +294,11 @@ __global__ __launch_bounds__(FIN_CH * FIN_PL) void cl_bwd_finalize_kernel(long l
                                                                          const float *__restrict__ stats,
                                                                          float *__restrict__ bsums,
                                                                          float *__restrict__ coef) {
-    __shared__ double red[FIN_PL][FIN_CH];
+    __shared__ double red[FIN_PL][FIN_CH], red2[FIN_PL][FIN_CH];
     const int c = blockIdx.x * FIN_CH + threadIdx.x % FIN_CH;
     const bool ok = c < C;
-    const double s1 = fin_reduce(part, nparts, (size_t)2 * C, c, ok, red);
-    __syncthreads();
-    const double s2 = fin_reduce(part, nparts, (size_t)2 * C, C + c, ok, red);
+    double s1, s2;
+    fin_reduce2(part, nparts, (size_t)2 * C, c, C, ok, red, red2, s1, s2);
     if (!ok || threadIdx.x >= FIN_CH) return;
     bsums[c] = (float)s1;
     bsums[C + c] = (float)s2;

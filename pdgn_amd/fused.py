@@ -64,7 +64,14 @@ def reset_zero_arena(device, owner):
 
 
 def release_zero_arena():
-    _ARENA["buf"] = None
+    """Drop the current arena (end of a step / of a graph capture): a backward outside FlatGrads.begin() then gets
+    ordinary torch.zeros tensors, never slices of memory another owner (or a hipGraph's private pool) holds."""
+    a = _ARENA
+    if a["owner"] is not None:
+        a["owner"].zero_arena_floats = max(getattr(a["owner"], "zero_arena_floats", 0), a["need"])
+    a["buf"] = None
+    a["owner"] = None
+    a["off"] = a["need"] = 0
 
 
 def _zeros(shape, device):

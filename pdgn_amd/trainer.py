@@ -292,6 +292,7 @@ class PDGNTrainer:
         for k in range(6):
             self._segment(st, k)
             self._comm(k)
+        release_zero_arena()
         return st["out"]
 
     def _step_overlapped(self, reals, z1, z2, st=None):
@@ -396,6 +397,7 @@ class PDGNTrainer:
         st["out"]["g_loss"], st["out"]["similar_loss"] = lossG.detach(), similar.detach()
         self._comm(4)
         self.optG.step()
+        release_zero_arena()                                # no later backward may receive slices of this step's arena
         mark("all-reduce + Adam G")
         return st["out"]
 
@@ -436,6 +438,7 @@ class PDGNTrainer:
             finally:
                 self._defer_d = defer
             self._graphs.append((g, 5))
+            release_zero_arena()                            # the arena of the capture lives in the graph's private pool
             return self
         for group in groups:
             g = torch.cuda.CUDAGraph()
@@ -445,6 +448,7 @@ class PDGNTrainer:
             pool = g.pool()
             self._graphs.append((g, group[-1]))
             self._comm(group[-1])
+        release_zero_arena()
         return self
 
     def _sync(self):
