@@ -328,7 +328,8 @@ def main():
     if rank == 0:
         ms = dt / args.steps * 1e3
         line = {
-            "metric": "generator+D step points/sec (B=35, 256->2048 pts)",
+            # BASELINE.json's metric at its own configuration; any other --batch / --base-points is named as what it is
+            "metric": "generator+D step points/sec (B=%d, %d->%d pts)" % (B, res[0], res[3]),
             "value": world * B * res[3] / (dt / args.steps),
             "unit": "points/s",
             "n_gpus": world, "rccl_ranks": dist.get_world_size() if dist.is_initialized() else 1,

@@ -70,7 +70,7 @@ struct NtArgs {
     float *C, *stat_part;
     int tiles_m, tiles_n, tile_begin, tile_end, kchunks;
     long long sk_per_wg;              // stream-K launch: (tile, chunk) iterations per workgroup
-    int dbg;                          // PDGN_NT_DBG (measurement only): 1 no stores, 2 no DMA
+    int dbg;                          // PDGN_NT_DBG (measurement only): 1 = stores dropped (out-of-range offsets)
 };
 
 template <int TM, int TN, int WM, int WN, bool ATOMIC, bool WT, bool AT>
@@ -202,7 +202,6 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_nt_kernel(const NtArgs p
         if (WT) rsW = nt_srd(p.W + (long long)ld_k0 * p.ldw + ld_n0, (unsigned)(((long long)(krows - 1) * p.ldw + ld_nrows) * 4));
     };
     auto issue_piece = [&](int i) {
-        if (p.dbg & 2) return;
         if (i < NPA) {
             const int j = i < NPA ? i : 0;
             if (!AT) nt_dma16(rsA, ld_dst + j * NW * 1024, ld_kok ? voffA[j] : NT_OOB, ld_k0 * 4);
