@@ -237,6 +237,21 @@ int pdgn_softmax_slots_permute_backward(long long m, int k, int c, const float *
 int pdgn_gemm_nt(long long m, int n, int k, const float *A, int lda, const float *W, int ldw,
                  const float *bias, const float *addend, int ldadd, float *C, int ldc, float *stat_part,
                  pdgn_stream_t stream);
+/* Dense layers with at most 4 channels on one side (the xyz-in / xyz-out layers: Conv1d(3, 64) of the discriminators
+ * and conv_xyz, models/PDGNet_v2.py:559-566, 886-1014; Conv1d(64, 3) of the heads, :835-862) as streaming kernels, no padding:
+ *   Y (m x n, pitch ldy) = X (m x k, pitch ldx) W'^T (+ bias[n]),   W'[j, kk] = W[j * wrs + kk * wcs]
+ * with either k <= 4 and n % 4 == 0 (Y 16-byte aligned rows) or n <= 4 and k % 4 == 0 (X 16-byte aligned rows).  The strides
+ * let one entry serve a weight and its transpose (forward: wrs = k, wcs = 1; input gradient dX = dY W: wrs = 1, wcs = C_in).
+ * stat_part (k <= 4 form only, may be NULL): pdgn_thin_stat_rows(m) rows of [2n] floats, the BatchNorm partials of Y in the
+ * layout pdgn_bn_stats_from_gemm_partials reads.  Returns -3 for shapes outside these two forms. */
+long long pdgn_thin_stat_rows(long long m);
+int pdgn_thin_nt(long long m, int n, int k, const float *X, int ldx, const float *W, int wrs, int wcs,
+                 const float *bias, float *Y, int ldy, float *stat_part, pdgn_stream_t stream);
+/* Weight (+ bias) gradient of such a layer: O[i * osi + j * osj] += sum_r A[r, i] B[r, j] for A (m x ta <= 4, pitch lda),
+ * B (m x wb, wb % 4 == 0, pitch ldb, 16-byte aligned rows); sum_a[ta] += column sums of A, sum_b[wb] += column sums of B
+ * (either may be NULL).  O and the sums are accumulated with fp32 atomics: the caller passes them zero-filled. */
+int pdgn_thin_tn(long long m, int ta, int wb, const float *A, int lda, const float *B, int ldb, float *O, int osi,
+                 int osj, float *sum_a, float *sum_b, pdgn_stream_t stream);
 /* The same product with the second operand given transposed, C = A Wt with Wt (k x n, row pitch ldw): the input
  * gradient dX = dY W of a dense layer straight from its (C_out x C_in) weight (models/PDGNet_v2.py conv / linear backward). */
 int pdgn_gemm_nn(long long m, int n, int k, const float *A, int lda, const float *Wt, int ldw,

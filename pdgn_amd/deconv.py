@@ -135,6 +135,7 @@ class EdgeGatherSum(Function):
             outs.append(out)
         specs = tuple(tuple(spec[:5]) for spec in specs)
         ctx.mark_non_differentiable(*partials)
+        ctx.set_materialize_grads(False)          # the partials' "gradients" would be zero-filled tensors of their size
         ctx.specs, ctx.shape = specs, (b, n, ldy, k)
         ctx.has_bias = [0 if bias is None else bias.dim() for bias in biases]   # 0 none, 1 shared, 2 per sample
         ctx.save_for_backward(idx)
@@ -143,8 +144,9 @@ class EdgeGatherSum(Function):
     @staticmethod
     def backward(ctx, *douts):
         (idx,) = ctx.saved_tensors
-        douts = douts[:len(ctx.specs)]                              # trailing outputs are statistics partials
         b, n, ldy, k = ctx.shape
+        douts = [d if d is not None else torch.zeros((b, n, P, C), dtype=F32, device=idx.device)       # an unused output
+                 for d, (T, P, C, off, offc) in zip(douts, ctx.specs)]      # (trailing outputs are statistics partials)
         L = _lib.lib()
         covered = sum(T * C + (C if offc >= 0 else 0) for (T, P, C, off, offc) in ctx.specs)
         vec_ok = ldy % 4 == 0 and k <= 31 and all(C % 4 == 0 and off % 4 == 0 and (offc < 0 or offc % 4 == 0)

@@ -291,6 +291,47 @@ def gemm_tn(dy, x):
     return dwp if (dyp.shape[1] == n and xp.shape[1] == k) else dwp[:n, :k]
 
 
+def _thin_ok(x, n, k):
+    """The layer has <= 4 channels on one side and fits pdgn_thin_nt (csrc/thin.hip): no zero-padded copies."""
+    return (k <= 4 and n % 4 == 0 and n <= 1024) or (n <= 4 and k % 4 == 0)
+
+
+def thin_nt(x, w, wrs, wcs, n, bias=None, want_stats=False):
+    """x (m, k) times W'^T with W'[j, kk] = w.flat[j * wrs + kk * wcs] (n rows) on pdgn_thin_nt; want_stats as gemm_nt."""
+    m, k = x.shape
+    if GEMM_LOG is not None:
+        GEMM_LOG.append(("thin", m, n, k))
+    x = x if (x.stride(1) == 1 and (k <= 4 or (x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0))) else x.contiguous()
+    L = _lib.lib()
+    out = torch.empty((m, n), dtype=F32, device=x.device)
+    part = None
+    if want_stats and k <= 4:
+        L.pdgn_thin_stat_rows.restype = ctypes.c_longlong
+        part = torch.empty((L.pdgn_thin_stat_rows(ctypes.c_longlong(m)), 2 * n), dtype=F32, device=x.device)
+    b = bias.detach().contiguous() if bias is not None else None
+    check(L.pdgn_thin_nt(ctypes.c_longlong(m), n, k, ptr(x), x.stride(0), ptr(w), wrs, wcs, ptr(b), ptr(out), n, ptr(part),
+                         stream_of(x)), "pdgn_thin_nt")
+    return (out, part) if want_stats else out
+
+
+def thin_tn(dy, x, want_db):
+    """dW (n, k) = dy (m, n)^T x (m, k) [, db = column sums of dy] for a layer with n <= 4 or k <= 4, on pdgn_thin_tn."""
+    m, n = dy.shape
+    k = x.shape[1]
+    if GEMM_LOG is not None:
+        GEMM_LOG.append(("thin_tn", m, n, k))
+    dw = _zeros((n, k), dy.device)
+    db = _zeros((n,), dy.device) if want_db else None
+    L = _lib.lib()
+    if k <= 4:                      # A = x (thin), B = dy (wide): O[i = kk, j = n] -> dw[j, i]
+        check(L.pdgn_thin_tn(ctypes.c_longlong(m), k, n, ptr(x), x.stride(0), ptr(dy), dy.stride(0), ptr(dw), 1, k, ptr(None),
+                             ptr(db), stream_of(dy)), "pdgn_thin_tn")
+    else:                           # A = dy (thin), B = x (wide): O[i = n, j = kk] -> dw[i, j]
+        check(L.pdgn_thin_tn(ctypes.c_longlong(m), n, k, ptr(dy), dy.stride(0), ptr(x), x.stride(0), ptr(dw), k, 1, ptr(db),
+                             ptr(None), stream_of(dy)), "pdgn_thin_tn")
+    return dw, db
+
+
 class LinearCL(Function):
     """y = x @ W^T (+ b) (+ addend) for point-major rows x (M, C_in): the reference's Conv2d / Conv1d / Linear layers
     (models/PDGNet_v2.py:559-625, 835-862, 886-1014) as row-matrix products on the hand-written MFMA kernels (see above)."""
@@ -298,8 +339,19 @@ class LinearCL(Function):
     @staticmethod
     def forward(ctx, x, weight, bias, addend, want_stats=False):
         ctx.save_for_backward(x, weight)
+        ctx.set_materialize_grads(False)          # no zero-filled "gradient" of the statistics partials (a launch per call)
         ctx.has_bias = bias is not None
         ctx.has_addend = addend is not None
+        ctx.thin = bool(x.is_cuda and x.shape[0] >= _OWN_MIN_ROWS and addend is None and weight.is_contiguous()
+                        and _thin_ok(x, weight.shape[0], weight.shape[1]))
+        if ctx.thin:
+            n, k = weight.shape
+            if want_stats and k <= 4:
+                y, part = thin_nt(x, weight, k, 1, n, bias, want_stats=True)
+                ctx.mark_non_differentiable(part)
+                return y, part
+            y = thin_nt(x, weight, k, 1, n, bias)
+            return (y, None) if want_stats else y
         if x.is_cuda and x.shape[0] >= _OWN_MIN_ROWS:
             if want_stats and weight.shape[0] % 4 == 0:
                 y, part = gemm_nt(x, weight, bias, addend, want_stats=True)
@@ -314,10 +366,25 @@ class LinearCL(Function):
     @staticmethod
     def backward(ctx, dy, *unused):
         x, weight = ctx.saved_tensors
+        if dy is None:
+            return None, None, None, None, None
         zero_db = ctx.has_bias and ctx.needs_input_grad[2] and has_zero_colsum(dy)
         dy = dy.contiguous()
         own = dy.is_cuda and dy.shape[0] >= _OWN_MIN_ROWS
         dx = dw = db = None
+        if ctx.thin:
+            n, k = weight.shape
+            if ctx.needs_input_grad[0]:
+                dx = thin_nt(dy, weight, 1, k, k)                  # dX = dY W: W'[j, kk] = weight[kk, j]
+            want_db = ctx.has_bias and ctx.needs_input_grad[2]
+            if ctx.needs_input_grad[1]:
+                xc = x if (x.stride(1) == 1 and (k <= 4 or (x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0))) else x.contiguous()
+                dw, db = thin_tn(dy, xc, want_db and not zero_db)
+                if want_db and zero_db:
+                    db = _zeros((n,), dy.device)
+            elif want_db:
+                db = _zeros((n,), dy.device) if zero_db else dy.sum(dim=0)
+            return dx, dw, db, None, None
         if ctx.needs_input_grad[0]:
             dx = gemm_nt(dy, weight, w_transposed=True) if own else dy.matmul(weight)
         if ctx.needs_input_grad[1]:

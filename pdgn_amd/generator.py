@@ -136,24 +136,38 @@ class PointGenerator(nn.Module):
         self.mlp1, self.mlp2 = _mlp_head(512 + 32), _mlp_head(512 + 64)
         self.mlp3, self.mlp4 = _mlp_head(512 + 128), _mlp_head(512)
 
-    def forward(self, z, idx=(None, None, None, None), stage_hook=None):
+    def forward(self, z, idx=(None, None, None, None), stage_hook=None, stop_before=None):
         """`stage_hook(level, cloud)`, if given, is called as soon as the cloud of a level exists (the trainer starts
-        that level's discriminator update on another stream while the deeper levels are still being generated)."""
+        that level's discriminator update on another stream while the deeper levels are still being generated).
+        stop_before=L: stop in front of block L (0-based) and return the pass's state instead of the clouds; `resume`
+        runs the remaining blocks -- the trainer continues one pass's deepest block on another stream, underneath the
+        next pass's first (latency-bound) blocks."""
         B = z.shape[0]
         xt = _small_seq(self.fc1, z, self.training).view(B, 32, self.base_points).transpose(1, 2).contiguous()    # (B,N0,32)
-        pct, const, clouds = None, None, []
+        state = {"B": B, "xt": xt, "pct": None, "const": None, "clouds": [], "pending": (None, None), "lvl": 0, "idx": idx}
+        return self._blocks(state, stage_hook, stop_before)
+
+    def resume(self, state, stage_hook=None):
+        """The remaining blocks of a pass stopped by forward(..., stop_before=L), on the CURRENT stream."""
+        return self._blocks(state, stage_hook, None)
+
+    def _blocks(self, s, stage_hook, stop_before):
+        B, idx = s["B"], s["idx"]
         blocks = (self.bilateral1, self.bilateral2, self.bilateral3, self.bilateral4)
         heads = (self.mlp1, self.mlp2, self.mlp3, self.mlp4)
-        pending = (None, None)
-        for lvl in range(4):
-            lvl_idx, lvl_ready = (idx[lvl], None) if idx[lvl] is not None else pending
+        for lvl in range(s["lvl"], 4):
+            if stop_before is not None and lvl == stop_before:
+                s["lvl"] = lvl
+                return s
+            xt, pct, const, clouds = s["xt"], s["pct"], s["const"], s["clouds"]
+            lvl_idx, lvl_ready = (idx[lvl], None) if idx[lvl] is not None else s["pending"]
             xs, x_ec, g = blocks[lvl].forward_cl(xt, pct, idx=lvl_idx, const=const, idx_ready=lvl_ready)
-            pending = (None, None)
+            s["pending"] = (None, None)
             if lvl < 3 and idx[lvl + 1] is None and x_ec.is_cuda:
                 # the next block's kNN graph only needs this block's outputs: start it now, underneath this level's
                 # MLP head, the next block's global branch and per-point GEMM
                 nxt = blocks[lvl + 1].upsample_cov
-                pending = _deconv.start_feature_knn(x_ec, xs, nxt.k)
+                s["pending"] = _deconv.start_feature_knn(x_ec, xs, nxt.k)
             M, Fo = x_ec.shape[1], x_ec.shape[2]
             rows = x_ec.reshape(B * M, Fo)
             if lvl < 3:
@@ -165,9 +179,10 @@ class PointGenerator(nn.Module):
             if stage_hook is not None:
                 _deconv.flush_bn_counters()
                 stage_hook(lvl, clouds[-1])
-            xt, const = x_ec, xs                    # next block's input is cat(xs broadcast, x_ec) :708
+            s["xt"], s["const"], s["pct"] = x_ec, xs, pct   # next block's input is cat(xs broadcast, x_ec) :708
+        s["lvl"] = 4
         _deconv.flush_bn_counters()
-        return tuple(clouds)
+        return tuple(s["clouds"])
 
 
 class PointDiscriminator(nn.Module):

@@ -100,6 +100,7 @@ class PDGNTrainer:
         self._lp_split = os.environ.get("PDGN_LP_SPLIT", "0") == "1"      # A/B switches, see _step_overlapped
         self._early_tail = os.environ.get("PDGN_EARLY_TAIL", "1") == "1"
         self._defer_d = os.environ.get("PDGN_DEFER_D", "1") == "1"
+        self._fork_l4 = os.environ.get("PDGN_FORK_L4", "0") == "1"
         self.sync_replicas()
 
     def sync_replicas(self, src=0):
@@ -323,7 +324,7 @@ class PDGNTrainer:
         def d_mark(level, cloud):
             st["fakes"][level] = cloud
             ev = torch.cuda.Event()
-            ev.record(main)
+            ev.record(torch.cuda.current_stream(self.device))
             levels.append((level, ev))
             if level < 3:
                 mark("G(z1) level %d" % (level + 1))
@@ -340,8 +341,28 @@ class PDGNTrainer:
             d_mark(level, cloud)
             d_update(*levels.pop())
 
+        # PDGN_FORK_L4=1 (measured, not the default -- DESIGN.md section 10b): G(z1)'s deepest block (no autograd, large
+        # kernels) continues on D4's stream -- idle until that block's cloud exists -- while the default stream already
+        # issues G(z2)'s first three blocks, chains of small latency-bound kernels (3 ms per pass).  G(z2)'s deepest
+        # block waits for G(z1)'s (l4_done): its BatchNorm layers update their running statistics in the reference's
+        # order.  The persistent GEMM workgroups of the deepest block hold every CU's registers, so the small kernels
+        # do not run underneath them but between them, and both chains get slower: 36.2-36.7 vs 35.7-35.8 ms/step.
+        fork, l4_done = self._fork_l4 and not torch.cuda.is_current_stream_capturing(), None
+        hook1 = d_mark if self._defer_d else d_now
         with torch.no_grad():
-            self.G(self._z(st, "z1"), stage_hook=d_mark if self._defer_d else d_now)
+            if fork:
+                s1 = self.G(self._z(st, "z1"), stage_hook=hook1, stop_before=3)
+                x4 = self._side[3]
+                x4.wait_stream(main)
+                for t in (s1["xt"], s1["const"], s1["pct"]):
+                    t.record_stream(x4)                     # allocated on the default stream, read on x4
+                with torch.cuda.stream(x4):
+                    self.G.resume(s1, stage_hook=hook1)
+                    l4_done = torch.cuda.Event()
+                    l4_done.record(x4)
+                del s1
+            else:
+                self.G(self._z(st, "z1"), stage_hook=hook1)
         for level, ev in levels:
             d_update(level, ev)
         mark("G(z1) level 4")
@@ -368,7 +389,13 @@ class PDGNTrainer:
             with torch.cuda.stream(side):
                 g_loss[level] = F.mse_loss(self.D[level](cloud), st["ones"])
 
-        gen = self.G(self._z(st, "z2"), stage_hook=tail if early else None)
+        if fork:
+            s2 = self.G(self._z(st, "z2"), stage_hook=tail if early else None, stop_before=3)
+            main.wait_event(l4_done)
+            gen = self.G.resume(s2, stage_hook=tail if early else None)
+            del s2
+        else:
+            gen = self.G(self._z(st, "z2"), stage_hook=tail if early else None)
         mark("G(z2) forward")
         if not early:
             split = self._lp_split

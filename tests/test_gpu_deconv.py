@@ -426,6 +426,44 @@ def test_linear_cl_autograd(M, N, K):
         np.testing.assert_allclose(got.cpu().numpy(), ref.cpu().numpy(), rtol=1e-4, atol=atol + 1e-6, err_msg=name)
 
 
+@pytest.mark.parametrize("M,N,K", [(71680, 64, 3), (1024, 3, 64), (2049, 32, 3), (5001, 3, 32), (1500, 4, 64), (1030, 64, 4),
+                                   (1024, 128, 1), (3000, 2, 256), (1100, 48, 3)])
+@pytest.mark.parametrize("bias", [True, False])
+def test_thin_layers(M, N, K, bias):
+    """The xyz-in / xyz-out layers (<= 4 channels on one side) on pdgn_thin_nt / pdgn_thin_tn: forward, the BatchNorm partials
+    of the k <= 4 form, input / weight / bias gradients against fp64."""
+    from pdgn_amd import fused
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    x = torch.randn(M, K, device="cuda", generator=g)
+    w = torch.randn(N, K, device="cuda", generator=g)
+    b = torch.randn(N, device="cuda", generator=g) if bias else None
+    dy = torch.randn(M, N, device="cuda", generator=g)
+    fused.GEMM_LOG = []
+    try:
+        leaves = [t.clone().requires_grad_(True) for t in (x, w)] + ([b.clone().requires_grad_(True)] if bias else [None])
+        y, part = fused.linear_cl(leaves[0], leaves[1], leaves[2], None, True)
+        y.backward(dy)
+        kinds = [e[0] for e in fused.GEMM_LOG]
+    finally:
+        fused.GEMM_LOG = None
+    assert kinds == ["thin", "thin", "thin_tn"], kinds                       # no padded launch on the MFMA kernels
+    ref = [t.double().clone().requires_grad_(True) for t in (x, w)] + ([b.double().clone().requires_grad_(True)] if bias else [None])
+    yr = torch.nn.functional.linear(*ref)
+    yr.backward(dy.double())
+    sc = float(M) ** 0.5
+    for name, got, want, atol in (("y", y.detach(), yr.detach(), 1e-4 * K), ("dx", leaves[0].grad, ref[0].grad, 1e-4 * N),
+                                  ("dw", leaves[1].grad, ref[1].grad, 2e-4 * sc)) + \
+            ((("db", leaves[2].grad, ref[2].grad, 2e-4 * sc),) if bias else ()):
+        np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), rtol=1e-4, atol=atol + 1e-6, err_msg=name)
+    if K <= 4:
+        assert part is not None and part.shape[1] == 2 * N
+        tot = part.double().sum(0).cpu().numpy()
+        np.testing.assert_allclose(tot[:N], yr.detach().sum(0).cpu().numpy(), rtol=1e-4, atol=1e-3 * sc)
+        np.testing.assert_allclose(tot[N:], (yr.detach() ** 2).sum(0).cpu().numpy(), rtol=1e-4, atol=1e-3 * sc)
+    else:
+        assert part is None
+
+
 @pytest.mark.parametrize("M,k,C", [(1000, 10, 16), (3584, 10, 512), (77, 4, 24), (500, 32, 3)])
 def test_softmax_slots_permute(M, k, C):
     from pdgn_amd.fused import softmax_slots_permute

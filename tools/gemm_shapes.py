@@ -37,6 +37,8 @@ tot_own = tot_lib = 0.0
 extra = {}
 rows = []
 for (kind, m, n, k), cnt in log.items():
+    if kind.startswith("thin"):
+        continue
     pad = lambda v: (v + 3) // 4 * 4
     if kind == "nn":
         a = torch.randn(m, pad(k), device="cuda"); w = torch.randn(pad(k), pad(n), device="cuda"); c = torch.empty(m, pad(n), device="cuda")
