@@ -20,9 +20,15 @@
 //     at the end (wave_select.h).
 // Nothing of size N^2 ever reaches HBM.
 #include "common.h"
+#ifdef FK_TIMING
+__device__ unsigned long long fk_dbg2[16];
+#define WSEL_T(n) do { if (blockIdx.x == 0 && threadIdx.x == 256) fk_dbg2[n] = clock64(); } while (0)
+extern "C" int fk_dbg2_copy(unsigned long long *host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(fk_dbg2), sizeof(fk_dbg2)); }
+#endif
 #include "wave_select.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define FK_THREADS 256
 #define FK_WAVES 4
@@ -191,15 +197,32 @@ __global__ __launch_bounds__(FK_THREADS) void feat_knn_kernel(
 }
 
 // ---------------------------------------------------------------------------- producer / consumer form
-// Regular shapes (n % 128 == 0, f == 2*FH): 8 waves per workgroup.  Waves 0-3 PRODUCE the Gram strips of
-// chunk i on the matrix cores while waves 4-7 CONSUME (select from) chunk i-1 on the vector ALU; the two
-// dist tiles alternate in LDS and one workgroup barrier per chunk hands them over.  Matrix and vector
-// work of different waves of a SIMD issue side by side, so the selection hides behind the MFMAs.
-// Both operands are fed from global memory (L2-resident) through 8-deep register rings.
-#define FKP_CW 8                 // consumer waves (the selection is latency-bound: two per SIMD next to one producer)
+// Regular shapes (n % 128 == 0, f == 2*FH): 12 waves per workgroup.  Waves 0-3 PRODUCE the Gram strips of
+// chunk i on the matrix cores, waves 4-11 CONSUME (select from) chunk i-1; the two dist tiles alternate in LDS and
+// one workgroup barrier per chunk hands them over.  Both operands are fed from global memory (L2-resident) through
+// 8-deep register rings.
+// Consumer waves.  Measured on gfx950 (tools/micro/mfma_ilp.hip, mfma_valu.hip): fp32 MFMAs execute on the SIMD's vector
+// ALU -- a wave that issues them back to back locks every other wave of its SIMD out completely (no VALU, LDS or scalar
+// instruction of theirs issues until the matrix stream stalls or ends; s_setprio does not change that), and inside one
+// wave every vector instruction between two MFMAs adds its full 4+ cycles.  The selection therefore does NOT hide behind
+// the Gram stream: per SIMD the chunk time is matrix time + selection time, the consumers running in the producer's
+// operand-wait gaps and after its last MFMA.  What counts is the instruction count of the selection (wave_select.h: four
+// queries interleaved per wave, scalar counters, no per-query branches, threshold + 64-bit-key ranking in the merge) and
+// an MFMA loop without vector address arithmetic (buffer loads with scalar row offsets).  8 consumer waves (4 queries
+// each) and 12 (3 each, 1024 threads, 128 VGPRs with spills) measure the same at N = 1024 and 8 are faster below.
+#define FKP_CW 8
 #define FKP_THREADS (256 + 64 * FKP_CW)
-#define FKP_QPW (FK_QB / FKP_CW)  // queries per consumer wave
+#define FKP_QPW (FK_QB / FKP_CW)  // queries per consumer wave (4: the row lists below)
+static_assert(FK_QB / FKP_CW == 4, "the consumer's row lists are written for 4 queries per wave");
 #define FKP_QCAP 64
+
+#ifdef FK_TIMING
+__device__ unsigned long long fk_dbg[8 * 64];
+extern "C" int fk_dbg_copy(unsigned long long *host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(fk_dbg), sizeof(fk_dbg)); }
+#define FK_T(slot) do { if (blockIdx.x == 0 && lane == 0 && it < 64) fk_dbg[(slot) * 64 + it] = clock64(); } while (0)
+#else
+#define FK_T(slot) do { } while (0)
+#endif
 
 template <int FH>
 __global__ __launch_bounds__(FKP_THREADS) void feat_knn_pc_kernel(
@@ -241,36 +264,41 @@ __global__ __launch_bounds__(FKP_THREADS) void feat_knn_pc_kernel(
             const int t0 = (it % nchunks) * FK_NC;
             const int strip = 128 * wave;
             if (it < total && t0 + strip < n) {
+                if (wave == 0) FK_T(0);
                 const float *X = x + (size_t)bs * f * n;
                 const float *SQ = sq + (size_t)bs * n;
                 const float sq_q = SQ[q0 + col];
                 const int a4 = ((lane >> 3) & 3) * 32 + (lane & 7) * 4;
                 const int cand = t0 + strip + a4;
-                const float *Af = X + (size_t)half * n + cand;
-                const float *Bf = X + (size_t)half * n + q0 + col;
+                // Operand rows through a raw buffer descriptor of the sample's feature matrix: the lane's byte offset is
+                // fixed for the whole chunk and the channel-pair row is a SCALAR offset, so a step issues two loads and four
+                // MFMAs and no vector address arithmetic (fp32 MFMA and VALU share the SIMD's issue slots).
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)X, 0, f * n * 4, 0x00020000);
+                const unsigned aoff = (unsigned)(half * n + cand) * 4u, boff = (unsigned)(half * n + q0 + col) * 4u;
+                const unsigned rowb = 2u * (unsigned)n * 4u;                 // bytes between channel pairs
                 f32x16 acc[4];
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[jj][r] = 0.f;
                 constexpr int PF = FH >= 128 ? 8 : 4;
-                float4 ring[PF];
+                f32x4 ring[PF];
                 float bring[PF];
 #pragma unroll
                 for (int i = 0; i < PF; ++i) {
-                    ring[i] = *reinterpret_cast<const float4 *>(Af + (size_t)(2 * i) * n);
-                    bring[i] = Bf[(size_t)(2 * i) * n];
+                    ring[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, aoff, (unsigned)i * rowb, 0));
+                    bring[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, boff, (unsigned)i * rowb, 0));
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #ifndef FK_ABLATE_MFMA
                 for (int s0 = 0; s0 < FH; s0 += PF) {
 #pragma unroll
                     for (int i = 0; i < PF; ++i) {
-                        const float4 v = ring[i];
+                        const f32x4 v = ring[i];
                         const float bv = bring[i];
-                        const int sn = min(s0 + PF + i, FH - 1);
-                        ring[i] = *reinterpret_cast<const float4 *>(Af + (size_t)(2 * sn) * n);
-                        bring[i] = Bf[(size_t)(2 * sn) * n];
+                        const unsigned so = (unsigned)min(s0 + PF + i, FH - 1) * rowb;
+                        ring[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, aoff, so, 0));
+                        bring[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, boff, so, 0));
                         __builtin_amdgcn_sched_barrier(0);
                         acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(v.x, bv, acc[0], 0, 0, 0);
                         acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(v.y, bv, acc[1], 0, 0, 0);
@@ -279,6 +307,7 @@ __global__ __launch_bounds__(FKP_THREADS) void feat_knn_pc_kernel(
                     }
                 }
 #endif
+                if (wave == 0) FK_T(1);
                 float (*D)[NCP] = dist[it & 1];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -291,36 +320,44 @@ __global__ __launch_bounds__(FKP_THREADS) void feat_knn_pc_kernel(
                     v.w = __fmaf_rn(-2.0f, acc[3][r], sq_q) + sc.w;
                     *reinterpret_cast<float4 *>(&D[col][lc]) = v;
                 }
+                if (wave == 0) FK_T(2);
             }
         } else if (it >= 1) {
+            if (wave == 4) FK_T(3);
             const int jt = (it - 1) / nchunks, ch = (it - 1) % nchunks;
             const int t0 = ch * FK_NC;
             const int tn = min(FK_NC, n - t0);
-#pragma unroll
-            for (int t = 0; t < FKP_QPW; ++t) {
-                const int ql = (wave - 4) * FKP_QPW + t;
-                const float *row = dist[(it - 1) & 1][ql];
+            const int cw = wave - 4, qb = cw * FKP_QPW;
+            DI *const qs[FKP_QPW] = {queue[qb], queue[qb + 1], queue[qb + 2], queue[qb + 3]};
 #ifndef FK_ABLATE_SELECT
-                wave_topk_append_cap([&](int c) { return row[c]; }, tn, t0, queue[ql], cnt[t], FKP_QCAP, K, rd[t], ri[t],
-                                     lane);
-#endif
+            {
+                const float *const rows[FKP_QPW] = {dist[(it - 1) & 1][qb], dist[(it - 1) & 1][qb + 1], dist[(it - 1) & 1][qb + 2],
+                                                    dist[(it - 1) & 1][qb + 3]};
+                wave_topk_append_multi<FKP_QPW>(rows, tn, t0, qs, cnt, FKP_QCAP, K, rd, ri, lane, [&](int t) {
+                    knn_flush_ranked(qs[t], cnt[t], K, rd[t], ri[t], lane, win[cw]);
+                    cnt[t] = 0;
+                });
             }
+#endif
+            if (wave == 4) FK_T(4);
             if (ch == nchunks - 1) {                           // the tile's last chunk: merge, emit its rows, start afresh
                 const int j = slot + jt * wpx;
                 const int bs = xcd + 8 * (j / tiles), q0 = (j % tiles) * FK_QB;
+                knn_flush_select_multi<FKP_QPW>(qs, cnt, K, rd, ri, lane, win[cw]);
+                if (wave == 4) FK_T(7);
 #pragma unroll
                 for (int t = 0; t < FKP_QPW; ++t) {
-                    const int ql = (wave - 4) * FKP_QPW + t;
-                    knn_flush_ranked(queue[ql], cnt[t], K, rd[t], ri[t], lane, win[wave - 4]);
                     if (lane >= 1 && lane <= k)
-                        idx[((size_t)bs * n + q0 + ql) * k + lane - 1] = rd[t] < INFINITY ? ri[t] : 0;
+                        idx[((size_t)bs * n + q0 + qb + t) * k + lane - 1] = rd[t] < INFINITY ? ri[t] : 0;
                     rd[t] = INFINITY;
                     ri[t] = 0x7fffffff;
                     cnt[t] = 0;
                 }
             }
+            if (wave == 4) FK_T(5);
         }
         __syncthreads();
+        if (wave == 0) FK_T(6);
     }
 }
 

@@ -5,7 +5,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from pdgn_amd import _lib
 from pdgn_amd._lib import ptr, stream_of
-L = _lib.lib()
+L = ctypes.CDLL(os.environ["PDGN_FK_SO"]) if os.environ.get("PDGN_FK_SO") else _lib.lib()
+_lib.lib()
 def t(fn, it=20):
     for _ in range(3): fn()
     torch.cuda.synchronize()
