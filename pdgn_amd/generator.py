@@ -136,22 +136,23 @@ class PointGenerator(nn.Module):
         self.mlp1, self.mlp2 = _mlp_head(512 + 32), _mlp_head(512 + 64)
         self.mlp3, self.mlp4 = _mlp_head(512 + 128), _mlp_head(512)
 
-    def forward(self, z, idx=(None, None, None, None), stage_hook=None, stop_before=None):
+    def forward(self, z, idx=(None, None, None, None), stage_hook=None, stop_before=None, feature_hook=None):
         """`stage_hook(level, cloud)`, if given, is called as soon as the cloud of a level exists (the trainer starts
         that level's discriminator update on another stream while the deeper levels are still being generated).
         stop_before=L: stop in front of block L (0-based) and return the pass's state instead of the clouds; `resume`
         runs the remaining blocks -- the trainer continues one pass's deepest block on another stream, underneath the
-        next pass's first (latency-bound) blocks."""
+        next pass's first (latency-bound) blocks.  `feature_hook(level, xt)` is called with the input features of every
+        block (the trainer hangs its early gradient bucket on the deepest block's)."""
         B = z.shape[0]
         xt = _small_seq(self.fc1, z, self.training).view(B, 32, self.base_points).transpose(1, 2).contiguous()    # (B,N0,32)
         state = {"B": B, "xt": xt, "pct": None, "const": None, "clouds": [], "pending": (None, None), "lvl": 0, "idx": idx}
-        return self._blocks(state, stage_hook, stop_before)
+        return self._blocks(state, stage_hook, stop_before, feature_hook)
 
-    def resume(self, state, stage_hook=None):
+    def resume(self, state, stage_hook=None, feature_hook=None):
         """The remaining blocks of a pass stopped by forward(..., stop_before=L), on the CURRENT stream."""
-        return self._blocks(state, stage_hook, None)
+        return self._blocks(state, stage_hook, None, feature_hook)
 
-    def _blocks(self, s, stage_hook, stop_before):
+    def _blocks(self, s, stage_hook, stop_before, feature_hook=None):
         B, idx = s["B"], s["idx"]
         blocks = (self.bilateral1, self.bilateral2, self.bilateral3, self.bilateral4)
         heads = (self.mlp1, self.mlp2, self.mlp3, self.mlp4)
@@ -160,6 +161,8 @@ class PointGenerator(nn.Module):
                 s["lvl"] = lvl
                 return s
             xt, pct, const, clouds = s["xt"], s["pct"], s["const"], s["clouds"]
+            if feature_hook is not None:
+                feature_hook(lvl, xt)
             lvl_idx, lvl_ready = (idx[lvl], None) if idx[lvl] is not None else s["pending"]
             xs, x_ec, g = blocks[lvl].forward_cl(xt, pct, idx=lvl_idx, const=const, idx_ready=lvl_ready)
             s["pending"] = (None, None)

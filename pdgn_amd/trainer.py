@@ -29,20 +29,31 @@ class FlatGrads:
     backward one multi-tensor copy packs the gradients into the buffer, ONE collective reduces the
     whole network (G: 50.8 MB, D1-4: 6.8 MB) and the parameters' ``.grad`` become views of it."""
 
-    def __init__(self, params):
-        self.params = [p for p in params if p.requires_grad]
+    def __init__(self, params, first=None):
+        """first: the parameters whose gradients a backward pass completes FIRST (the deepest block's); they are laid
+        out in front and form the early bucket of reduce_early()."""
+        ps = [p for p in params if p.requires_grad]
+        early = {id(p) for p in (first or [])}
+        self.params = [p for p in ps if id(p) in early] + [p for p in ps if id(p) not in early]
+        self.n_early = sum(1 for p in ps if id(p) in early)
         total = sum(p.numel() for p in self.params)
         ref = self.params[0]
         self.buf = torch.zeros(total, dtype=ref.dtype, device=ref.device)
         self.views, off = [], 0
-        for p in self.params:
+        for i, p in enumerate(self.params):
+            if i == self.n_early:
+                self.early_numel = off
             self.views.append(self.buf[off:off + p.numel()].view_as(p))
             off += p.numel()
+        if self.n_early == len(self.params):
+            self.early_numel = off
+        self._early_work, self._early_done = None, False
 
     def begin(self):
         """Before a backward: drop the old gradients (autograd then writes, never accumulates)."""
         for p in self.params:
             p.grad = None
+        self._early_work, self._early_done = None, False
         clear_zero_colsum()
         if self.params and self.params[0].is_cuda:
             reset_zero_arena(self.params[0].device, self)
@@ -51,20 +62,41 @@ class FlatGrads:
         self.buf.zero_()
 
     def pack(self):
-        """Gather the fresh .grad tensors into the flat buffer and re-point .grad at its views."""
-        have = [(v, p) for v, p in zip(self.views, self.params) if p.grad is not None]
-        missing = [v for v, p in zip(self.views, self.params) if p.grad is None]
+        """Gather the fresh .grad tensors into the flat buffer and re-point .grad at its views (the early bucket only
+        if reduce_early() has not already taken it: its slice may be inside a running all-reduce)."""
+        self._pack(self.n_early if self._early_done else 0, len(self.params))
+
+    def _pack(self, lo, hi):
+        views, params = self.views[lo:hi], self.params[lo:hi]
+        have = [(v, p) for v, p in zip(views, params) if p.grad is not None]
+        missing = [v for v, p in zip(views, params) if p.grad is None]
         if have:
             torch._foreach_copy_([v for v, _ in have], [p.grad for _, p in have])
         for v in missing:
             v.zero_()
-        for v, p in zip(self.views, self.params):
+        for v, p in zip(views, params):
             p.grad = v
+
+    def reduce_early(self, group=None):
+        """Called from inside the backward once the early bucket's gradients exist: pack them and start their
+        all-reduce (asynchronous: on RCCL's stream, underneath the rest of the backward).  all_reduce_mean() later
+        reduces the rest and joins.  No-op without a process group or without an early bucket."""
+        if self._early_done or self.n_early == 0 or not (dist.is_available() and dist.is_initialized()):
+            return
+        self._pack(0, self.n_early)
+        self._early_done = True
+        self._early_work = dist.all_reduce(self.buf[:self.early_numel], op=dist.ReduceOp.SUM, group=group, async_op=True)
 
     def all_reduce_mean(self, group=None):
         """Average over ranks (RCCL all-reduce over xGMI when the backend is nccl)."""
         if dist.is_available() and dist.is_initialized():
-            dist.all_reduce(self.buf, op=dist.ReduceOp.SUM, group=group)
+            if self._early_done:
+                if self.early_numel < self.buf.numel():
+                    dist.all_reduce(self.buf[self.early_numel:], op=dist.ReduceOp.SUM, group=group)
+                self._early_work.wait()
+                self._early_work = None
+            else:
+                dist.all_reduce(self.buf, op=dist.ReduceOp.SUM, group=group)
             if dist.get_world_size(group) > 1:
                 self.buf.div_(dist.get_world_size(group))
 
@@ -86,7 +118,11 @@ class PDGNTrainer:
                   (discriminators or [PointDiscriminator(i, (2 * base_points) << (i - 1)) for i in (1, 2, 3, 4)])]
         self.local_pair = LocalPairLoss(20)
         self.distributed = world_size() > 1 if distributed is None else distributed
-        self.gradG = FlatGrads(self.G.parameters())
+        # the deepest block's gradients are complete when the backward reaches that block's input: they form the early
+        # bucket whose all-reduce runs underneath the rest of the backward (PDGN_BUCKETS=0: one all-reduce at the end)
+        self._buckets = os.environ.get("PDGN_BUCKETS", "1") == "1"
+        deepest = (list(self.G.bilateral4.parameters()) + list(self.G.mlp4.parameters())) if self._buckets and hasattr(self.G, "bilateral4") else None
+        self.gradG = FlatGrads(self.G.parameters(), first=deepest)
         self.gradD = [FlatGrads(d.parameters()) for d in self.D]
         cap = self.device.type == "cuda"                     # device-side step counter: graph-capturable
         adam = lambda m: torch.optim.Adam(m.parameters(), lr=lr, betas=(0.5, 0.999), capturable=cap, fused=cap and os.environ.get("PDGN_FUSED_ADAM", "1") == "1")
@@ -250,7 +286,7 @@ class PDGNTrainer:
             # The reference lets lossG.backward() also fill the discriminators' .grad and throws
             # that away at the next zero_grad (:183); freezing D skips those weight-gradient GEMMs.
             self._freeze_D(True)
-            gen = self.G(self._z(st, "z2"))
+            gen = self.G(self._z(st, "z2"), feature_hook=self._early_bucket_hook)
             similar = self.similar_loss(gen)
             g_loss = [F.mse_loss(self.D[i](gen[i]), st["ones"]) for i in range(4)]
             adv = 1.2 * g_loss[0] + 1.2 * g_loss[1] + 1.2 * g_loss[2] + g_loss[3]
@@ -264,6 +300,12 @@ class PDGNTrainer:
             st["out"]["g_loss"], st["out"]["similar_loss"] = lossG.detach(), similar.detach()
         else:
             self.optG.step()
+
+    def _early_bucket_hook(self, lvl, xt):
+        """PointGenerator feature hook: the gradient of the deepest block's input is the point of the backward at which
+        that block's (and its head's) parameter gradients are complete -- start their all-reduce there."""
+        if lvl == 3 and self.distributed and self._buckets and xt.requires_grad:
+            xt.register_hook(lambda g: self.gradG.reduce_early())
 
     def _z(self, st, name):
         """Noise of a generator pass: the caller's tensor, or -- when it is None -- drawn on the
@@ -390,12 +432,12 @@ class PDGNTrainer:
                 g_loss[level] = F.mse_loss(self.D[level](cloud), st["ones"])
 
         if fork:
-            s2 = self.G(self._z(st, "z2"), stage_hook=tail if early else None, stop_before=3)
+            s2 = self.G(self._z(st, "z2"), stage_hook=tail if early else None, stop_before=3, feature_hook=self._early_bucket_hook)
             main.wait_event(l4_done)
-            gen = self.G.resume(s2, stage_hook=tail if early else None)
+            gen = self.G.resume(s2, stage_hook=tail if early else None, feature_hook=self._early_bucket_hook)
             del s2
         else:
-            gen = self.G(self._z(st, "z2"), stage_hook=tail if early else None)
+            gen = self.G(self._z(st, "z2"), stage_hook=tail if early else None, feature_hook=self._early_bucket_hook)
         mark("G(z2) forward")
         if not early:
             split = self._lp_split

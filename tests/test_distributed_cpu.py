@@ -213,3 +213,39 @@ def test_shard_pairs_without_process_group_is_identity():
     from pdgn_amd.evaluation import shard_pairs
     a, = shard_pairs(5, lambda lo, hi: (torch.arange(lo, hi),))
     assert a.tolist() == [0, 1, 2, 3, 4]
+
+
+def _worker_buckets(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    res = {}
+    for mode in ("1", "0"):
+        os.environ["PDGN_BUCKETS"] = mode
+        tr = _build_trainer(distributed=True)
+        reals, z1, z2 = _batch(rank)
+        tr.step(reals, z1, z2)
+        res["early" + mode] = bool(tr.gradG._early_done)
+        res["n_early" + mode] = tr.gradG.n_early
+        res["params" + mode] = torch.cat([p.detach().reshape(-1) for p in tr.G.parameters()]).numpy()
+        # the reduced gradient per PARAMETER (the flat layouts of the two modes differ)
+        res["grads" + mode] = torch.cat([p.grad.detach().reshape(-1) for p in tr.G.parameters()]).numpy()
+    os.environ.pop("PDGN_BUCKETS")
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), **res)
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_bucketed_all_reduce_equals_flat_gloo():
+    """The deepest block's gradients all-reduced from inside the backward (early bucket, asynchronous) + the rest at the end
+    give the same reduced gradients and the same updated parameters as one flat all-reduce."""
+    world = 2
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker_buckets, args=(world, _free_port(), d), nprocs=world, join=True)
+        r = [dict(np.load(os.path.join(d, "rank%d.npz" % i))) for i in range(world)]
+    for x in r:
+        assert bool(x["early1"]) and int(x["n_early1"]) > 0          # the early bucket was taken from inside the backward
+        assert not bool(x["early0"]) and int(x["n_early0"]) == 0
+        np.testing.assert_array_equal(x["grads1"], x["grads0"])
+        np.testing.assert_array_equal(x["params1"], x["params0"])
+    np.testing.assert_array_equal(r[0]["params1"], r[1]["params1"])
