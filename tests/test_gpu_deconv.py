@@ -59,6 +59,25 @@ def test_feature_knn_duplicates_drop_rank0():
     assert idx[0, 30].tolist() == [21, 22, 23, 24, 25, 26]
 
 
+@pytest.mark.parametrize("F,N", [(32, 256), (64, 512), (256, 1024)])
+def test_feature_knn_mass_ties_on_the_producer_consumer_kernel(F, N):
+    """Regular shapes (the persistent producer / consumer kernel): clusters of 100 identical points -- more equal distances
+    than a survivor queue holds (in-scan merges) and more than 32 entries at the K-th distance (the general merge path);
+    integer features, so every distance is exact and the expected graph is the index order inside the query's cluster."""
+    from pdgn_amd.deconv import feature_knn
+    k = 10
+    cluster = torch.arange(N) // 100
+    x = (cluster.float() * 3.0).view(1, 1, N).expand(2, F, N).contiguous()
+    x[1] = x[1].flip(-1)                                    # second sample: clusters in reverse index order
+    idx = feature_knn(dev(x), k).cpu()
+    for b in range(2):
+        cl = cluster if b == 0 else cluster.flip(0)
+        for q in (0, 1, 57, 99, 100, 163, N - 57, N - 1):
+            members = torch.nonzero(cl == cl[q]).flatten().tolist()
+            assert len(members) >= k + 1
+            assert idx[b, q].tolist() == members[1:k + 1], (b, q)      # rank 0 (the cluster's first index) dropped
+
+
 @pytest.mark.parametrize("B,N,k,ldy,spec", [(2, 50, 10, 64, (6, 5, 8, 0, 48)), (2, 33, 10, 40, (10, 1, 3, 1, 31)),
                                             (3, 64, 10, 32, (1, 10, 16, 0, 16)), (2, 40, 4, 24, (3, 2, 4, 4, -1)),
                                             (2, 512, 10, 7200, (6, 5, 1024, 0, 6144)),
