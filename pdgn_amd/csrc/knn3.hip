@@ -169,13 +169,36 @@ __global__ __launch_bounds__(KNN4_THREADS) void knn3_wave4_kernel(
 #pragma unroll
                 for (int q = 0; q < KNN4_Q; ++q) {
                     const float d = sqdist3(qx[q], qy[q], qz[q], p[j].x, p[j].y, p[j].z);
-                    lmin[q] = d < lmin[q] ? d : lmin[q];
+                    lmin[q] = d < lmin[q] ? d : lmin[q];         // (fminf would add a canonicalising v_max per value)
                 }
         }
         float tau[KNN4_Q];
+        {   // 16-bit upper bounds of the K-th smallest lane minimum, the queries' bisections interleaved stage by stage
+            unsigned key[KNN4_Q], prefix[KNN4_Q];
 #pragma unroll
-        for (int q = 0; q < KNN4_Q; ++q) tau[q] = fminf(wave_kth_smallest_ub16(lmin[q], K), __shfl(rd[q], K - 1, 64));
-        // pass B: survivors into the per-query queues
+            for (int q = 0; q < KNN4_Q; ++q) { key[q] = __float_as_uint(lmin[q]) | 0x80000000u; prefix[q] = 0x80000000u; }
+#pragma unroll
+            for (int bit = 30; bit >= 15; --bit) {
+                unsigned long long lo[KNN4_Q];
+#pragma unroll
+                for (int q = 0; q < KNN4_Q; ++q) lo[q] = __ballot(key[q] < (prefix[q] | (1u << bit)));
+#pragma unroll
+                for (int q = 0; q < KNN4_Q; ++q)
+                    prefix[q] = __builtin_amdgcn_readfirstlane(__popcll(lo[q]) < K ? (prefix[q] | (1u << bit)) : prefix[q]);
+            }
+#pragma unroll
+            for (int q = 0; q < KNN4_Q; ++q) {
+                const unsigned ub = min(prefix[q] | 0x7fffu, 0xff800000u);
+                tau[q] = fminf(__uint_as_float(ub & 0x7fffffffu), __shfl(rd[q], K - 1, 64));
+            }
+        }
+        // pass B: survivors into the per-query queues.  Written for few VALU -> SALU -> VALU round trips: the compares of a
+        // step for both queries, ONE scalar overflow test, then the predicated writes at mbcnt slots (wave_select.h).
+#pragma unroll
+        for (int q = 0; q < KNN4_Q; ++q) tau[q] = fminf(tau[q], 3.402823466e38f);   // finite: "d <= tau" keeps +inf out
+        int sc[KNN4_Q];
+#pragma unroll
+        for (int q = 0; q < KNN4_Q; ++q) sc[q] = __builtin_amdgcn_readfirstlane(cnt[q]);
         for (int c0 = 0; c0 < tp; c0 += 128) {
             float4 p[2];
 #pragma unroll
@@ -183,32 +206,53 @@ __global__ __launch_bounds__(KNN4_THREADS) void knn3_wave4_kernel(
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int c = c0 + 64 * j + lane;
+                float d[KNN4_Q];
+                unsigned long long mask[KNN4_Q];
+                int add[KNN4_Q];
+                bool over = false;
 #pragma unroll
                 for (int q = 0; q < KNN4_Q; ++q) {
-                    const float d = sqdist3(qx[q], qy[q], qz[q], p[j].x, p[j].y, p[j].z);
-                    bool keep = d <= tau[q] && d < INFINITY;
-                    unsigned long long mask = __ballot(keep);
-                    if (mask) {
+                    d[q] = sqdist3(qx[q], qy[q], qz[q], p[j].x, p[j].y, p[j].z);
+                    mask[q] = __ballot(d[q] <= tau[q]);
+                }
+#pragma unroll
+                for (int q = 0; q < KNN4_Q; ++q) {
+                    add[q] = __popcll(mask[q]);
+                    over = over || sc[q] + add[q] > KNN4_QCAP;
+                }
+                if (!over) {
+#pragma unroll
+                    for (int q = 0; q < KNN4_Q; ++q) {
+                        const int pos = __builtin_amdgcn_mbcnt_hi((unsigned)(mask[q] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask[q], sc[q]));
+                        if (d[q] <= tau[q]) { queue[wave][q][pos].d = d[q]; queue[wave][q][pos].i = t0 + c; }
+                        sc[q] += add[q];
+                    }
+                } else {                                         // rare (duplicates, > 64 ties): merge, tighten, re-filter
+#pragma unroll
+                    for (int q = 0; q < KNN4_Q; ++q) {
                         DI *qq = queue[wave][q];
-                        if (cnt[q] + __popcll(mask) > KNN4_QCAP) {   // rare (duplicates, > 64 ties): merge, tighten, re-filter
-                            knn_flush_ranked(qq, cnt[q], K, rd[q], ri[q], lane, win[wave][q]);
-                            cnt[q] = 0;
+                        bool keep = d[q] <= tau[q];
+                        unsigned long long mk = mask[q];
+                        if (sc[q] + add[q] > KNN4_QCAP) {
+                            knn_flush_ranked(qq, sc[q], K, rd[q], ri[q], lane, win[wave][q]);
+                            sc[q] = 0;
                             tau[q] = fminf(tau[q], __shfl(rd[q], K - 1, 64));
-                            keep = keep && d <= tau[q];
-                            mask = __ballot(keep);
+                            keep = keep && d[q] <= tau[q];
+                            mk = __ballot(keep);
                         }
-                        const int pos = cnt[q] + __popcll(mask & ((1ull << lane) - 1ull));
-                        if (keep) { qq[pos].d = d; qq[pos].i = t0 + c; }
-                        cnt[q] += __popcll(mask);
+                        const int pos = sc[q] + __popcll(mk & ((1ull << lane) - 1ull));
+                        if (keep) { qq[pos].d = d[q]; qq[pos].i = t0 + c; }
+                        sc[q] = __builtin_amdgcn_readfirstlane(sc[q] + __popcll(mk));
                     }
                 }
             }
         }
-#pragma unroll
-        for (int q = 0; q < KNN4_Q; ++q) {
-            knn_flush_ranked(queue[wave][q], cnt[q], K, rd[q], ri[q], lane, win[wave][q]);
-            cnt[q] = 0;
+        {
+            DI *const qs[KNN4_Q] = {queue[wave][0], queue[wave][1]};
+            knn_flush_select_multi<KNN4_Q>(qs, sc, K, rd, ri, lane, win[wave][0]);
         }
+#pragma unroll
+        for (int q = 0; q < KNN4_Q; ++q) cnt[q] = 0;
     }
 #pragma unroll
     for (int q = 0; q < KNN4_Q; ++q) {
