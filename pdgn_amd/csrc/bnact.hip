@@ -37,6 +37,8 @@ struct ClGeom {
 
 // part[blockIdx.y][c] = sum_r x[r,c];  part[blockIdx.y][C + c] = sum_r x[r,c]^2 over the block's rows
 // (fp32 partials over <= 64K rows; the finalize kernels combine them in fp64 -- no atomics).
+// The sums are taken of x - pivot, pivot = row 0 of x (the same for every block): E[x^2] - mean^2 on raw sums cancels
+// quadratically in |mean| / std, on shifted sums it does not (the finalize kernel adds the pivot back).
 __global__ __launch_bounds__(BN_THREADS) void cl_stats_kernel(long long R, int C, int cgb, int rows_per_block,
                                                               const float *__restrict__ x,
                                                               float *__restrict__ part) {
@@ -49,6 +51,7 @@ __global__ __launch_bounds__(BN_THREADS) void cl_stats_kernel(long long R, int C
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f), q = make_float4(0.f, 0.f, 0.f, 0.f);
     if (cok) {
         const float *X = x + cgi * 4;
+        const float4 pv = *reinterpret_cast<const float4 *>(X);                 // pivot: row 0
         long long r = r0 + rlane;
         for (; r + 3LL * rl < r1; r += 4LL * rl) {              // four independent row loads in flight
             float4 v[4];
@@ -56,16 +59,18 @@ __global__ __launch_bounds__(BN_THREADS) void cl_stats_kernel(long long R, int C
             for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4 *>(X + (r + (long long)u * rl) * C);
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w;
-                q.x = __fmaf_rn(v[u].x, v[u].x, q.x); q.y = __fmaf_rn(v[u].y, v[u].y, q.y);
-                q.z = __fmaf_rn(v[u].z, v[u].z, q.z); q.w = __fmaf_rn(v[u].w, v[u].w, q.w);
+                const float dx = v[u].x - pv.x, dy = v[u].y - pv.y, dz = v[u].z - pv.z, dw = v[u].w - pv.w;
+                s.x += dx; s.y += dy; s.z += dz; s.w += dw;
+                q.x = __fmaf_rn(dx, dx, q.x); q.y = __fmaf_rn(dy, dy, q.y);
+                q.z = __fmaf_rn(dz, dz, q.z); q.w = __fmaf_rn(dw, dw, q.w);
             }
         }
         for (; r < r1; r += rl) {
             const float4 v = *reinterpret_cast<const float4 *>(X + r * C);
-            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-            q.x = __fmaf_rn(v.x, v.x, q.x); q.y = __fmaf_rn(v.y, v.y, q.y);
-            q.z = __fmaf_rn(v.z, v.z, q.z); q.w = __fmaf_rn(v.w, v.w, q.w);
+            const float dx = v.x - pv.x, dy = v.y - pv.y, dz = v.z - pv.z, dw = v.w - pv.w;
+            s.x += dx; s.y += dy; s.z += dz; s.w += dw;
+            q.x = __fmaf_rn(dx, dx, q.x); q.y = __fmaf_rn(dy, dy, q.y);
+            q.z = __fmaf_rn(dz, dz, q.z); q.w = __fmaf_rn(dw, dw, q.w);
         }
     }
     red[0][threadIdx.x] = s;
@@ -148,16 +153,18 @@ __device__ __forceinline__ void fin_reduce2(const float *__restrict__ part, int 
 __global__ __launch_bounds__(FIN_CH * FIN_PL) void cl_finalize_kernel(
     long long R, int C, int nparts, float eps, float momentum, const float *__restrict__ part,
     const float *__restrict__ gamma, const float *__restrict__ beta, const float *__restrict__ pre_bias,
-    float *__restrict__ running_mean, float *__restrict__ running_var, float *__restrict__ stats) {
+    float *__restrict__ running_mean, float *__restrict__ running_var, float *__restrict__ stats,
+    const float *__restrict__ pivot) {                      // the sums are of (x - pivot[c]) when given (cl_stats_kernel)
     __shared__ double red[FIN_PL][FIN_CH], red2[FIN_PL][FIN_CH];
     const int c = blockIdx.x * FIN_CH + threadIdx.x % FIN_CH;
     const bool ok = c < C;
     double s1, s2;
     fin_reduce2(part, nparts, (size_t)2 * C, c, C, ok, red, red2, s1, s2);
     if (!ok || threadIdx.x >= FIN_CH) return;
-    const double mean = s1 / (double)R;
-    double var = s2 / (double)R - mean * mean;
+    const double ms = s1 / (double)R;                       // mean of the (shifted) values
+    double var = s2 / (double)R - ms * ms;
     var = var < 0 ? 0 : var;
+    const double mean = ms + (pivot ? (double)pivot[c] : 0.0);
     const float invstd = (float)(1.0 / sqrt(var + (double)eps));
     const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
     const float scale = g * invstd;
@@ -379,7 +386,7 @@ extern "C" int pdgn_bn_stats(long long rows, int c, float eps, float momentum, c
     cl_geometry(rows, c, &cgb, &gx, &gy, &rpb);
     hipLaunchKernelGGL(cl_stats_kernel, dim3(gx, gy), dim3(BN_THREADS), 0, s, rows, c, cgb, rpb, x, scratch);
     hipLaunchKernelGGL(cl_finalize_kernel, dim3(cdiv(c, FIN_CH)), dim3(FIN_CH * FIN_PL), 0, s, rows, c, gy, eps, momentum, scratch,
-                       gamma, beta, pre_bias, running_mean, running_var, stats);
+                       gamma, beta, pre_bias, running_mean, running_var, stats, x);
     return pdgn_launch_status();
 }
 
@@ -392,7 +399,7 @@ extern "C" int pdgn_bn_stats_from_partials(long long rows, int c, float eps, flo
     int cgb, gx, gy, rpb;
     cl_geometry(rows, c, &cgb, &gx, &gy, &rpb);
     hipLaunchKernelGGL(cl_finalize_kernel, dim3(cdiv(c, FIN_CH)), dim3(FIN_CH * FIN_PL), 0, (hipStream_t)stream, rows, c, gy, eps,
-                       momentum, scratch, gamma, beta, pre_bias, running_mean, running_var, stats);
+                       momentum, scratch, gamma, beta, pre_bias, running_mean, running_var, stats, (const float *)nullptr);
     return pdgn_launch_status();
 }
 
@@ -404,7 +411,8 @@ extern "C" int pdgn_bn_stats_from_gemm_partials(long long rows, int c, long long
                                                 float *stats, pdgn_stream_t stream) {
     if (rows < 1 || c < 4 || c % 4 || nparts < 1 || nparts > 0x7fffffffLL) return PDGN_ERR_INVALID;
     hipLaunchKernelGGL(cl_finalize_kernel, dim3(cdiv(c, FIN_CH)), dim3(FIN_CH * FIN_PL), 0, (hipStream_t)stream, rows, c,
-                       (int)nparts, eps, momentum, partials, gamma, beta, pre_bias, running_mean, running_var, stats);
+                       (int)nparts, eps, momentum, partials, gamma, beta, pre_bias, running_mean, running_var, stats,
+                       (const float *)nullptr);
     return pdgn_launch_status();
 }
 

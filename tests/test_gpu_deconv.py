@@ -310,6 +310,28 @@ def test_fused_bn_act_vs_torch(rows, C, act, use_mul, training):
         np.testing.assert_allclose(a, b, rtol=1e-4, atol=1e-4 * max(1.0, np.abs(b).max()), err_msg=name)
 
 
+@pytest.mark.parametrize("shift", [30.0, 300.0, 1000.0])
+def test_bn_act_large_mean(shift):
+    """|mean| >> std (round-1 advice): the statistics pass sums x - x[0] (shifted sums), so that the variance does not
+    cancel -- output, input gradient and running statistics against fp64 at the north star's 1e-4."""
+    from pdgn_amd.fused import bn_act
+    rows, C = 50000, 64
+    g = torch.Generator(device="cuda").manual_seed(int(shift))
+    x = (torch.randn(rows, C, device="cuda", generator=g) * torch.linspace(0.5, 2.0, C, device="cuda") + shift).requires_grad_(True)
+    gout = torch.randn(rows, C, device="cuda", generator=g)
+    bn = torch.nn.BatchNorm1d(C).cuda().train()
+    y = bn_act(x, bn, True, act="none")                     # (an activation's kink would make the gradient check ill-posed)
+    y.backward(gout)
+    xr = x.detach().double().requires_grad_(True)
+    ref_bn = torch.nn.BatchNorm1d(C).cuda().double().train()
+    yr = ref_bn(xr)
+    yr.backward(gout.double())
+    assert (y.detach().double() - yr.detach()).abs().max().item() < 1e-4
+    assert (x.grad.double() - xr.grad).abs().max().item() < 1e-4 * max(1.0, xr.grad.abs().max().item())
+    np.testing.assert_allclose(bn.running_mean.cpu().numpy(), ref_bn.running_mean.cpu().numpy(), rtol=1e-5)
+    np.testing.assert_allclose(bn.running_var.cpu().numpy(), ref_bn.running_var.cpu().numpy(), rtol=2e-4)
+
+
 def test_graphed_step_equals_eager_step():
     """hipGraph replay (trainer.capture / step_graphed) reproduces the eager iteration."""
     from pdgn_amd.trainer import PDGNTrainer, noise, synthetic_batch
