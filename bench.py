@@ -198,7 +198,8 @@ def barrier():
     import torch.distributed as dist
     if dist.is_initialized():
         dist.barrier()
-    torch.cuda.synchronize()
+    if torch.cuda.is_available():                 # (the CPU / gloo tests of this file's rank logic have no GPU)
+        torch.cuda.synchronize()
 
 
 def executed_flops(trainer, reals, z1, z2):
@@ -208,7 +209,8 @@ def executed_flops(trainer, reals, z1, z2):
     from pdgn_amd import deconv, fused
     fused.GEMM_LOG, deconv.KNN_LOG = [], []
     trainer.step(reals, z1, z2)
-    torch.cuda.synchronize()
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
     gemm, knn = fused.GEMM_LOG, deconv.KNN_LOG
     fused.GEMM_LOG = deconv.KNN_LOG = None
     f_gemm = sum(2.0 * m * n * k for (_, m, n, k) in gemm)
@@ -296,6 +298,19 @@ def main():
     gen = torch.Generator().manual_seed(1234 + rank)
     zs = [(noise(B, device, gen), noise(B, device, gen)) for _ in range(args.warmup + args.steps)]
 
+    measure_and_report(args, trainer, reals, zs, world, rank, device, res)
+    if dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def measure_and_report(args, trainer, reals, zs, world, rank, device, res):
+    """Warm-up, the timed region (barrier + synchronise on both sides, max over ranks), the flop-logging iteration and
+    rank 0's JSON line.  Everything in here that issues a collective runs on EVERY rank (tests/test_distributed_cpu.py
+    drives this function with two gloo ranks)."""
+    import torch
+    import torch.distributed as dist
+    B = args.batch
     step, graphed = trainer.step, False
     if args.graph and not args.no_graph and not trainer.distributed:
         try:                                   # one hipGraph per iteration (trainer.capture)
@@ -325,6 +340,16 @@ def main():
         dt = max(dts)
     finite = all(torch.isfinite(v).item() for v in out.values())
 
+    # The flop-logging iteration is a full trainer.step(): under data parallelism it issues the gradient all-reduces, so
+    # EVERY rank runs it (rank 0 alone would wait for collectives nobody else joins); only rank 0's log is reported.
+    flops = None
+    if not graphed:
+        try:
+            flops = executed_flops(trainer, reals, *zs[0])
+        except Exception as e:
+            flops = {"error": repr(e)}
+        barrier()
+
     if rank == 0:
         ms = dt / args.steps * 1e3
         line = {
@@ -343,17 +368,15 @@ def main():
                        "global_batch": world * B, "points_all_resolutions_per_s": world * B * sum(res) / (dt / args.steps),
                        "parallelism": "dp%d" % world, "losses_finite": finite, "hipgraph": graphed},
         }
-        if not graphed:
-            try:
-                fl = executed_flops(trainer, reals, *zs[0])
-                total = fl["gemm"] + fl["feature_knn_gram"]
-                line["executed_flops_per_step"] = total
-                line["executed_flops_detail"] = fl
-                line["step_mfma_frac"] = total / (ms * 1e-3) / (MFMA_F32_PEAK_TFLOPS * 1e12)
-                line["direct_form_flops_per_step"] = DIRECT_FORM_FLOPS_PER_SAMPLE * B
-                line["algebraic_saving"] = DIRECT_FORM_FLOPS_PER_SAMPLE * B / total
-            except Exception as e:
-                line["executed_flops_per_step"] = {"error": repr(e)}
+        if flops is not None and "error" in flops:
+            line["executed_flops_per_step"] = flops
+        elif flops is not None:
+            total = flops["gemm"] + flops["feature_knn_gram"]                 # per rank = per GPU
+            line["executed_flops_per_step"] = total
+            line["executed_flops_detail"] = flops
+            line["step_mfma_frac"] = total / (ms * 1e-3) / (MFMA_F32_PEAK_TFLOPS * 1e12)
+            line["direct_form_flops_per_step"] = DIRECT_FORM_FLOPS_PER_SAMPLE * B
+            line["algebraic_saving"] = DIRECT_FORM_FLOPS_PER_SAMPLE * B / total if total else None
         if not args.no_roofline:
             try:
                 from pdgn_amd import roofline
@@ -363,9 +386,8 @@ def main():
         if not args.no_cpu_baseline and world == 1:          # host baseline: rank 0, N = 1 only
             line["cpu_baseline"] = cpu_baseline(args.cpu_sample_batch)
         print(json.dumps(line), flush=True)
-    if dist.is_initialized():
-        dist.barrier()
-        dist.destroy_process_group()
+        return line
+    return None
 
 
 if __name__ == "__main__":

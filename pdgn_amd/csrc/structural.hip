@@ -13,6 +13,8 @@
 //  * emd_cost: the same 9-level auction with phase 3 accumulating match*dist on the fly --
 //    the (b,m,n) match matrix (8.6 GB at b=512, 2048^2) never touches HBM.
 #include "common.h"
+#include <type_traits>
+#include <cstdlib>
 
 #define SL_THREADS 256
 #define SL_TILE 2048
@@ -308,6 +310,199 @@ __global__ __launch_bounds__(AM_THREADS) void approxmatch_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------- fused EMD cost (round 3)
+// The same 9-level auction as approxmatch_kernel, restructured around what its inner loops cost on gfx950 (one
+// v_exp_f32 = two full-rate slots; every other operation one packed slot per two points):
+//  * the exponent's two multiplies are gone: coordinates are pre-scaled per level by s_j = 2^j sqrt(log2 e), so that the
+//    squared distance of the scaled points IS the (negated) v_exp_f32 argument, 4^j |p - q|^2 log2 e;
+//  * phase 3 of level j and phase 1 of level j-1 sweep the same (k, all l) pairs and depend on each other only through
+//    remainL[k], which phase 1 needs as a numerator AFTER its sum: they run as ONE sweep.  Its exponential is taken at
+//    the lower level, e' = exp(-4^(j-1) d2), and the upper level's is e'^4 (two packed multiplies), so a level costs two
+//    sweeps and two exponentials per pair of points instead of three and three: 19 n m exponentials per cloud pair, not 27;
+//  * sqrt(d2) of the cost term is v_sqrt_f32 of the scaled squared distance, un-scaled once per sweep.
+// Same phase order, guards (1e-9), integer multiL / multiR and clamps as approxmatch.cu:3-224; results agree with the
+// line-by-line form to ~1e-6 relative (the tests hold it to 1e-4 against the C oracle).
+#define EMD_SQRT_LOG2E 0x1.337f14p+0f          // sqrt(log2 e) = 1.2011224
+__device__ __forceinline__ f2 exp2neg_pk(f2 a) { return f2{__builtin_amdgcn_exp2f(-a.x), __builtin_amdgcn_exp2f(-a.y)}; }
+
+__global__ __launch_bounds__(AM_THREADS) void emd_cost_kernel(
+    int n, int m, const float *__restrict__ xyz1, const float *__restrict__ xyz2, float *__restrict__ temp,
+    float *__restrict__ cost_out, const int32_t *__restrict__ ia, const int32_t *__restrict__ ib) {
+    __shared__ float4 buf[AM_TILE];            // scaled opposite point + its weight of the phase being evaluated
+    __shared__ float buf2[AM_TILE];            // merged sweeps: remainR[l] (the weight of the NEXT level's phase 1)
+    __shared__ float red[AM_THREADS / PDGN_WAVE];
+    const int pair = blockIdx.x, tid = threadIdx.x;
+    const float *A = xyz1 + (size_t)(ia ? ia[pair] : pair) * n * 3;
+    const float *B = xyz2 + (size_t)(ib ? ib[pair] : pair) * m * 3;
+    float *remainL = temp + (size_t)pair * (n + m) * 2, *remainR = remainL + n, *ratioL = remainR + m, *ratioR = ratioL + n;
+    const float multiL = n >= m ? 1.f : (float)(m / n);     // integer division, approxmatch.cu:6-12
+    const float multiR = n >= m ? (float)(n / m) : 1.f;
+    for (int k = tid; k < n; k += AM_THREADS) remainL[k] = multiL;
+    for (int l = tid; l < m; l += AM_THREADS) remainR[l] = multiR;
+    __syncthreads();
+    float cost = 0.f;
+
+    // one sweep with the thread owning points of cloud A: MODE 0 = phase 1 of level j (first level only),
+    // 1 = phase 3 of level j merged with phase 1 of level j-1 (coordinates scaled for level j-1), 2 = phase 3 only (last level)
+    auto sweep_a = [&](auto mode_c, const float s) {
+        constexpr int mode = decltype(mode_c)::value;
+        for (int k0 = 0; k0 < n; k0 += AM_SWEEP) {
+            f2 ax[AM_PPT / 2], ay[AM_PPT / 2], az[AM_PPT / 2], ar[AM_PPT / 2], a1[AM_PPT / 2], a3[AM_PPT / 2], cs[AM_PPT / 2];
+#pragma unroll
+            for (int i = 0; i < AM_PPT / 2; ++i) {
+                float v[2][4];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int k = k0 + tid + (2 * i + h) * AM_THREADS;
+                    const bool ok = k < n;
+                    v[h][0] = ok ? A[k * 3] * s : 0.f; v[h][1] = ok ? A[k * 3 + 1] * s : 0.f; v[h][2] = ok ? A[k * 3 + 2] * s : 0.f;
+                    v[h][3] = (ok && mode != 0) ? ratioL[k] : 0.f;
+                }
+                ax[i] = f2{v[0][0], v[1][0]}; ay[i] = f2{v[0][1], v[1][1]}; az[i] = f2{v[0][2], v[1][2]};
+                ar[i] = f2{v[0][3], v[1][3]};
+                a1[i] = f2{1e-9f, 1e-9f}; a3[i] = f2{0.f, 0.f}; cs[i] = f2{0.f, 0.f};
+            }
+            for (int l0 = 0; l0 < m; l0 += AM_TILE) {
+                const int lend = min(AM_TILE, m - l0);
+                __syncthreads();
+                const int lpad = (lend + 3) & ~3;           // the loops below take four staged points per trip: the tail is
+                for (int l = tid; l < lpad; l += AM_THREADS) {       // padded with weight-zero points (they add exact zeros)
+                    const bool ok = l < lend;
+                    const float w0 = !ok ? 0.f : (mode == 0 ? remainR[l0 + l] : ratioR[l0 + l]);
+                    buf[l] = ok ? make_float4(B[(l0 + l) * 3] * s, B[(l0 + l) * 3 + 1] * s, B[(l0 + l) * 3 + 2] * s, w0)
+                                : make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (mode == 1) buf2[l] = ok ? remainR[l0 + l] : 0.f;
+                }
+                __syncthreads();
+                if (mode == 0) {
+#pragma unroll 4
+                    for (int l = 0; l < lpad; ++l) {
+                        const float4 q = buf[l];
+                        const f2 qw = {q.w, q.w};
+#pragma unroll
+                        for (int i = 0; i < AM_PPT / 2; ++i)
+                            a1[i] = __builtin_elementwise_fma(exp2neg_pk(sq3_pk(q.x, q.y, q.z, ax[i], ay[i], az[i], true)), qw, a1[i]);
+                    }
+                } else if (mode == 1) {
+#pragma unroll 4
+                    for (int l = 0; l < lpad; ++l) {
+                        const float4 q = buf[l];
+                        const float rr = buf2[l];
+                        const f2 qw = {q.w, q.w}, qr = {rr, rr};
+#pragma unroll
+                        for (int i = 0; i < AM_PPT / 2; ++i) {
+                            const f2 d2 = sq3_pk(q.x, q.y, q.z, ax[i], ay[i], az[i], true);
+                            const f2 e1 = exp2neg_pk(d2);                    // exp(-4^(j-1) |p-q|^2): next level's phase 1
+                            const f2 e2 = e1 * e1;
+                            const f2 w = ((e2 * e2) * ar[i]) * qw;           // exp(-4^j |p-q|^2) ratioL[k] ratioR[l]
+                            const f2 r = {__builtin_amdgcn_sqrtf(d2.x), __builtin_amdgcn_sqrtf(d2.y)};
+                            cs[i] = __builtin_elementwise_fma(w, r, cs[i]);
+                            a3[i] += w;
+                            a1[i] = __builtin_elementwise_fma(e1, qr, a1[i]);
+                        }
+                    }
+                } else {
+#pragma unroll 4
+                    for (int l = 0; l < lpad; ++l) {
+                        const float4 q = buf[l];
+                        const f2 qw = {q.w, q.w};
+#pragma unroll
+                        for (int i = 0; i < AM_PPT / 2; ++i) {
+                            const f2 d2 = sq3_pk(q.x, q.y, q.z, ax[i], ay[i], az[i], true);
+                            const f2 w = (exp2neg_pk(d2) * ar[i]) * qw;
+                            const f2 r = {__builtin_amdgcn_sqrtf(d2.x), __builtin_amdgcn_sqrtf(d2.y)};
+                            cs[i] = __builtin_elementwise_fma(w, r, cs[i]);
+                            a3[i] += w;
+                        }
+                    }
+                }
+            }
+            float csum = 0.f;
+#pragma unroll
+            for (int i = 0; i < AM_PPT / 2; ++i) {
+                csum += cs[i].x + cs[i].y;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int k = k0 + tid + (2 * i + h) * AM_THREADS;
+                    if (k < n) {
+                        float rl = remainL[k];
+                        if (mode != 0) {
+                            rl = fmaxf(0.0f, rl - (h ? a3[i].y : a3[i].x));   // :160-162
+                            remainL[k] = rl;
+                        }
+                        if (mode != 2) ratioL[k] = rl / (h ? a1[i].y : a1[i].x);   // :59-61 (of the next level when merged)
+                    }
+                }
+            }
+            cost += csum / s;                                                // sqrt of the scaled d2 = s * distance
+        }
+    };
+
+    sweep_a(std::integral_constant<int, 0>{}, ldexpf(EMD_SQRT_LOG2E, 7));
+    for (int j = 7; j > -2; --j) {                          // 9 levels; the reference's j == -2 branch is dead
+        const float s = ldexpf(EMD_SQRT_LOG2E, j);          // s^2 = 4^j log2 e
+        __syncthreads();
+        // ---- phase 2 (:78-111): the thread owns points of cloud B
+        for (int l0 = 0; l0 < m; l0 += AM_SWEEP) {
+            f2 ax[AM_PPT / 2], ay[AM_PPT / 2], az[AM_PPT / 2], ac[AM_PPT / 2];
+#pragma unroll
+            for (int i = 0; i < AM_PPT / 2; ++i) {
+                float v[2][3];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int l = l0 + tid + (2 * i + h) * AM_THREADS;
+                    const bool ok = l < m;
+                    v[h][0] = ok ? B[l * 3] * s : 0.f; v[h][1] = ok ? B[l * 3 + 1] * s : 0.f; v[h][2] = ok ? B[l * 3 + 2] * s : 0.f;
+                }
+                ax[i] = f2{v[0][0], v[1][0]}; ay[i] = f2{v[0][1], v[1][1]}; az[i] = f2{v[0][2], v[1][2]};
+                ac[i] = f2{0.f, 0.f};
+            }
+            for (int k0 = 0; k0 < n; k0 += AM_TILE) {
+                const int kend = min(AM_TILE, n - k0);
+                __syncthreads();
+                const int kpad = (kend + 3) & ~3;
+                for (int k = tid; k < kpad; k += AM_THREADS)
+                    buf[k] = k < kend ? make_float4(A[(k0 + k) * 3] * s, A[(k0 + k) * 3 + 1] * s, A[(k0 + k) * 3 + 2] * s, ratioL[k0 + k])
+                                      : make_float4(0.f, 0.f, 0.f, 0.f);
+                __syncthreads();
+#pragma unroll 4
+                for (int k = 0; k < kpad; ++k) {
+                    const float4 q = buf[k];
+                    const f2 qw = {q.w, q.w};
+#pragma unroll
+                    for (int i = 0; i < AM_PPT / 2; ++i)
+                        ac[i] = __builtin_elementwise_fma(exp2neg_pk(sq3_pk(q.x, q.y, q.z, ax[i], ay[i], az[i], false)), qw, ac[i]);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < AM_PPT / 2; ++i)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int l = l0 + tid + (2 * i + h) * AM_THREADS;
+                    if (l < m) {
+                        const float r = remainR[l];
+                        const float sumr = (h ? ac[i].y : ac[i].x) * r;
+                        const float consumption = fminf(r / (sumr + 1e-9f), 1.0f);
+                        ratioR[l] = consumption * r;
+                        remainR[l] = fmaxf(0.0f, r - sumr);
+                    }
+                }
+        }
+        __syncthreads();
+        // ---- phase 3 of this level (:130-163) [+ phase 1 of the next one (:29-62)]
+        if (j > -1) sweep_a(std::integral_constant<int, 1>{}, ldexpf(EMD_SQRT_LOG2E, j - 1));
+        else sweep_a(std::integral_constant<int, 2>{}, s);
+    }
+    for (int off = 32; off > 0; off >>= 1) cost += __shfl_down(cost, off, 64);
+    if ((tid & 63) == 0) red[tid >> 6] = cost;
+    __syncthreads();
+    if (tid == 0) {
+        float t = 0.f;
+        for (int w = 0; w < AM_THREADS / PDGN_WAVE; ++w) t += red[w];
+        cost_out[pair] = t;
+    }
+}
+
 // matchcostkernel approxmatch.cu:184-224: out[b] = sum_{k<m, j<n} match[k*n+j]*sqrt(|xyz2[k]-xyz1[j]|^2)
 __global__ __launch_bounds__(AM_THREADS) void matchcost_kernel(
     int n, int m, const float *__restrict__ xyz1, const float *__restrict__ xyz2,
@@ -452,8 +647,13 @@ extern "C" int pdgn_emd_cost(int b, int n, int m, const float *xyz1, const float
                              float *out, pdgn_stream_t stream) {
     if (!am_dims_ok(b, n, m)) return PDGN_ERR_INVALID;
     if (b == 0) return 0;
-    hipLaunchKernelGGL(approxmatch_kernel<true>, dim3(b), dim3(AM_THREADS), 0, (hipStream_t)stream, n, m,
-                       xyz1, xyz2, (float *)nullptr, temp, out, (const int32_t *)nullptr, (const int32_t *)nullptr);
+    static const int old = getenv("PDGN_EMD_OLD") ? atoi(getenv("PDGN_EMD_OLD")) : 0;      // A/B, this round only
+    if (old)
+        hipLaunchKernelGGL(approxmatch_kernel<true>, dim3(b), dim3(AM_THREADS), 0, (hipStream_t)stream, n, m,
+                           xyz1, xyz2, (float *)nullptr, temp, out, (const int32_t *)nullptr, (const int32_t *)nullptr);
+    else
+    hipLaunchKernelGGL(emd_cost_kernel, dim3(b), dim3(AM_THREADS), 0, (hipStream_t)stream, n, m, xyz1, xyz2, temp, out,
+                       (const int32_t *)nullptr, (const int32_t *)nullptr);
     return pdgn_launch_status();
 }
 
@@ -463,8 +663,8 @@ extern "C" int pdgn_emd_cost_indexed(int npairs, int n, int m, const float *xyz1
                                      pdgn_stream_t stream) {
     if (!am_dims_ok(npairs, n, m)) return PDGN_ERR_INVALID;
     if (npairs == 0) return 0;
-    hipLaunchKernelGGL(approxmatch_kernel<true>, dim3(npairs), dim3(AM_THREADS), 0, (hipStream_t)stream, n, m,
-                       xyz1, xyz2, (float *)nullptr, temp, out, ia, ib);
+    hipLaunchKernelGGL(emd_cost_kernel, dim3(npairs), dim3(AM_THREADS), 0, (hipStream_t)stream, n, m, xyz1, xyz2, temp, out,
+                       ia, ib);
     return pdgn_launch_status();
 }
 

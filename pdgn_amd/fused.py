@@ -293,7 +293,7 @@ def gemm_tn(dy, x):
 
 def _thin_ok(x, n, k):
     """The layer has <= 4 channels on one side and fits pdgn_thin_nt (csrc/thin.hip): no zero-padded copies."""
-    return (k <= 4 and n % 4 == 0 and n <= 1024) or (n <= 4 and k % 4 == 0)
+    return (k <= 4 and n % 4 == 0 and n <= 1024) or (n <= 4 and k % 4 == 0 and k <= 1024)   # (the backward runs the wide side as n)
 
 
 def thin_nt(x, w, wrs, wcs, n, bias=None, want_stats=False):

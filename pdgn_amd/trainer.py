@@ -83,6 +83,8 @@ class FlatGrads:
         reduces the rest and joins.  No-op without a process group or without an early bucket."""
         if self._early_done or self.n_early == 0 or not (dist.is_available() and dist.is_initialized()):
             return
+        if _capturing(self.buf.device):
+            return
         self._pack(0, self.n_early)
         self._early_done = True
         self._early_work = dist.all_reduce(self.buf[:self.early_numel], op=dist.ReduceOp.SUM, group=group, async_op=True)
@@ -99,6 +101,10 @@ class FlatGrads:
                 dist.all_reduce(self.buf, op=dist.ReduceOp.SUM, group=group)
             if dist.get_world_size(group) > 1:
                 self.buf.div_(dist.get_world_size(group))
+
+
+def _capturing(device):
+    return device.type == "cuda" and torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
 
 
 def world_size():
@@ -304,7 +310,9 @@ class PDGNTrainer:
     def _early_bucket_hook(self, lvl, xt):
         """PointGenerator feature hook: the gradient of the deepest block's input is the point of the backward at which
         that block's (and its head's) parameter gradients are complete -- start their all-reduce there."""
-        if lvl == 3 and self.distributed and self._buckets and xt.requires_grad:
+        if lvl == 3 and self.distributed and self._buckets and xt.requires_grad and not _capturing(self.device):
+            # (never inside a hipGraph capture: a collective cannot be captured, and the Python bookkeeping of the
+            # early bucket would not re-run on replay -- the graphed path reduces the whole buffer between its graphs)
             xt.register_hook(lambda g: self.gradG.reduce_early())
 
     def _z(self, st, name):
@@ -540,6 +548,8 @@ class PDGNTrainer:
             g.replay()
             if self.distributed and last < 5:
                 self._sync()
+                fg = self.gradD[last] if last < 4 else self.gradG
+                fg._early_work, fg._early_done = None, False        # begin() is captured Python: it does not re-run
                 self._comm(last)
                 self._sync()
         return st["out"]

@@ -360,6 +360,15 @@ def _ref_graph(x, k):
     return torch.sort(dist, dim=2)[1][:, :, 1:k + 1].contiguous()
 
 
+GRAD_SLICE = 256
+G_GRAD_SLICES = ("fc1.0.weight", "bilateral1.upsample_cov.0.conv2.conv.weight", "bilateral2.upsample_cov.conv_xyz.0.weight",
+                 "bilateral3.upsample_cov.conv_all.3.weight", "bilateral4.upsample_cov.conv2.conv.weight",
+                 "bilateral4.upsample_cov.inte_conv_hk.0.weight", "bilateral4.upsample_cov.conv_fea.0.weight",
+                 "bilateral4.upsample_cov.conv_all.0.weight", "bilateral4.bn_uc.weight", "bilateral4.fc.0.weight",
+                 "mlp4.0.weight", "mlp4.4.weight", "mlp2.2.weight")
+D_GRAD_SLICES = ("fc1.0.weight", "fc1.6.weight", "mlp.0.weight")
+
+
 def gen_step(G, Ds, B, record_graphs=False):
     """COMPOSED: reference torch modules / ChamferLoss / compute_mean_covariance / Adam with
     the C oracle standing in for the CUDA knnquery+grouping (models/PDGNet_v2.py:171-256).
@@ -391,6 +400,10 @@ def gen_step(G, Ds, B, record_graphs=False):
         optD[i].zero_grad()
         lossD = (mse(Ds[i](reals[i]), ones) + mse(Ds[i](fakes[i].detach()), zeros)) / 2.0
         lossD.backward()
+        res["d_grad_norm%d" % (i + 1)] = torch.sqrt(sum((q.grad ** 2).sum() for q in Ds[i].parameters())).item()
+        for n, q in Ds[i].named_parameters():
+            if n in D_GRAD_SLICES:
+                res["d%d_grad.%s" % (i + 1, n)] = q.grad.detach().reshape(-1)[:GRAD_SLICE].clone()
         optD[i].step()
         res["d_loss%d" % (i + 1)] = lossD.item()
     optG.zero_grad()
@@ -416,9 +429,20 @@ def gen_step(G, Ds, B, record_graphs=False):
     lossG = (1.2 * g[0] + 1.2 * g[1] + 1.2 * g[2] + g[3]) + 0.1 * sim
     lossG.backward()
     gnorm = torch.sqrt(sum((q.grad ** 2).sum() for q in G.parameters())).item()
+    # what a test needs to be sensitive to the BACKWARD of the whole network: the norm of every
+    # parameter's gradient (in named_parameters order), leading slices of a few of them, and the first Adam update in
+    # units of lr (= -sign-like g / (|g| + eps'): O(1), where the updated weights themselves move by 1e-4)
+    names = [n for n, _ in G.named_parameters()]
+    res["g_param_grad_norms"] = torch.stack([q.grad.norm() for q in G.parameters()])
+    for n, q in G.named_parameters():
+        if n in G_GRAD_SLICES:
+            res["g_grad." + n] = q.grad.detach().reshape(-1)[:GRAD_SLICE].clone()
+    w_before = G.fc1[0].weight.detach()[:4, :8].clone()
     optG.step()
     res.update(g_loss=lossG.item(), similar_loss=sim.item(), g_grad_norm=gnorm,
-               g_fc1_w_after=G.fc1[0].weight.detach()[:4, :8].clone())
+               g_fc1_w_after=G.fc1[0].weight.detach()[:4, :8].clone(),
+               g_fc1_update_over_lr=(G.fc1[0].weight.detach()[:4, :8] - w_before) / 1e-4)
+    res["g_param_names"] = np.array(names)
     for h in hooks:
         h.remove()
     if record_graphs:

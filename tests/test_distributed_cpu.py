@@ -249,3 +249,48 @@ def test_bucketed_all_reduce_equals_flat_gloo():
         np.testing.assert_array_equal(x["grads1"], x["grads0"])
         np.testing.assert_array_equal(x["params1"], x["params0"])
     np.testing.assert_array_equal(r[0]["params1"], r[1]["params1"])
+
+
+def _worker_bench(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    import argparse
+    import contextlib
+    import io
+    import bench
+    tr = _build_trainer(distributed=True)
+    B = 4
+    g = torch.Generator().manual_seed(100 + rank)
+    res = (32, 64, 128, 256)
+    reals = [torch.randn(B, 3, n, generator=g) for n in res]
+    args = argparse.Namespace(batch=B, steps=1, warmup=0, graph=False, no_graph=False, no_roofline=True,
+                              no_cpu_baseline=True, base_points=16, cpu_sample_batch=2)
+    zs = [(torch.randn(B, 128, generator=g) * 0.2, torch.randn(B, 128, generator=g) * 0.2)]
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        line = bench.measure_and_report(args, tr, reals, zs, world, rank, torch.device("cpu"), res)
+    dist.barrier()                                         # every rank gets here: nobody hangs in a lone collective
+    np.savez(os.path.join(out_dir, "bench%d.npz" % rank), printed=buf.getvalue(), has_line=line is not None)
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_bench_measurement_with_two_ranks_gloo():
+    """bench.py's flop-logging iteration is a full trainer.step() with its gradient all-reduces -- run by
+    rank 0 alone it waits for collectives nobody joins.  bench.measure_and_report (everything between building the
+    trainer and printing the line) with two gloo ranks: both return, rank 0 prints one line with n_gpus = 2 and the
+    executed flops, rank 1 prints nothing."""
+    import json
+    world = 2
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker_bench, args=(world, _free_port(), d), nprocs=world, join=True)
+        r = [dict(np.load(os.path.join(d, "bench%d.npz" % i))) for i in range(world)]
+    assert bool(r[0]["has_line"]) and not bool(r[1]["has_line"]) and str(r[1]["printed"]) == ""
+    lines = [l for l in str(r[0]["printed"]).splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and line["config"]["global_batch"] == 8
+    assert line["config"]["losses_finite"] is True and line["ms_per_step_min_rank"] <= line["ms_per_step_max_rank"]
+    assert "error" not in json.dumps(line.get("executed_flops_per_step"))

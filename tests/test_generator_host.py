@@ -85,3 +85,32 @@ def test_one_step_matches_composed_reference(golden, patched, monkeypatch, B, rt
         np.testing.assert_allclose(out[key].item(), g[key], rtol=rtol, err_msg=key)
     np.testing.assert_allclose(tr.G.fc1[0].weight.detach()[:4, :8].numpy(), g["g_fc1_w_after"],
                                rtol=1e-3, atol=2e-4 if B == 2 else 2e-6)
+
+
+def test_one_step_b8_backward_against_the_references_gradients(golden, patched, monkeypatch):
+    """Host logic of the BACKWARD (weight re-association, constant-channel split, gather-sum adjoint, zero bias gradients,
+    frozen discriminators) against the reference's own gradients: tests/golden/step_b8_graphs.npz with the reference's
+    eight kNN graphs forced in, so that what is left is arithmetic (step_checks.check_step_gradients)."""
+    from pdgn_amd.trainer import PDGNTrainer
+    from step_checks import check_step_gradients
+    g = golden("step_b8_graphs.npz")
+    graphs = [torch.from_numpy(g["graph%d" % i].astype(np.int32)) for i in range(8)]
+    calls = []
+
+    def forced(x, k):
+        calls.append(tuple(x.shape))
+        return graphs[len(calls) - 1]
+    monkeypatch.setattr(patched, "feature_knn", forced)
+    tr = PDGNTrainer(device="cpu", distributed=False)
+    fill_module(tr.G, salt=1)
+    for i, d in enumerate(tr.D):
+        fill_module(d, salt=10 + i)
+    patch_losses(monkeypatch)
+    tr.train()
+    B = 8
+    reals = [hash_tensor("real%d" % i, (B, 3, n), 0.8) for i, n in enumerate((256, 512, 1024, 2048))]
+    out = tr.step(reals, hash_tensor("step_z1", (B, 128), 0.2), hash_tensor("step_z2", (B, 128), 0.2))
+    assert len(calls) == 8
+    for key in ("d_loss1", "d_loss2", "d_loss3", "d_loss4", "g_loss", "similar_loss"):
+        np.testing.assert_allclose(out[key].item(), float(g[key]), rtol=2e-3, err_msg=key)
+    check_step_gradients(tr, g)

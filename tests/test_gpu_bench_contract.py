@@ -46,12 +46,32 @@ def test_bench_prints_one_json_line_with_roofline_and_cpu_baseline():
 
 @pytest.mark.timeout(600)
 def test_bench_eval_mode_c5_line():
-    """bench.py --eval: config C5 (Chamfer + EMD on 2048-point pairs) at a reduced pair count."""
+    """bench.py --eval: config C5 (Chamfer + EMD on 512 pairs of 2048-point clouds) at its stated batch."""
     env = dict(os.environ)
     env.pop("RANK", None), env.pop("WORLD_SIZE", None)
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--eval", "--eval-pairs", "64", "--steps", "2",
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--eval", "--eval-pairs", "512", "--steps", "2",
                         "--warmup", "1"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=550)
     assert p.returncode == 0, p.stderr[-2000:]
     d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
     assert d["unit"] == "pairs/s" and d["value"] > 0 and d["config"]["finite"] is True
     assert d["roofline"]["kernel"].startswith("approxmatch_kernel") and 0 < d["roofline"]["frac"] < 1
+
+
+@pytest.mark.timeout(900)
+def test_bench_two_gpus_over_rccl():
+    """the first box with two GPUs exercises the N > 1 path on hardware -- bench.py launches its own two
+    ranks, RCCL all-reduces (early bucket underneath the backward included), the post-communicator stream -> queue
+    probe, the flop-logging iteration on every rank.  Skipped on the single-GPU boxes of this pool."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--no-cpu-baseline", "--no-roofline"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=850)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["config"]["global_batch"] == 70
+    assert d["config"]["losses_finite"] is True and d["executed_flops_per_step"] > 1e12
+    assert abs(d["value"] - 2 * 35 * 2048 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]

@@ -95,5 +95,15 @@ def test_rccl_path_at_world_size_one_equals_single_process():
         for da, db in zip(a.D, b.D):
             for pa, pb in zip(da.parameters(), db.parameters()):
                 assert (pa - pb).abs().max().item() <= 3e-4
+        assert b.gradG.n_early > 0 and b.gradG._early_done            # the eager step took the early bucket
+        # the graphed distributed path -- six hipGraphs with the all-reduces between them.  The early
+        # bucket's collective must stay out of the capture, and a replay must not find stale bucket state.
+        b.capture(reals, z1, z2, warmup=1)
+        for _ in range(2):
+            lg = b.step_graphed(reals, z1, z2)
+            torch.cuda.synchronize()
+            assert all(torch.isfinite(v).item() for v in lg.values())
+            assert not b.gradG._early_done and b.gradG._early_work is None
+        assert len(b._graphs) == 6
     finally:
         dist.destroy_process_group()

@@ -110,3 +110,30 @@ def test_emd_properties_full_size(sl):
     # Chamfer lower-bounds any matching cost: mean NN distance <= EMD/n
     emd = sl.emd_cost(ta, tc) / n
     assert (d1.sqrt().mean(1) <= emd * 1.001).all()
+
+
+def test_emd_config_c5_at_its_stated_batch(sl):
+    """BASELINE.json configs[4] at its own size: B = 512 pairs of 2048 x 2048 points in ONE call.  The fused cost against
+    the C oracle on the first and the last pair (what the oracle finishes in seconds), size-independent properties on
+    all 512, and the API-faithful route (ApproxMatch -> the (512, 2048, 2048) `match` tensor, 8.6 GB -> MatchCost,
+    evaluation/pytorch_structural_losses/match_cost.py:10-23) against the fused one."""
+    rng = np.random.default_rng(9999)
+    b, n = 512, 2048
+    a = rng.uniform(-1, 1, (b, n, 3)).astype(np.float32)
+    c = rng.uniform(-1, 1, (b, n, 3)).astype(np.float32)
+    ta, tc = dev(a), dev(c)
+    fused = sl.emd_cost(ta, tc)
+    assert fused.shape == (b,) and torch.isfinite(fused).all()
+    for i in (0, b - 1):
+        m = cref.approxmatch(a[i:i + 1], c[i:i + 1])
+        np.testing.assert_allclose(fused[i].item(), cref.matchcost(a[i:i + 1], c[i:i + 1], m)[0], rtol=RTOL)
+    # pairs are independent: the batch equals its halves evaluated alone, bit for bit
+    assert torch.equal(fused[:7], sl.emd_cost(ta[:7].contiguous(), tc[:7].contiguous()))
+    assert torch.equal(fused[300:], sl.emd_cost(ta[300:].contiguous(), tc[300:].contiguous()))
+    same = sl.emd_cost(ta, ta) / n
+    assert same.abs().max().item() < 1e-4
+    d1, _ = sl.nn_distance(ta, tc)
+    assert (d1.sqrt().mean(1) <= fused / n * 1.001).all()        # Chamfer lower-bounds any matching cost
+    with torch.no_grad():
+        api = sl.match_cost(ta, tc)                              # materialises match (512, 2048, 2048)
+    np.testing.assert_allclose(api.cpu().numpy(), fused.cpu().numpy(), rtol=RTOL)
