@@ -50,6 +50,7 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true", help="skip the roofline kernels (for clean rocprof traces)")
     ap.add_argument("--eval", action="store_true", help="time config C5 (Chamfer + EMD, 512 pairs of 2048 points)")
     ap.add_argument("--eval-pairs", type=int, default=512)
+    ap.add_argument("--no-eval-c5", action="store_true", help="leave the C5 sub-object (eval_c5) out of the default line")
     ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo-stub"),
                     help="gloo-stub: CPU-only plumbing check of the N-rank launch path (tests), no HIP work")
     ap.add_argument("--master-port", type=int, default=0)
@@ -230,12 +231,32 @@ def _event_ms(fn, iters=5):
     return s.elapsed_time(e) / iters
 
 
-def eval_main(args):
-    """Config C5: Chamfer (nn_distance) + approximate EMD (fused pdgn_emd_cost) on `pairs` pairs of 2048 x 2048 points."""
+# Instruction mix of emd_cost_kernel's four inner loops (csrc/structural.hip), read off the gfx950 ISA hipcc emits
+# (tools/emd_isa_mix.sh): vector instructions per 16 (own point, staged point) elements of a lane -- one unrolled trip of
+# 4 staged points x 4 own points -- as (packed-fp32 + plain, transcendental).  Issue cost per wave instruction from
+# MI355X_MICROARCH.md, cycle constants: v_add / v_fma / v_pk_* 4 cycles, v_exp_f32 / v_sqrt_f32 8.
+EMD_LOOPS = {"phase1_or_2": (61, 16), "phase3_plus_next_phase1": (111, 32), "phase3_last": (85, 32)}
+EMD_SWEEPS = {"phase1_or_2": 10, "phase3_plus_next_phase1": 8, "phase3_last": 1}      # per cloud pair: 9 levels
+
+
+def emd_issue_model(n, m):
+    """(issue cycles per cloud pair on one SIMD lane-group, vector instructions per element, share of them spent on
+    transcendentals) of the fused EMD cost at n x m points."""
+    cyc = ins = trans = 0.0
+    for name, sweeps in EMD_SWEEPS.items():
+        plain, tr = EMD_LOOPS[name]
+        cyc += sweeps * (plain * 4 + tr * 8) / 16.0
+        ins += sweeps * (plain + tr) / 16.0
+        trans += sweeps * tr * 8 / 16.0
+    return cyc * n * m / 64.0, ins / 19.0, trans / cyc
+
+
+def eval_c5(pairs=512, steps=5, warmup=1):
+    """Config C5: Chamfer (nn_distance) + approximate EMD (fused pdgn_emd_cost) on `pairs` pairs of 2048 x 2048 points,
+    evaluation/evaluation_metrics.py:26-45, 85-121.  Returns the fields of its bench line."""
     import torch
     from pdgn_amd.structural_losses import emd_cost, nn_distance
-    torch.cuda.set_device(0)
-    P, N = args.eval_pairs, 2048
+    P, N = pairs, 2048
     g = torch.Generator().manual_seed(9999)
     a = (torch.rand(P, N, 3, generator=g) * 2 - 1).cuda()
     b = (torch.rand(P, N, 3, generator=g) * 2 - 1).cuda()
@@ -244,33 +265,47 @@ def eval_main(args):
         d1, d2 = nn_distance(a, b)
         return d1.mean(1) + d2.mean(1), emd_cost(a, b)
 
-    for _ in range(max(args.warmup, 1)):
+    for _ in range(max(warmup, 1)):
         cd, emd = step()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         cd, emd = step()
     torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / args.steps
+    dt = (time.perf_counter() - t0) / steps
     ms_emd, ms_cd = _event_ms(lambda: emd_cost(a, b)), _event_ms(lambda: nn_distance(a, b))
-    # approxmatch_kernel<true>: 9 levels x 3 phases, one v_exp_f32 per (point, point) pair and phase;
-    # transcendental issue: 8 cycles per wave64 instruction (MI355X_MICROARCH.md, cycle constants) = 8 lanes/clk/SIMD
-    exp_peak = 8 * 4 * 256 * 2.4e9
-    exps = P * 27.0 * N * N
-    line = {"metric": "Chamfer + approx-EMD structural losses, pairs/sec (2048-pt pairs, B=%d)" % P,
-            "value": P / dt, "unit": "pairs/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic",
-            "config": {"workload": "eval path C5: nn_distance (Chamfer) + fused approximate EMD cost on %d pairs of 2048 x 2048 "
-                                   "uniform points in [-1, 1]^3 (evaluation_metrics.py:26-45, 85-121)" % P,
-                       "finite": bool(torch.isfinite(cd).all() and torch.isfinite(emd).all())},
-            "roofline": {"kernel": "approxmatch_kernel<true> (fused EMD cost)", "bound": "valu-transcendental",
-                         "achieved": exps / (ms_emd * 1e-3) / 1e9, "peak": exp_peak / 1e9, "unit": "G exp/s",
-                         "frac": exps / (ms_emd * 1e-3) / exp_peak, "traffic": None, "us_per_launch": ms_emd * 1e3,
+    # emd_cost_kernel is bound by vector-instruction ISSUE, not by HBM (inputs: 25 MB) and not by the transcendental
+    # unit alone: `peak` = the pair rate at which its own instruction stream would issue back to back on all 1024 SIMDs
+    # at 2.4 GHz; `exp_frac` = the share of those issue cycles taken by v_exp_f32 / v_sqrt_f32
+    cyc_per_pair, instr_per_element, exp_frac = emd_issue_model(N, N)
+    peak_pairs = 4 * 256 * 2.4e9 / cyc_per_pair
+    ach = P / (ms_emd * 1e-3)
+    return {"pairs": P, "pairs_per_s": P / dt, "ms_per_step": dt * 1e3, "ms_per_512": dt * 1e3 * 512.0 / P,
+            "finite": bool(torch.isfinite(cd).all() and torch.isfinite(emd).all()),
+            "roofline": {"kernel": "emd_cost_kernel (fused approximate-EMD cost)", "bound": "valu-issue",
+                         "achieved": ach, "peak": peak_pairs, "unit": "pairs/s", "frac": ach / peak_pairs,
+                         "instr_per_element": instr_per_element, "exp_frac": exp_frac,
+                         "exp_evaluations_per_pair": 19.0 * N * N, "traffic": None, "us_per_launch": ms_emd * 1e3,
                          "algorithmic_bytes_per_launch": P * 2.0 * N * 12,
                          "others": [{"kernel": "nndist_kernel (both Chamfer directions)", "bound": "valu",
                                      "achieved": 2.0 * P * N * N / (ms_cd * 1e-3) / 1e9, "unit": "G pair evaluations/s",
                                      "us_per_launch": ms_cd * 1e3, "algorithmic_bytes_per_launch": P * (2.0 * N) * 20}]}}
+
+
+def eval_main(args):
+    """bench.py --eval: config C5 as a line of its own."""
+    import torch
+    torch.cuda.set_device(0)
+    r = eval_c5(args.eval_pairs, args.steps, args.warmup)
+    P = r["pairs"]
+    line = {"metric": "Chamfer + approx-EMD structural losses, pairs/sec (2048-pt pairs, B=%d)" % P,
+            "value": r["pairs_per_s"], "unit": "pairs/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": r["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "eval path C5: nn_distance (Chamfer) + fused approximate EMD cost on %d pairs of 2048 x 2048 "
+                                   "uniform points in [-1, 1]^3 (evaluation_metrics.py:26-45, 85-121)" % P,
+                       "finite": r["finite"]},
+            "roofline": r["roofline"]}
     print(json.dumps(line), flush=True)
 
 
@@ -383,6 +418,11 @@ def measure_and_report(args, trainer, reals, zs, world, rank, device, res):
                 line["roofline"] = roofline.measure(args.batch, args.base_points, device)
             except Exception as e:                               # never lose the headline number
                 line["roofline"] = {"error": repr(e)}
+        if world == 1 and not args.no_eval_c5:               # BASELINE.json configs[4], ~0.3 s: Chamfer + EMD, 512 pairs
+            try:
+                line["eval_c5"] = eval_c5()
+            except Exception as e:
+                line["eval_c5"] = {"error": repr(e)}
         if not args.no_cpu_baseline and world == 1:          # host baseline: rank 0, N = 1 only
             line["cpu_baseline"] = cpu_baseline(args.cpu_sample_batch)
         print(json.dumps(line), flush=True)

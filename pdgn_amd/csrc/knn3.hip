@@ -4,18 +4,16 @@
 // interpolation/interpolation_cuda_kernel.cu:134-176 of the reference -- ascending
 // (squared distance, index), strict '<', tail idx 0 / +inf when the set is short.
 //
-// Design (not the reference's one-thread-per-query insertion sort): ONE WAVE PER QUERY.
-//   * the candidate set of a batch is staged once per workgroup into LDS as float4
-//     (coalesced global reads, conflict-free ds_read_b128, shared by the block's waves);
-//   * pass A: lane l scans candidates l, l+64, ... and keeps only its minimum; the K-th
-//     smallest of the 64 lane minima (wave bitonic sort over ds_bpermute) is an upper
-//     bound tau of the K-th nearest distance;
-//   * pass B: lanes recompute their distances and compact the survivors (d <= tau) into a
-//     per-wave LDS queue with ballot/popcount prefix sums (typically 25-40 survivors);
-//   * the survivors are sorted, 64 at a time, by (distance, index) with a wave-wide bitonic
-//     network and merged into the running best-K held by lanes 0..K-1.
-// (distance, index) is a strict total order, so the result is bit-identical to the
-// reference's stable insertion regardless of scheduling.
+// Design (not the reference's one-thread-per-query insertion sort): a wave serves a GROUP of queries (knn3_wave4_kernel).
+//   * the candidate set of a batch is staged once per workgroup into LDS as float4, padded with points at infinity
+//     (coalesced global reads, guard-free scans, one ds_read_b128 of a candidate feeds every query of the group);
+//   * pass A: lane l scans candidates l, l+64, ... and keeps only its minimum per query; a 16-bit ballot bisection over
+//     the 64 lane minima gives an upper bound tau of the K-th nearest distance;
+//   * pass B: lanes recompute their distances and compact the survivors (d <= tau) into per-query LDS queues with
+//     ballot / popcount prefix sums (typically 25-40 survivors);
+//   * the survivors are ranked by (distance, index) (broadcast LDS reads, no cross-lane chain) and written in order.
+// (distance, index) is a strict total order, so the result is bit-identical to the reference's stable insertion
+// regardless of scheduling.  k > 32 (the reference allows 200) runs on knn3_generic_kernel, one thread per query.
 #include "common.h"
 #include "wave_select.h"
 
@@ -24,53 +22,6 @@
 #define KNN_TILE 4096        // candidates staged per pass: 64 KiB of float4
 #define KNN_FAST_MAX_K 32
 
-__global__ __launch_bounds__(KNN_THREADS) void knn3_wave_kernel(
-    int n, int m, int K, int qpw, const float *__restrict__ xyz, const float *__restrict__ new_xyz,
-    int32_t *__restrict__ idx, float *__restrict__ dist2) {
-    __shared__ float4 cand[KNN_TILE];
-    __shared__ DI queue[KNN_WAVES][WSEL_QCAP];
-
-    const int bs = blockIdx.y;
-    const int lane = lane_id();
-    const int wave = threadIdx.x / PDGN_WAVE;
-    const float *P = xyz + (size_t)bs * n * 3;
-    DI *q = queue[wave];
-
-    // This kernel keeps the running best-K of every query of the wave in registers across
-    // candidate tiles, so the tile loop is outermost only when n > KNN_TILE (rare); the
-    // common case stages once and walks the wave's queries.
-    const int q0 = (blockIdx.x * KNN_WAVES + wave) * qpw;
-
-    for (int qi = 0; qi < qpw; ++qi) {
-        const int query = q0 + qi;              // wave-uniform
-        float rd = INFINITY;                    // running best-K: lanes 0..K-1
-        int ri = 0x7fffffff;
-        float qx = 0.f, qy = 0.f, qz = 0.f;
-        if (query < m) {
-            const float *Q = new_xyz + ((size_t)bs * m + query) * 3;
-            qx = Q[0]; qy = Q[1]; qz = Q[2];
-        }
-        for (int t0 = 0; t0 < n; t0 += KNN_TILE) {
-            const int tn = min(KNN_TILE, n - t0);
-            if (qi == 0 || n > KNN_TILE) {
-                __syncthreads();                // previous tile fully consumed
-                for (int e = threadIdx.x; e < tn * 3; e += KNN_THREADS)
-                    reinterpret_cast<float *>(cand)[(e / 3) * 4 + (e % 3)] = P[(size_t)t0 * 3 + e];
-                __syncthreads();
-            }
-            if (query >= m) continue;
-            wave_topk_scan(
-                [&](int c) { float4 p = cand[c]; return sqdist3(qx, qy, qz, p.x, p.y, p.z); },
-                tn, t0, q, K, rd, ri, lane);
-        }
-        if (query < m && lane < K) {
-            size_t o = ((size_t)bs * m + query) * K + lane;
-            bool valid = rd < INFINITY;
-            idx[o] = valid ? ri : 0;            // reference tail: idx 0 / dist 1e40 -> +inf
-            if (dist2) dist2[o] = rd;
-        }
-    }
-}
 
 // ---------------------------------------------------------------------------------------------------------------
 // Several queries per wave (round 2; KNN4_Q = 2 measured fastest: 4 halves the occupancy, 1 the reuse).  The one-query kernel above spends most of a query's ~5000 cycles in dependent chains
@@ -342,29 +293,10 @@ extern "C" int pdgn_knnquery(int b, int n, int m, int nsample, const float *xyz,
     if (b == 0 || m == 0) return 0;
     if (b > 65535) return PDGN_ERR_INVALID;
     hipStream_t s = (hipStream_t)stream;
-    static int use4 = -1;
-    if (use4 < 0) { const char *e = getenv("PDGN_KNN3_WAVE4"); use4 = e ? atoi(e) : 1; }
-    if (nsample <= KNN_FAST_MAX_K && use4) {
-        // groups per wave: amortise the staging of the tile while keeping several rounds of workgroups on the chip
-        static int qpw_env = -1;
-        if (qpw_env < 0) { const char *e = getenv("PDGN_KNN3_QPW"); qpw_env = e ? atoi(e) : 0; }
-        int qpw = 1;
-        if (n <= KNN4_TILE) {
-            const long long wgs1 = (long long)b * cdiv(m, KNN4_WAVES * KNN4_Q);
-            qpw = qpw_env > 0 ? qpw_env : 1;            // measured (tools/knn3_bench.py): 1 is fastest at the step's shapes
-            (void)wgs1;
-        }
-        dim3 grid(cdiv(m, KNN4_WAVES * KNN4_Q * qpw), b);
-        hipLaunchKernelGGL(knn3_wave4_kernel, grid, dim3(KNN4_THREADS), 0, s, n, m, nsample, qpw, xyz, new_xyz, idx, dist2);
-    } else if (nsample <= KNN_FAST_MAX_K) {
-        // queries per wave: enough workgroups to cover 256 CUs several times over, while
-        // amortising the LDS staging of the candidate set when there are many queries.
-        long long waves = (long long)b * m;
-        int qpw = (int)(waves / 8192);
-        qpw = qpw < 1 ? 1 : (qpw > 8 ? 8 : qpw);
-        dim3 grid(cdiv(m, KNN_WAVES * qpw), b);
-        hipLaunchKernelGGL(knn3_wave_kernel, grid, dim3(KNN_THREADS), 0, s, n, m, nsample, qpw, xyz,
-                           new_xyz, idx, dist2);
+    if (nsample <= KNN_FAST_MAX_K) {
+        // one query group per wave: measured fastest at the step's shapes (tools/knn3_bench.py)
+        dim3 grid(cdiv(m, KNN4_WAVES * KNN4_Q), b);
+        hipLaunchKernelGGL(knn3_wave4_kernel, grid, dim3(KNN4_THREADS), 0, s, n, m, nsample, 1, xyz, new_xyz, idx, dist2);
     } else {
         dim3 grid(cdiv(m, KNN_THREADS), b);
         hipLaunchKernelGGL(knn3_generic_kernel, grid, dim3(KNN_THREADS), 0, s, n, m, nsample, xyz,

@@ -14,7 +14,6 @@
 //    the (b,m,n) match matrix (8.6 GB at b=512, 2048^2) never touches HBM.
 #include "common.h"
 #include <type_traits>
-#include <cstdlib>
 
 #define SL_THREADS 256
 #define SL_TILE 2048
@@ -114,21 +113,16 @@ __device__ __forceinline__ f2 exp_pk(float level, f2 d2) {              // __exp
     return r;
 }
 
-// FUSED = false: writes match (b,m,n) like approxmatchkernel (approxmatch.cu:3-182).
-// FUSED = true : accumulates sum match*sqrt(d2) instead (matchcostkernel :184-224 folded in).
-template <bool FUSED>
+// Writes match (b,m,n) like approxmatchkernel (approxmatch.cu:3-182), line by line: phases 1 and 2 with packed arithmetic,
+// phase 3 is the read-modify-write of `match` (HBM-bound).  The cost-only evaluation path uses emd_cost_kernel below.
 __global__ __launch_bounds__(AM_THREADS) void approxmatch_kernel(
     int n, int m, const float *__restrict__ xyz1, const float *__restrict__ xyz2,
-    float *__restrict__ match, float *__restrict__ temp, float *__restrict__ cost_out,
-    const int32_t *__restrict__ ia, const int32_t *__restrict__ ib) {
+    float *__restrict__ match, float *__restrict__ temp) {
     __shared__ float4 buf[AM_TILE];
-    __shared__ float red[AM_THREADS / PDGN_WAVE];
     const int pair = blockIdx.x;
-    // optional pair lists: pair p matches cloud ia[p] of xyz1 with cloud ib[p] of xyz2 (all-pairs
-    // evaluation without expanding the clouds, evaluation_metrics.py:85-121)
-    const float *A = xyz1 + (size_t)(ia ? ia[pair] : pair) * n * 3;
-    const float *B = xyz2 + (size_t)(ib ? ib[pair] : pair) * m * 3;
-    float *M = FUSED ? nullptr : match + (size_t)pair * n * m;
+    const float *A = xyz1 + (size_t)pair * n * 3;
+    const float *B = xyz2 + (size_t)pair * m * 3;
+    float *M = match + (size_t)pair * n * m;
     // remainL | remainR | ratioL | ratioR, as approxmatch.cu:4 lays out `temp`
     float *remainL = temp + (size_t)pair * (n + m) * 2, *remainR = remainL + n,
           *ratioL = remainR + m, *ratioR = ratioL + n;
@@ -138,7 +132,6 @@ __global__ __launch_bounds__(AM_THREADS) void approxmatch_kernel(
     for (int k = tid; k < n; k += AM_THREADS) remainL[k] = multiL;
     for (int l = tid; l < m; l += AM_THREADS) remainR[l] = multiR;
     __syncthreads();
-    float cost = 0.f;
 
     for (int j = 7; j > -2; --j) {                          // 9 levels; the j==-2 branch is dead
         const float level = -ldexpf(1.0f, 2 * j);           // -4^j
@@ -243,36 +236,6 @@ __global__ __launch_bounds__(AM_THREADS) void approxmatch_kernel(
                 for (int l = tid; l < lend; l += AM_THREADS)
                     buf[l] = make_float4(B[(l0 + l) * 3], B[(l0 + l) * 3 + 1], B[(l0 + l) * 3 + 2], ratioR[l0 + l]);
                 __syncthreads();
-                if (FUSED) {
-                    // cost-only form: packed arithmetic, and v_sqrt_f32 itself (<= 1 ulp) instead of sqrtf's correctly
-                    // rounded expansion (16 instructions per element -- half of this loop); the sum of 4M such terms
-                    // is compared at 1e-4
-                    f2 ax[AM_PPT / 2], ay[AM_PPT / 2], az[AM_PPT / 2], ar[AM_PPT / 2], ac[AM_PPT / 2], cs[AM_PPT / 2];
-#pragma unroll
-                    for (int i = 0; i < AM_PPT / 2; ++i) {
-                        ax[i] = f2{px[2 * i], px[2 * i + 1]}; ay[i] = f2{py[2 * i], py[2 * i + 1]};
-                        az[i] = f2{pz[2 * i], pz[2 * i + 1]}; ar[i] = f2{rl[2 * i], rl[2 * i + 1]};
-                        ac[i] = f2{acc[2 * i], acc[2 * i + 1]}; cs[i] = f2{0.f, 0.f};
-                    }
-                    for (int l = 0; l < lend; ++l) {
-                        const float4 q = buf[l];
-                        const f2 qw = {q.w, q.w};
-#pragma unroll
-                        for (int i = 0; i < AM_PPT / 2; ++i) {
-                            const f2 d2 = sq3_pk(q.x, q.y, q.z, ax[i], ay[i], az[i], true);
-                            const f2 w = (exp_pk(level, d2) * ar[i]) * qw;
-                            const f2 r = {__builtin_amdgcn_sqrtf(d2.x), __builtin_amdgcn_sqrtf(d2.y)};
-                            cs[i] = __builtin_elementwise_fma(w, r, cs[i]);
-                            ac[i] += w;
-                        }
-                    }
-#pragma unroll
-                    for (int i = 0; i < AM_PPT / 2; ++i) {
-                        acc[2 * i] = ac[i].x; acc[2 * i + 1] = ac[i].y;
-                        cost += cs[i].x + cs[i].y;
-                    }
-                    continue;
-                }
                 for (int l = 0; l < lend; ++l) {
                     float4 q = buf[l];
 #pragma unroll
@@ -280,9 +243,7 @@ __global__ __launch_bounds__(AM_THREADS) void approxmatch_kernel(
                         int k = k0 + tid + i * AM_THREADS;
                         float d2 = sq3(q.x, q.y, q.z, px[i], py[i], pz[i]);
                         float w = __expf(level * d2) * rl[i] * q.w;
-                        if (FUSED) {
-                            cost = __fmaf_rn(w, sqrtf(d2), cost);
-                        } else if (k < n) {
+                        if (k < n) {
                             float *dst = &M[(size_t)(l0 + l) * n + k];
                             *dst = (j == 7) ? w : *dst + w;   // first level overwrites: no zero-fill pass
                         }
@@ -297,16 +258,6 @@ __global__ __launch_bounds__(AM_THREADS) void approxmatch_kernel(
             }
         }
         __syncthreads();
-    }
-    if (FUSED) {
-        for (int off = 32; off > 0; off >>= 1) cost += __shfl_down(cost, off, 64);
-        if ((tid & 63) == 0) red[tid >> 6] = cost;
-        __syncthreads();
-        if (tid == 0) {
-            float s = 0.f;
-            for (int w = 0; w < AM_THREADS / PDGN_WAVE; ++w) s += red[w];
-            cost_out[pair] = s;
-        }
     }
 }
 
@@ -638,8 +589,7 @@ extern "C" int pdgn_approxmatch(int b, int n, int m, const float *xyz1, const fl
                                 float *temp, pdgn_stream_t stream) {
     if (!am_dims_ok(b, n, m)) return PDGN_ERR_INVALID;
     if (b == 0) return 0;
-    hipLaunchKernelGGL(approxmatch_kernel<false>, dim3(b), dim3(AM_THREADS), 0, (hipStream_t)stream, n, m,
-                       xyz1, xyz2, match, temp, (float *)nullptr, (const int32_t *)nullptr, (const int32_t *)nullptr);
+    hipLaunchKernelGGL(approxmatch_kernel, dim3(b), dim3(AM_THREADS), 0, (hipStream_t)stream, n, m, xyz1, xyz2, match, temp);
     return pdgn_launch_status();
 }
 
@@ -647,11 +597,6 @@ extern "C" int pdgn_emd_cost(int b, int n, int m, const float *xyz1, const float
                              float *out, pdgn_stream_t stream) {
     if (!am_dims_ok(b, n, m)) return PDGN_ERR_INVALID;
     if (b == 0) return 0;
-    static const int old = getenv("PDGN_EMD_OLD") ? atoi(getenv("PDGN_EMD_OLD")) : 0;      // A/B, this round only
-    if (old)
-        hipLaunchKernelGGL(approxmatch_kernel<true>, dim3(b), dim3(AM_THREADS), 0, (hipStream_t)stream, n, m,
-                           xyz1, xyz2, (float *)nullptr, temp, out, (const int32_t *)nullptr, (const int32_t *)nullptr);
-    else
     hipLaunchKernelGGL(emd_cost_kernel, dim3(b), dim3(AM_THREADS), 0, (hipStream_t)stream, n, m, xyz1, xyz2, temp, out,
                        (const int32_t *)nullptr, (const int32_t *)nullptr);
     return pdgn_launch_status();

@@ -34,11 +34,6 @@ from .fused import (_zeros, bilateral_weighting, bn_act,  # noqa: F401
 
 F32, I32 = torch.float32, torch.int32
 _KNN_OVERLAP = __import__("os").environ.get("PDGN_KNN_OVERLAP", "1") == "1"
-# conv2's neighbour half (its first k slots, one window position) as K columns of dense GEMMs over the GATHERED
-# neighbour features instead of N columns of the per-point GEMM: with a single window position the re-association
-# buys no flops there, but costs a (B*N, k*2Fo) segment of Y written and re-read per pass (734 MB at stage 4)
-_CONV2_GATHER = __import__("os").environ.get("PDGN_CONV2_GATHER", "0") == "1"    # measured: 36.4-36.7 vs 36.2-36.3 ms/step -> off
-
 
 def _knn_stream(device):
     """The kNN side stream of the issuing stream (one per (device, issuing stream): concurrent generator passes must
@@ -381,26 +376,14 @@ class PointDeconv(nn.Module):
             biases = [bias.unsqueeze(0) + Yc[:, sp[4]:sp[4] + sp[2]] + Yc[:, sp[3]:sp[3] + sp[0] * sp[2]].reshape(B, sp[0], sp[2]).sum(1)
                       for sp, bias in zip(specs_full, biases)]       # sp = (T, P, C, off, offc)
         x2d = xt.reshape(B * N, Fv)
-        gather2 = _CONV2_GATHER and Fv % 4 == 0
-        if gather2:
-            # per-point GEMM without conv2's k tap blocks; conv2 keeps only its centre term there (T = 0 spec)
-            Wpp = torch.cat((WcatV[:o_a], WcatV[o_ca:]), 0)
-            W2n = WcatV[o_a:o_ca].view(k, 2 * Fo, Fv).permute(1, 0, 2).reshape(2 * Fo, k * Fv)
-            shift = k * 2 * Fo
-            specs = [(T, P, 4 * Fi, o_i, o_ci, fuse_stats), (0, 1, 2 * Fo, o_a, o_a)]
-            if self.bilateral:
-                specs.append((1, k, 16, o_p - shift, o_p - shift + 16))
-            Y = linear_cl(x2d, Wpp).view(B, N, -1)
-        else:
-            specs = [(T, P, 4 * Fi, o_i, o_ci, fuse_stats)] + specs_full[1:]
-            Y = linear_cl(x2d, WcatV).view(B, N, -1)                   # (B,N,Mw) -- per-point GEMM
+        specs = [(T, P, 4 * Fi, o_i, o_ci, fuse_stats)] + specs_full[1:]
+        Y = linear_cl(x2d, WcatV).view(B, N, -1)                       # (B,N,Mw) -- per-point GEMM
         if knn_side is not None:
             torch.cuda.current_stream(idx.device).wait_event(knn_side)
             idx.record_stream(torch.cuda.current_stream(idx.device))
         outs = EdgeGatherSum.apply(Y, idx, tuple(specs), *biases)
         inte_pre, a_pre = outs[0], outs[1]                             # (B,N,P,4F), (B,N,1,2Fo)
         part_i = outs[-1] if fuse_stats else None                      # BatchNorm partials of inte_pre
-        gath = EdgeGatherSum.apply(xt.contiguous(), idx, ((1, k, Fv, 0, -1),), None)[0] if gather2 else None   # (B,N,k,Fv)
         w = None
         if self.bilateral:
             Wx = _w2d(self.conv_xyz[0])                   # (16, 6)
@@ -427,8 +410,6 @@ class PointDeconv(nn.Module):
             # inte = LeakyReLU(BN(inte_pre))  (:637)
             inte = bn_act(inte_pre.view(-1, 4 * Fi), self.inte_conv_hk[1], training, partials=part_i)
         out_pre = linear_cl(inte.view(B * N, P * 4 * Fi), Wb, None, a_pre.view(B * N, 2 * Fo))    # sum in the GEMM's epilogue
-        if gath is not None:
-            out_pre = linear_cl(gath.view(B * N, k * Fv), W2n, None, out_pre)
         out = bn_act(out_pre, self.conv2.bn, training, act="relu")     # (B*N, 2Fo): channel 2c+j
         # (B,2Fout,N,1) -> view(B,Fout,2,N) -> (B,Fout,2N) (:645-647): point j*N+n of channel c is conv
         # channel 2c+j at point n; in point-major form that is (B, 2, N, Fout) -> (B, 2N, Fout)

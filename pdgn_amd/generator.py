@@ -136,30 +136,17 @@ class PointGenerator(nn.Module):
         self.mlp1, self.mlp2 = _mlp_head(512 + 32), _mlp_head(512 + 64)
         self.mlp3, self.mlp4 = _mlp_head(512 + 128), _mlp_head(512)
 
-    def forward(self, z, idx=(None, None, None, None), stage_hook=None, stop_before=None, feature_hook=None):
+    def forward(self, z, idx=(None, None, None, None), stage_hook=None, feature_hook=None):
         """`stage_hook(level, cloud)`, if given, is called as soon as the cloud of a level exists (the trainer starts
         that level's discriminator update on another stream while the deeper levels are still being generated).
-        stop_before=L: stop in front of block L (0-based) and return the pass's state instead of the clouds; `resume`
-        runs the remaining blocks -- the trainer continues one pass's deepest block on another stream, underneath the
-        next pass's first (latency-bound) blocks.  `feature_hook(level, xt)` is called with the input features of every
-        block (the trainer hangs its early gradient bucket on the deepest block's)."""
+        `feature_hook(level, xt)` is called with the input features of every block (the trainer hangs its early gradient
+        bucket on the deepest block's)."""
         B = z.shape[0]
         xt = _small_seq(self.fc1, z, self.training).view(B, 32, self.base_points).transpose(1, 2).contiguous()    # (B,N0,32)
-        state = {"B": B, "xt": xt, "pct": None, "const": None, "clouds": [], "pending": (None, None), "lvl": 0, "idx": idx}
-        return self._blocks(state, stage_hook, stop_before, feature_hook)
-
-    def resume(self, state, stage_hook=None, feature_hook=None):
-        """The remaining blocks of a pass stopped by forward(..., stop_before=L), on the CURRENT stream."""
-        return self._blocks(state, stage_hook, None, feature_hook)
-
-    def _blocks(self, s, stage_hook, stop_before, feature_hook=None):
-        B, idx = s["B"], s["idx"]
+        s = {"xt": xt, "pct": None, "const": None, "clouds": [], "pending": (None, None)}
         blocks = (self.bilateral1, self.bilateral2, self.bilateral3, self.bilateral4)
         heads = (self.mlp1, self.mlp2, self.mlp3, self.mlp4)
-        for lvl in range(s["lvl"], 4):
-            if stop_before is not None and lvl == stop_before:
-                s["lvl"] = lvl
-                return s
+        for lvl in range(4):
             xt, pct, const, clouds = s["xt"], s["pct"], s["const"], s["clouds"]
             if feature_hook is not None:
                 feature_hook(lvl, xt)
@@ -183,7 +170,6 @@ class PointGenerator(nn.Module):
                 _deconv.flush_bn_counters()
                 stage_hook(lvl, clouds[-1])
             s["xt"], s["const"], s["pct"] = x_ec, xs, pct   # next block's input is cat(xs broadcast, x_ec) :708
-        s["lvl"] = 4
         _deconv.flush_bn_counters()
         return tuple(s["clouds"])
 

@@ -139,10 +139,8 @@ class PDGNTrainer:
         self._lw = {}
         for ws in {1, world_size() if self.distributed else 1}:
             self._loss_weights(ws)
-        self._lp_split = os.environ.get("PDGN_LP_SPLIT", "0") == "1"      # A/B switches, see _step_overlapped
         self._early_tail = os.environ.get("PDGN_EARLY_TAIL", "1") == "1"
         self._defer_d = os.environ.get("PDGN_DEFER_D", "1") == "1"
-        self._fork_l4 = os.environ.get("PDGN_FORK_L4", "0") == "1"
         self.sync_replicas()
 
     def sync_replicas(self, src=0):
@@ -391,28 +389,9 @@ class PDGNTrainer:
             d_mark(level, cloud)
             d_update(*levels.pop())
 
-        # PDGN_FORK_L4=1 (measured, not the default -- DESIGN.md section 10b): G(z1)'s deepest block (no autograd, large
-        # kernels) continues on D4's stream -- idle until that block's cloud exists -- while the default stream already
-        # issues G(z2)'s first three blocks, chains of small latency-bound kernels (3 ms per pass).  G(z2)'s deepest
-        # block waits for G(z1)'s (l4_done): its BatchNorm layers update their running statistics in the reference's
-        # order.  The persistent GEMM workgroups of the deepest block hold every CU's registers, so the small kernels
-        # do not run underneath them but between them, and both chains get slower: 36.2-36.7 vs 35.7-35.8 ms/step.
-        fork, l4_done = self._fork_l4 and not torch.cuda.is_current_stream_capturing(), None
         hook1 = d_mark if self._defer_d else d_now
         with torch.no_grad():
-            if fork:
-                s1 = self.G(self._z(st, "z1"), stage_hook=hook1, stop_before=3)
-                x4 = self._side[3]
-                x4.wait_stream(main)
-                for t in (s1["xt"], s1["const"], s1["pct"]):
-                    t.record_stream(x4)                     # allocated on the default stream, read on x4
-                with torch.cuda.stream(x4):
-                    self.G.resume(s1, stage_hook=hook1)
-                    l4_done = torch.cuda.Event()
-                    l4_done.record(x4)
-                del s1
-            else:
-                self.G(self._z(st, "z1"), stage_hook=hook1)
+            self.G(self._z(st, "z1"), stage_hook=hook1)
         for level, ev in levels:
             d_update(level, ev)
         mark("G(z1) level 4")
@@ -424,7 +403,6 @@ class PDGNTrainer:
         # they are enqueued from the generator's stage hook and run underneath the deeper blocks; after the forward
         # only D4(gen) and the three pairs with the 2048-point cloud are left to wait for.  Being created last, those
         # are also the first adjoints autograd issues -- the ones block 4's backward waits for.
-        # (PDGN_LP_SPLIT=1, the lighter pairs on the default stream instead: measured, no gain.)
         terms, own, g_loss, gen_so_far = {}, {}, [None] * 4, []
         early = self._early_tail
 
@@ -439,25 +417,16 @@ class PDGNTrainer:
             with torch.cuda.stream(side):
                 g_loss[level] = F.mse_loss(self.D[level](cloud), st["ones"])
 
-        if fork:
-            s2 = self.G(self._z(st, "z2"), stage_hook=tail if early else None, stop_before=3, feature_hook=self._early_bucket_hook)
-            main.wait_event(l4_done)
-            gen = self.G.resume(s2, stage_hook=tail if early else None, feature_hook=self._early_bucket_hook)
-            del s2
-        else:
-            gen = self.G(self._z(st, "z2"), stage_hook=tail if early else None, feature_hook=self._early_bucket_hook)
+        gen = self.G(self._z(st, "z2"), stage_hook=tail if early else None, feature_hook=self._early_bucket_hook)
         mark("G(z2) forward")
         if not early:
-            split = self._lp_split
             self._side_lp.wait_stream(main)
             with torch.cuda.stream(self._side_lp):
-                terms = self.similar_terms(gen, PAIRS[-1:] if split else PAIRS)
+                terms = self.similar_terms(gen, PAIRS)
             for i, side in enumerate(self._side):
                 side.wait_stream(main)
                 with torch.cuda.stream(side):
                     g_loss[i] = F.mse_loss(self.D[i](gen[i]), st["ones"])
-            if split:
-                terms.update(self.similar_terms(gen, PAIRS[:-1]))
         for side in self._side:
             main.wait_stream(side)
         main.wait_stream(self._side_lp)

@@ -42,6 +42,9 @@ def test_bench_prints_one_json_line_with_roofline_and_cpu_baseline():
     assert d["rccl_ranks"] == 1 and d["ms_per_step_min_rank"] <= d["ms_per_step_max_rank"]
     assert d["executed_flops_per_step"] > 1e12 and 0.0 < d["step_mfma_frac"] < 1.0 and d["algebraic_saving"] > 1.0
     assert r["kernel"].startswith("gemm_nt_kernel") and "Cijk" not in json.dumps(r)      # the roofline names own kernels only
+    c5 = d["eval_c5"]                                            # config C5 rides in the default line
+    assert c5["pairs"] == 512 and c5["finite"] is True and c5["pairs_per_s"] > 0 and c5["ms_per_512"] > 0
+    assert c5["roofline"]["bound"] == "valu-issue" and 0 < c5["roofline"]["frac"] < 1 and 0 < c5["roofline"]["exp_frac"] < 1
 
 
 @pytest.mark.timeout(600)
@@ -54,7 +57,7 @@ def test_bench_eval_mode_c5_line():
     assert p.returncode == 0, p.stderr[-2000:]
     d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
     assert d["unit"] == "pairs/s" and d["value"] > 0 and d["config"]["finite"] is True
-    assert d["roofline"]["kernel"].startswith("approxmatch_kernel") and 0 < d["roofline"]["frac"] < 1
+    assert d["roofline"]["kernel"].startswith("emd_cost_kernel") and 0 < d["roofline"]["frac"] < 1
 
 
 @pytest.mark.timeout(900)

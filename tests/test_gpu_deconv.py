@@ -681,24 +681,6 @@ def test_assemble_weights_kernel_vs_torch(F_, Fo, k, bilateral, Fc):
             torch.testing.assert_close(a, b, rtol=1e-6, atol=1e-6)
 
 
-def test_conv2_neighbour_half_as_gathered_gemm_matches(golden, monkeypatch):
-    """PDGN_CONV2_GATHER=1 (conv2's neighbour slots contracted on dense GEMMs over the gathered neighbour features, T = 0
-    centre-only gather-sum spec) is the same function as the default path: bilateral block fixture, outputs and gradients."""
-    from pdgn_amd import deconv
-    g = golden("deconv_bilateral_k10.npz")
-    res = []
-    for flag in (False, True):
-        monkeypatch.setattr(deconv, "_CONV2_GATHER", flag)
-        mod = fill_module(deconv.PointDeconv(int(g["F"]), int(g["Fout"]), int(g["k"]), bilateral=True), salt=3).cuda().train()
-        x = dev(g["x"]).requires_grad_(True)
-        pc = dev(g["pc"]).requires_grad_(True)
-        y = mod(x, pc, idx=dev(g["idx"].astype(np.int32)))
-        y.backward(dev(g["gout"]))
-        res.append([y.detach(), x.grad, pc.grad] + [p.grad for p in mod.parameters()])
-    for a, b in zip(*res):
-        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=2e-4, atol=2e-5 * float(b.abs().max()) + 1e-7)
-
-
 def test_config_c4_reference_blocks_fixture(golden):
     """BASELINE.json configs[3] against the reference's OWN block classes (Note C4):
     tests/golden/generator_c4_b4.npz was computed by a reference PointGenerator whose fc1 / bilateral1..4 were swapped
