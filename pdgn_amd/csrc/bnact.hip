@@ -500,9 +500,37 @@ __global__ __launch_bounds__(BN_THREADS) void bilateral_bwd_kernel(
             for (int p = 0; p < KM / 2; ++p)
                 if (KT || p < P) {
                     uv[p] = *reinterpret_cast<const float4 *>(u + ou + (size_t)p * Cu);
-                    wv[p] = *reinterpret_cast<const float4 *>(w + ou + (size_t)p * Cu);
+                    if (w) wv[p] = *reinterpret_cast<const float4 *>(w + ou + (size_t)p * Cu);
                     gv[p] = *reinterpret_cast<const float4 *>(dy + ou + (size_t)p * Cu);
                 }
+            if (!w) {
+                // w is a function of x alone: recomputed from the slots this thread holds anyway, with the forward's own
+                // expression (bn_softmax_perm_mul_fwd_kernel) -- the (M, k/2, 2C) weight tensor is neither written by the
+                // forward nor read here: one edge-sized write and two reads per block and iteration less
+                float h0[KM], h1[KM];
+                float mx0 = -INFINITY, mx1 = -INFINITY;
+#pragma unroll
+                for (int s = 0; s < KM; ++s)
+                    if (KT || s < k) {
+                        h0[s] = act_fwd(__fmaf_rn(xv[s].x, scx.x, shx.x), act);
+                        h1[s] = act_fwd(__fmaf_rn(xv[s].y, scx.y, shx.y), act);
+                        mx0 = fmaxf(mx0, h0[s]);
+                        mx1 = fmaxf(mx1, h1[s]);
+                    }
+                float e0 = 0.f, e1 = 0.f;
+#pragma unroll
+                for (int s = 0; s < KM; ++s)
+                    if (KT || s < k) {
+                        h0[s] = __expf(h0[s] - mx0);
+                        h1[s] = __expf(h1[s] - mx1);
+                        e0 += h0[s];
+                        e1 += h1[s];
+                    }
+                const float i0 = 1.0f / e0, i1 = 1.0f / e1;
+#pragma unroll
+                for (int p = 0; p < KM / 2; ++p)
+                    if (KT || p < P) wv[p] = make_float4(h0[p] * i0, h0[P + p] * i0, h1[p] * i1, h1[P + p] * i1);
+            }
             float dot0 = 0.f, dot1 = 0.f;
 #pragma unroll
             for (int p = 0; p < KM / 2; ++p)
@@ -591,7 +619,7 @@ extern "C" long long pdgn_bilateral_scratch_floats(long long m, int k, int c) {
 }
 
 // Adjoint of pdgn_bn_softmax_slots_permute_mul: x (m,k,c), u / w / dy (m,k/2,2c); bsums_x (2c) = [dbeta_x | dgamma_x],
-// bsums_u (4c) likewise for BN_u; dx (m,k,c), du (m,k/2,2c).  c even.
+// bsums_u (4c) likewise for BN_u; dx (m,k,c), du (m,k/2,2c).  c even.  w == NULL: the weights are recomputed from x.
 extern "C" int pdgn_bilateral_weighting_backward(long long m, int k, int c, int act, int training, const float *x,
                                                  const float *stats_x, const float *u, const float *stats_u,
                                                  const float *w, const float *dy, float *scratch, float *bsums_x,

@@ -491,8 +491,8 @@ def bn_softmax_slots_permute(x2d, bn, training, k, act="leaky_relu", pre_bias=No
 class BilateralWeighting(Function):
     """y = act(BN_u(u)) * softmax_slots_permute(act(BN_x(x)))  -- the bilateral weighting of a deconvolution block
     (models/PDGNet_v2.py:623-642) with both BatchNorms, both activations, the slot softmax, the channel interleave and
-    the product in one pass over x (M*k, C) and u (M*k/2, 2C).  Saved for backward: x, u, w and the two statistics
-    rows; under no_grad w is not even written."""
+    the product in one pass over x (M*k, C) and u (M*k/2, 2C).  Saved for backward: x, u and the two statistics rows;
+    the softmax weights w are recomputed from x by the fused adjoint (k = 4, 10) and never reach HBM."""
 
     @staticmethod
     def forward(ctx, x, u, gx, bx, rmx, rvx, pbx, gu, bu, rmu, rvu, pbu, training, momentum_x, eps_x, momentum_u, eps_u,
@@ -505,7 +505,8 @@ class BilateralWeighting(Function):
                             momentum_x, eps_x, partials_x)
         stats_u = _bn_stats(L, u, u.shape[0], 2 * C, gu.detach().contiguous(), bu.detach().contiguous(), pbu, rmu, rvu,
                             training, momentum_u, eps_u, partials_u)
-        need_w = any(ctx.needs_input_grad)
+        # the fused adjoint (k = 4, 10) recomputes w from x; only the generic chain of separate adjoint kernels reads it back
+        need_w = any(ctx.needs_input_grad) and k not in (4, 10)
         w = torch.empty((m, k // 2, 2 * C), dtype=F32, device=x.device) if need_w else None
         y = torch.empty_like(u)
         check(L.pdgn_bn_softmax_slots_permute_mul(ctypes.c_longlong(m), k, C, act, ptr(x), ptr(stats_x), act, ptr(u),

@@ -58,6 +58,12 @@ class FlatGrads:
         if self.params and self.params[0].is_cuda:
             reset_zero_arena(self.params[0].device, self)
 
+    def resume(self):
+        """A further backward pass whose gradients will be ADDED to the ones already there (the second half of a split
+        discriminator update): nothing is cleared, only the zero arena is re-opened on the current stream."""
+        if self.params and self.params[0].is_cuda:
+            reset_zero_arena(self.params[0].device, self)
+
     def zero_(self):                       # kept for callers that accumulate into the views
         self.buf.zero_()
 
@@ -140,6 +146,8 @@ class PDGNTrainer:
         for ws in {1, world_size() if self.distributed else 1}:
             self._loss_weights(ws)
         self._early_tail = os.environ.get("PDGN_EARLY_TAIL", "1") == "1"
+        self._g1_ahead = os.environ.get("PDGN_G1_AHEAD", "0") == "1"
+        self._split_d = os.environ.get("PDGN_SPLIT_D", "1") == "1"
         self._defer_d = os.environ.get("PDGN_DEFER_D", "1") == "1"
         self.sync_replicas()
 
@@ -274,6 +282,32 @@ class PDGNTrainer:
         lossD.backward()
         st["out"]["d_loss%d" % (i + 1)] = lossD.detach()
 
+    # The same update in two halves (overlapped schedule): lossD = mse(D(real), 1) / 2 + mse(D(fake), 0) / 2 (:186-190) is
+    # a sum of two terms that share nothing but the parameters, and the REAL term does not depend on the generator at all.
+    # Its forward and backward are issued at the start of the iteration and run underneath generator pass #1 (whose first
+    # three blocks are small kernels that leave the chip idle); when the fake cloud exists only the fake term's forward
+    # and backward are left on the discriminator's chain, which was as long as the generator's own.
+    # Same order of D's forward calls (real, then fake: BatchNorm running statistics), gradients summed once.
+    def _seg_d_real(self, st, i):
+        D = self.D[i]
+        self.gradD[i].begin()
+        params = self.gradD[i].params
+        loss_r = F.mse_loss(D(st["reals"][i]), st["ones"]) / 2.0
+        st["d_half"][i] = (loss_r.detach(), torch.autograd.grad(loss_r, params))
+
+    def _seg_d_fake(self, st, i):
+        D = self.D[i]
+        fg = self.gradD[i]
+        fg.resume()
+        loss_f = F.mse_loss(D(st["fakes"][i]), st["zeros"]) / 2.0
+        loss_r, g_real = st["d_half"][i]
+        g_fake = torch.autograd.grad(loss_f, fg.params)
+        torch._foreach_add_(g_real, g_fake)
+        for p, g in zip(fg.params, g_real):
+            p.grad = g
+        st["d_half"][i] = None
+        st["out"]["d_loss%d" % (i + 1)] = loss_r + loss_f.detach()
+
     def _segment(self, st, k):
         if k == 0:
             # generator pass #1 (:179): only its detached outputs are ever used => no graph needed;
@@ -377,24 +411,58 @@ class PDGNTrainer:
             if level < 3:
                 mark("G(z1) level %d" % (level + 1))
 
+        split = self._split_d
+
         def d_update(level, ev):
             side = self._side[level]
             side.wait_event(ev)
             with torch.cuda.stream(side), torch.enable_grad():
-                self._seg_d(st, level)
+                if split:
+                    self._seg_d_fake(st, level)
+                else:
+                    self._seg_d(st, level)
                 self._comm(level)
                 self.optD[level].step()
+
+        if split:
+            st["d_half"] = [None] * 4
+            for level, side in enumerate(self._side):
+                side.wait_stream(main)                      # (the real batch / targets may have been produced on `main`)
+                with torch.cuda.stream(side), torch.enable_grad():
+                    self._seg_d_real(st, level)
 
         def d_now(level, cloud):
             d_mark(level, cloud)
             d_update(*levels.pop())
 
         hook1 = d_mark if self._defer_d else d_now
-        with torch.no_grad():
-            self.G(self._z(st, "z1"), stage_hook=hook1)
-        for level, ev in levels:
-            d_update(level, ev)
-        mark("G(z1) level 4")
+        ahead = self._g1_ahead and not torch.cuda.is_current_stream_capturing()
+        if ahead:
+            # PDGN_G1_AHEAD=1: the first three blocks of the two generator passes are chains of small, latency-bound kernels
+            # (2.9 + 3.3 ms one after the other).  Pass #1's chain runs on D4's stream (idle until level 4 exists), ONE
+            # LEVEL AHEAD of pass #2's chain on the issuing stream: block l of pass #2 starts when block l of pass #1 is
+            # complete, so every BatchNorm layer still updates its running statistics in the reference's order (z1, then
+            # z2).  The two deepest blocks (large kernels that fill the chip) follow one after the other on the issuing stream.
+            g1 = self._side[3]
+            g1.wait_stream(main)
+            done1 = []
+
+            def after_level(level, cloud):
+                hook1(level, cloud)
+                e = torch.cuda.Event()
+                e.record(torch.cuda.current_stream(self.device))
+                done1.append(e)
+            with torch.no_grad(), torch.cuda.stream(g1):
+                s1 = self.G(self._z(st, "z1"), stage_hook=after_level, levels=(0, 3))
+            for level, ev in levels:
+                d_update(level, ev)
+            del levels[:]
+        else:
+            with torch.no_grad():
+                self.G(self._z(st, "z1"), stage_hook=hook1)
+            for level, ev in levels:
+                d_update(level, ev)
+            mark("G(z1) level 4")
         self.gradG.begin()
         self._freeze_D(True)
         # The shape-preserving loss (12 kNN + Chamfer terms) and the four D(gen) passes read the clouds and nothing of
@@ -417,7 +485,27 @@ class PDGNTrainer:
             with torch.cuda.stream(side):
                 g_loss[level] = F.mse_loss(self.D[level](cloud), st["ones"])
 
-        gen = self.G(self._z(st, "z2"), stage_hook=tail if early else None, feature_hook=self._early_bucket_hook)
+        if ahead:
+            s2 = self.G(self._z(st, "z2"), stage_hook=tail if early else None, feature_hook=self._early_bucket_hook, levels=(0, 3),
+                        level_hook=lambda lvl: main.wait_event(done1[lvl]))
+            mark("G(z1 | z2) levels 1-3")
+            for t in (s1["xt"], s1["const"], s1["pct"]):
+                t.record_stream(main)                       # allocated on g1, read by pass #1's deepest block on `main`
+            with torch.no_grad():
+                self.G(None, stage_hook=hook1, levels=(3, 4), state=s1)
+            for p in self.D[3].parameters():                # D4's update is issued inside the generator's frozen-D window
+                p.requires_grad_(True)
+            for level, ev in levels:
+                d_update(level, ev)
+            for p in self.D[3].parameters():
+                p.requires_grad_(False)
+            self.gradG.begin()                              # (D4's backward took the zero arena: hand it back to G's)
+            del s1
+            mark("G(z1) level 4")
+            gen = self.G(None, stage_hook=tail if early else None, feature_hook=self._early_bucket_hook, levels=(3, 4), state=s2)
+            del s2
+        else:
+            gen = self.G(self._z(st, "z2"), stage_hook=tail if early else None, feature_hook=self._early_bucket_hook)
         mark("G(z2) forward")
         if not early:
             self._side_lp.wait_stream(main)

@@ -567,9 +567,12 @@ def test_bn_softmax_slots_permute(M, k, C, training):
         np.testing.assert_allclose(bnd.running_var.cpu().numpy(), bnr.running_var.numpy(), rtol=1e-5, atol=1e-6)
 
 
-@pytest.mark.parametrize("M,k,C,training", [(640, 10, 16, True), (896, 10, 256, True), (33, 4, 24, True), (200, 10, 64, False)])
+@pytest.mark.parametrize("M,k,C,training", [(640, 10, 16, True), (896, 10, 256, True), (33, 4, 24, True), (200, 10, 64, False),
+                                            (96, 6, 32, True)])
 def test_bilateral_weighting(M, k, C, training):
-    """both BatchNorms + activations + slot softmax + interleave + product in one pass vs the same chain in fp64"""
+    """both BatchNorms + activations + slot softmax + interleave + product in one pass vs the same chain in fp64.  k = 4, 10:
+    the fused adjoint, which recomputes the softmax weights from x (they are never written); k = 6: the generic chain of
+    separate adjoint kernels over the saved weights."""
     import copy
     import torch.nn as nn
     from pdgn_amd.fused import bilateral_weighting

@@ -107,3 +107,38 @@ def test_rccl_path_at_world_size_one_equals_single_process():
         assert len(b._graphs) == 6
     finally:
         dist.destroy_process_group()
+
+
+def test_g1_ahead_schedule_equals_default(monkeypatch):
+    """PDGN_G1_AHEAD=1 (the first three blocks of generator pass #1 on a side stream, one level ahead of pass #2's) with
+    the split discriminator updates (the real half issued at the start of the iteration) against the plain overlapped
+    schedule with whole updates: the same iteration -- losses, parameters and BatchNorm running statistics after one step
+    from identical state."""
+    from pdgn_amd.trainer import PDGNTrainer, noise, synthetic_batch
+    dev = torch.device("cuda:0")
+    torch.manual_seed(4)
+    a = PDGNTrainer(device=dev, distributed=False)
+    b = PDGNTrainer(device=dev, distributed=False, generator=copy.deepcopy(a.G),
+                    discriminators=[copy.deepcopy(d) for d in a.D])
+    a.train(), b.train()
+    a._g1_ahead, b._g1_ahead = False, True
+    a._split_d, b._split_d = False, True                         # ... and the discriminator updates in two halves (real early)
+    B = 6
+    reals = synthetic_batch(B, dev)
+    g = torch.Generator().manual_seed(8)
+    z1, z2 = noise(B, dev, g), noise(B, dev, g)
+    la, lb = a.step(reals, z1, z2), b.step(reals, z1, z2)
+    torch.cuda.synchronize()
+    for k in la:
+        va, vb = float(la[k]), float(lb[k])
+        assert abs(va - vb) <= 2e-3 * max(1.0, abs(vb)), (k, va, vb)
+    for (na, pa), (nb, pb) in zip(a.G.named_parameters(), b.G.named_parameters()):
+        assert (pa - pb).abs().max().item() <= 3e-4, na
+    for da, db in zip(a.D, b.D):
+        for pa, pb in zip(da.parameters(), db.parameters()):
+            assert (pa - pb).abs().max().item() <= 3e-4
+    for (ka, va), (kb, vb) in zip(a.G.state_dict().items(), b.G.state_dict().items()):
+        if "running_" in ka:                                     # updated in the reference's order: z1, then z2
+            torch.testing.assert_close(va, vb, rtol=1e-4, atol=1e-6, msg=ka)
+        if "num_batches_tracked" in ka:
+            assert int(va) == int(vb) == 2, ka
