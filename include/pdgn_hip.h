@@ -168,9 +168,10 @@ int pdgn_bn_eval_stats(int c, float eps, const float *gamma, const float *beta, 
 int pdgn_bn_stats_from_partials(long long rows, int c, float eps, float momentum, const float *gamma,
                                 const float *beta, const float *pre_bias, float *running_mean, float *running_var,
                                 const float *scratch, float *stats, pdgn_stream_t stream);
-/* The same second stage over an explicit number of partial rows: the per-row-block column sums pdgn_gemm_nt /
- * pdgn_gemm_nn write from their epilogue (pdgn_gemm_nt_stat_rows(m, n, k) rows of [2c] floats). */
-int pdgn_bn_stats_from_gemm_partials(long long rows, int c, long long nparts, float eps, float momentum,
+/* The second stage over the BLOCK-SHIFTED partials pdgn_gemm_nt / pdgn_gemm_nn / pdgn_thin_nt write from their epilogue:
+ * nparts rows of [3c] floats, row b = per-column  sum (x - pv_b) | sum (x - pv_b)^2 | pv_b  over rows b*block_rows .. of x,
+ * pv_b = the block's own first row (no cancellation when |mean| >> std); combined per block in fp64. */
+int pdgn_bn_stats_from_gemm_partials(long long rows, int c, long long nparts, int block_rows, float eps, float momentum,
                                      const float *gamma, const float *beta, const float *pre_bias,
                                      float *running_mean, float *running_var, const float *partials,
                                      float *stats, pdgn_stream_t stream);
@@ -230,8 +231,9 @@ int pdgn_softmax_slots_permute_backward(long long m, int k, int c, const float *
  * all row-major; n, k and every pitch are multiples of 4 floats, base pointers 16-byte aligned.
  * (The reference's Conv2d/Conv1d/Linear forward at models/PDGNet_v2.py:559-625, 835-862, 886-1014 in
  * point-major form; with the transposed weight it is their input gradient dX = dY W.)  stat_part (may be
- * NULL): pdgn_gemm_nt_stat_rows(m, n, k) rows of [2n] floats = per-column sum | sum of squares of row
- * blocks of C, the partials pdgn_bn_stats_from_gemm_partials turns into BatchNorm statistics.  Without
+ * NULL): pdgn_gemm_nt_stat_rows(m, n, k) rows of [3n] floats = per-column sum (x - pv) | sum (x - pv)^2 | pv of blocks of
+ * pdgn_gemm_nt_stat_block_rows(m, n, k) rows of C (pv: the block's first row), the partials
+ * pdgn_bn_stats_from_gemm_partials turns into BatchNorm statistics.  Without
  * stat_part and with ldc == n the launch may add partial tiles with fp32 atomics (C is zero-filled by the
  * call itself where needed). */
 int pdgn_gemm_nt(long long m, int n, int k, const float *A, int lda, const float *W, int ldw,
@@ -242,9 +244,11 @@ int pdgn_gemm_nt(long long m, int n, int k, const float *A, int lda, const float
  *   Y (m x n, pitch ldy) = X (m x k, pitch ldx) W'^T (+ bias[n]),   W'[j, kk] = W[j * wrs + kk * wcs]
  * with either k <= 4 and n % 4 == 0 (Y 16-byte aligned rows) or n <= 4 and k % 4 == 0 (X 16-byte aligned rows).  The strides
  * let one entry serve a weight and its transpose (forward: wrs = k, wcs = 1; input gradient dX = dY W: wrs = 1, wcs = C_in).
- * stat_part (k <= 4 form only, may be NULL): pdgn_thin_stat_rows(m) rows of [2n] floats, the BatchNorm partials of Y in the
- * layout pdgn_bn_stats_from_gemm_partials reads.  Returns -3 for shapes outside these two forms. */
+ * stat_part (k <= 4 form only, may be NULL): pdgn_thin_stat_rows(m) rows of [3n] floats (blocks of pdgn_thin_stat_block_rows()
+ * rows), the BatchNorm partials of Y in the layout pdgn_bn_stats_from_gemm_partials reads.  Returns -3 for shapes outside
+ * these two forms. */
 long long pdgn_thin_stat_rows(long long m);
+int pdgn_thin_stat_block_rows(void);
 int pdgn_thin_nt(long long m, int n, int k, const float *X, int ldx, const float *W, int wrs, int wcs,
                  const float *bias, float *Y, int ldy, float *stat_part, pdgn_stream_t stream);
 /* Weight (+ bias) gradient of such a layer: O[i * osi + j * osj] += sum_r A[r, i] B[r, j] for A (m x ta <= 4, pitch lda),
@@ -263,6 +267,7 @@ int pdgn_gemm_nn(long long m, int n, int k, const float *A, int lda, const float
 int pdgn_gemm_tn_big(long long m, int n, int k, const float *dY, int ldy, const float *X, int ldx, float *dW,
                      pdgn_stream_t stream);
 long long pdgn_gemm_nt_stat_rows(long long m, int n, int k);
+int pdgn_gemm_nt_stat_block_rows(long long m, int n, int k);
 /* Tile configuration the launch model picks (0: 256x128, 1: 128x128, 2: 160x64, 3: 128x64 workgroup tiles); host only. */
 int pdgn_gemm_nt_config(long long m, int n, int k, int with_stats);
 

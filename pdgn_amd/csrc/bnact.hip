@@ -181,6 +181,59 @@ __global__ __launch_bounds__(FIN_CH * FIN_PL) void cl_finalize_kernel(
     }
 }
 
+// The same finalisation from BLOCK-SHIFTED partials (the epilogues of pdgn_gemm_nt / pdgn_gemm_nn / pdgn_thin_nt): partial
+// row b covers rows b*rpp .. of x and holds [sum (x - pv_b) | sum (x - pv_b)^2 | pv_b] with pv_b the block's own first row.
+// Per block: mean_b = pv_b + s/n, M2_b = q - s^2/n (no cancellation: |x - pv_b| ~ std); the blocks are combined in fp64:
+// mean = sum n_b mean_b / R, var = (sum M2_b + sum n_b mean_b^2) / R - mean^2.
+__global__ __launch_bounds__(FIN_CH * FIN_PL) void cl_finalize_blocks_kernel(
+    long long R, int C, int nparts, int rpp, float eps, float momentum, const float *__restrict__ part,
+    const float *__restrict__ gamma, const float *__restrict__ beta, const float *__restrict__ pre_bias,
+    float *__restrict__ running_mean, float *__restrict__ running_var, float *__restrict__ stats) {
+    __shared__ double red[FIN_PL][FIN_CH], red2[FIN_PL][FIN_CH];
+    const int cl = threadIdx.x % FIN_CH, pl = threadIdx.x / FIN_CH;
+    const int c = blockIdx.x * FIN_CH + cl;
+    const bool ok = c < C;
+    double a = 0, b = 0;
+    if (ok)
+        for (int p = pl; p < nparts; p += FIN_PL) {
+            const long long left = R - (long long)p * rpp;
+            if (left <= 0) break;
+            const double n = (double)(left < rpp ? left : rpp);
+            const float *q = part + (size_t)p * 3 * C + c;
+            const double s = (double)q[0], sq = (double)q[C], pv = (double)q[2 * C];
+            const double mb = pv + s / n;
+            a += n * mb;
+            b += (sq - s * s / n) + n * mb * mb;
+        }
+    red[pl][cl] = a;
+    red2[pl][cl] = b;
+    __syncthreads();
+    for (int h = FIN_PL / 2; h > 0; h >>= 1) {
+        if (pl < h) {
+            red[pl][cl] += red[pl + h][cl];
+            red2[pl][cl] += red2[pl + h][cl];
+        }
+        __syncthreads();
+    }
+    if (!ok || threadIdx.x >= FIN_CH) return;
+    const double mean = red[0][cl] / (double)R;
+    double var = red2[0][cl] / (double)R - mean * mean;
+    var = var < 0 ? 0 : var;
+    const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float g = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
+    const float scale = g * invstd;
+    stats[c] = scale;
+    stats[C + c] = be - (float)mean * scale;
+    stats[2 * C + c] = (float)mean;
+    stats[3 * C + c] = invstd;
+    if (running_mean) {
+        const double unbiased = R > 1 ? var * (double)R / (double)(R - 1) : var;
+        const float mb = (float)mean + (pre_bias ? pre_bias[c] : 0.f);
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mb;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+    }
+}
+
 // eval mode: scale/shift from the running statistics
 __global__ void cl_eval_stats_kernel(int C, float eps, const float *__restrict__ gamma, const float *__restrict__ beta,
                                      const float *__restrict__ pre_bias, const float *__restrict__ running_mean,
@@ -403,16 +456,18 @@ extern "C" int pdgn_bn_stats_from_partials(long long rows, int c, float eps, flo
     return pdgn_launch_status();
 }
 
-// The same second stage over an explicit number of partial rows ([2c] floats each: per-column sum | sum of squares of a
-// row block): the partials pdgn_gemm_nt / pdgn_gemm_nn write from their epilogue (pdgn_gemm_nt_stat_rows of them).
-extern "C" int pdgn_bn_stats_from_gemm_partials(long long rows, int c, long long nparts, float eps, float momentum,
-                                                const float *gamma, const float *beta, const float *pre_bias,
+// The second stage over the BLOCK-SHIFTED partials a GEMM epilogue writes: `nparts` rows of [3c] floats (per-column
+// sum (x - pv) | sum (x - pv)^2 | pv of a block of `block_rows` rows; pdgn_gemm_nt_stat_rows / _stat_block_rows,
+// pdgn_thin_stat_rows / _stat_block_rows).
+extern "C" int pdgn_bn_stats_from_gemm_partials(long long rows, int c, long long nparts, int block_rows, float eps,
+                                                float momentum, const float *gamma, const float *beta, const float *pre_bias,
                                                 float *running_mean, float *running_var, const float *partials,
                                                 float *stats, pdgn_stream_t stream) {
-    if (rows < 1 || c < 4 || c % 4 || nparts < 1 || nparts > 0x7fffffffLL) return PDGN_ERR_INVALID;
-    hipLaunchKernelGGL(cl_finalize_kernel, dim3(cdiv(c, FIN_CH)), dim3(FIN_CH * FIN_PL), 0, (hipStream_t)stream, rows, c,
-                       (int)nparts, eps, momentum, partials, gamma, beta, pre_bias, running_mean, running_var, stats,
-                       (const float *)nullptr);
+    if (rows < 1 || c < 4 || c % 4 || nparts < 1 || nparts > 0x7fffffffLL || block_rows < 1 ||
+        nparts * (long long)block_rows < rows)
+        return PDGN_ERR_INVALID;
+    hipLaunchKernelGGL(cl_finalize_blocks_kernel, dim3(cdiv(c, FIN_CH)), dim3(FIN_CH * FIN_PL), 0, (hipStream_t)stream, rows, c,
+                       (int)nparts, block_rows, eps, momentum, partials, gamma, beta, pre_bias, running_mean, running_var, stats);
     return pdgn_launch_status();
 }
 

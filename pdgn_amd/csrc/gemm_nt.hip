@@ -319,19 +319,25 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_nt_kernel(const NtArgs p
                 }
             }
             if (p.stat_part) {
-                // per-column sum / sum of squares over the wave's rows: in registers over a, then over the 16 lanes of
-                // equal lg; one partial row of [2N] floats per (tile row, wave row)
-                float *P = p.stat_part + ((size_t)tm * WM + wm) * 2 * p.N;
+                // per-column statistics of the wave's 16*TM rows, SHIFTED by the block's first row (pv): sum (x - pv),
+                // sum (x - pv)^2 and pv itself -- E[x^2] - mean^2 on raw fp32 sums cancels quadratically in |mean| / std,
+                // on sums shifted by a value of the same block it does not, and cl_finalize_blocks_kernel combines the
+                // blocks in fp64 (Chan et al.).  In registers over a, then over the 16 lanes of equal lg; one partial
+                // row of [3N] floats per (tile row, wave row).
+                float *P = p.stat_part + ((size_t)tm * WM + wm) * 3 * p.N;
 #pragma unroll
                 for (int b = 0; b < TN; ++b) {
-                    float cs[4] = {0.f, 0.f, 0.f, 0.f}, cq[4] = {0.f, 0.f, 0.f, 0.f};
+                    float cs[4] = {0.f, 0.f, 0.f, 0.f}, cq[4] = {0.f, 0.f, 0.f, 0.f}, pv[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) pv[r] = __shfl(acc[0][b][r], lane & 48, 64);   // row li = 0 of row block a = 0
 #pragma unroll
                     for (int a = 0; a < TM; ++a)
                         if (mloc0 + 16 * a < mrows) {
 #pragma unroll
                             for (int r = 0; r < 4; ++r) {
-                                cs[r] += acc[a][b][r];
-                                cq[r] = __fmaf_rn(acc[a][b][r], acc[a][b][r], cq[r]);
+                                const float d = acc[a][b][r] - pv[r];
+                                cs[r] += d;
+                                cq[r] = __fmaf_rn(d, d, cq[r]);
                             }
                         }
 #pragma unroll
@@ -345,6 +351,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_nt_kernel(const NtArgs p
                     if (li == 0 && nl < ncols) {
                         *reinterpret_cast<float4 *>(P + n0 + nl) = make_float4(cs[0], cs[1], cs[2], cs[3]);
                         *reinterpret_cast<float4 *>(P + p.N + n0 + nl) = make_float4(cq[0], cq[1], cq[2], cq[3]);
+                        *reinterpret_cast<float4 *>(P + 2 * p.N + n0 + nl) = make_float4(pv[0], pv[1], pv[2], pv[3]);
                     }
                 }
             }
@@ -637,7 +644,8 @@ static int nt_dispatch(long long m, int n, int k, const float *A, int lda, const
 
 // C (m x n, row pitch ldc) = A (m x k, pitch lda) W (n x k, pitch ldw)^T (+ bias[n]) (+ addend (m x n, pitch ldadd)).
 // n, k and every pitch are multiples of 4 floats and all base pointers 16-byte aligned.  stat_part (may be NULL):
-// pdgn_gemm_nt_stat_rows(m, n, k) rows of [2n] floats = per-column sum | sum of squares of row blocks of C.
+// pdgn_gemm_nt_stat_rows(m, n, k) rows of [3n] floats = per-column sum (x - pv) | sum (x - pv)^2 | pv of row blocks of C
+// (pv: the block's first row; pdgn_gemm_nt_stat_block_rows rows per block) for pdgn_bn_stats_from_gemm_partials.
 extern "C" int pdgn_gemm_nt(long long m, int n, int k, const float *A, int lda, const float *W, int ldw,
                             const float *bias, const float *addend, int ldadd, float *C, int ldc, float *stat_part,
                             pdgn_stream_t stream) {
@@ -672,7 +680,7 @@ extern "C" int pdgn_gemm_tn_big(long long m, int n, int k, const float *dY, int 
     }
 }
 
-// Number of [2n] partial-statistics rows pdgn_gemm_nt writes for this problem (tile rows x waves along m).
+// Number of [3n] partial-statistics rows pdgn_gemm_nt writes for this problem (tile rows x waves along m).
 extern "C" long long pdgn_gemm_nt_stat_rows(long long m, int n, int k) {
     if (m < 1 || n < 1 || k < 1) return PDGN_ERR_INVALID;
     switch (nt_pick(m, n, k, true)) {
@@ -680,6 +688,17 @@ extern "C" long long pdgn_gemm_nt_stat_rows(long long m, int n, int k) {
         case 2: return (long long)cdiv(m, NtTall::BM) * 2;
         case 3: return (long long)cdiv(m, NtNarrow::BM) * 2;
         default: return (long long)cdiv(m, NtSquare::BM) * 2;
+    }
+}
+
+// Rows of C each of those partial rows covers (partial p: rows p * block .. ; the blocks past m are empty).
+extern "C" int pdgn_gemm_nt_stat_block_rows(long long m, int n, int k) {
+    if (m < 1 || n < 1 || k < 1) return PDGN_ERR_INVALID;
+    switch (nt_pick(m, n, k, true)) {
+        case 0: return NtBig::BM / 4;
+        case 2: return NtTall::BM / 2;
+        case 3: return NtNarrow::BM / 2;
+        default: return NtSquare::BM / 2;
     }
 }
 

@@ -29,9 +29,21 @@ __global__ __launch_bounds__(THIN_THREADS) void thin_k_kernel(long long m, int n
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) w[j][kk] = kk < k ? W[(size_t)(c4 * 4 + j) * wrs + (size_t)kk * wcs] : 0.f;
     }
-    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f}, pv[4] = {0.f, 0.f, 0.f, 0.f};
     const long long r0 = (long long)blockIdx.x * THIN_ROWS;
     const long long r1 = r0 + THIN_ROWS < m ? r0 + THIN_ROWS : m;
+    if (part) {
+        // the statistics are sums of (y - pv), pv = this block's first output row (recomputed by every thread with the
+        // row loop's own expression): shifted sums do not cancel when |mean| >> std (see cl_finalize_blocks_kernel)
+        const float *xr = X + r0 * ldx;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float acc = b[j];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) acc = __fmaf_rn(kk < k ? xr[kk] : 0.f, w[j][kk], acc);
+            pv[j] = acc;
+        }
+    }
     if (ro < rpp) {
         for (long long r = r0 + ro; r < r1; r += rpp) {
             const float *xr = X + r * ldx;
@@ -46,14 +58,15 @@ __global__ __launch_bounds__(THIN_THREADS) void thin_k_kernel(long long m, int n
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) acc = __fmaf_rn(x[kk], w[j][kk], acc);
                 ov[j] = acc;
-                s1[j] += acc;
-                s2[j] = __fmaf_rn(acc, acc, s2[j]);
+                const float d = acc - pv[j];
+                s1[j] += d;
+                s2[j] = __fmaf_rn(d, d, s2[j]);
             }
             *reinterpret_cast<float4 *>(Y + r * ldy + c4 * 4) = o;
         }
     }
     if (!part) return;
-    // per-column sum | sum of squares of this workgroup's rows: one partial row of [2n] floats
+    // per-column sum (y - pv) | sum (y - pv)^2 | pv of this workgroup's rows: one partial row of [3n] floats
 #pragma unroll
     for (int j = 0; j < 4; ++j) { red[threadIdx.x * 8 + j] = s1[j]; red[threadIdx.x * 8 + 4 + j] = s2[j]; }
     __syncthreads();
@@ -61,8 +74,10 @@ __global__ __launch_bounds__(THIN_THREADS) void thin_k_kernel(long long m, int n
         const int cc = t >> 3, j = t & 7;                             // column group, component (4 sums | 4 squares)
         float acc = 0.f;
         for (int q = 0; q < rpp; ++q) acc += red[(q * n4 + cc) * 8 + j];
-        part[(size_t)blockIdx.x * 2 * n + (j < 4 ? 0 : n) + cc * 4 + (j & 3)] = acc;
+        part[(size_t)blockIdx.x * 3 * n + (j < 4 ? 0 : n) + cc * 4 + (j & 3)] = acc;
     }
+    if (ro == 0)
+        *reinterpret_cast<float4 *>(part + (size_t)blockIdx.x * 3 * n + 2 * n + c4 * 4) = make_float4(pv[0], pv[1], pv[2], pv[3]);
 }
 
 // 16 lanes per row, each a float4 of the row per step; n <= 4 dot products reduced across the 16 lanes.
@@ -166,6 +181,7 @@ __global__ __launch_bounds__(THIN_THREADS) void thin_tn_kernel(long long m, int 
 static bool thin_aligned(const void *p, int ld) { return ((uintptr_t)p & 15) == 0 && ld % 4 == 0; }
 
 extern "C" long long pdgn_thin_stat_rows(long long m) { return (m + THIN_ROWS - 1) / THIN_ROWS; }
+extern "C" int pdgn_thin_stat_block_rows(void) { return THIN_ROWS; }      // rows of Y per [3n] partial row
 
 extern "C" int pdgn_thin_nt(long long m, int n, int k, const float *X, int ldx, const float *W, int wrs, int wcs,
                             const float *bias, float *Y, int ldy, float *stat_part, pdgn_stream_t stream) {

@@ -49,12 +49,34 @@ __global__ __launch_bounds__(WGS_THREADS) void wgs_fwd_kernel(
 // take ids of one residue class, consecutive in launch order, and the re-reads hit that XCD's L2.
 #define WGS_CW 16          // default chunk width in float4 (64 channels); kernels are templated on it
 #define WGS_XU 4          // rows in flight per thread: all their index loads, then all their row loads
+// Addressing: everything a task touches lies in ONE sample's slabs of Y / idx / out (tens of MB), so the kernels of this
+// mapping use raw buffer descriptors (scalar base per sample) with 32-bit byte offsets built from 24-bit multiplies, and
+// the row -> (point, position) split is one multiply-high by a host-computed reciprocal.  (The first version computed a
+// 64-bit address per load: 430 vector instructions per thread for 33 loads, 75 of them quarter-rate v_mul_lo_u32 --
+// the address arithmetic, not the memory system, set the kernel's time.)
+typedef float wgs_vec_t __attribute__((ext_vector_type(4)));
+typedef unsigned wgs_u4_t __attribute__((ext_vector_type(4)));
+#define WGS_OOB 0x80000000u                              // past every slab (< 2^31 bytes, checked by the launchers)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t wgs_rsrc(const void *base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ wgs_vec_t wgs_ld4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(wgs_vec_t, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
+}
+__device__ __forceinline__ unsigned wgs_mul24(unsigned a, unsigned b) { return __umul24(a, b); }
+__device__ __forceinline__ unsigned wgs_div(unsigned x, int d, unsigned magic) { return d == 1 ? x : __umulhi(x, magic); }
+static unsigned wgs_magic(int d) { return d == 1 ? 0u : (unsigned)(0x100000000ULL / (unsigned)d) + 1u; }   // x / d == umulhi(x, magic) for x * d < 2^32 (d > 1)
+static bool wgs_slabs_ok(int n, int k, int ldy, int P, int C) {
+    return (long long)n * ldy * 4 < 0x7fffffffLL && (long long)n * P * C * 4 < 0x7fffffffLL && (long long)n * k * 4 < 0x7fffffffLL &&
+           (long long)n * P * P < 0x100000000LL && ldy * 4LL < (1 << 24) && (long long)P * C * 4 < (1 << 24) && n < (1 << 24);
+}
+
 template <int TT, int CW>   // compile-time tap count (0 = runtime T <= 8), chunk width in float4
 __global__ __launch_bounds__(WGS_THREADS) void wgs_fwd_xcd_kernel(
-    int ntasks, int bpt, int n, int k, int ldy, int T, int P, int CV, int nchunk, int off, int offc,
+    int ntasks, int bpt, int n, int k, int ldy, int T, int P, unsigned pmagic, int CV, int nchunk, int off, int offc,
     const float *__restrict__ Y, const int32_t *__restrict__ idx, const float *__restrict__ bias,
     int bias_bstride, float *__restrict__ out) {
-    typedef float vec_t __attribute__((ext_vector_type(4)));
+    typedef wgs_vec_t vec_t;
     constexpr int MAXT = TT ? TT : 8, RL = WGS_THREADS / CW;
     const int seq = blockIdx.x >> 3;
     const int task = (seq / bpt) * 8 + (blockIdx.x & 7);
@@ -62,32 +84,34 @@ __global__ __launch_bounds__(WGS_THREADS) void wgs_fwd_xcd_kernel(
     const int b = task / nchunk, chunk = task - b * nchunk;
     const int cv = chunk * CW + (threadIdx.x % CW);
     if (cv >= CV) return;
-    const int c = cv * 4, R = n * P;
+    const int R = n * P;
     const int r0 = (seq % bpt) * (RL * WGS_XU) + threadIdx.x / CW;      // output rows r0 + u*RL of this sample
-    const long long b0 = (long long)b * n;
-    int pt[WGS_XU], nb[WGS_XU][MAXT];
+    const __amdgpu_buffer_rsrc_t rsY = wgs_rsrc(Y + (size_t)b * n * ldy, (unsigned)n * ldy * 4u);
+    const __amdgpu_buffer_rsrc_t rsI = wgs_rsrc(idx + (size_t)b * n * k, (unsigned)n * k * 4u);
+    const __amdgpu_buffer_rsrc_t rsO = wgs_rsrc(out + (size_t)b * R * CV * 4, (unsigned)R * CV * 16u);
+    const unsigned cb = (unsigned)cv * 16u, ldy4 = (unsigned)ldy * 4u, C4 = (unsigned)CV * 16u;
+    unsigned pt[WGS_XU], nb[WGS_XU][MAXT];
     bool live[WGS_XU];
 #pragma unroll
     for (int u = 0; u < WGS_XU; ++u) {
         const int r = r0 + u * RL;
         live[u] = r < R;
-        const int rr = live[u] ? r : r0 < R ? r0 : 0;
-        pt[u] = rr / P;
-        const int32_t *I = idx + (b0 + pt[u]) * k + (rr - pt[u] * P);
+        const unsigned rr = live[u] ? r : r0 < R ? r0 : 0;
+        pt[u] = wgs_div(rr, P, pmagic);
+        const unsigned io = (wgs_mul24(pt[u], k) + (rr - wgs_mul24(pt[u], P))) * 4u;
 #pragma unroll
         for (int t = 0; t < MAXT; ++t)
-            if (TT || t < T) nb[u][t] = I[t];
+            if (TT || t < T) nb[u][t] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rsI, (int)(io + 4u * t), 0, 0);
     }
     vec_t acc[WGS_XU], ctr[WGS_XU], tap[WGS_XU][MAXT];
     const vec_t zero = {0.f, 0.f, 0.f, 0.f};
-    const vec_t bv = bias ? *reinterpret_cast<const vec_t *>(bias + (long long)b * bias_bstride + c) : zero;
-    const float *Yt = Y + off + c;
+    const vec_t bv = bias ? *reinterpret_cast<const vec_t *>(bias + (long long)b * bias_bstride + cv * 4) : zero;
 #pragma unroll
     for (int u = 0; u < WGS_XU; ++u) {
-        ctr[u] = offc >= 0 ? *reinterpret_cast<const vec_t *>(Y + (b0 + pt[u]) * ldy + offc + c) : zero;
+        ctr[u] = offc >= 0 ? wgs_ld4(rsY, wgs_mul24(pt[u], ldy4) + cb, (unsigned)offc * 4u) : zero;
 #pragma unroll
         for (int t = 0; t < MAXT; ++t)
-            if (TT || t < T) tap[u][t] = *reinterpret_cast<const vec_t *>(Yt + (b0 + nb[u][t]) * ldy + t * CV * 4);
+            if (TT || t < T) tap[u][t] = wgs_ld4(rsY, wgs_mul24(nb[u][t], ldy4) + cb, (unsigned)off * 4u + t * C4);
     }
 #pragma unroll
     for (int u = 0; u < WGS_XU; ++u) {
@@ -95,8 +119,8 @@ __global__ __launch_bounds__(WGS_THREADS) void wgs_fwd_xcd_kernel(
 #pragma unroll
         for (int t = 0; t < MAXT; ++t)
             if (TT || t < T) acc[u] += tap[u][t];
-        if (live[u])
-            __builtin_nontemporal_store(acc[u], reinterpret_cast<vec_t *>(out + ((b0 * P + r0 + u * RL) * CV + cv) * 4));
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(wgs_u4_t, acc[u]), rsO,
+                                               live[u] ? (int)(wgs_mul24(r0 + u * RL, C4) + cb) : (int)WGS_OOB, 0, 2 /* nt */);
     }
 }
 
@@ -182,10 +206,10 @@ __global__ __launch_bounds__(WGS_THREADS) void wgs_fwd_stats_kernel(
 // statistics; blocks past the tasks zero the partial rows the BatchNorm geometry has beyond b*bpt.
 template <int TT, int CW>
 __global__ __launch_bounds__(WGS_THREADS) void wgs_fwd_stats_xcd_kernel(
-    int ntasks, int bpt, int rpb, int main_blocks, int gy_used, int n, int k, int ldy, int T, int P, int CV, int nchunk,
-    int off, int offc, const float *__restrict__ Y, const int32_t *__restrict__ idx, const float *__restrict__ bias,
+    int ntasks, int bpt, int rpb, int main_blocks, int gy_used, int n, int k, int ldy, int T, int P, unsigned pmagic, int CV,
+    int nchunk, int off, int offc, const float *__restrict__ Y, const int32_t *__restrict__ idx, const float *__restrict__ bias,
     int bias_bstride, float *__restrict__ out, float *__restrict__ part) {
-    typedef float vec_t __attribute__((ext_vector_type(4)));
+    typedef wgs_vec_t vec_t;
     constexpr int MAXT = TT ? TT : 8, RL = WGS_THREADS / CW;
     __shared__ vec_t red[2][WGS_THREADS];
     const int C = CV * 4;
@@ -203,34 +227,36 @@ __global__ __launch_bounds__(WGS_THREADS) void wgs_fwd_stats_xcd_kernel(
     const int cv = chunk * CW + cvl;
     const bool cok = cv < CV;
     const int c = cv * 4, R = n * P;
-    const long long b0 = (long long)b * n;
     const vec_t zero = {0.f, 0.f, 0.f, 0.f};
     vec_t s = zero, q = zero;
     if (cok) {
+        const __amdgpu_buffer_rsrc_t rsY = wgs_rsrc(Y + (size_t)b * n * ldy, (unsigned)n * ldy * 4u);
+        const __amdgpu_buffer_rsrc_t rsI = wgs_rsrc(idx + (size_t)b * n * k, (unsigned)n * k * 4u);
+        const __amdgpu_buffer_rsrc_t rsO = wgs_rsrc(out + (size_t)b * R * CV * 4, (unsigned)R * CV * 16u);
+        const unsigned cb = (unsigned)cv * 16u, ldy4 = (unsigned)ldy * 4u, C4 = (unsigned)CV * 16u;
         const vec_t bv = bias ? *reinterpret_cast<const vec_t *>(bias + (long long)b * bias_bstride + c) : zero;
-        const float *Yt = Y + off + c;
         const int rend = min(R, (blk + 1) * rpb);
         for (int r0 = blk * rpb + rlane; r0 < rend; r0 += RL * WGS_XU) {
-            int pt[WGS_XU], nb[WGS_XU][MAXT];
+            unsigned pt[WGS_XU], nb[WGS_XU][MAXT];
             bool live[WGS_XU];
 #pragma unroll
             for (int u = 0; u < WGS_XU; ++u) {
                 const int r = r0 + u * RL;
                 live[u] = r < rend;
-                const int rr = live[u] ? r : r0;
-                pt[u] = rr / P;
-                const int32_t *I = idx + (b0 + pt[u]) * k + (rr - pt[u] * P);
+                const unsigned rr = live[u] ? r : r0;
+                pt[u] = wgs_div(rr, P, pmagic);
+                const unsigned io = (wgs_mul24(pt[u], k) + (rr - wgs_mul24(pt[u], P))) * 4u;
 #pragma unroll
                 for (int t = 0; t < MAXT; ++t)
-                    if (TT || t < T) nb[u][t] = I[t];
+                    if (TT || t < T) nb[u][t] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rsI, (int)(io + 4u * t), 0, 0);
             }
             vec_t ctr[WGS_XU], tap[WGS_XU][MAXT];
 #pragma unroll
             for (int u = 0; u < WGS_XU; ++u) {
-                ctr[u] = offc >= 0 ? *reinterpret_cast<const vec_t *>(Y + (b0 + pt[u]) * ldy + offc + c) : zero;
+                ctr[u] = offc >= 0 ? wgs_ld4(rsY, wgs_mul24(pt[u], ldy4) + cb, (unsigned)offc * 4u) : zero;
 #pragma unroll
                 for (int t = 0; t < MAXT; ++t)
-                    if (TT || t < T) tap[u][t] = *reinterpret_cast<const vec_t *>(Yt + (b0 + nb[u][t]) * ldy + t * C);
+                    if (TT || t < T) tap[u][t] = wgs_ld4(rsY, wgs_mul24(nb[u][t], ldy4) + cb, (unsigned)off * 4u + t * C4);
             }
 #pragma unroll
             for (int u = 0; u < WGS_XU; ++u) {
@@ -239,7 +265,8 @@ __global__ __launch_bounds__(WGS_THREADS) void wgs_fwd_stats_xcd_kernel(
                 for (int t = 0; t < MAXT; ++t)
                     if (TT || t < T) a += tap[u][t];
                 if (live[u]) {
-                    *reinterpret_cast<vec_t *>(out + ((b0 * P + r0 + u * RL) * CV + cv) * 4) = a;
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(wgs_u4_t, a), rsO,
+                                                           (int)(wgs_mul24(r0 + u * RL, C4) + cb), 0, 0);
                     s += a;
                     q.x = __fmaf_rn(a.x, a.x, q.x); q.y = __fmaf_rn(a.y, a.y, q.y);
                     q.z = __fmaf_rn(a.z, a.z, q.z); q.w = __fmaf_rn(a.w, a.w, q.w);
@@ -309,7 +336,7 @@ extern "C" int pdgn_window_gather_sum(int b, int n, int k, int ldy, int T, int P
     const bool v4 = (C % 4 == 0) && (ldy % 4 == 0) && (off % 4 == 0) && (offc < 0 || offc % 4 == 0) &&
                     (!bias || (bias_bstride % 4 == 0 && ((size_t)bias & 15) == 0));
     static const int xcd = getenv("PDGN_WGS_XCD") ? atoi(getenv("PDGN_WGS_XCD")) : 1;
-    if (v4 && xcd && T <= 8 && (long long)n * P * (C / 4) >= 65536) {   // enough re-read volume for the L2 mapping to matter
+    if (v4 && xcd && T <= 8 && (long long)n * P * (C / 4) >= 65536 && wgs_slabs_ok(n, k, ldy, P, C)) {   // enough re-read volume for the L2 mapping to matter
         static const int cw = wgs_cw("PDGN_WGS_CW", 32);
         const int CV = C / 4, nchunk = cdiv(CV, cw), ntasks = b * nchunk;
         const int bpt = cdiv((long long)n * P, WGS_THREADS / cw * WGS_XU);
@@ -318,10 +345,10 @@ extern "C" int pdgn_window_gather_sum(int b, int n, int k, int ldy, int T, int P
 #define WGS_CALL(W)                                                                                                        \
     if (T == 6)                                                                                                            \
         hipLaunchKernelGGL((wgs_fwd_xcd_kernel<6, W>), dim3((unsigned)blocks), dim3(WGS_THREADS), 0, s, ntasks, bpt, n, k, \
-                           ldy, T, P, CV, nchunk, off, offc, Y, idx, bias, bias_bstride, out);                             \
+                           ldy, T, P, wgs_magic(P), CV, nchunk, off, offc, Y, idx, bias, bias_bstride, out);               \
     else                                                                                                                   \
         hipLaunchKernelGGL((wgs_fwd_xcd_kernel<0, W>), dim3((unsigned)blocks), dim3(WGS_THREADS), 0, s, ntasks, bpt, n, k, \
-                           ldy, T, P, CV, nchunk, off, offc, Y, idx, bias, bias_bstride, out)
+                           ldy, T, P, wgs_magic(P), CV, nchunk, off, offc, Y, idx, bias, bias_bstride, out)
         WGS_DISPATCH_CW(cw, WGS_CALL);
 #undef WGS_CALL
     } else if (v4) {
@@ -348,7 +375,7 @@ extern "C" int pdgn_window_gather_sum_stats(int b, int n, int k, int ldy, int T,
     int cgb, gx, gy, rpb;
     cl_geometry(R, C, &cgb, &gx, &gy, &rpb);
     static const int xcd = getenv("PDGN_WGS_XCD") ? atoi(getenv("PDGN_WGS_XCD")) : 1;
-    if (xcd && (long long)n * P * (C / 4) >= 65536 && gy >= b) {
+    if (xcd && (long long)n * P * (C / 4) >= 65536 && gy >= b && wgs_slabs_ok(n, k, ldy, P, C)) {
         // partial rows: one per (sample, row block); the BatchNorm geometry's gy bounds them, the rest are zeroed
         static const int cw = wgs_cw("PDGN_WGS_SCW", 16);
         const int RLU = WGS_THREADS / cw * WGS_XU;
@@ -362,12 +389,12 @@ extern "C" int pdgn_window_gather_sum_stats(int b, int n, int k, int ldy, int T,
 #define WGS_CALL(W)                                                                                                             \
     if (T == 6)                                                                                                                 \
         hipLaunchKernelGGL((wgs_fwd_stats_xcd_kernel<6, W>), dim3((unsigned)blocks), dim3(WGS_THREADS), 0, (hipStream_t)stream, \
-                           ntasks, bpt, rows, (int)main_blocks, b * bpt, n, k, ldy, T, P, CV, nchunk, off, offc, Y, idx, bias,  \
-                           bias_bstride, out, scratch);                                                                         \
+                           ntasks, bpt, rows, (int)main_blocks, b * bpt, n, k, ldy, T, P, wgs_magic(P), CV, nchunk, off, offc,  \
+                           Y, idx, bias, bias_bstride, out, scratch);                                                           \
     else                                                                                                                        \
         hipLaunchKernelGGL((wgs_fwd_stats_xcd_kernel<0, W>), dim3((unsigned)blocks), dim3(WGS_THREADS), 0, (hipStream_t)stream, \
-                           ntasks, bpt, rows, (int)main_blocks, b * bpt, n, k, ldy, T, P, CV, nchunk, off, offc, Y, idx, bias,  \
-                           bias_bstride, out, scratch)
+                           ntasks, bpt, rows, (int)main_blocks, b * bpt, n, k, ldy, T, P, wgs_magic(P), CV, nchunk, off, offc,  \
+                           Y, idx, bias, bias_bstride, out, scratch)
             WGS_DISPATCH_CW(cw, WGS_CALL);
 #undef WGS_CALL
             return pdgn_launch_status();
@@ -492,7 +519,7 @@ __global__ __launch_bounds__(WGS_THREADS) void wgs_bwd_csr_xcd_kernel(
     int ntasks, int bpt, int n, int k, int ldy, int T, int P, int CV, int nchunk, int off, int offc,
     const float *__restrict__ dout, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ edges,
     float *__restrict__ dY) {
-    typedef float vec_t __attribute__((ext_vector_type(4)));
+    typedef wgs_vec_t vec_t;
     constexpr int MAXT = TT ? TT : 8, JB = WGS_THREADS / 64, WGS_EL = 64 / CW;   // source points per block; edge lanes per column
     const int seq = blockIdx.x >> 3;
     const int task = (seq / bpt) * 8 + (blockIdx.x & 7);
@@ -503,33 +530,35 @@ __global__ __launch_bounds__(WGS_THREADS) void wgs_bwd_csr_xcd_kernel(
     const int j = (seq % bpt) * JB + (threadIdx.x >> 6);
     if (j >= n) return;                                        // wave-uniform
     const bool cok = cv < CV;
-    const int C = CV * 4, c = (cok ? cv : 0) * 4;
-    const long long b0 = (long long)b * n;
+    // one sample's slabs through buffer descriptors, 32-bit offsets (see wgs_fwd_xcd_kernel)
+    const unsigned C4 = (unsigned)CV * 16u, PC4 = (unsigned)P * C4, cb = (unsigned)(cok ? cv : 0) * 16u, ldy4 = (unsigned)ldy * 4u;
+    const __amdgpu_buffer_rsrc_t rsD = wgs_rsrc(dout + (size_t)b * n * P * CV * 4, (unsigned)n * PC4);
+    const __amdgpu_buffer_rsrc_t rsE = wgs_rsrc(edges + (size_t)b * n * k, (unsigned)n * k * 4u);
+    const __amdgpu_buffer_rsrc_t rsY = wgs_rsrc(dY + (size_t)b * n * ldy, (unsigned)n * ldy4);
     const vec_t zero = {0.f, 0.f, 0.f, 0.f};
     vec_t acc[MAXT];
 #pragma unroll
     for (int t = 0; t < MAXT; ++t) acc[t] = zero;
-    const int32_t *E = edges + b0 * k;
     const int e0 = rowptr[(long long)b * (n + 1) + j], e1 = rowptr[(long long)b * (n + 1) + j + 1];
-    const float *D = dout + b0 * P * C + c;
     for (int q = e0 + el; q < e1; q += 2 * WGS_EL) {           // this lane's edges, two at a time
         const bool two = q + WGS_EL < e1;
-        const int ra = E[q], rb = two ? E[q + WGS_EL] : 0;
-        const float *Da = D + (long long)(ra >> 5) * P * C, *Db = D + (long long)(rb >> 5) * P * C;
-        const int sa = ra & 31, sb = two ? (rb & 31) : -64;
+        const unsigned ra = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rsE, q * 4, 0, 0);
+        const unsigned rb = two ? (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rsE, (q + WGS_EL) * 4, 0, 0) : 0u;
+        const unsigned oa = wgs_mul24(ra >> 5, PC4) + cb, ob = wgs_mul24(rb >> 5, PC4) + cb;
+        const int sa = ra & 31, sb = two ? (int)(rb & 31) : -64;
         vec_t va[MAXT], vb[MAXT];
 #pragma unroll
         for (int t = 0; t < MAXT; ++t) {
-            const int pa = sa - t, pb = sb - t;
-            va[t] = ((TT || t < T) && pa >= 0 && pa < P) ? *reinterpret_cast<const vec_t *>(Da + pa * C) : zero;
-            vb[t] = ((TT || t < T) && pb >= 0 && pb < P) ? *reinterpret_cast<const vec_t *>(Db + pb * C) : zero;
+            const int pa = sa - t, pb = sb - t;                // out-of-window taps issue no load (exec-masked)
+            va[t] = ((TT || t < T) && pa >= 0 && pa < P) ? wgs_ld4(rsD, oa + wgs_mul24(pa, C4), 0) : zero;
+            vb[t] = ((TT || t < T) && pb >= 0 && pb < P) ? wgs_ld4(rsD, ob + wgs_mul24(pb, C4), 0) : zero;
         }
 #pragma unroll
         for (int t = 0; t < MAXT; ++t) acc[t] += va[t] + vb[t];
     }
     vec_t ctr = zero;
     if (offc >= 0)                                             // centre columns: the point's own P windows, split too
-        for (int p = el; p < P; p += WGS_EL) ctr += *reinterpret_cast<const vec_t *>(D + ((long long)j * P + p) * C);
+        for (int p = el; p < P; p += WGS_EL) ctr += wgs_ld4(rsD, wgs_mul24(j, PC4) + wgs_mul24(p, C4) + cb, 0);
     // sum over the four edge lanes (lanes l, l+16, l+32, l+48): afterwards every lane holds the totals
 #pragma unroll
     for (int t = 0; t < MAXT; ++t)
@@ -550,11 +579,13 @@ __global__ __launch_bounds__(WGS_THREADS) void wgs_bwd_csr_xcd_kernel(
         ctr[i] = v;
     }
     if (!cok) return;
-    float *O = dY + (b0 + j) * ldy + c;
+    const unsigned oj = wgs_mul24(j, ldy4) + cb;
 #pragma unroll
     for (int t = 0; t < MAXT; ++t)                             // the stores are dealt out over the edge lanes as well
-        if ((TT || t < T) && (t % WGS_EL) == el) *reinterpret_cast<vec_t *>(O + off + t * C) = acc[t];
-    if (offc >= 0 && el == WGS_EL - 1) *reinterpret_cast<vec_t *>(O + offc) = ctr;
+        if ((TT || t < T) && (t % WGS_EL) == el)
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(wgs_u4_t, acc[t]), rsY, (int)oj, (int)((unsigned)off * 4u + t * C4), 0);
+    if (offc >= 0 && el == WGS_EL - 1)
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(wgs_u4_t, ctr), rsY, (int)oj, (int)((unsigned)offc * 4u), 0);
 }
 
 extern "C" int pdgn_knn_graph_transpose(int b, int n, int k, const int32_t *idx, int32_t *rowptr,
@@ -580,7 +611,7 @@ extern "C" int pdgn_window_gather_sum_backward_csr(int b, int n, int k, int ldy,
         return PDGN_ERR_INVALID;
     if (b == 0) return 0;
     static const int xcd = getenv("PDGN_WGS_XCD") ? atoi(getenv("PDGN_WGS_XCD")) : 1;
-    if (xcd && (T <= 8 || T == 10) && (long long)n * T * (C / 4) >= 65536) {
+    if (xcd && (T <= 8 || T == 10) && (long long)n * T * (C / 4) >= 65536 && wgs_slabs_ok(n, k, ldy, P, C)) {
         static const int cw = wgs_cw("PDGN_WGS_BCW", 64);
         const int CV = C / 4, nchunk = cdiv(CV, cw), ntasks = b * nchunk, bpt = cdiv(n, WGS_THREADS / 64);
         const long long blocks = (long long)cdiv(ntasks, 8) * 8 * bpt;

@@ -94,8 +94,12 @@ def _bn_stats(L, x, rows, C, g, b, pre_bias, running_mean, running_var, training
     training, running statistics in eval.  pre_bias: see include/pdgn_hip.h (the producer's bias, left out of x)."""
     stats = torch.empty(4 * C, dtype=F32, device=x.device)
     pb = pre_bias.detach().contiguous() if pre_bias is not None else None
-    if training and partials is not None and partials.dim() == 2:   # (nparts, 2C) rows from a GEMM's epilogue
-        check(L.pdgn_bn_stats_from_gemm_partials(ctypes.c_longlong(rows), C, ctypes.c_longlong(partials.shape[0]),
+    if training and partials is not None and partials.dim() == 2:   # (nparts, 3C) block-shifted rows from a GEMM's epilogue
+        nparts = partials.shape[0]
+        block = getattr(partials, "_pdgn_block", None)          # set by gemm_nt / thin_nt on the tensor they return
+        if block is None:                           # (lost on the way: the kernels' block sizes are 64, 80 and 256 rows)
+            block = next(bs for bs in (64, 80, 256) if -(-rows // bs) <= nparts < -(-rows // bs) + 4 and bs * nparts >= rows)
+        check(L.pdgn_bn_stats_from_gemm_partials(ctypes.c_longlong(rows), C, ctypes.c_longlong(nparts), block,
                                                  ctypes.c_float(eps), ctypes.c_float(momentum), ptr(g), ptr(b), ptr(pb),
                                                  ptr(running_mean), ptr(running_var), ptr(partials), ptr(stats), stream_of(x)),
               "pdgn_bn_stats_from_gemm_partials")
@@ -229,7 +233,8 @@ def gemm_nt(a, w, bias=None, addend=None, want_stats=False, w_transposed=False):
     """a (m, k) @ w (n, k)^T (+ bias) (+ addend) on pdgn_gemm_nt -- or, with w_transposed, a (m, k) @ w (k, n) on
     pdgn_gemm_nn (the input gradient dy @ W straight from the layer's weight).  Channel counts that are not multiples
     of 4 (the xyz layers: k = 3, the heads' last conv: n = 3) are zero-padded for the launch.  want_stats: also returns
-    the BatchNorm partial sums of the result ((parts, 2n) fp32: per-column sum | sum of squares of row blocks)."""
+    the BatchNorm partials of the result ((parts, 3n) fp32, block-shifted: per-column sum (x - pv) | sum (x - pv)^2 | pv of
+    row blocks, pv = the block's first row)."""
     m, k = a.shape
     n = w.shape[1] if w_transposed else w.shape[0]
     if GEMM_LOG is not None:
@@ -255,7 +260,8 @@ def gemm_nt(a, w, bias=None, addend=None, want_stats=False, w_transposed=False):
     part = None
     if want_stats:
         L.pdgn_gemm_nt_stat_rows.restype = ctypes.c_longlong
-        part = torch.empty((L.pdgn_gemm_nt_stat_rows(ctypes.c_longlong(m), np_, kp), 2 * np_), dtype=F32, device=a.device)
+        part = torch.empty((L.pdgn_gemm_nt_stat_rows(ctypes.c_longlong(m), np_, kp), 3 * np_), dtype=F32, device=a.device)
+        part._pdgn_block = int(L.pdgn_gemm_nt_stat_block_rows(ctypes.c_longlong(m), np_, kp))
     b = bias.detach().contiguous() if bias is not None else None
     fn = L.pdgn_gemm_nn if w_transposed else L.pdgn_gemm_nt
     check(fn(ctypes.c_longlong(m), np_, kp, ptr(ap), ap.stride(0), ptr(wp), wp.stride(0), ptr(b), ptr(addend),
@@ -307,7 +313,8 @@ def thin_nt(x, w, wrs, wcs, n, bias=None, want_stats=False):
     part = None
     if want_stats and k <= 4:
         L.pdgn_thin_stat_rows.restype = ctypes.c_longlong
-        part = torch.empty((L.pdgn_thin_stat_rows(ctypes.c_longlong(m)), 2 * n), dtype=F32, device=x.device)
+        part = torch.empty((L.pdgn_thin_stat_rows(ctypes.c_longlong(m)), 3 * n), dtype=F32, device=x.device)
+        part._pdgn_block = int(L.pdgn_thin_stat_block_rows())
     b = bias.detach().contiguous() if bias is not None else None
     check(L.pdgn_thin_nt(ctypes.c_longlong(m), n, k, ptr(x), x.stride(0), ptr(w), wrs, wcs, ptr(b), ptr(out), n, ptr(part),
                          stream_of(x)), "pdgn_thin_nt")

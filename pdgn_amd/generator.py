@@ -136,27 +136,17 @@ class PointGenerator(nn.Module):
         self.mlp1, self.mlp2 = _mlp_head(512 + 32), _mlp_head(512 + 64)
         self.mlp3, self.mlp4 = _mlp_head(512 + 128), _mlp_head(512)
 
-    def forward(self, z, idx=(None, None, None, None), stage_hook=None, feature_hook=None, levels=(0, 4), state=None,
-                level_hook=None):
+    def forward(self, z, idx=(None, None, None, None), stage_hook=None, feature_hook=None):
         """`stage_hook(level, cloud)`, if given, is called as soon as the cloud of a level exists (the trainer starts
         that level's discriminator update on another stream while the deeper levels are still being generated).
         `feature_hook(level, xt)` is called with the input features of every block (the trainer hangs its early gradient
-        bucket on the deepest block's).  `levels=(lo, hi)` runs blocks lo .. hi-1 only: with hi < 4 the pass's STATE is
-        returned instead of the clouds, and a later call with `state=` continues it (the trainer runs the first three
-        blocks of the two generator passes of an iteration on two streams).  `level_hook(level)` is called in front of
-        every block."""
-        lo, hi = levels
-        if state is None:
-            B = z.shape[0]
-            xt = _small_seq(self.fc1, z, self.training).view(B, 32, self.base_points).transpose(1, 2).contiguous()    # (B,N0,32)
-            s = {"B": B, "xt": xt, "pct": None, "const": None, "clouds": [], "pending": (None, None)}
-        else:
-            s, B = state, state["B"]
+        bucket on the deepest block's)."""
+        B = z.shape[0]
+        xt = _small_seq(self.fc1, z, self.training).view(B, 32, self.base_points).transpose(1, 2).contiguous()    # (B,N0,32)
+        s = {"xt": xt, "pct": None, "const": None, "clouds": [], "pending": (None, None)}
         blocks = (self.bilateral1, self.bilateral2, self.bilateral3, self.bilateral4)
         heads = (self.mlp1, self.mlp2, self.mlp3, self.mlp4)
-        for lvl in range(lo, hi):
-            if level_hook is not None:
-                level_hook(lvl)
+        for lvl in range(4):
             xt, pct, const, clouds = s["xt"], s["pct"], s["const"], s["clouds"]
             if feature_hook is not None:
                 feature_hook(lvl, xt)
@@ -181,7 +171,7 @@ class PointGenerator(nn.Module):
                 stage_hook(lvl, clouds[-1])
             s["xt"], s["const"], s["pct"] = x_ec, xs, pct   # next block's input is cat(xs broadcast, x_ec) :708
         _deconv.flush_bn_counters()
-        return tuple(s["clouds"]) if hi == 4 else s
+        return tuple(s["clouds"])
 
 
 class PointDiscriminator(nn.Module):

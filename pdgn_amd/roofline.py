@@ -196,6 +196,18 @@ def knn3_largest(B, base_points, device):
     return e
 
 
+def emd_cost_c5(B, base_points, device, pairs=512):
+    """Config C5's dominant kernel (not part of a training step: the target of the eval PMC pass, tools/run_pmc_roofline.sh):
+    the fused approximate-EMD cost on `pairs` pairs of 2048 x 2048 points."""
+    from .structural_losses import emd_cost
+    g = torch.Generator().manual_seed(9999)
+    a = (torch.rand(pairs, 2048, 3, generator=g) * 2 - 1).to(device)
+    b = (torch.rand(pairs, 2048, 3, generator=g) * 2 - 1).to(device)
+    us = _time_us(lambda: emd_cost(a, b))
+    return {"kernel": "emd_cost_kernel (%d pairs of 2048 x 2048)" % pairs, "bound": "valu-issue", "us_per_launch": us,
+            "pairs_per_s": pairs / us * 1e6}
+
+
 ENTRIES = (conv2_dense_stage4, per_point_stage4, conv2_dense_dx_stage4, weight_grad_stage4, bn_act_backward_stage4,
            window_gather_sum_stage4, feature_knn_stage4, knn3_largest)
 

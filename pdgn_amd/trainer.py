@@ -146,7 +146,6 @@ class PDGNTrainer:
         for ws in {1, world_size() if self.distributed else 1}:
             self._loss_weights(ws)
         self._early_tail = os.environ.get("PDGN_EARLY_TAIL", "1") == "1"
-        self._g1_ahead = os.environ.get("PDGN_G1_AHEAD", "0") == "1"
         self._split_d = os.environ.get("PDGN_SPLIT_D", "1") == "1"
         self._defer_d = os.environ.get("PDGN_DEFER_D", "1") == "1"
         self.sync_replicas()
@@ -436,33 +435,11 @@ class PDGNTrainer:
             d_update(*levels.pop())
 
         hook1 = d_mark if self._defer_d else d_now
-        ahead = self._g1_ahead and not torch.cuda.is_current_stream_capturing()
-        if ahead:
-            # PDGN_G1_AHEAD=1: the first three blocks of the two generator passes are chains of small, latency-bound kernels
-            # (2.9 + 3.3 ms one after the other).  Pass #1's chain runs on D4's stream (idle until level 4 exists), ONE
-            # LEVEL AHEAD of pass #2's chain on the issuing stream: block l of pass #2 starts when block l of pass #1 is
-            # complete, so every BatchNorm layer still updates its running statistics in the reference's order (z1, then
-            # z2).  The two deepest blocks (large kernels that fill the chip) follow one after the other on the issuing stream.
-            g1 = self._side[3]
-            g1.wait_stream(main)
-            done1 = []
-
-            def after_level(level, cloud):
-                hook1(level, cloud)
-                e = torch.cuda.Event()
-                e.record(torch.cuda.current_stream(self.device))
-                done1.append(e)
-            with torch.no_grad(), torch.cuda.stream(g1):
-                s1 = self.G(self._z(st, "z1"), stage_hook=after_level, levels=(0, 3))
-            for level, ev in levels:
-                d_update(level, ev)
-            del levels[:]
-        else:
-            with torch.no_grad():
-                self.G(self._z(st, "z1"), stage_hook=hook1)
-            for level, ev in levels:
-                d_update(level, ev)
-            mark("G(z1) level 4")
+        with torch.no_grad():
+            self.G(self._z(st, "z1"), stage_hook=hook1)
+        for level, ev in levels:
+            d_update(level, ev)
+        mark("G(z1) level 4")
         self.gradG.begin()
         self._freeze_D(True)
         # The shape-preserving loss (12 kNN + Chamfer terms) and the four D(gen) passes read the clouds and nothing of
@@ -485,27 +462,7 @@ class PDGNTrainer:
             with torch.cuda.stream(side):
                 g_loss[level] = F.mse_loss(self.D[level](cloud), st["ones"])
 
-        if ahead:
-            s2 = self.G(self._z(st, "z2"), stage_hook=tail if early else None, feature_hook=self._early_bucket_hook, levels=(0, 3),
-                        level_hook=lambda lvl: main.wait_event(done1[lvl]))
-            mark("G(z1 | z2) levels 1-3")
-            for t in (s1["xt"], s1["const"], s1["pct"]):
-                t.record_stream(main)                       # allocated on g1, read by pass #1's deepest block on `main`
-            with torch.no_grad():
-                self.G(None, stage_hook=hook1, levels=(3, 4), state=s1)
-            for p in self.D[3].parameters():                # D4's update is issued inside the generator's frozen-D window
-                p.requires_grad_(True)
-            for level, ev in levels:
-                d_update(level, ev)
-            for p in self.D[3].parameters():
-                p.requires_grad_(False)
-            self.gradG.begin()                              # (D4's backward took the zero arena: hand it back to G's)
-            del s1
-            mark("G(z1) level 4")
-            gen = self.G(None, stage_hook=tail if early else None, feature_hook=self._early_bucket_hook, levels=(3, 4), state=s2)
-            del s2
-        else:
-            gen = self.G(self._z(st, "z2"), stage_hook=tail if early else None, feature_hook=self._early_bucket_hook)
+        gen = self.G(self._z(st, "z2"), stage_hook=tail if early else None, feature_hook=self._early_bucket_hook)
         mark("G(z2) forward")
         if not early:
             self._side_lp.wait_stream(main)
@@ -576,7 +533,10 @@ class PDGNTrainer:
             return self
         for group in groups:
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, pool=pool):
+            # thread_local: with a communicator alive its watchdog thread polls events (hipEventQuery) at any time; under
+            # the default "global" capture mode such a call from ANOTHER thread invalidates the capture (and surfaced as an
+            # abort when the process group was destroyed, one run in four)
+            with torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local"):
                 for k in group:
                     self._segment(self._static, k)
             pool = g.pool()

@@ -182,6 +182,17 @@ def _composed_step(B, graph, monkeypatch):
     return tr, out
 
 
+def _raw_sums(part, M, block, N):
+    """[sum x | sum x^2] per column from BLOCK-SHIFTED partials (rows of [sum (x - pv) | sum (x - pv)^2 | pv] over blocks of
+    `block` rows, pv = the block's first row), in fp64."""
+    p = part.double().cpu().numpy()
+    nb = np.clip(M - np.arange(p.shape[0]) * block, 0, block).astype(np.float64)[:, None]
+    s, q, pv = p[:, :N], p[:, N:2 * N], p[:, 2 * N:]
+    live = nb[:, 0] > 0
+    s, q, pv, nb = s[live], q[live], pv[live], nb[live]
+    return np.concatenate([(s + nb * pv).sum(0), (q + 2 * pv * s + nb * pv * pv).sum(0)])
+
+
 LOSS_KEYS = ("d_loss1", "d_loss2", "d_loss3", "d_loss4", "g_loss", "similar_loss")
 
 
@@ -509,8 +520,8 @@ def test_thin_layers(M, N, K, bias):
             ((("db", leaves[2].grad, ref[2].grad, 2e-4 * sc),) if bias else ()):
         np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), rtol=1e-4, atol=atol + 1e-6, err_msg=name)
     if K <= 4:
-        assert part is not None and part.shape[1] == 2 * N
-        tot = part.double().sum(0).cpu().numpy()
+        assert part is not None and part.shape[1] == 3 * N
+        tot = _raw_sums(part, M, 256, N)
         np.testing.assert_allclose(tot[:N], yr.detach().sum(0).cpu().numpy(), rtol=1e-4, atol=1e-3 * sc)
         np.testing.assert_allclose(tot[N:], (yr.detach() ** 2).sum(0).cpu().numpy(), rtol=1e-4, atol=1e-3 * sc)
     else:
@@ -789,16 +800,16 @@ def test_gemm_nt_with_epilogues(M, N, K, cfg, monkeypatch):
     ref = A[:rows].double() @ W.double().t()
     assert ((C[:rows].double() - ref).abs() / scale[:rows].double()).max().item() < 1e-5
     nparts = L.pdgn_gemm_nt_stat_rows(ctypes.c_longlong(M), N, K)
-    part = torch.full((nparts, 2 * N), float("nan"), device="cuda")
+    part = torch.full((nparts, 3 * N), float("nan"), device="cuda")
     C2 = torch.full((M, N), float("nan"), device="cuda")
     assert L.pdgn_gemm_nt(ctypes.c_longlong(M), N, K, ptr(A), K, ptr(W), K, ptr(bias), ptr(add), N, ptr(C2), N, ptr(part),
                           stream_of(A)) == 0
     ref2 = (A @ W.t() + bias + add)
     assert ((C2 - ref2).abs() / scale).max().item() < 2e-5
     c64 = C2.double()
-    np.testing.assert_allclose(part[:, :N].double().sum(0).cpu().numpy(), c64.sum(0).cpu().numpy(), rtol=1e-4,
-                               atol=1e-4 * float(c64.abs().sum(0).max()))
-    np.testing.assert_allclose(part[:, N:].double().sum(0).cpu().numpy(), (c64 * c64).sum(0).cpu().numpy(), rtol=1e-4)
+    tot = _raw_sums(part, M, L.pdgn_gemm_nt_stat_block_rows(ctypes.c_longlong(M), N, K), N)
+    np.testing.assert_allclose(tot[:N], c64.sum(0).cpu().numpy(), rtol=1e-4, atol=1e-4 * float(c64.abs().sum(0).max()))
+    np.testing.assert_allclose(tot[N:], (c64 * c64).sum(0).cpu().numpy(), rtol=1e-4)
 
 
 @pytest.mark.parametrize("cfg", [None, 0, 1, 2, 3])
@@ -829,14 +840,39 @@ def test_gemm_nn_input_gradient_form(M, N, K, cfg, monkeypatch):
     ref = A[:rows].double() @ Wt.double()
     assert ((C[:rows].double() - ref).abs() / scale[:rows].double()).max().item() < 1e-5
     nparts = L.pdgn_gemm_nt_stat_rows(ctypes.c_longlong(M), N, K)
-    part = torch.full((nparts, 2 * N), float("nan"), device="cuda")
+    part = torch.full((nparts, 3 * N), float("nan"), device="cuda")
     C2 = torch.full((M, N), float("nan"), device="cuda")
     assert L.pdgn_gemm_nn(ctypes.c_longlong(M), N, K, ptr(A), K, ptr(Wt), N, ptr(bias), ptr(add), N, ptr(C2), N, ptr(part),
                           stream_of(A)) == 0
     assert ((C2 - (A @ Wt + bias + add)).abs() / scale).max().item() < 2e-5
     c64 = C2.double()
-    np.testing.assert_allclose(part[:, :N].double().sum(0).cpu().numpy(), c64.sum(0).cpu().numpy(), rtol=1e-4,
-                               atol=1e-4 * float(c64.abs().sum(0).max()))
+    tot = _raw_sums(part, M, L.pdgn_gemm_nt_stat_block_rows(ctypes.c_longlong(M), N, K), N)
+    np.testing.assert_allclose(tot[:N], c64.sum(0).cpu().numpy(), rtol=1e-4, atol=1e-4 * float(c64.abs().sum(0).max()))
+
+
+@pytest.mark.parametrize("ratio", [30.0, 300.0, 1000.0])
+def test_epilogue_statistics_large_mean(ratio):
+    """|mean| >> std through the PRODUCER path: linear_cl(want_stats=True) -> bn_act with the
+    GEMM's / thin layer's block-shifted partials against fp64 -- normalised output at the north star's 1e-4 where raw
+    fp32 sums (E[x^2] - mean^2) are off by 3e-3 .. 3e-2 (tools/bn_shift.py)."""
+    import torch.nn as nn
+    from pdgn_amd import fused
+    g = torch.Generator(device="cuda").manual_seed(int(ratio))
+    for M, K, N in ((35840, 64, 128), (8960, 3, 64)):
+        x = torch.randn(M, K, device="cuda", generator=g)
+        w = torch.randn(N, K, device="cuda", generator=g) / K ** 0.5
+        add = torch.full((M, N), ratio, device="cuda") if K > 4 else None      # a large common offset: mean / std = ratio
+        b = None if K > 4 else torch.full((N,), ratio, device="cuda")
+        bn = nn.BatchNorm1d(N).cuda().train()
+        y, part = fused.linear_cl(x, w, b, add, True)
+        assert part is not None and part.shape[1] == 3 * N
+        out = fused.bn_act(y, bn, True, act="none", partials=part)
+        y64 = y.double()
+        want = (y64 - y64.mean(0)) / torch.sqrt(y64.var(0, unbiased=False) + bn.eps)
+        err = (out.double() - want).abs().max().item()
+        assert err < 1e-4 * max(1.0, want.abs().max().item()), (M, K, N, ratio, err)
+        np.testing.assert_allclose(bn.running_var.cpu().numpy(), (0.9 + 0.1 * y64.var(0, unbiased=True)).float().cpu().numpy(),
+                                   rtol=1e-4)
 
 
 def test_gemm_nt_strided_operands():

@@ -105,15 +105,16 @@ def test_rccl_path_at_world_size_one_equals_single_process():
             assert all(torch.isfinite(v).item() for v in lg.values())
             assert not b.gradG._early_done and b.gradG._early_work is None
         assert len(b._graphs) == 6
+        b._graphs, b._static = [], None                          # the graphs go before the communicator does
+        torch.cuda.synchronize()
     finally:
         dist.destroy_process_group()
 
 
-def test_g1_ahead_schedule_equals_default(monkeypatch):
-    """PDGN_G1_AHEAD=1 (the first three blocks of generator pass #1 on a side stream, one level ahead of pass #2's) with
-    the split discriminator updates (the real half issued at the start of the iteration) against the plain overlapped
-    schedule with whole updates: the same iteration -- losses, parameters and BatchNorm running statistics after one step
-    from identical state."""
+def test_split_discriminator_updates_equal_whole_updates():
+    """PDGN_SPLIT_D=1 (the default: lossD's real term -- forward and backward -- issued at the start of the iteration, the
+    fake term when the fake cloud exists, gradients summed once) against whole discriminator updates: the same iteration,
+    losses, parameters and BatchNorm running statistics after one step from identical state."""
     from pdgn_amd.trainer import PDGNTrainer, noise, synthetic_batch
     dev = torch.device("cuda:0")
     torch.manual_seed(4)
@@ -121,8 +122,7 @@ def test_g1_ahead_schedule_equals_default(monkeypatch):
     b = PDGNTrainer(device=dev, distributed=False, generator=copy.deepcopy(a.G),
                     discriminators=[copy.deepcopy(d) for d in a.D])
     a.train(), b.train()
-    a._g1_ahead, b._g1_ahead = False, True
-    a._split_d, b._split_d = False, True                         # ... and the discriminator updates in two halves (real early)
+    a._split_d, b._split_d = False, True
     B = 6
     reals = synthetic_batch(B, dev)
     g = torch.Generator().manual_seed(8)
@@ -137,8 +137,10 @@ def test_g1_ahead_schedule_equals_default(monkeypatch):
     for da, db in zip(a.D, b.D):
         for pa, pb in zip(da.parameters(), db.parameters()):
             assert (pa - pb).abs().max().item() <= 3e-4
-    for (ka, va), (kb, vb) in zip(a.G.state_dict().items(), b.G.state_dict().items()):
-        if "running_" in ka:                                     # updated in the reference's order: z1, then z2
-            torch.testing.assert_close(va, vb, rtol=1e-4, atol=1e-6, msg=ka)
-        if "num_batches_tracked" in ka:
-            assert int(va) == int(vb) == 2, ka
+        for (ka, va), (kb, vb) in zip(da.state_dict().items(), db.state_dict().items()):
+            if "running_" in ka:                                 # D's forward calls in the reference's order: real, fake, gen
+                # (the third forward, D(gen), already runs on weights that differ by the rounding of the two schedules'
+                # gradient sums -- one Adam step of 1e-4 on them)
+                torch.testing.assert_close(va, vb, rtol=2e-2, atol=2e-3, msg=ka)
+            if "num_batches_tracked" in ka:
+                assert int(va) == int(vb) == 3, ka

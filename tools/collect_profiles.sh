@@ -1,12 +1,12 @@
 #!/bin/bash
 # Everything under profiles/ for one round, on one MI355X box (run through gpurun from the repo root):
-#   bash tools/collect_profiles.sh gpurun_out/prof r02
+#   bash tools/collect_profiles.sh gpurun_out/prof r03
 set -u
-OUT=${1:-gpurun_out/prof}; TAG=${2:-r02}
+OUT=${1:-gpurun_out/prof}; TAG=${2:-r03}
 mkdir -p $OUT
 python3 bench.py --steps 30 --warmup 5 > $OUT/${TAG}_bench_full.json 2> $OUT/bench.err
 python3 bench.py --eval --steps 10 --warmup 2 > $OUT/${TAG}_eval_c5.json 2>> $OUT/bench.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_bench -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline > $OUT/kt_bench.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_bench -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline --no-eval-c5 > $OUT/kt_bench.log 2>&1
 cp $(find $OUT/kt_bench -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_bench_kernel_stats.csv
 python3 tools/step_kernels.py $OUT/kt_bench 8 > $OUT/${TAG}_step_kernels.txt
 MS=$(python3 -c "import json,sys; print(json.load(open(sys.argv[1]))[\"ms_per_step\"])" $OUT/${TAG}_bench_full.json)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Reduce the per-entry rocprofv3 --pmc passes of tools/roofline_entry.py (run by tools/run_pmc_roofline.sh) into
-  profiles/r02_pmc_mfma.csv  -- matrix-pipe / vector-ALU utilisation and clock of each roofline kernel
+  profiles/r03_pmc_mfma.csv  -- matrix-pipe / vector-ALU utilisation and clock of each roofline kernel
   profiles/traffic.json      -- HBM bytes per launch (FETCH_SIZE + WRITE_SIZE)
 
 Corrections (/opt/skills/guides/MI355X_MICROARCH.md): FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports
@@ -14,7 +14,7 @@ import csv, glob, json, os, sys
 ENTRIES = {   # entry function -> (kernel-name substrings whose dispatches belong to it, FETCH correction, roofline key prefix)
     "conv2_dense_stage4": (["gemm_nt_kernel"], 2.0, "gemm_nt_kernel (conv2 dense half forward"),
     "per_point_stage4": (["gemm_nt_kernel"], 2.0, "gemm_nt_kernel (per-point GEMM"),
-    "conv2_dense_dx_stage4": (["gemm_nt_kernel"], 2.0, "gemm_nt_kernel (conv2 dense half input gradient"),
+    "conv2_dense_dx_stage4": (["gemm_nt_kernel"], 2.0, "gemm_nt_kernel<WT> = pdgn_gemm_nn (conv2 dense half input gradient"),
     "weight_grad_stage4": (["gemm_tn_kernel"], 2.0, "gemm_tn_kernel"),
     "bn_act_backward_stage4": (["cl_bwd_reduce_kernel", "cl_bwd_apply_kernel"], 2.0, "cl_bwd_reduce + cl_bwd_apply"),
     "window_gather_sum_stage4": (["wgs_fwd_xcd_kernel"], 2.0, "wgs_fwd_xcd_kernel"),
@@ -51,7 +51,7 @@ def per_launch(d, subs):
 
 def main():
     root, out_csv, out_json = sys.argv[1:4]
-    traffic = {"_meta": {"batch": 35, "base_points": 128, "arch": "gfx950", "recorded": "round 2, profiles/r02_pmc_mfma.csv run"}}
+    traffic = {"_meta": {"batch": 35, "base_points": 128, "arch": "gfx950", "recorded": "round 3, profiles/r03_pmc_mfma.csv run"}}
     lines = ["entry,kernels,us_per_launch,mfma_busy_frac_of_simd_cycles,valu_insts_per_launch,wave_wait_any_frac,"
              "wave_wait_inst_frac,clock_GHz,fetch_MB,write_MB,traffic_MB"]
     for entry, (subs, corr, key) in ENTRIES.items():
@@ -70,6 +70,21 @@ def main():
     open(out_csv, "w").write("\n".join(lines) + "\n")
     json.dump(traffic, open(out_json, "w"), indent=1)
     print("\n".join(lines))
+    # config C5's kernel: vector-ALU issue (SQ_INSTS_VALU per launch against the instruction model of bench.py::EMD_LOOPS,
+    # issue utilisation = SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES, waves parked = SQ_WAIT_ANY / SQ_WAVE_CYCLES)
+    ed = os.path.join(root, "emd_cost_c5", "valu")
+    if os.path.isdir(ed):
+        m, dm = per_launch(ed, ["emd_cost_kernel"])
+        us = dm.get("SQ_BUSY_CU_CYCLES", 0.0)
+        wc = max(m.get("SQ_WAVE_CYCLES", 1.0), 1.0)
+        el = ["kernel,us_per_launch,valu_insts_per_launch,valu_insts_per_pair_element_sweep,busy_cu_cycles,wave_cycles_quad,"
+              "valu_active_frac_of_wave_cycles,wave_wait_any_frac,wave_wait_inst_frac,clock_GHz",
+              "emd_cost_kernel,%.1f,%.5g,%.3f,%.5g,%.5g,%.3f,%.3f,%.3f,%.2f" % (
+                  us, m.get("SQ_INSTS_VALU", 0.0), m.get("SQ_INSTS_VALU", 0.0) * 64.0 / (512.0 * 19 * 2048 * 2048),
+                  m.get("SQ_BUSY_CU_CYCLES", 0.0), wc, m.get("SQ_ACTIVE_INST_VALU", 0.0) / wc, m.get("SQ_WAIT_ANY", 0.0) / wc,
+                  m.get("SQ_WAIT_INST_ANY", 0.0) / wc, m.get("GRBM_GUI_ACTIVE", 0.0) / 8.0 / max(us, 1e-9) / 1e3)]
+        open(os.path.join(os.path.dirname(out_csv), "r03_eval_pmc.csv"), "w").write("\n".join(el) + "\n")
+        print("\n".join(el))
 
 
 if __name__ == "__main__":
