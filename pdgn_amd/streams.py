@@ -84,8 +84,7 @@ def plan(device):
     if got is not None:
         return got
     capturing = torch.cuda.is_current_stream_capturing()
-    prio = int(os.environ.get("PDGN_SIDE_PRIO", "0"))          # A/B: HIP priority of the side streams (lower = higher priority)
-    cands = [torch.cuda.Stream(device=device, priority=prio) for _ in range(_CANDIDATES)]
+    cands = [torch.cuda.Stream(device=device) for _ in range(_CANDIDATES)]
     if capturing or os.environ.get("PDGN_STREAM_PROBE", "1") != "1":
         # no timing inside a graph capture (and an A/B switch): creation order, as before the probe existed
         p = _PLANS[key] = StreamPlan(cands[:4], cands[4], cands[5], 0, False)
