@@ -251,6 +251,10 @@ long long pdgn_thin_stat_rows(long long m);
 int pdgn_thin_stat_block_rows(void);
 int pdgn_thin_nt(long long m, int n, int k, const float *X, int ldx, const float *W, int wrs, int wcs,
                  const float *bias, float *Y, int ldy, float *stat_part, pdgn_stream_t stream);
+/* The same with a LeakyReLU-derivative factor (k <= 4 form): Y *= (gate > 0 ? 1 : 0.01), gate (m x n, pitch ldgate) a saved
+ * activation -- Y is then the gradient wrt that activation's input (backward of the heads, models/PDGNet_v2.py:835-862). */
+int pdgn_thin_nt_ex(long long m, int n, int k, const float *X, int ldx, const float *W, int wrs, int wcs,
+                    const float *bias, float *Y, int ldy, float *stat_part, const float *gate, int ldgate, pdgn_stream_t stream);
 /* Weight (+ bias) gradient of such a layer: O[i * osi + j * osj] += sum_r A[r, i] B[r, j] for A (m x ta <= 4, pitch lda),
  * B (m x wb, wb % 4 == 0, pitch ldb, 16-byte aligned rows); sum_a[ta] += column sums of A, sum_b[wb] += column sums of B
  * (either may be NULL).  O and the sums are accumulated with fp32 atomics: the caller passes them zero-filled. */
@@ -266,6 +270,16 @@ int pdgn_gemm_nn(long long m, int n, int k, const float *A, int lda, const float
  * least one 128 x 64 tile (pdgn_gemm_tn keeps the small ones). */
 int pdgn_gemm_tn_big(long long m, int n, int k, const float *dY, int ldy, const float *X, int ldx, float *dW,
                      pdgn_stream_t stream);
+/* pdgn_gemm_nt / pdgn_gemm_nn (transposed_w != 0) with an extended epilogue, applied after bias / addend in this order:
+ *   + row_bias[(row / rows_per_group) * ld_rb + col]   a bias per group of rows (the per-sample term of the generator's heads:
+ *                                                      mlp1..4 on cat([g broadcast, x]), models/PDGNet_v2.py:835-862, 868-876)
+ *   LeakyReLU(0.01) on the result (act = 2; 0 = none)
+ *   * (gate[row, col] > 0 ? 1 : 0.01)                  the LeakyReLU derivative of a saved activation: C is then the gradient
+ *                                                      wrt that layer's pre-activation
+ * each replacing an elementwise pass over C.  Whole tiles only (no stream-K tail).  row_bias / gate may be NULL. */
+int pdgn_gemm_nt_ex(long long m, int n, int k, const float *A, int lda, const float *W, int ldw, const float *bias,
+                    const float *addend, int ldadd, float *C, int ldc, float *stat_part, const float *row_bias, int ld_rb,
+                    int rows_per_group, int act, const float *gate, int ldgate, int transposed_w, pdgn_stream_t stream);
 long long pdgn_gemm_nt_stat_rows(long long m, int n, int k);
 int pdgn_gemm_nt_stat_block_rows(long long m, int n, int k);
 /* Tile configuration the launch model picks (0: 256x128, 1: 128x128, 2: 160x64, 3: 128x64 workgroup tiles); host only. */

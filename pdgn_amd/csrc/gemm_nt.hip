@@ -71,9 +71,16 @@ struct NtArgs {
     int tiles_m, tiles_n, tile_begin, tile_end, kchunks;
     long long sk_per_wg;              // stream-K launch: (tile, chunk) iterations per workgroup
     int dbg;                          // PDGN_NT_DBG (measurement only): 1 = stores dropped (out-of-range offsets)
+    // extended epilogue (pdgn_gemm_nt_ex), applied in this order after bias / addend:
+    const float *row_bias;            // + row_bias[(row / rows_per_group) * ld_rb + col]: a bias per GROUP of rows (per sample)
+    int ld_rb, rows_per_group;
+    unsigned rpg_magic;               // row / rows_per_group == umulhi(row, rpg_magic) (rows_per_group > 1)
+    int act;                          // 2: LeakyReLU(0.01) on the result
+    const float *gate;                // result *= (gate[row, col] > 0 ? 1 : 0.01): the LeakyReLU derivative of a saved activation
+    int ldgate;
 };
 
-template <int TM, int TN, int WM, int WN, bool ATOMIC, bool WT, bool AT>
+template <int TM, int TN, int WM, int WN, bool ATOMIC, bool WT, bool AT, bool EPI = false>   // EPI: the extended epilogue of pdgn_gemm_nt_ex
 __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_nt_kernel(const NtArgs p) {
     constexpr int NW = WM * WN, BM = 16 * TM * WM, BN = 16 * TN * WN;
     // WT: the weight operand is given TRANSPOSED, W^T (K x N) row-major (the input gradient dX = dY W uses the layer's own
@@ -318,6 +325,42 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_nt_kernel(const NtArgs p
                     for (int a = 0; a < TM; ++a) acc[a][b] += bz;
                 }
             }
+            if (EPI && p.row_bias) {                               // a bias per group of rows: the heads' per-sample term
+                __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc((void *)p.row_bias, 0, 0x7ffffff0, 0x00020000);
+#pragma unroll
+                for (int a = 0; a < TM; ++a) {
+                    const unsigned row = (unsigned)(m0 + mloc0 + 16 * a);
+                    const unsigned grp = row < (unsigned)p.M ? (p.rows_per_group == 1 ? row : __umulhi(row, p.rpg_magic)) : 0u;
+#pragma unroll
+                    for (int b = 0; b < TN; ++b) {
+                        const int nl = nloc0 + 16 * b;
+                        acc[a][b] += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                                 rsR, nl < ncols ? (grp * (unsigned)p.ld_rb + n0 + nl) * 4u : NT_OOB, 0, 0));
+                    }
+                }
+            }
+            if (EPI && p.act == 2) {
+#pragma unroll
+                for (int a = 0; a < TM; ++a)
+#pragma unroll
+                    for (int b = 0; b < TN; ++b)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc[a][b][r] = acc[a][b][r] > 0.f ? acc[a][b][r] : 0.01f * acc[a][b][r];
+            }
+            if (EPI && p.gate) {                                   // all tile loads in flight at once; out of range reads 0
+                __amdgpu_buffer_rsrc_t rsG = __builtin_amdgcn_make_buffer_rsrc((void *)(p.gate + m0 * p.ldgate + n0), 0,
+                                                                               (int)(mrows * p.ldgate * 4), 0x00020000);
+#pragma unroll
+                for (int b = 0; b < TN; ++b)
+#pragma unroll
+                    for (int a = 0; a < TM; ++a) {
+                        const int ml = mloc0 + 16 * a, nl = nloc0 + 16 * b;
+                        const f32x4 g = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                                     rsG, nl < ncols ? (unsigned)(ml * p.ldgate + nl) * 4u : NT_OOB, 0, 0));
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc[a][b][r] *= g[r] > 0.f ? 1.f : 0.01f;
+                    }
+            }
             if (p.stat_part) {
                 // per-column statistics of the wave's 16*TM rows, SHIFTED by the block's first row (pv): sum (x - pv),
                 // sum (x - pv)^2 and pv itself -- E[x^2] - mean^2 on raw fp32 sums cancels quadratically in |mean| / std,
@@ -506,6 +549,14 @@ static int nt_cus() {
     return cached;
 }
 
+struct NtEpi {                        // extended epilogue of pdgn_gemm_nt_ex (all optional)
+    const float *row_bias = nullptr;
+    int ld_rb = 0, rows_per_group = 1, act = 0;
+    const float *gate = nullptr;
+    int ldgate = 0;
+    bool any() const { return row_bias || act || gate; }
+};
+
 template <int TM, int TN, int WM, int WN, int MAXWG>
 struct NtCfg {
     static constexpr int BM = 16 * TM * WM, BN = 16 * TN * WN;
@@ -579,12 +630,16 @@ struct NtCfg {
 
     template <bool WT, bool AT = false>
     static int launch(long long m, int n, int k, const float *A, int lda, const float *W, int ldw, const float *bias,
-                      const float *addend, int ldadd, float *C, int ldc, float *stat_part, hipStream_t s) {
-        const bool allow_sk = stat_part == nullptr && ldc == n;
+                      const float *addend, int ldadd, float *C, int ldc, float *stat_part, hipStream_t s,
+                      const NtEpi &epi = NtEpi()) {
+        const bool allow_sk = stat_part == nullptr && ldc == n && !epi.any();
         const Plan pl = plan(m, n, k, allow_sk);
         NtArgs a;
         a.M = m; a.N = n; a.K = k; a.lda = lda; a.ldw = ldw; a.ldc = ldc; a.ldadd = ldadd;
         a.A = A; a.W = W; a.bias = bias; a.addend = addend; a.C = C; a.stat_part = stat_part;
+        a.row_bias = epi.row_bias; a.ld_rb = epi.ld_rb; a.rows_per_group = epi.rows_per_group > 0 ? epi.rows_per_group : 1;
+        a.rpg_magic = a.rows_per_group > 1 ? (unsigned)(0x100000000ULL / (unsigned)a.rows_per_group) + 1u : 0u;
+        a.act = epi.act; a.gate = epi.gate; a.ldgate = epi.ldgate;
         a.tiles_m = pl.tiles_m; a.tiles_n = pl.tiles_n; a.kchunks = pl.kchunks;
         { const char *e = getenv("PDGN_NT_DBG"); a.dbg = e ? atoi(e) : 0; }
         const long long T = (long long)pl.tiles_m * pl.tiles_n;
@@ -596,7 +651,10 @@ struct NtCfg {
         }
         if (pl.grid_dp) {
             a.tile_begin = 0; a.tile_end = pl.dp_tiles; a.sk_per_wg = 0;
-            hipLaunchKernelGGL((gemm_nt_kernel<TM, TN, WM, WN, false, WT, AT>), dim3(pl.grid_dp), dim3(64 * WM * WN), 0, s, a);
+            if (!AT && epi.any())
+                hipLaunchKernelGGL((gemm_nt_kernel<TM, TN, WM, WN, false, WT, false, true>), dim3(pl.grid_dp), dim3(64 * WM * WN), 0, s, a);
+            else
+                hipLaunchKernelGGL((gemm_nt_kernel<TM, TN, WM, WN, false, WT, AT>), dim3(pl.grid_dp), dim3(64 * WM * WN), 0, s, a);
         }
         if (pl.grid_sk) {
             a.tile_begin = pl.dp_tiles; a.tile_end = (int)T; a.sk_per_wg = pl.sk_per_wg;
@@ -633,12 +691,13 @@ static bool nt_args_ok(long long m, int n, int k, int lda, int ldw, int ldadd, i
 
 template <bool WT>
 static int nt_dispatch(long long m, int n, int k, const float *A, int lda, const float *W, int ldw, const float *bias,
-                       const float *addend, int ldadd, float *C, int ldc, float *stat_part, hipStream_t s) {
-    switch (nt_pick(m, n, k, stat_part != nullptr)) {
-        case 0: return NtBig::launch<WT>(m, n, k, A, lda, W, ldw, bias, addend, ldadd, C, ldc, stat_part, s);
-        case 2: return NtTall::launch<WT>(m, n, k, A, lda, W, ldw, bias, addend, ldadd, C, ldc, stat_part, s);
-        case 3: return NtNarrow::launch<WT>(m, n, k, A, lda, W, ldw, bias, addend, ldadd, C, ldc, stat_part, s);
-        default: return NtSquare::launch<WT>(m, n, k, A, lda, W, ldw, bias, addend, ldadd, C, ldc, stat_part, s);
+                       const float *addend, int ldadd, float *C, int ldc, float *stat_part, hipStream_t s,
+                       const NtEpi &epi = NtEpi()) {
+    switch (nt_pick(m, n, k, stat_part != nullptr || epi.any())) {
+        case 0: return NtBig::launch<WT>(m, n, k, A, lda, W, ldw, bias, addend, ldadd, C, ldc, stat_part, s, epi);
+        case 2: return NtTall::launch<WT>(m, n, k, A, lda, W, ldw, bias, addend, ldadd, C, ldc, stat_part, s, epi);
+        case 3: return NtNarrow::launch<WT>(m, n, k, A, lda, W, ldw, bias, addend, ldadd, C, ldc, stat_part, s, epi);
+        default: return NtSquare::launch<WT>(m, n, k, A, lda, W, ldw, bias, addend, ldadd, C, ldc, stat_part, s, epi);
     }
 }
 
@@ -660,6 +719,25 @@ extern "C" int pdgn_gemm_nn(long long m, int n, int k, const float *A, int lda, 
                             pdgn_stream_t stream) {
     if (!nt_args_ok(m, n, k, lda, ldw, ldadd, ldc, addend, true)) return PDGN_ERR_INVALID;
     return nt_dispatch<true>(m, n, k, A, lda, Wt, ldw, bias, addend, ldadd, C, ldc, stat_part, (hipStream_t)stream);
+}
+
+// pdgn_gemm_nt / pdgn_gemm_nn (transposed_w != 0) with the extended epilogue:  C = act(A W^T + bias + addend +
+// row_bias[row / rows_per_group]) * lrelu'(gate)  -- a bias per group of rows (the per-sample term of the generator's heads,
+// models/PDGNet_v2.py:835-862 on cat([g broadcast, x])), LeakyReLU(0.01) on the result (act = 2), and / or the LeakyReLU
+// derivative of a saved activation as a factor (gate: the result is the gradient wrt that layer's PRE-activation).  Each of
+// them replaces a full elementwise pass over C.  No stream-K tail (whole tiles only), like a launch with statistics.
+extern "C" int pdgn_gemm_nt_ex(long long m, int n, int k, const float *A, int lda, const float *W, int ldw, const float *bias,
+                               const float *addend, int ldadd, float *C, int ldc, float *stat_part, const float *row_bias,
+                               int ld_rb, int rows_per_group, int act, const float *gate, int ldgate, int transposed_w,
+                               pdgn_stream_t stream) {
+    if (!nt_args_ok(m, n, k, lda, ldw, ldadd, ldc, addend, transposed_w != 0)) return PDGN_ERR_INVALID;
+    if ((act != 0 && act != 2) || (row_bias && (ld_rb < n || ld_rb % 4 || rows_per_group < 1)) ||
+        (gate && (ldgate < n || ldgate % 4)) || m >= (1LL << 31) || (row_bias && m * rows_per_group >= (1LL << 32)))
+        return PDGN_ERR_INVALID;
+    NtEpi e;
+    e.row_bias = row_bias; e.ld_rb = ld_rb; e.rows_per_group = rows_per_group; e.act = act; e.gate = gate; e.ldgate = ldgate;
+    return transposed_w ? nt_dispatch<true>(m, n, k, A, lda, W, ldw, bias, addend, ldadd, C, ldc, stat_part, (hipStream_t)stream, e)
+                        : nt_dispatch<false>(m, n, k, A, lda, W, ldw, bias, addend, ldadd, C, ldc, stat_part, (hipStream_t)stream, e);
 }
 
 // Weight gradient of a point-major dense layer, dW (n x k) = dY (m x n)^T X (m x k): the same kernel with BOTH operands

@@ -17,7 +17,7 @@
 __global__ __launch_bounds__(THIN_THREADS) void thin_k_kernel(long long m, int n, int k, const float *__restrict__ X, int ldx,
                                                               const float *__restrict__ W, int wrs, int wcs,
                                                               const float *__restrict__ bias, float *__restrict__ Y, int ldy,
-                                                              float *__restrict__ part) {
+                                                              float *__restrict__ part, const float *__restrict__ gate, int ldg) {
     __shared__ float red[THIN_THREADS * 8];
     const int n4 = n >> 2;                       // threads per row
     const int rpp = THIN_THREADS / n4;           // rows per pass
@@ -58,6 +58,7 @@ __global__ __launch_bounds__(THIN_THREADS) void thin_k_kernel(long long m, int n
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) acc = __fmaf_rn(x[kk], w[j][kk], acc);
                 ov[j] = acc;
+                if (gate) ov[j] = acc = acc * (gate[r * ldg + c4 * 4 + j] > 0.f ? 1.f : 0.01f);   // LeakyReLU derivative of a saved activation
                 const float d = acc - pv[j];
                 s1[j] += d;
                 s2[j] = __fmaf_rn(d, d, s2[j]);
@@ -183,16 +184,20 @@ static bool thin_aligned(const void *p, int ld) { return ((uintptr_t)p & 15) == 
 extern "C" long long pdgn_thin_stat_rows(long long m) { return (m + THIN_ROWS - 1) / THIN_ROWS; }
 extern "C" int pdgn_thin_stat_block_rows(void) { return THIN_ROWS; }      // rows of Y per [3n] partial row
 
-extern "C" int pdgn_thin_nt(long long m, int n, int k, const float *X, int ldx, const float *W, int wrs, int wcs,
-                            const float *bias, float *Y, int ldy, float *stat_part, pdgn_stream_t stream) {
+// gate (k <= 4 form only, may be NULL; (m x n), pitch ldgate): Y *= (gate > 0 ? 1 : 0.01) -- the LeakyReLU derivative of a
+// saved activation, when Y is the gradient wrt that activation (the heads' backward, no separate elementwise pass).
+extern "C" int pdgn_thin_nt_ex(long long m, int n, int k, const float *X, int ldx, const float *W, int wrs, int wcs,
+                               const float *bias, float *Y, int ldy, float *stat_part, const float *gate, int ldgate,
+                               pdgn_stream_t stream) {
     if (m <= 0 || n <= 0 || k <= 0 || !X || !W || !Y) return -1;
     hipStream_t s = (hipStream_t)stream;
     if (k <= 4 && n % 4 == 0 && n <= 4 * THIN_THREADS) {
-        if (!thin_aligned(Y, ldy)) return -2;
+        if (!thin_aligned(Y, ldy) || (gate && ldgate < n)) return -2;
         hipLaunchKernelGGL(thin_k_kernel, dim3(cdiv(m, THIN_ROWS)), dim3(THIN_THREADS), 0, s, m, n, k, X, ldx, W, wrs, wcs, bias,
-                           Y, ldy, stat_part);
+                           Y, ldy, stat_part, gate, ldgate);
         return pdgn_launch_status();
     }
+    if (gate) return -3;
     if (n <= 4 && k % 4 == 0 && !stat_part) {
         if (!thin_aligned(X, ldx)) return -2;
         hipLaunchKernelGGL(thin_n_kernel, dim3(cdiv(m, THIN_THREADS / 16)), dim3(THIN_THREADS), 0, s, m, n, k, X, ldx, W, wrs, wcs,
@@ -200,6 +205,11 @@ extern "C" int pdgn_thin_nt(long long m, int n, int k, const float *X, int ldx, 
         return pdgn_launch_status();
     }
     return -3;
+}
+
+extern "C" int pdgn_thin_nt(long long m, int n, int k, const float *X, int ldx, const float *W, int wrs, int wcs,
+                            const float *bias, float *Y, int ldy, float *stat_part, pdgn_stream_t stream) {
+    return pdgn_thin_nt_ex(m, n, k, X, ldx, W, wrs, wcs, bias, Y, ldy, stat_part, nullptr, 0, stream);
 }
 
 extern "C" int pdgn_thin_tn(long long m, int ta, int wb, const float *A, int lda, const float *B, int ldb, float *O, int osi,

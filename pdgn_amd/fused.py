@@ -401,6 +401,71 @@ class LinearCL(Function):
         return dx, dw, db, (dy if ctx.has_addend and ctx.needs_input_grad[3] else None), None
 
 
+def gemm_nt_ex(a, w, ldw, n, bias=None, row_bias=None, rows_per_group=1, act=0, gate=None, w_transposed=False):
+    """pdgn_gemm_nt_ex: act(a (m, k) @ W^T + bias + row_bias[row // rows_per_group]) * lrelu'(gate), W given as a data pointer
+    with row pitch ldw ((n, k) rows, or (k, n) with w_transposed): a column slice of a wider weight needs no copy."""
+    m, k = a.shape
+    if GEMM_LOG is not None:
+        GEMM_LOG.append(("nn" if w_transposed else "nt", m, n, k))
+    out = torch.empty((m, n), dtype=F32, device=a.device)
+    b = bias.detach().contiguous() if bias is not None else None
+    check(_lib.lib().pdgn_gemm_nt_ex(ctypes.c_longlong(m), n, k, ptr(a), a.stride(0), ptr(w), ldw, ptr(b), None, 0, ptr(out), n, None,
+                                     ptr(row_bias), row_bias.stride(0) if row_bias is not None else 0, rows_per_group, act,
+                                     ptr(gate), gate.stride(0) if gate is not None else 0, int(w_transposed), stream_of(a)),
+          "pdgn_gemm_nt_ex")
+    return out
+
+
+class HeadMLP(Function):
+    """mlp1..mlp4 of the generator (models/PDGNet_v2.py:835-862) on point-major rows whose input is cat([g broadcast, x]):
+        y1 = LeakyReLU(x W0[:, nc:]^T + (g W0[:, :nc]^T + b0)[sample]),  y2 = LeakyReLU(y1 W2^T + b2),  p = y2 W3^T + b3
+    with the per-sample term, both activations and -- in backward -- both activation derivatives in GEMM / thin-layer epilogues
+    (pdgn_gemm_nt_ex, pdgn_thin_nt_ex): no elementwise pass over the (rows, 256) / (rows, 64) hidden tensors in either direction
+    (they were two adds, two LeakyReLUs and two LeakyReLU adjoints per head and pass: ~1 ms of kernel time and ~50 launches per
+    iteration).  x (B*M, Fo), g (B, nc); W0 (256, nc + Fo), W2 (64, 256), W3 (3, 64) as (C_out, C_in) views."""
+
+    @staticmethod
+    def forward(ctx, x, g, W0, b0, W2, b2, W3, b3, B):
+        x = x.contiguous()
+        rows, Fo = x.shape
+        nc, M = g.shape[1], rows // B
+        W0, W2, W3 = W0.contiguous(), W2.contiguous(), W3.contiguous()
+        rb = torch.addmm(b0, g, W0[:, :nc].t())                                   # (B, 256): 35 rows, the library's skinny GEMM
+        w0x = W0[:, nc:]                                                          # (256, Fo) view, row pitch nc + Fo
+        y1 = gemm_nt_ex(x, w0x, W0.stride(0), W0.shape[0], row_bias=rb, rows_per_group=M, act=2)
+        y2 = gemm_nt_ex(y1, W2, W2.stride(0), W2.shape[0], bias=b2, act=2)
+        p = thin_nt(y2, W3, W3.shape[1], 1, W3.shape[0], b3)
+        ctx.save_for_backward(x, g, W0, W2, W3, y1, y2)
+        ctx.cfg = (B, M, nc)
+        return p
+
+    @staticmethod
+    def backward(ctx, dp):
+        x, g, W0, W2, W3, y1, y2 = ctx.saved_tensors
+        B, M, nc = ctx.cfg
+        dp = dp.contiguous()
+        rows = x.shape[0]
+        L = _lib.lib()
+        dW3, db3 = thin_tn(dp, y2, True)
+        n3, k3 = W3.shape
+        if GEMM_LOG is not None:
+            GEMM_LOG.append(("thin", rows, k3, n3))
+        dpre2 = torch.empty((rows, k3), dtype=F32, device=x.device)               # (dp W3) * lrelu'(y2)
+        check(L.pdgn_thin_nt_ex(ctypes.c_longlong(rows), k3, n3, ptr(dp), dp.stride(0), ptr(W3), 1, k3, None, ptr(dpre2), k3, None,
+                                ptr(y2), y2.stride(0), stream_of(x)), "pdgn_thin_nt_ex")
+        dW2 = gemm_tn(dpre2, y1)
+        db2 = dpre2.sum(dim=0)
+        dpre1 = gemm_nt_ex(dpre2, W2, W2.stride(0), W2.shape[1], gate=y1, w_transposed=True)     # (dpre2 W2) * lrelu'(y1)
+        w0x = W0[:, nc:]
+        dx = gemm_nt_ex(dpre1, w0x, W0.stride(0), x.shape[1], w_transposed=True) if ctx.needs_input_grad[0] else None
+        drb = dpre1.view(B, M, -1).sum(dim=1)                                      # (B, 256): the per-sample term's gradient
+        dW0 = torch.empty_like(W0)
+        dW0[:, :nc].copy_(drb.t().mm(g))
+        dW0[:, nc:].copy_(gemm_tn(dpre1, x))
+        dg = drb.mm(W0[:, :nc]) if ctx.needs_input_grad[1] else None
+        return dx, dg, dW0, drb.sum(dim=0), dW2, db2, dW3, db3, None
+
+
 def linear_cl(x2d, weight, bias=None, addend=None, want_stats=None):
     """Dense layer on point-major rows (see LinearCL); `addend` (M, C_out) is added in the GEMM's epilogue.
     want_stats (True / False, not None): returns the PAIR (y, partials) -- with True the BatchNorm partial sums of y from

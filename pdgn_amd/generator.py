@@ -51,6 +51,10 @@ def _head_rows(head, x_rows, B, g=None, n_const=0):
     are applied once per batch and broadcast, never concatenated."""
     c0 = head[0]
     W = _deconv._w2d(c0)
+    if g is not None and x_rows.is_cuda and x_rows.shape[0] >= 1024 and x_rows.shape[1] % 4 == 0 and n_const % 4 == 0:
+        # on the GPU: per-sample term, activations and their derivatives in the GEMMs' epilogues (fused.HeadMLP)
+        from .fused import HeadMLP
+        return HeadMLP.apply(x_rows, g, W, c0.bias, _deconv._w2d(head[2]), head[2].bias, _deconv._w2d(head[4]), head[4].bias, B)
     h = _linear(x_rows, W[:, n_const:].contiguous())                       # (B*M, 256)
     if g is not None:
         M = x_rows.shape[0] // B

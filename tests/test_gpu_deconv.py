@@ -1049,3 +1049,68 @@ def test_point_max_forward_backward(B, N, C):
             arg[b, c] = int(torch.nonzero(x[b, :, c] == ref[b, c])[0])
     want = torch.zeros_like(x).scatter_(1, arg.unsqueeze(1), g.unsqueeze(1))
     assert torch.equal(xg.grad.cpu(), want)
+
+
+@pytest.mark.parametrize("cfg", [None, 0, 1, 2, 3])
+@pytest.mark.parametrize("M,N,K,rpg", [(35840, 256, 128, 1024), (5000, 132, 36, 250), (8960, 64, 256, 8960), (1000, 36, 20, 1)])
+def test_gemm_nt_extended_epilogue(M, N, K, rpg, cfg, monkeypatch):
+    """pdgn_gemm_nt_ex through the C ABI, every tile configuration: bias per group of rows + LeakyReLU on the result (the
+    heads' first layer), and the LeakyReLU-derivative gate on the transposed-weight form (their backward), against fp64."""
+    import ctypes
+    from pdgn_amd import _lib
+    from pdgn_amd._lib import ptr, stream_of
+    if cfg is None:
+        monkeypatch.delenv("PDGN_NT_CFG", raising=False)
+    else:
+        monkeypatch.setenv("PDGN_NT_CFG", str(cfg))
+    L = _lib.lib()
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    A = torch.randn(M, K, device="cuda", generator=g)
+    W = torch.randn(N, K, device="cuda", generator=g)
+    bias = torch.randn(N, device="cuda", generator=g)
+    groups = -(-M // rpg)
+    rb = torch.randn(groups, N + 4, device="cuda", generator=g)[:, :N]          # pitch > width
+    C = torch.full((M, N), float("nan"), device="cuda")
+    assert L.pdgn_gemm_nt_ex(ctypes.c_longlong(M), N, K, ptr(A), K, ptr(W), K, ptr(bias), None, 0, ptr(C), N, None, ptr(rb),
+                             rb.stride(0), rpg, 2, None, 0, 0, stream_of(A)) == 0
+    grp = torch.arange(M, device="cuda") // rpg
+    ref = torch.nn.functional.leaky_relu(A.double() @ W.double().t() + bias.double() + rb.double()[grp])
+    scale = (A.abs() @ W.abs().t()) + 1
+    assert ((C.double() - ref).abs() / scale.double()).max().item() < 1e-5
+    # transposed-weight form with a gate: C2 = (A2 Wt) * lrelu'(gate)
+    A2 = torch.randn(M, N, device="cuda", generator=g)
+    gate = torch.randn(M, K + 8, device="cuda", generator=g)[:, :K]
+    C2 = torch.full((M, K), float("nan"), device="cuda")
+    assert L.pdgn_gemm_nt_ex(ctypes.c_longlong(M), K, N, ptr(A2), N, ptr(W), K, None, None, 0, ptr(C2), K, None, None, 0, 1, 0,
+                             ptr(gate), gate.stride(0), 1, stream_of(A)) == 0
+    ref2 = (A2.double() @ W.double()) * torch.where(gate > 0, 1.0, 0.01).double()
+    scale2 = (A2.abs() @ W.abs()) + 1
+    assert ((C2.double() - ref2).abs() / scale2.double()).max().item() < 1e-5
+
+
+@pytest.mark.parametrize("B,M,Fo,nc", [(3, 512, 64, 512), (2, 2048, 256, 256), (5, 256, 32, 512)])
+def test_head_mlp_vs_torch(B, M, Fo, nc):
+    """fused.HeadMLP (mlp1..4 with the per-sample term, activations and their derivatives in GEMM epilogues) against the same
+    head on cat([g broadcast, x]) in fp64 torch: output, input gradients and every parameter gradient."""
+    import torch.nn as nn
+    from pdgn_amd.fused import HeadMLP
+    torch.manual_seed(B * M + Fo)
+    head = nn.Sequential(nn.Conv1d(nc + Fo, 256, 1), nn.LeakyReLU(), nn.Conv1d(256, 64, 1), nn.LeakyReLU(), nn.Conv1d(64, 3, 1)).cuda()
+    x = torch.randn(B * M, Fo, device="cuda", requires_grad=True)
+    g = torch.randn(B, nc, device="cuda", requires_grad=True)
+    dp = torch.randn(B * M, 3, device="cuda")
+    w2 = lambda c: c.weight.view(c.weight.shape[0], c.weight.shape[1])
+    p = HeadMLP.apply(x, g, w2(head[0]), head[0].bias, w2(head[2]), head[2].bias, w2(head[4]), head[4].bias, B)
+    p.backward(dp)
+    got = [p.detach(), x.grad, g.grad] + [q.grad.reshape(q.grad.shape[0], -1) if q.grad.dim() == 3 else q.grad for q in head.parameters()]
+    ref = nn.Sequential(nn.Conv1d(nc + Fo, 256, 1), nn.LeakyReLU(), nn.Conv1d(256, 64, 1), nn.LeakyReLU(), nn.Conv1d(64, 3, 1)).double().cuda()
+    ref.load_state_dict({k: v.double() for k, v in head.state_dict().items()})
+    xr, gr = x.detach().double().requires_grad_(True), g.detach().double().requires_grad_(True)
+    inp = torch.cat((gr.unsqueeze(2).expand(-1, -1, M), xr.view(B, M, Fo).transpose(1, 2)), 1)       # (B, nc + Fo, M)
+    pr = ref(inp).transpose(1, 2).reshape(B * M, 3)
+    pr.backward(dp.double())
+    want = [pr.detach(), xr.grad, gr.grad] + [q.grad.reshape(q.grad.shape[0], -1) if q.grad.dim() == 3 else q.grad for q in ref.parameters()]
+    names = ["p", "dx", "dg", "dW0", "db0", "dW2", "db2", "dW3", "db3"]
+    for n, a, b in zip(names, got, want):
+        tol = 1e-4 * max(1.0, float(b.abs().max()))
+        assert (a.double() - b).abs().max().item() < tol * (20 if n.startswith("d") and n != "dx" else 1), n
