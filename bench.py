@@ -231,24 +231,59 @@ def _event_ms(fn, iters=5):
     return s.elapsed_time(e) / iters
 
 
-# Instruction mix of emd_cost_kernel's four inner loops (csrc/structural.hip), read off the gfx950 ISA hipcc emits
+# Instruction mix of emd_cost_kernel<true>'s inner loops (csrc/structural.hip), read off the gfx950 ISA hipcc emits
 # (tools/emd_isa_mix.sh): vector instructions per 16 (own point, staged point) elements of a lane -- one unrolled trip of
 # 4 staged points x 4 own points -- as (packed-fp32 + plain, transcendental).  Issue cost per wave instruction from
 # MI355X_MICROARCH.md, cycle constants: v_add / v_fma / v_pk_* 4 cycles, v_exp_f32 / v_sqrt_f32 8.
-EMD_LOOPS = {"phase1_or_2": (61, 16), "phase3_plus_next_phase1": (111, 32), "phase3_last": (85, 32)}
-EMD_SWEEPS = {"phase1_or_2": 10, "phase3_plus_next_phase1": 8, "phase3_last": 1}      # per cloud pair: 9 levels
+EMD_LOOPS = {"phase1_or_2": (63, 16), "phase3_plus_next_phase1": (112, 32), "phase3_last": (87, 32)}
 
 
-def emd_issue_model(n, m):
-    """(issue cycles per cloud pair on one SIMD lane-group, vector instructions per element, share of them spent on
-    transcendentals) of the fused EMD cost at n x m points."""
-    cyc = ins = trans = 0.0
-    for name, sweeps in EMD_SWEEPS.items():
+def emd_executed_elements(a, b):
+    """Point-pair elements emd_cost_kernel<SORTED> really evaluates, per sweep kind, summed over the pairs (a (P, n, 3),
+    b (P, m, 3) on the GPU, n, m <= 2048): both clouds are sorted by x and a wave (256 own points, x in [xlo, xhi]) walks of
+    every staged tile (1024 points) only the run with x in [xlo - r, xhi + r], r = sqrt(150) / s -- everything outside would
+    have added exact zeros (csrc/structural.hip).  Restated here with torch.searchsorted so that the roofline's work is the
+    work executed, not the dense 19 n m."""
+    import torch
+    P, n, m = a.shape[0], a.shape[1], b.shape[1]
+    xa, xb = a[:, :, 0].sort(dim=1)[0].contiguous(), b[:, :, 0].sort(dim=1)[0].contiguous()
+    SQ = 1.2011224087864498                                    # sqrt(log2 e)
+
+    def sweep(own, staged, s):
+        r = 12.2475 / s
+        tot = 0.0
+        for w0 in range(0, own.shape[1], 256):
+            blk = own[:, w0:w0 + 256]
+            lo_x, hi_x = blk[:, :1] - r, blk[:, -1:] + r
+            for t0 in range(0, staged.shape[1], 1024):
+                tile = staged[:, t0:t0 + 1024].contiguous()
+                lo = torch.searchsorted(tile, lo_x.contiguous(), right=False)
+                hi = torch.searchsorted(tile, hi_x.contiguous(), right=True)
+                lpad = (tile.shape[1] + 3) // 4 * 4
+                run = (torch.clamp((hi + 3) // 4 * 4, max=lpad) - lo // 4 * 4).clamp(min=0)
+                tot += float(run.sum().item()) * 256.0
+        return tot
+    out = {"phase1_or_2": sweep(xa, xb, SQ * 2.0 ** 7), "phase3_plus_next_phase1": 0.0, "phase3_last": 0.0}
+    for j in range(7, -2, -1):
+        out["phase1_or_2"] += sweep(xb, xa, SQ * 2.0 ** j)
+        if j > -1:
+            out["phase3_plus_next_phase1"] += sweep(xa, xb, SQ * 2.0 ** (j - 1))
+        else:
+            out["phase3_last"] += sweep(xa, xb, SQ * 2.0 ** j)
+    return out
+
+
+def emd_issue_model(elements):
+    """(issue cycles over all pairs on one SIMD, vector instructions per executed element, share of the cycles spent on
+    transcendentals) for `elements` = {sweep kind: executed point-pair elements}."""
+    cyc = ins = trans = tot = 0.0
+    for name, el in elements.items():
         plain, tr = EMD_LOOPS[name]
-        cyc += sweeps * (plain * 4 + tr * 8) / 16.0
-        ins += sweeps * (plain + tr) / 16.0
-        trans += sweeps * tr * 8 / 16.0
-    return cyc * n * m / 64.0, ins / 19.0, trans / cyc
+        cyc += el * (plain * 4 + tr * 8) / 16.0
+        ins += el * (plain + tr) / 16.0
+        trans += el * tr * 8 / 16.0
+        tot += el
+    return cyc / 64.0, ins / tot, trans / cyc
 
 
 def eval_c5(pairs=512, steps=5, warmup=1):
@@ -275,17 +310,22 @@ def eval_c5(pairs=512, steps=5, warmup=1):
     dt = (time.perf_counter() - t0) / steps
     ms_emd, ms_cd = _event_ms(lambda: emd_cost(a, b)), _event_ms(lambda: nn_distance(a, b))
     # emd_cost_kernel is bound by vector-instruction ISSUE, not by HBM (inputs: 25 MB) and not by the transcendental
-    # unit alone: `peak` = the pair rate at which its own instruction stream would issue back to back on all 1024 SIMDs
-    # at 2.4 GHz; `exp_frac` = the share of those issue cycles taken by v_exp_f32 / v_sqrt_f32
-    cyc_per_pair, instr_per_element, exp_frac = emd_issue_model(N, N)
-    peak_pairs = 4 * 256 * 2.4e9 / cyc_per_pair
+    # unit alone: `peak` = the pair rate at which the instruction stream it EXECUTES on this input (the sorted sweeps skip
+    # runs of exact zeros: emd_executed_elements) would issue back to back on all 1024 SIMDs at 2.4 GHz; `exp_frac` = the
+    # share of those issue cycles taken by v_exp_f32 / v_sqrt_f32
+    elements = emd_executed_elements(a, b)
+    cyc, instr_per_element, exp_frac = emd_issue_model(elements)
+    peak_pairs = 4 * 256 * 2.4e9 / (cyc / P)
     ach = P / (ms_emd * 1e-3)
+    dense = 19.0 * N * N * P
     return {"pairs": P, "pairs_per_s": P / dt, "ms_per_step": dt * 1e3, "ms_per_512": dt * 1e3 * 512.0 / P,
             "finite": bool(torch.isfinite(cd).all() and torch.isfinite(emd).all()),
             "roofline": {"kernel": "emd_cost_kernel (fused approximate-EMD cost)", "bound": "valu-issue",
                          "achieved": ach, "peak": peak_pairs, "unit": "pairs/s", "frac": ach / peak_pairs,
                          "instr_per_element": instr_per_element, "exp_frac": exp_frac,
-                         "exp_evaluations_per_pair": 19.0 * N * N, "traffic": None, "us_per_launch": ms_emd * 1e3,
+                         "executed_elements_per_pair": sum(elements.values()) / P, "dense_elements_per_pair": 19.0 * N * N,
+                         "executed_fraction_of_dense": sum(elements.values()) / dense,
+                         "traffic": None, "us_per_launch": ms_emd * 1e3,
                          "algorithmic_bytes_per_launch": P * 2.0 * N * 12,
                          "others": [{"kernel": "nndist_kernel (both Chamfer directions)", "bound": "valu",
                                      "achieved": 2.0 * P * N * N / (ms_cd * 1e-3) / 1e9, "unit": "G pair evaluations/s",

@@ -99,7 +99,9 @@ int pdgn_matchcost_grad(int b, int n, int m, const float *xyz1, const float *xyz
 /* Fused forward-only EMD cost for the eval path (evaluation_metrics.py:26-31 calls
  * ApproxMatch then MatchCost and drops `match`): same arithmetic as
  * pdgn_approxmatch + pdgn_matchcost but `match` is never written to HBM.
- * temp (b, 2*(n+m)) scratch, out (b). */
+ * temp: pdgn_emd_cost_temp_floats(b, n, m) floats of scratch (per pair the reference's remain / ratio vectors and the two
+ * clouds as x-sorted float4 rows: the sweeps skip the runs of a tile whose exponentials are exactly zero), out (b). */
+long long pdgn_emd_cost_temp_floats(long long pairs, int n, int m);
 int pdgn_emd_cost(int b, int n, int m, const float *xyz1, const float *xyz2, float *temp,
                   float *out, pdgn_stream_t stream);
 

@@ -8,6 +8,8 @@ README.md:47).  Here the (N_sample x N_ref) matrices are filled by the pair-list
 temporaries, tens of thousands of pairs per launch.  MMD / COV / 1-NNA are the reference's small
 torch reductions over those matrices.
 """
+import ctypes
+
 import torch
 import torch.distributed as dist
 
@@ -72,7 +74,8 @@ def pairwise_emd_cd(sample_pcs, ref_pcs, batch_size=None, shard_over_ranks=False
                   "pdgn_chamfer_gram_indexed")
             # distChamfer returns (P.min(1), P.min(2)) = (per ref point, per sample point); :108 adds their means
             cd[start - lo:stop - lo] = miny.mean(dim=1) + minx.mean(dim=1)
-            temp = torch.empty((npairs, 2 * (N + M)), dtype=F32, device=dev)
+            L.pdgn_emd_cost_temp_floats.restype = ctypes.c_longlong
+            temp = torch.empty(L.pdgn_emd_cost_temp_floats(ctypes.c_longlong(npairs), N, M), dtype=F32, device=dev)
             out = torch.empty((npairs,), dtype=F32, device=dev)
             check(L.pdgn_emd_cost_indexed(npairs, N, M, ptr(sample_pcs), ptr(ia), ptr(ref_pcs), ptr(ib), ptr(temp),
                                           ptr(out), stream_of(sample_pcs)), "pdgn_emd_cost_indexed")

@@ -1,6 +1,8 @@
 """Approximate EMD.  Mirrors evaluation/pytorch_structural_losses/match_cost.py:6-44
 (MatchCostFunction) and the pybind entry points ApproxMatch / MatchCost / MatchCostGrad
 (src/structural_loss.cpp:22-78): the callee allocates outputs."""
+import ctypes
+
 import torch
 from torch.autograd import Function
 
@@ -75,7 +77,9 @@ def emd_cost(seta, setb):
     require(setb, "setb", F32, 3)
     b, n, _ = seta.shape
     m = setb.shape[1]
-    temp = torch.empty((b, (n + m) * 2), dtype=F32, device=seta.device)
+    L = _lib.lib()
+    L.pdgn_emd_cost_temp_floats.restype = ctypes.c_longlong
+    temp = torch.empty(L.pdgn_emd_cost_temp_floats(ctypes.c_longlong(b), n, m), dtype=F32, device=seta.device)
     out = torch.empty((b,), dtype=F32, device=seta.device)
     check(_lib.lib().pdgn_emd_cost(b, n, m, ptr(seta), ptr(setb), ptr(temp), ptr(out), stream_of(seta)),
           "pdgn_emd_cost")

@@ -78,6 +78,31 @@ def test_approxmatch_and_cost_vs_oracle(sl, b, n, m):
         np.testing.assert_allclose(sl.match_cost(dev(a), dev(c)).cpu().numpy(), ref_cost, rtol=RTOL)
 
 
+@pytest.mark.parametrize("case", ["over_lds_sort", "equal_x", "two_clusters", "far_apart", "tiny"])
+def test_emd_cost_sorted_sweeps_edge_cases(sl, case):
+    """emd_cost_kernel sorts both clouds by x and skips the runs whose terms are exact zeros (csrc/structural.hip): clouds
+    beyond the LDS sort buffer (the unsorted instance), ties in x, clouds whose sweeps are almost all skipped, and clouds too
+    far apart for any term at the fine levels to survive, each against the C oracle of approxmatch.cu:22-179."""
+    rng = np.random.default_rng(len(case))
+    if case == "over_lds_sort":
+        a = rng.uniform(-1, 1, (1, 2304, 3)); c = rng.uniform(-1, 1, (1, 2100, 3))
+    elif case == "equal_x":
+        a = rng.uniform(-1, 1, (2, 700, 3)); c = rng.uniform(-1, 1, (2, 900, 3))
+        a[..., 0] = 0.25; c[:, ::2, 0] = 0.25; c[:, 1::2, 0] = -0.5
+    elif case == "two_clusters":
+        a = rng.normal(0, 0.02, (2, 1500, 3)); a[:, :700] += 0.8; a[:, 700:] -= 0.8
+        c = rng.normal(0, 0.02, (2, 2048, 3)); c[:, :300] += 0.8; c[:, 300:] -= 0.8
+    elif case == "far_apart":
+        a = rng.uniform(-1, 1, (2, 1024, 3)); c = rng.uniform(-1, 1, (2, 1024, 3)) + 40.0
+    else:
+        a = rng.uniform(-1, 1, (3, 1, 3)); c = rng.uniform(-1, 1, (3, 5, 3))
+    a, c = a.astype(np.float32), c.astype(np.float32)
+    ref = cref.matchcost(a, c, cref.approxmatch(a, c))
+    np.testing.assert_allclose(sl.emd_cost(dev(a), dev(c)).cpu().numpy(), ref, rtol=RTOL)
+    np.testing.assert_allclose(sl.emd_cost(dev(c), dev(a)).cpu().numpy(), cref.matchcost(c, a, cref.approxmatch(c, a)),
+                               rtol=RTOL)
+
+
 def test_match_cost_backward(sl):
     rng = np.random.default_rng(2)
     a = rng.uniform(-1, 1, (2, 200, 3)).astype(np.float32)

@@ -77,7 +77,7 @@ def main():
         m, dm = per_launch(ed, ["emd_cost_kernel"])
         us = dm.get("SQ_BUSY_CU_CYCLES", 0.0)
         wc = max(m.get("SQ_WAVE_CYCLES", 1.0), 1.0)
-        el = ["kernel,us_per_launch,valu_insts_per_launch,valu_insts_per_pair_element_sweep,busy_cu_cycles,wave_cycles_quad,"
+        el = ["kernel,us_per_launch,valu_insts_per_launch,valu_insts_per_dense_element,busy_cu_cycles,wave_cycles_quad,"
               "valu_active_frac_of_wave_cycles,wave_wait_any_frac,wave_wait_inst_frac,clock_GHz",
               "emd_cost_kernel,%.1f,%.5g,%.3f,%.5g,%.5g,%.3f,%.3f,%.3f,%.2f" % (
                   us, m.get("SQ_INSTS_VALU", 0.0), m.get("SQ_INSTS_VALU", 0.0) * 64.0 / (512.0 * 19 * 2048 * 2048),
