@@ -28,57 +28,7 @@
 //     in that XCD's L2), and, when the tile count does not fill the last round of CUs, the remaining tiles
 //     in a second launch that splits the flattened (tile, k chunk) space evenly ("stream-K" launch, partial
 //     tiles added with fp32 atomics into the zero-filled rows).
-#include <type_traits>
-
-#include "common.h"
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-typedef __attribute__((address_space(3))) void lds_void_t;
-
-#define NT_BK 32
-#define NT_GROUP_M 8
-#define NT_OOB 0x40000000u            // a byte offset past every tile descriptor (num_records < 2^30)
-
-typedef int i32x4 __attribute__((ext_vector_type(4)));
-
-// Buffer descriptor (raw, stride 0): offsets >= bytes read as zero / are not written.
-__device__ __forceinline__ i32x4 nt_srd(const void *base, unsigned bytes) {
-    const unsigned long long b = (unsigned long long)base;
-    i32x4 r;
-    r.x = __builtin_amdgcn_readfirstlane((int)(unsigned)b);
-    r.y = __builtin_amdgcn_readfirstlane((int)((unsigned)(b >> 32) & 0xffffu));
-    r.z = __builtin_amdgcn_readfirstlane((int)bytes);
-    r.w = 0x00020000;
-    return r;
-}
-
-// One LDS-DMA wave instruction: 64 lanes x 16 B, lane l -> LDS byte lds_base + 16 l, from descriptor offset
-// voff (per lane) + soff (scalar).  Issued as inline asm so that the compiler does not order every later LDS read
-// behind it with s_waitcnt vmcnt(0) -- the kernel counts these operations itself.
-__device__ __forceinline__ void nt_dma16(i32x4 srd, unsigned lds_base, unsigned voff, unsigned soff) {
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
-                 :
-                 : "s"(lds_base), "v"(voff), "s"(srd), "s"(soff)
-                 : "memory", "m0");
-}
-
-struct NtArgs {
-    long long M;
-    int N, K, lda, ldw, ldc, ldadd;
-    const float *A, *W, *bias, *addend;
-    float *C, *stat_part;
-    int tiles_m, tiles_n, tile_begin, tile_end, kchunks;
-    long long sk_per_wg;              // stream-K launch: (tile, chunk) iterations per workgroup
-    int dbg;                          // PDGN_NT_DBG (measurement only): 1 = stores dropped (out-of-range offsets)
-    // extended epilogue (pdgn_gemm_nt_ex), applied in this order after bias / addend:
-    const float *row_bias;            // + row_bias[(row / rows_per_group) * ld_rb + col]: a bias per GROUP of rows (per sample)
-    int ld_rb, rows_per_group;
-    unsigned rpg_magic;               // row / rows_per_group == umulhi(row, rpg_magic) (rows_per_group > 1)
-    int act;                          // 2: LeakyReLU(0.01) on the result
-    const float *gate;                // result *= (gate[row, col] > 0 ? 1 : 0.01): the LeakyReLU derivative of a saved activation
-    int ldgate;
-};
+#include "gemm_shared.h"
 
 template <int TM, int TN, int WM, int WN, bool ATOMIC, bool WT, bool AT, bool EPI = false>   // EPI: the extended epilogue of pdgn_gemm_nt_ex
 __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_nt_kernel(const NtArgs p) {
@@ -533,30 +483,6 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_nt_kernel(const NtArgs p
     }
 }
 
-// ------------------------------------------------------------------ host side
-struct NtDev {
-    int cus;
-};
-static int nt_cus() {
-    static int cached = 0;
-    if (!cached) {
-        int dev = 0, cus = 0;
-        if (hipGetDevice(&dev) != hipSuccess ||
-            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1)
-            return 256;
-        cached = cus;
-    }
-    return cached;
-}
-
-struct NtEpi {                        // extended epilogue of pdgn_gemm_nt_ex (all optional)
-    const float *row_bias = nullptr;
-    int ld_rb = 0, rows_per_group = 1, act = 0;
-    const float *gate = nullptr;
-    int ldgate = 0;
-    bool any() const { return row_bias || act || gate; }
-};
-
 template <int TM, int TN, int WM, int WN, int MAXWG>
 struct NtCfg {
     static constexpr int BM = 16 * TM * WM, BN = 16 * TN * WN;
@@ -705,7 +631,7 @@ static int nt_dispatch(long long m, int n, int k, const float *A, int lda, const
 // n, k and every pitch are multiples of 4 floats and all base pointers 16-byte aligned.  stat_part (may be NULL):
 // pdgn_gemm_nt_stat_rows(m, n, k) rows of [3n] floats = per-column sum (x - pv) | sum (x - pv)^2 | pv of row blocks of C
 // (pv: the block's first row; pdgn_gemm_nt_stat_block_rows rows per block) for pdgn_bn_stats_from_gemm_partials.
-extern "C" int pdgn_gemm_nt(long long m, int n, int k, const float *A, int lda, const float *W, int ldw,
+int fp32_gemm_nt(long long m, int n, int k, const float *A, int lda, const float *W, int ldw,
                             const float *bias, const float *addend, int ldadd, float *C, int ldc, float *stat_part,
                             pdgn_stream_t stream) {
     if (!nt_args_ok(m, n, k, lda, ldw, ldadd, ldc, addend, false)) return PDGN_ERR_INVALID;
@@ -714,7 +640,7 @@ extern "C" int pdgn_gemm_nt(long long m, int n, int k, const float *A, int lda, 
 
 // The same product with the second operand given transposed: C (m x n) = A (m x k) Wt (k x n, row pitch ldw) -- the
 // input gradient dX = dY W of a dense layer straight from its (C_out x C_in) weight.
-extern "C" int pdgn_gemm_nn(long long m, int n, int k, const float *A, int lda, const float *Wt, int ldw,
+int fp32_gemm_nn(long long m, int n, int k, const float *A, int lda, const float *Wt, int ldw,
                             const float *bias, const float *addend, int ldadd, float *C, int ldc, float *stat_part,
                             pdgn_stream_t stream) {
     if (!nt_args_ok(m, n, k, lda, ldw, ldadd, ldc, addend, true)) return PDGN_ERR_INVALID;
@@ -726,7 +652,7 @@ extern "C" int pdgn_gemm_nn(long long m, int n, int k, const float *A, int lda, 
 // models/PDGNet_v2.py:835-862 on cat([g broadcast, x])), LeakyReLU(0.01) on the result (act = 2), and / or the LeakyReLU
 // derivative of a saved activation as a factor (gate: the result is the gradient wrt that layer's PRE-activation).  Each of
 // them replaces a full elementwise pass over C.  No stream-K tail (whole tiles only), like a launch with statistics.
-extern "C" int pdgn_gemm_nt_ex(long long m, int n, int k, const float *A, int lda, const float *W, int ldw, const float *bias,
+int fp32_gemm_nt_ex(long long m, int n, int k, const float *A, int lda, const float *W, int ldw, const float *bias,
                                const float *addend, int ldadd, float *C, int ldc, float *stat_part, const float *row_bias,
                                int ld_rb, int rows_per_group, int act, const float *gate, int ldgate, int transposed_w,
                                pdgn_stream_t stream) {
@@ -744,7 +670,7 @@ extern "C" int pdgn_gemm_nt_ex(long long m, int n, int k, const float *A, int ld
 // given transposed, the reduction over the m rows split over the workgroups (stream-K launch, fp32 atomics into dW,
 // which the launch zero-fills itself).  For outputs of at least one 128 x 64 tile; pdgn_gemm_tn (gemm_tn.hip) keeps the
 // small ones.
-extern "C" int pdgn_gemm_tn_big(long long m, int n, int k, const float *dY, int ldy, const float *X, int ldx, float *dW,
+int fp32_gemm_tn_big(long long m, int n, int k, const float *dY, int ldy, const float *X, int ldx, float *dW,
                                 pdgn_stream_t stream) {
     if (m < 1 || n < 4 || k < 4 || n % 4 || k % 4 || ldy % 4 || ldx % 4 || ldy < n || ldx < k || ldy >= (1 << 19) ||
         ldx >= (1 << 19) || m > 0x7fffffffLL * 16)
@@ -759,7 +685,7 @@ extern "C" int pdgn_gemm_tn_big(long long m, int n, int k, const float *dY, int 
 }
 
 // Number of [3n] partial-statistics rows pdgn_gemm_nt writes for this problem (tile rows x waves along m).
-extern "C" long long pdgn_gemm_nt_stat_rows(long long m, int n, int k) {
+long long fp32_gemm_nt_stat_rows(long long m, int n, int k) {
     if (m < 1 || n < 1 || k < 1) return PDGN_ERR_INVALID;
     switch (nt_pick(m, n, k, true)) {
         case 0: return (long long)cdiv(m, NtBig::BM) * 4;
@@ -770,7 +696,7 @@ extern "C" long long pdgn_gemm_nt_stat_rows(long long m, int n, int k) {
 }
 
 // Rows of C each of those partial rows covers (partial p: rows p * block .. ; the blocks past m are empty).
-extern "C" int pdgn_gemm_nt_stat_block_rows(long long m, int n, int k) {
+int fp32_gemm_nt_stat_block_rows(long long m, int n, int k) {
     if (m < 1 || n < 1 || k < 1) return PDGN_ERR_INVALID;
     switch (nt_pick(m, n, k, true)) {
         case 0: return NtBig::BM / 4;
@@ -782,7 +708,7 @@ extern "C" int pdgn_gemm_nt_stat_block_rows(long long m, int n, int k) {
 
 // Tile configuration pdgn_gemm_nt picks for a problem (0: 256x128, 1: 128x128, 2: 160x64, 3: 128x64), + 16 when a
 // stream-K launch follows the data-parallel one; host-side only.
-extern "C" int pdgn_gemm_nt_config(long long m, int n, int k, int with_stats) {
+int fp32_gemm_nt_config(long long m, int n, int k, int with_stats) {
     if (m < 1 || n < 1 || k < 1) return PDGN_ERR_INVALID;
     const int c = nt_pick(m, n, k, with_stats != 0);
     const bool sk = !with_stats;

@@ -1,0 +1,93 @@
+// gemm_shared.h -- what the two dense-contraction kernels (gemm_nt.hip: fp32 matrix instructions; gemm_x3.hip: fp32 operands
+// split into three bf16 parts) have in common: operand descriptors, the LDS-DMA instruction, the argument block.
+#pragma once
+#include <type_traits>
+
+#include "common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void lds_void_t;
+
+#define NT_BK 32
+#define NT_GROUP_M 8
+#define NT_OOB 0x40000000u            // a byte offset past every tile descriptor (num_records < 2^30)
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+// Buffer descriptor (raw, stride 0): offsets >= bytes read as zero / are not written.
+__device__ __forceinline__ i32x4 nt_srd(const void *base, unsigned bytes) {
+    const unsigned long long b = (unsigned long long)base;
+    i32x4 r;
+    r.x = __builtin_amdgcn_readfirstlane((int)(unsigned)b);
+    r.y = __builtin_amdgcn_readfirstlane((int)((unsigned)(b >> 32) & 0xffffu));
+    r.z = __builtin_amdgcn_readfirstlane((int)bytes);
+    r.w = 0x00020000;
+    return r;
+}
+
+// One LDS-DMA wave instruction: 64 lanes x 16 B, lane l -> LDS byte lds_base + 16 l, from descriptor offset
+// voff (per lane) + soff (scalar).  Issued as inline asm so that the compiler does not order every later LDS read
+// behind it with s_waitcnt vmcnt(0) -- the kernel counts these operations itself.
+__device__ __forceinline__ void nt_dma16(i32x4 srd, unsigned lds_base, unsigned voff, unsigned soff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                 :
+                 : "s"(lds_base), "v"(voff), "s"(srd), "s"(soff)
+                 : "memory", "m0");
+}
+
+struct NtArgs {
+    long long M;
+    int N, K, lda, ldw, ldc, ldadd;
+    const float *A, *W, *bias, *addend;
+    float *C, *stat_part;
+    int tiles_m, tiles_n, tile_begin, tile_end, kchunks;
+    long long sk_per_wg;              // stream-K launch: (tile, chunk) iterations per workgroup
+    int dbg;                          // PDGN_NT_DBG (measurement only): 1 = stores dropped (out-of-range offsets)
+    // extended epilogue (pdgn_gemm_nt_ex), applied in this order after bias / addend:
+    const float *row_bias;            // + row_bias[(row / rows_per_group) * ld_rb + col]: a bias per GROUP of rows (per sample)
+    int ld_rb, rows_per_group;
+    unsigned rpg_magic;               // row / rows_per_group == umulhi(row, rpg_magic) (rows_per_group > 1)
+    int act;                          // 2: LeakyReLU(0.01) on the result
+    const float *gate;                // result *= (gate[row, col] > 0 ? 1 : 0.01): the LeakyReLU derivative of a saved activation
+    int ldgate;
+};
+
+// ------------------------------------------------------------------ host side
+struct NtDev {
+    int cus;
+};
+static inline int nt_cus() {
+    static int cached = 0;
+    if (!cached) {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1)
+            return 256;
+        cached = cus;
+    }
+    return cached;
+}
+
+struct NtEpi {                        // extended epilogue of pdgn_gemm_nt_ex (all optional)
+    const float *row_bias = nullptr;
+    int ld_rb = 0, rows_per_group = 1, act = 0;
+    const float *gate = nullptr;
+    int ldgate = 0;
+    bool any() const { return row_bias || act || gate; }
+};
+
+
+// The fp32-matrix-instruction forms of the public entry points (gemm_nt.hip); gemm_x3.hip dispatches between the two.
+int fp32_gemm_nt(long long m, int n, int k, const float *A, int lda, const float *W, int ldw, const float *bias,
+                 const float *addend, int ldadd, float *C, int ldc, float *stat_part, pdgn_stream_t stream);
+int fp32_gemm_nn(long long m, int n, int k, const float *A, int lda, const float *Wt, int ldw, const float *bias,
+                 const float *addend, int ldadd, float *C, int ldc, float *stat_part, pdgn_stream_t stream);
+int fp32_gemm_nt_ex(long long m, int n, int k, const float *A, int lda, const float *W, int ldw, const float *bias,
+                    const float *addend, int ldadd, float *C, int ldc, float *stat_part, const float *row_bias, int ld_rb,
+                    int rows_per_group, int act, const float *gate, int ldgate, int transposed_w, pdgn_stream_t stream);
+int fp32_gemm_tn_big(long long m, int n, int k, const float *dY, int ldy, const float *X, int ldx, float *dW,
+                     pdgn_stream_t stream);
+long long fp32_gemm_nt_stat_rows(long long m, int n, int k);
+int fp32_gemm_nt_stat_block_rows(long long m, int n, int k);
+int fp32_gemm_nt_config(long long m, int n, int k, int with_stats);

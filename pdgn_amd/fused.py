@@ -97,8 +97,8 @@ def _bn_stats(L, x, rows, C, g, b, pre_bias, running_mean, running_var, training
     if training and partials is not None and partials.dim() == 2:   # (nparts, 3C) block-shifted rows from a GEMM's epilogue
         nparts = partials.shape[0]
         block = getattr(partials, "_pdgn_block", None)          # set by gemm_nt / thin_nt on the tensor they return
-        if block is None:                           # (lost on the way: the kernels' block sizes are 64, 80 and 256 rows)
-            block = next(bs for bs in (64, 80, 256) if -(-rows // bs) <= nparts < -(-rows // bs) + 4 and bs * nparts >= rows)
+        if block is None:                           # (lost on the way: the kernels' block sizes are 64, 80, 128 and 256 rows)
+            block = next(bs for bs in (64, 80, 128, 256) if -(-rows // bs) <= nparts < -(-rows // bs) + 4 and bs * nparts >= rows)
         check(L.pdgn_bn_stats_from_gemm_partials(ctypes.c_longlong(rows), C, ctypes.c_longlong(nparts), block,
                                                  ctypes.c_float(eps), ctypes.c_float(momentum), ptr(g), ptr(b), ptr(pb),
                                                  ptr(running_mean), ptr(running_var), ptr(partials), ptr(stats), stream_of(x)),
