@@ -31,8 +31,11 @@
 
 #include "gemm_shared.h"
 
+#ifndef X3_FENCE
+#define X3_FENCE 2                    // MFMAs per scheduling region of the main loop
+#endif
 #ifndef X3_ABLATE
-#define X3_ABLATE 0                   // tools/x3_bench.hip (measurement only): 1 no splits, 2 no refills, 4 no stores, 8 no barrier, 16 no LDS reads
+#define X3_ABLATE 0                   // tools/x3_bench.hip (measurement only): 1 no conversion tasks, 2 no operand loads, 4 no stores, 8 no barrier, 16 no fragment reads, 32 no split arithmetic, 64 one LDS write per group
 #endif
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -64,25 +67,15 @@ __device__ __forceinline__ f32x16 x3_mfma(const u32x4 a, const u32x4 b, const f3
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
-// TM x TN blocks of 32 x 32 per wave, WM x WN waves, OCC workgroups per CU by registers.
+// TM x TN blocks of 32 x 32 per wave, WM x WN waves, OCC workgroups per CU.
 template <int TM, int TN, int WM, int WN, int OCC, bool ATOMIC, bool WT, bool AT, bool EPI = false>
 __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_x3_kernel(const NtArgs p) {
-    constexpr int NW = WM * WN, BM = 32 * TM * WM, BN = 32 * TN * WN;
-    // WT / AT: the operand is given transposed (K x N / K x M row-major), its chunk is [32 k][BN or BM] in LDS in 1-KB
-    // pieces padded apart so that the b32 fragment reads of rows k and k + 8 (the two lane groups) fall on different banks.
-    constexpr int WROWS = 256 / (BN > 256 ? 256 : BN), WPAD = WT ? 4 * WROWS : 0;
-    constexpr int AROWS = 256 / (BM > 256 ? 256 : BM), APAD = AT ? 4 * AROWS : 0;
-    static_assert(!AT || (BM <= 256 && 256 % BM == 0 && 8 % AROWS == 0), "A^T pieces: whole rows, a divisor of 8 per piece");
-    static_assert(!WT || (BN <= 256 && 256 % BN == 0 && 8 % WROWS == 0), "W^T pieces: whole rows, a divisor of 8 per piece");
-    constexpr int A_FLOATS = BM * NT_BK + (BM / 8) * APAD;
-    constexpr int STAGE_FLOATS = A_FLOATS + BN * NT_BK + (BN / 8) * WPAD;
-    constexpr int NPA = BM / 8 / NW, NPB = BN / 8 / NW, NP = NPA + NPB;   // 1-KB DMA pieces per wave and chunk
-    constexpr int NS = ATOMIC ? 0 : 4 * TM * TN;                          // counted stores per wave and item
-    static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "pieces must divide over the waves");
-    constexpr int TOTAL = 6 * TM * TN;                                    // MFMAs of one k step
-    constexpr int NPAIR = 4 * (TM + TN);                                  // value pairs to split per k step
-    static_assert(TOTAL >= 2 * NP, "a k step must have room for the DMA pieces between its MFMAs");
-    __shared__ __attribute__((aligned(1024))) float smem[2 * STAGE_FLOATS];
+    constexpr int NW = WM * WN, NTH = 64 * NW, BM = 32 * TM * WM, BN = 32 * TN * WN;
+    // A chunk in LDS: per operand three bf16 parts of [rows][32 k] (64 B per row); the 16-B column c (k = 8c .. 8c + 7) of
+    // row r is stored at position c ^ ((r >> 1) & 3): the b128 fragment reads (8 consecutive rows, one column) and the
+    // b64 writes of the loaders (16 lanes = 2 rows x 64 B) are bank-conflict-free.
+    constexpr int PART_A = BM * 64, PART_W = BN * 64, STAGE = 3 * (PART_A + PART_W);
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * STAGE];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -141,20 +134,48 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_x3_kernel(const NtArgs
     cp = ld;
     if (!ld.valid) return;
 
-    // ---- per-lane constants of the DMA: piece i of a wave covers rows 8*(wave + i*NW) .. +7 of the A (then W) part
-    const int drow = lane >> 3;                                   // row inside the piece == (row & 7)
-    const int dcol = (lane & 7) ^ drow;                           // 16-B source column stored at position lane & 7
-    unsigned voffA[NPA], voffB[NPB];
-#pragma unroll
-    for (int i = 0; i < NPA; ++i)
-        voffA[i] = AT ? (unsigned)(((wave + i * NW) * AROWS + lane / (BM / 4)) * p.lda + (lane % (BM / 4)) * 4) * 4u
-                      : (unsigned)(((wave + i * NW) * 8 + drow) * p.lda + dcol * 4) * 4u;
-#pragma unroll
-    for (int i = 0; i < NPB; ++i)
-        voffB[i] = WT ? (unsigned)(((wave + i * NW) * WROWS + lane / (BN / 4)) * p.ldw + (lane % (BN / 4)) * 4) * 4u
-                      : (unsigned)(((wave + i * NW) * 8 + drow) * p.ldw + dcol * 4) * 4u;
+    // ---- loaders: global -> registers (one chunk ahead of the conversion, two ahead of the products).  A load is 16 B per
+    // lane = 4 values; the 64 lanes of a wave instruction cover whole 128-B lines:
+    //   row-major operand: 8 rows x 32 k (lane: row l >> 3, k quad l & 7);
+    //   transposed operand (K x rows in memory): 4 loads = k rows 4 kq .. 4 kq + 3 at the same 4 columns, transposed in
+    //   registers into 4 rows x 4 k.
+    // Either way a thread ends up with "quads": 4 consecutive k of one row = one 8-B write per part.
+    constexpr int QA = BM * 8 / NTH, QW = BN * 8 / NTH, NQ = QA + QW;        // quads per thread and chunk
+    static_assert(QA * NTH == BM * 8 && QW * NTH == BN * 8, "loader quads must divide over the threads");
+    constexpr int CUA = QA % 4 == 0 ? 4 : 2, CUW = QW % 4 == 0 ? 4 : 2;     // columns per transposed unit (16-B or 8-B loads)
+    static_assert((!AT || QA % CUA == 0) && (!WT || QW % CUW == 0), "transposed operand: whole units per thread");
+    float raw[NQ][4];
+    // quad q of the thread: row-major: piece (wave + j NW) of 8 rows; transposed: unit (tid + j NTH) = (k quad, column quad)
+    unsigned goffA0, goffW0, woffA0, woffW0;                       // byte offsets of quad 0 (global: inside the tile / chunk; LDS: part 0)
+    int kqA, kqW;                                                  // k quad of the thread's row-major quads (one per operand)
+    {
+        const int r8 = lane >> 3, c16 = lane & 7;
+        kqA = kqW = c16;
+        if (!AT) {
+            const int row = wave * 8 + r8;
+            goffA0 = (unsigned)(row * p.lda + 4 * c16) * 4u;
+            woffA0 = (unsigned)(row * 64 + (((c16 >> 1) ^ ((row >> 1) & 3)) * 16) + (c16 & 1) * 8);
+        } else {
+            const int cq = tid % (BM / CUA), kq = tid / (BM / CUA);          // units per chunk: 8 k quads x BM / CUA column groups
+            goffA0 = (unsigned)((4 * kq) * p.lda + CUA * cq) * 4u;
+            woffA0 = 0;                                            // (computed per quad in conv_write)
+        }
+        if (!WT) {
+            const int row = wave * 8 + r8;
+            goffW0 = (unsigned)(row * p.ldw + 4 * c16) * 4u;
+            woffW0 = (unsigned)(3 * PART_A + row * 64 + (((c16 >> 1) ^ ((row >> 1) & 3)) * 16) + (c16 & 1) * 8);
+        } else {
+            const int cq = tid % (BN / CUW), kq = tid / (BN / CUW);
+            goffW0 = (unsigned)((4 * kq) * p.ldw + CUW * cq) * 4u;
+            woffW0 = 0;
+        }
+    }
+    // transposed: the thread's units are NTH apart in unit index = NTH / (B / CU) k quads further (B / CU column groups per k quad)
+    constexpr int KQ_STEP_A = NTH / (BM / CUA > NTH ? NTH : BM / CUA), KQ_STEP_W = NTH / (BN / CUW > NTH ? NTH : BN / CUW);
+    static_assert(!AT || (BM / CUA <= NTH && NTH % (BM / CUA) == 0), "A^T units");
+    static_assert(!WT || (BN / CUW <= NTH && NTH % (BN / CUW) == 0), "W^T units");
 
-    i32x4 rsA, rsW;
+    __amdgpu_buffer_rsrc_t rsA, rsW;                               // descriptors of the load cursor's chunk
     long long ld_m0 = 0;
     int ld_n0 = 0, ld_mrows = 0, ld_nrows = 0;
     auto make_srds = [&](int tile) {
@@ -164,37 +185,60 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_x3_kernel(const NtArgs
         ld_n0 = tn * BN;
         ld_mrows = (int)min((long long)BM, p.M - ld_m0);
         ld_nrows = min(BN, p.N - ld_n0);
-        if (!AT) rsA = nt_srd(p.A + ld_m0 * p.lda, (unsigned)((long long)ld_mrows * p.lda * 4));
-        if (!WT) rsW = nt_srd(p.W + (long long)ld_n0 * p.ldw, (unsigned)(ld_nrows * p.ldw * 4));
     };
     make_srds(ld.tile);
-
-    const unsigned smem_base = (unsigned)(size_t)(lds_void_t *)smem;
     int ld_k0 = 0;
-    bool ld_kok = true;
-    unsigned ld_dst = 0, ld_dst_w = 0, ld_dst_a = 0;
-    auto issue_begin = [&](int stage) {
+    bool kokA = true, kokW = true;
+    auto issue_begin = [&]() {                                     // the load cursor's chunk; past the end of the sequence: empty descriptors
         ld_k0 = ld.kc * NT_BK;
-        ld_kok = ld_k0 + dcol * 4 < p.K;                           // K % 4 == 0: a 16-B column is all in or all out
-        ld_dst = smem_base + (unsigned)(stage * STAGE_FLOATS + wave * 256) * 4u;
-        ld_dst_w = smem_base + (unsigned)(stage * STAGE_FLOATS + A_FLOATS + wave * (256 + WPAD)) * 4u;
-        ld_dst_a = smem_base + (unsigned)(stage * STAGE_FLOATS + wave * (256 + APAD)) * 4u;
-        const int krows = min(NT_BK, p.K - ld_k0);                 // reduction rows of this chunk: the rest reads as zero
-        if (AT) rsA = nt_srd(p.A + (long long)ld_k0 * p.lda + ld_m0, (unsigned)(((long long)(krows - 1) * p.lda + ld_mrows) * 4));
-        if (WT) rsW = nt_srd(p.W + (long long)ld_k0 * p.ldw + ld_n0, (unsigned)(((long long)(krows - 1) * p.ldw + ld_nrows) * 4));
+        kokA = ld_k0 + 4 * kqA < p.K;                              // K % 4 == 0: a 16-B column is all in or all out
+        kokW = ld_k0 + 4 * kqW < p.K;
+        const int krows = min(NT_BK, p.K - ld_k0);
+        const bool ok = ld.valid;
+        if (!AT) rsA = __builtin_amdgcn_make_buffer_rsrc((void *)(p.A + ld_m0 * p.lda + ld_k0), 0,
+                                                         ok ? (int)(((long long)(ld_mrows - 1) * p.lda + (p.K - ld_k0)) * 4) : 0, 0x00020000);
+        else rsA = __builtin_amdgcn_make_buffer_rsrc((void *)(p.A + (long long)ld_k0 * p.lda + ld_m0), 0,
+                                                     ok ? (int)(((long long)(krows - 1) * p.lda + ld_mrows) * 4) : 0, 0x00020000);
+        if (!WT) rsW = __builtin_amdgcn_make_buffer_rsrc((void *)(p.W + (long long)ld_n0 * p.ldw + ld_k0), 0,
+                                                         ok ? (int)(((long long)(ld_nrows - 1) * p.ldw + (p.K - ld_k0)) * 4) : 0, 0x00020000);
+        else rsW = __builtin_amdgcn_make_buffer_rsrc((void *)(p.W + (long long)ld_k0 * p.ldw + ld_n0), 0,
+                                                     ok ? (int)(((long long)(krows - 1) * p.ldw + ld_nrows) * 4) : 0, 0x00020000);
     };
-    auto issue_piece = [&](int i) {
-        if (i < NPA) {
-            const int j = i < NPA ? i : 0;
-            if (!AT) nt_dma16(rsA, ld_dst + j * NW * 1024, ld_kok ? voffA[j] : NT_OOB, ld_k0 * 4);
-            else nt_dma16(rsA, ld_dst_a + j * NW * (1024 + APAD * 4), voffA[j], 0);
-        } else {
-            const int j = i < NPA ? 0 : i - NPA;
-            if (!WT) nt_dma16(rsW, ld_dst + A_FLOATS * 4 + j * NW * 1024, ld_kok ? voffB[j] : NT_OOB, ld_k0 * 4);
-            else nt_dma16(rsW, ld_dst_w + j * NW * (1024 + WPAD * 4), voffB[j], 0);
+    // the load(s) that fill quad q (transposed: the 4 loads of its unit, issued with the unit's first quad)
+    auto load_quad = [&](int q) {
+        const bool isA = q < QA;
+        const bool tr = isA ? AT : WT;
+        const int j = isA ? q : q - QA;
+        const __amdgpu_buffer_rsrc_t rs = isA ? rsA : rsW;
+        const int ld_ = isA ? p.lda : p.ldw;
+        const unsigned g0 = isA ? goffA0 : goffW0;
+        if (!tr) {
+            const unsigned off = g0 + (unsigned)(j * NW * 8 * ld_) * 4u;
+            const f32x4 x = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (isA ? kokA : kokW) ? off : NT_OOB, 0, 0));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) raw[q][e] = x[e];
+        } else if ((isA ? CUA : CUW) == 4) {
+            if ((j & 3) == 0) {
+                const unsigned off = g0 + (unsigned)((j >> 2) * (isA ? KQ_STEP_A : KQ_STEP_W) * 4 * ld_) * 4u;
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const f32x4 x = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off + (unsigned)(kk * ld_) * 4u, 0, 0));
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) raw[q + c][kk] = x[c];
+                }
+            }
+        } else if ((j & 1) == 0) {
+            const unsigned off = g0 + (unsigned)((j >> 1) * (isA ? KQ_STEP_A : KQ_STEP_W) * 4 * ld_) * 4u;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const f32x2 x = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs, off + (unsigned)(kk * ld_) * 4u, 0, 0));
+                raw[q][kk] = x[0];
+                raw[q + 1][kk] = x[1];
+            }
         }
     };
     auto advance_load = [&]() {
+        if (!ld.valid) return;
         ld.kc++;
         if (ld.kc == ld.ke) {
             next_item(ld);
@@ -202,60 +246,71 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_x3_kernel(const NtArgs
         }
     };
 
-    // ---- fragment reads.  Row-major operand: row li of a 32-row block, the 16-B columns 4s + 2 lg and + 1 of k step s,
-    // stored at (column ^ (row & 7)): the second one is the first's position ^ 1.
-    const int fo[2] = {li * NT_BK + 4 * ((2 * lg) ^ (li & 7)), li * NT_BK + 4 * ((4 + 2 * lg) ^ (li & 7))};
-    const int abase = wm * 32 * TM * NT_BK, bbase = A_FLOATS + wn * 32 * TN * NT_BK;
-    // transposed operand: k row r of the chunk sits at float (r / ROWS) * (256 + PAD) + (r % ROWS) * B; a lane's element u
-    // of k step s is row 16 s + 8 lg + u (8 lg never carries across a piece: ROWS | 8), column w * 32 T + 32 block + li
-    const int wt_lane = ((8 * lg) / WROWS) * (256 + WPAD) + wn * 32 * TN + li;
-    const int at_lane = ((8 * lg) / AROWS) * (256 + APAD) + wm * 32 * TM + li;
-    float rawa[TM][8], raww[TN][8];                                // the k step being split
-    auto read_a = [&](int stage, int s, int a) {
-        if (!AT) {
-            const float *sa = smem + stage * STAGE_FLOATS + abase + a * 32 * NT_BK;
-            const float4 x = *reinterpret_cast<const float4 *>(sa + fo[s]);
-            const float4 y = *reinterpret_cast<const float4 *>(sa + (fo[s] ^ 4));
-            rawa[a][0] = x.x; rawa[a][1] = x.y; rawa[a][2] = x.z; rawa[a][3] = x.w;
-            rawa[a][4] = y.x; rawa[a][5] = y.y; rawa[a][6] = y.z; rawa[a][7] = y.w;
-        } else {
-            const float *sa = smem + stage * STAGE_FLOATS + at_lane + 32 * a;
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int r = 16 * s + u;
-                rawa[a][u] = sa[(r / AROWS) * (256 + APAD) + (r % AROWS) * BM];
-            }
+    // ---- conversion: the 4 values of quad q -> three 8-B writes into stage `st`
+    unsigned cvh[2], cvm[2], cvl[2];
+    auto conv_pair = [&](int q, int e) {
+        const float a = raw[q][2 * e], b = raw[q][2 * e + 1];
+        if (X3_ABLATE & 32) {                                      // (measurement: no arithmetic)
+            cvh[e] = __float_as_uint(a);
+            cvm[e] = __float_as_uint(b);
+            cvl[e] = cvh[e] ^ cvm[e];
+            return;
         }
+        const unsigned h = x3_cvt_pk(a, b);
+        const float ra = a - __uint_as_float(h << 16), rb = b - __uint_as_float(h & 0xffff0000u);      // exact
+        const unsigned m = x3_cvt_pk(ra, rb);
+        const float sa = ra - __uint_as_float(m << 16), sb = rb - __uint_as_float(m & 0xffff0000u);    // exact
+        cvh[e] = h;
+        cvm[e] = m;
+        cvl[e] = x3_cvt_pk(sa, sb);
     };
-    auto read_w = [&](int stage, int s, int b) {
-        if (!WT) {
-            const float *sb = smem + stage * STAGE_FLOATS + bbase + b * 32 * NT_BK;
-            const float4 x = *reinterpret_cast<const float4 *>(sb + fo[s]);
-            const float4 y = *reinterpret_cast<const float4 *>(sb + (fo[s] ^ 4));
-            raww[b][0] = x.x; raww[b][1] = x.y; raww[b][2] = x.z; raww[b][3] = x.w;
-            raww[b][4] = y.x; raww[b][5] = y.y; raww[b][6] = y.z; raww[b][7] = y.w;
+    auto conv_write = [&](int st, int q) {
+        const bool isA = q < QA;
+        const bool tr = isA ? AT : WT;
+        const int j = isA ? q : q - QA;
+        const int ps = isA ? PART_A : PART_W;
+        unsigned off = isA ? woffA0 : woffW0;
+        if (!tr) {
+            off += (unsigned)(j * NW * 8 * 64);                    // 8 rows per piece, pieces NW apart: (row >> 1) & 3 unchanged
         } else {
-            const float *sb = smem + stage * STAGE_FLOATS + A_FLOATS + wt_lane + 32 * b;
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int r = 16 * s + u;
-                raww[b][u] = sb[(r / WROWS) * (256 + WPAD) + (r % WROWS) * BN];
-            }
+            // unit j / CU: k quad kq0 + (j / CU) KQ_STEP: 16-B column (kq >> 1) ^ swizzle, half kq & 1; row CU cq + j % CU
+            const int CU = isA ? CUA : CUW;
+            const int d = (j / CU) * (isA ? KQ_STEP_A : KQ_STEP_W);
+            const int kq0 = isA ? (int)(tid / (BM / CUA)) : (int)(tid / (BN / CUW));
+            const int cq = isA ? (int)(tid % (BM / CUA)) : (int)(tid % (BN / CUW));
+            const int row = CU * cq + (j % CU), kq = kq0 + d;
+            off = (unsigned)((isA ? 0 : 3 * PART_A) + row * 64 + (((kq >> 1) ^ ((row >> 1) & 3)) * 16) + (kq & 1) * 8);
         }
-    };
-    auto read_step = [&](int stage, int s) {
-#pragma unroll
-        for (int a = 0; a < TM; ++a) read_a(stage, s, a);
-#pragma unroll
-        for (int b = 0; b < TN; ++b) read_w(stage, s, b);
+        unsigned char *dst = smem + st * STAGE + off;
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        if (X3_ABLATE & 64) {                                      // (measurement: one write instead of three)
+            *reinterpret_cast<u32x2 *>(dst) = (u32x2){cvh[0] ^ cvm[0] ^ cvl[0], cvh[1] ^ cvm[1] ^ cvl[1]};
+            return;
+        }
+        *reinterpret_cast<u32x2 *>(dst) = (u32x2){cvh[0], cvh[1]};
+        *reinterpret_cast<u32x2 *>(dst + ps) = (u32x2){cvm[0], cvm[1]};
+        *reinterpret_cast<u32x2 *>(dst + 2 * ps) = (u32x2){cvl[0], cvl[1]};
     };
 
-    X3Parts pa[2][TM], pw[2][TN];                                  // [parity of the k step]
-    // pair j of a k step (A fragments first): split into the parts of parity `par`
-    auto split_pair = [&](int par, int j) {
-        const int f = j >> 2, e = j & 3;
-        if (f < TM) x3_split_pair(rawa[f][2 * e], rawa[f][2 * e + 1], pa[par][f], e);
-        else x3_split_pair(raww[f - TM][2 * e], raww[f - TM][2 * e + 1], pw[par][f - TM], e);
+    // ---- fragments: lane (li, lg) of k step s holds k = 16 s + 8 lg .. + 7 of row li of a 32-row block: column 2 s + lg
+    const unsigned a_rd = (unsigned)((wm * 32 * TM + li) * 64 + ((lg ^ ((li >> 1) & 3)) * 16));
+    const unsigned w_rd = (unsigned)(3 * PART_A + (wn * 32 * TN + li) * 64 + ((lg ^ ((li >> 1) & 3)) * 16));
+    X3Parts fa[2][TM], fw[2][TN];                                  // [parity of the k step]
+    // fragment read r of k step s (A blocks first, 3 parts each) from stage st into parity `par`
+    auto read_frag = [&](int st, int s, int par, int r) {
+        const int f = r / 3, part = r % 3;
+        if (f < TM) {
+            const u32x4 x = *reinterpret_cast<const u32x4 *>(smem + st * STAGE + ((a_rd ^ (unsigned)(32 * s)) + f * 32 * 64 + part * PART_A));
+            if (part == 0) fa[par][f].h = x;
+            else if (part == 1) fa[par][f].m = x;
+            else fa[par][f].l = x;
+        } else {
+            const int b = f - TM;
+            const u32x4 x = *reinterpret_cast<const u32x4 *>(smem + st * STAGE + ((w_rd ^ (unsigned)(32 * s)) + b * 32 * 64 + part * PART_W));
+            if (part == 0) fw[par][b].h = x;
+            else if (part == 1) fw[par][b].m = x;
+            else fw[par][b].l = x;
+        }
     };
 
     f32x16 acc[TM][TN];
@@ -424,118 +479,117 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_x3_kernel(const NtArgs
         }
     };
 
-    // ---- one k step: the 6 TM TN MFMAs on the parts of parity CUR; between them (fixed places, fenced against the
-    // compiler's scheduler) the split of the step read before into parity CUR ^ 1 (SPLIT) and the DMA pieces of the refill
-    // (DMA).  FIRST: the step restarts the accumulators, each block's pending stores right before its restart.
-    auto k_step = [&](auto cur_c, auto first_c, auto split_c, auto dma_c) {
-        constexpr int CUR = decltype(cur_c)::value;
-        constexpr bool FIRST = decltype(first_c)::value, SPLIT = decltype(split_c)::value, DMA = decltype(dma_c)::value;
-        constexpr int LEAD = 2;                                    // MFMAs before the first split: the reads are landing
-        constexpr int EVERY = TOTAL / NP;
-#pragma unroll
-        for (int a = 0; a < TM; ++a)
-#pragma unroll
-            for (int b = 0; b < TN; ++b) {
-                f32x16 c = acc[a][b];
-#pragma unroll
-                for (int t = 0; t < 6; ++t) {
-                    const int idx = (a * TN + b) * 6 + t;
-                    if (FIRST && t == 0) {
-                        if (!ATOMIC) {
-                            __builtin_amdgcn_sched_barrier(0);
-                            store_block(a, b);
-                            __builtin_amdgcn_sched_barrier(0);
-                        }
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) c[r] = 0.f;
-                    }
-                    const X3Parts &A = pa[CUR][a], &W = pw[CUR][b];
-                    const u32x4 ap = t == 0 ? A.l : (t == 1 || t == 3) ? A.m : A.h;          // al wh, am wm, ah wl, am wh, ah wm, ah wh
-                    const u32x4 wp = t == 2 ? W.l : (t == 1 || t == 4) ? W.m : W.h;
-                    c = ATOMIC ? x3_mfma(ap, wp, c) : x3_mfma(wp, ap, c);
-                    if (SPLIT) {
-                        // pairs [idx' * NPAIR / (TOTAL - LEAD), ...) after MFMA idx = LEAD + idx'
-                        const int i0 = idx - LEAD;
-                        if (i0 >= 0) {
-                            const int j0 = (i0 * NPAIR) / (TOTAL - LEAD), j1 = ((i0 + 1) * NPAIR) / (TOTAL - LEAD);
-                            if (j1 > j0) {
-                                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                                for (int j = j0; j < j1; ++j)
-                                    if (!(X3_ABLATE & 1)) split_pair(CUR ^ 1, j);
-                                __builtin_amdgcn_sched_barrier(0);
-                            }
-                        }
-                    }
-                    if (DMA && idx % EVERY == EVERY / 2 && idx / EVERY < NP) {
-                        __builtin_amdgcn_sched_barrier(0);
-                        if (!(X3_ABLATE & 2)) issue_piece(idx / EVERY);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                }
-                acc[a][b] = c;
-            }
+    // ---- one chunk: two k steps of 6 TM TN MFMAs, each step: the six partial products in turn (smallest first), every one
+    // over all the wave's blocks (consecutive MFMAs are independent).  Between the MFMAs, at fixed places and fenced against
+    // the compiler's scheduler:
+    //   * the conversion of the NEXT chunk (in the raw registers) into the other stage, quad by quad, each quad's registers
+    //     reloaded with the chunk after next as soon as it is written;
+    //   * the fragment reads of the next k step;
+    //   * BAR MFMAs before the end: the barrier (the next chunk's parts complete and visible, this stage read to the end), after
+    //     which the remaining MFMAs cover the first fragment reads of the next chunk.
+    constexpr int SM = 6 * TM * TN, NM = 2 * SM, NFR = 3 * (TM + TN);        // MFMAs per k step / chunk, fragment reads per step
+    constexpr int BAR = 2 * TM * TN > NFR + 2 ? 2 * TM * TN : NFR + 2;       // MFMAs after the barrier
+    constexpr int CT_PER_Q = 4, NCT = NQ * CT_PER_Q;               // conversion tasks: per quad 2 pairs, the writes, the reload
+    constexpr int C_LO = 1, C_HI = NM - BAR - 1;                   // MFMA gaps that take them
+    static_assert(BAR < SM && NFR + 2 <= SM, "k step too short for its fragment reads");
+    auto conv_task = [&](int st, int k) {
+        const int q = k / CT_PER_Q, sub = k % CT_PER_Q;
+        if (X3_ABLATE & 1) return;
+        if (sub < 2) conv_pair(q, sub);
+        else if (sub == 2) conv_write(st, q);
+        else {
+            const bool tr = q < QA ? AT : WT;
+            if (X3_ABLATE & 2) return;
+            const int CU = q < QA ? CUA : CUW, j = q < QA ? q : q - QA;
+            if (!tr) load_quad(q);
+            else if (j % CU == CU - 1) load_quad(q - (CU - 1));                  // after the unit's last quad
+        }
     };
-    typedef std::integral_constant<int, 0> I0;
-    typedef std::integral_constant<int, 1> I1;
-    typedef std::true_type T;
-    typedef std::false_type F;
+    auto chunk = [&](auto first_c, int st) {                       // FIRST: the item's first chunk restarts the accumulators
+        constexpr bool FIRST = decltype(first_c)::value;
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int t = 0; t < 6; ++t)
+#pragma unroll
+                for (int a = 0; a < TM; ++a)
+#pragma unroll
+                    for (int b = 0; b < TN; ++b) {
+                        const int is = (t * TM + a) * TN + b, idx = s * SM + is;
+                        if (idx == NM - BAR) {
+                            // the barrier: my conversion writes and fragment reads are done; then everyone's
+                            __builtin_amdgcn_sched_barrier(0);
+                            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                            if (!(X3_ABLATE & 8)) __builtin_amdgcn_s_barrier();
+                            asm volatile("" ::: "memory");
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                        f32x16 c = acc[a][b];
+                        if (FIRST && s == 0 && t == 0) {           // the pending stores of the block, then its restart from zero
+                            if (!ATOMIC) store_block(a, b);
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) c[r] = 0.f;
+                        }
+                        const X3Parts &A = fa[s][a], &W = fw[s][b];
+                        const u32x4 ap = t == 0 ? A.l : (t == 1 || t == 3) ? A.m : A.h;      // al wh, am wm, ah wl, am wh, ah wm, ah wh
+                        const u32x4 wp = t == 2 ? W.l : (t == 1 || t == 4) ? W.m : W.h;
+                        acc[a][b] = ATOMIC ? x3_mfma(ap, wp, c) : x3_mfma(wp, ap, c);
+                        // fillers after MFMA idx; the scheduler's regions are X3_FENCE MFMAs long
+                        if (idx % X3_FENCE == 0) __builtin_amdgcn_sched_barrier(0);
+                        if (!(X3_ABLATE & 16)) {
+                            // k step 0: the fragments of step 1, from its second MFMA on; step 1: of the next chunk's step 0 (other
+                            // stage), right after the barrier
+                            if (s == 0 && is >= 1 && is < 1 + NFR) read_frag(st, 1, 1, is - 1);
+                            if (s == 1 && idx >= NM - BAR && idx < NM - BAR + NFR) read_frag(st ^ 1, 0, 0, idx - (NM - BAR));
+                        }
+                        if (idx >= C_LO && idx < C_HI) {
+                            const int i0 = idx - C_LO, span = C_HI - C_LO;
+                            const int k0 = (i0 * NCT) / span, k1 = ((i0 + 1) * NCT) / span;
+#pragma unroll
+                            for (int k = k0; k < k1; ++k) conv_task(st ^ 1, k);
+                        }
+                    }
+    };
 
-    // ---- prologue: chunks 0 and 1 in flight, chunk 0 landed, its first k step split
-    long long todo;                                                // chunks of this workgroup's sequence still to multiply
-    if (ATOMIC) todo = ld.f1 - (long long)v * p.sk_per_wg;
-    else todo = (long long)((p.tile_end - 1 - (p.tile_begin + v)) / G + 1) * KC;
-    issue_begin(0);
+    // ---- prologue: chunk 0 converted into stage 0, chunk 1 in the raw registers, the first fragments read
+    issue_begin();
 #pragma unroll
-    for (int i = 0; i < NP; ++i) issue_piece(i);
+    for (int q = 0; q < NQ; ++q) load_quad(q);
     advance_load();
-    if (ld.valid) {
-        issue_begin(1);
 #pragma unroll
-        for (int i = 0; i < NP; ++i) issue_piece(i);
-        advance_load();
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP) : "memory");
-    } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for (int q = 0; q < NQ; ++q) {
+        conv_pair(q, 0);
+        conv_pair(q, 1);
+        conv_write(0, q);
     }
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    read_step(0, 0);
+    issue_begin();
 #pragma unroll
-    for (int j = 0; j < NPAIR; ++j) split_pair(0, j);
+    for (int q = 0; q < NQ; ++q) load_quad(q);
+    advance_load();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int r = 0; r < NFR; ++r) read_frag(0, 0, 0, r);
     int stage = 0;
     while (cp.valid) {
-        bool first = true;
-        for (;;) {
-            // (A) the chunk's second k step read and split while its first is multiplied
-            if (!(X3_ABLATE & 16)) read_step(stage, 1);
+        // the item's first chunk is peeled off the loop: one code path per loop body, so the loop-carried registers (raw
+        // values in flight, accumulators) need no copies at a merge
+        issue_begin();                                             // the chunk the conversion tasks reload the registers with
+        __builtin_amdgcn_sched_barrier(0);
+        chunk(std::true_type(), stage);
+        __builtin_amdgcn_sched_barrier(0);
+        advance_load();
+        stage ^= 1;
+        cp.kc++;
+        while (cp.kc != cp.ke) {
+            issue_begin();
             __builtin_amdgcn_sched_barrier(0);
-            if (first) k_step(I0(), T(), T(), F());
-            else k_step(I0(), F(), T(), F());
-            // (B) everyone has read this stage to the end, and the next chunk has landed everywhere: my own pieces
-            // (counted wait: only the stores of (A) were issued after them), then the barrier
+            chunk(std::false_type(), stage);
             __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (first) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NS > 63 ? 63 : NS) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (!(X3_ABLATE & 8)) __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
-            // (C) the next chunk's first k step read and split, this stage refilled with the chunk after next, while the
-            // second k step is multiplied
-            first = false;
-            todo--;
-            if (todo > 0 && !(X3_ABLATE & 16)) read_step(stage ^ 1, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (ld.valid) {
-                issue_begin(stage);
-                k_step(I1(), F(), T(), T());
-                advance_load();
-            } else {
-                k_step(I1(), F(), T(), F());
-            }
+            advance_load();
             stage ^= 1;
             cp.kc++;
-            if (cp.kc == cp.ke) break;
         }
         __builtin_amdgcn_sched_barrier(0);
         finish_item();
@@ -552,7 +606,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_x3_kernel(const NtArgs
 }
 
 // ------------------------------------------------------------------ host side
-template <int TM, int TN, int WM, int WN, int OCC>
+template <int TM, int TN, int WM, int WN, int OCC, int RATE>      // RATE: fp32-equivalent kflop / us a CU sustains on this tile's loop
 struct X3Cfg {
     static constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     static constexpr int LDS = 2 * ((BM + BN) * NT_BK + (BM / 8 + BN / 8) * 16) * 4;        // with both operands' piece padding
@@ -563,7 +617,7 @@ struct X3Cfg {
         long long sk_per_wg;
         double cost;                                               // launch model, microseconds
     };
-    // Launch model as in gemm_nt.hip, with this loop's rate: a CU multiplies ~1.0 Mflop/us (fp32-equivalent).
+    // Launch model as in gemm_nt.hip, with this loop's measured rate (tools/x3_check.py on MI355X).
     static int dp_grid(long long tiles, int slots, int kc) {
         int tpw = (64 + kc - 1) / kc;
         tpw = tpw < 1 ? 1 : (tpw > 8 ? 8 : tpw);
@@ -571,12 +625,7 @@ struct X3Cfg {
         const long long lo = tiles < slots ? tiles : slots;
         return (int)(g < lo ? lo : g);
     }
-    static double chunk_us(int w) { return 2.0 * BM * BN * NT_BK * w / x3_rate(); }
-    static double x3_rate() {
-        static double r = 0.0;
-        if (r == 0.0) { const char *e = getenv("PDGN_X3_RATE"); r = e ? atof(e) * 1e6 : 1.0e6; }
-        return r;
-    }
+    static double chunk_us(int w) { return 2.0 * BM * BN * NT_BK * w / (RATE * 1e3); }
     static Plan plan(long long m, int n, int k, bool allow_sk) {
         Plan pl;
         pl.tiles_m = cdiv(m, BM);
@@ -585,7 +634,7 @@ struct X3Cfg {
         const long long T = (long long)pl.tiles_m * pl.tiles_n;
         const int cus = nt_cus(), slots = cus * WG_PER_CU, KC = pl.kchunks;
         const long long rounds = T / slots, tail = T - rounds * slots;
-        const double ov = 3.0;
+        const double ov = 2.0;
         const double full = (double)rounds * (KC + ov) * chunk_us(WG_PER_CU);
         pl.dp_tiles = (int)T;
         pl.grid_dp = dp_grid(T, slots, KC);
@@ -653,9 +702,9 @@ struct X3Cfg {
     }
 };
 
-typedef X3Cfg<2, 2, 2, 2, 1> X3Square;   // 128 x 128, 4 waves of 64 x 64 (64 KB): one per CU (the parts of two k steps + accumulators exceed 256 registers)
-typedef X3Cfg<4, 2, 2, 2, 1> X3Big;      // 256 x 128, 4 waves of 128 x 64 (96 KB): one per CU, one wave per SIMD
-typedef X3Cfg<2, 1, 2, 2, 2> X3Narrow;   // 128 x 64, 4 waves of 64 x 32 (48 KB): two per CU
+typedef X3Cfg<2, 2, 2, 2, 1, 660> X3Square;   // 128 x 128, 4 waves of 64 x 64 (64 KB): one per CU (the parts of two k steps + accumulators exceed 256 registers)
+typedef X3Cfg<4, 2, 2, 2, 1, 760> X3Big;      // 256 x 128, 4 waves of 128 x 64 (96 KB): one per CU, one wave per SIMD
+typedef X3Cfg<2, 1, 2, 2, 2, 590> X3Narrow;   // 128 x 64, 4 waves of 64 x 32 (48 KB): two per CU
 
 static int x3_mode() {                   // PDGN_GEMM: "x3" (default) or "fp32" (gemm_nt.hip: the fp32 matrix instructions)
     const char *e = getenv("PDGN_GEMM");
@@ -667,9 +716,9 @@ static int x3_pick(long long m, int n, int k, bool stats) {
     if (e && *e) return atoi(e) < 0 ? 0 : (atoi(e) > 2 ? 2 : atoi(e));
     const bool sk = !stats;
     const double c[3] = {X3Big::plan(m, n, k, sk).cost, X3Square::plan(m, n, k, sk).cost, X3Narrow::plan(m, n, k, sk).cost};
-    int best = 1;
-    for (int i = 0; i < 3; ++i)
-        if (c[i] < c[best] * 0.97) best = i;
+    int best = 0;
+    for (int i = 1; i < 3; ++i)
+        if (c[i] < c[best]) best = i;
     return best;
 }
 
