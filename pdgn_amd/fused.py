@@ -207,13 +207,16 @@ def bn_act(x2d, bn, training, act="leaky_relu", mul=None, pre_bias=None, partial
 
 
 # ---------------------------------------------------------------------------------------------------------------
-# Dense layers on point-major rows.  Every contraction with >= _OWN_MIN_ROWS rows runs on the hand-written fp32-MFMA
-# kernels of libpdgn_hip.so: forward y = x W^T and input gradient dx = dy W on pdgn_gemm_nt (csrc/gemm_nt.hip: the
-# second with the transposed weight as its "W"), the weight gradient dW = dy^T x on pdgn_gemm_tn (csrc/gemm_tn.hip).
+# Dense layers on point-major rows.  Every contraction with >= _OWN_MIN_ROWS rows runs on the hand-written matrix-core
+# kernels of libpdgn_hip.so: forward y = x W^T and input gradient dx = dy W on pdgn_gemm_nt / pdgn_gemm_nn (csrc/gemm_x3.hip:
+# fp32 operands, products on the bf16 matrix cores; PDGN_GEMM=fp32: csrc/gemm_nt.hip, the fp32 matrix instructions), the
+# weight gradient dW = dy^T x on pdgn_gemm_tn_big (the same kernels) or pdgn_gemm_tn (csrc/gemm_tn.hip, small outputs).
 # No BLAS library, no run-time back-end selection.  Below that row count (the 35-row per-sample layers) torch's
 # default matmul is used as it is.
 _OWN_MIN_ROWS = 1024
 _TN_BIG = os.environ.get("PDGN_TN_BIG", "1") == "1"            # A/B switch: weight gradients of >= 128 x 64 outputs on pdgn_gemm_tn_big
+_GEMM_X3 = not os.environ.get("PDGN_GEMM", "x3").startswith("f")    # pdgn_gemm_* on the bf16 matrix cores (csrc/gemm_x3.hip) | PDGN_GEMM=fp32
+_TN_BIG_MAX = (1 << 22) if _GEMM_X3 else (1 << 20)             # x3: also the two largest outputs (measured 0.88x / 0.90x pdgn_gemm_tn's time)
 
 
 def _pad_cols(t, mult=4):
@@ -279,10 +282,11 @@ def gemm_tn(dy, x):
     if GEMM_LOG is not None:
         GEMM_LOG.append(("tn", m, n, k))
     dyp, xp = _pad_cols(dy), _pad_cols(x)
-    if _TN_BIG and dyp.shape[1] >= 64 and xp.shape[1] >= 64 and 65536 <= dyp.shape[1] * xp.shape[1] <= (1 << 20):
+    if _TN_BIG and dyp.shape[1] >= 64 and xp.shape[1] >= 64 and 65536 <= dyp.shape[1] * xp.shape[1] <= _TN_BIG_MAX:
         # mid-sized outputs (4 .. 64 tiles of 128 x 128): the stream-K launch of the pdgn_gemm_nt kernel with both operands
         # transposed balances them better than pdgn_gemm_tn's split (measured, tools/gemm_shapes.py: 0.70-0.94x its time);
-        # smaller outputs and the two largest ones (conv2's dense half, the per-point GEMM) stay on pdgn_gemm_tn
+        # smaller outputs (and, on the fp32 kernels, the two largest ones: conv2's dense half, the per-point GEMM) stay on
+        # pdgn_gemm_tn
         dwp = torch.empty((dyp.shape[1], xp.shape[1]), dtype=F32, device=dy.device)
         check(_lib.lib().pdgn_gemm_tn_big(ctypes.c_longlong(m), dyp.shape[1], xp.shape[1], ptr(dyp), dyp.stride(0), ptr(xp),
                                           xp.stride(0), ptr(dwp), stream_of(dy)), "pdgn_gemm_tn_big")

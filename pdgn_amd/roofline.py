@@ -19,6 +19,8 @@ from ._lib import check, ptr, stream_of
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s achievable)
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32-input MFMA peak
+MFMA_BF16_PEAK_TFLOPS = 2500.0 # MI355X_MICROARCH.md: bf16 MFMA, dense
+X3_PRODUCTS = 6                # bf16 MFMA products per fp32 product in gemm_x3.hip (csrc/gemm_x3.hip header)
 _TRAFFIC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "traffic.json")
 
 
@@ -35,15 +37,29 @@ def _time_us(fn, iters=20, warm=3):
     return s.elapsed_time(e) * 1e3 / iters
 
 
-def _entry(name, bound, work, us, **extra):
+def gemm_mode():
+    """"x3" (fp32 operands split into three bf16 parts, products on the bf16 matrix cores: csrc/gemm_x3.hip, the default) or
+    "fp32" (PDGN_GEMM=fp32: the fp32 matrix instructions, csrc/gemm_nt.hip) -- what pdgn_gemm_nt / nn / tn_big launch."""
+    return "fp32" if os.environ.get("PDGN_GEMM", "x3").startswith("f") else "x3"
+
+
+def _entry(name, bound, work, us, x3=False, **extra):
     if bound == "hbm":
         ach, peak, unit = work / us / 1e3, HBM_PEAK_GBS, "GB/s"
         key = "algorithmic_bytes_per_launch"
     else:
-        ach, peak, unit = work / us / 1e6, MFMA_F32_PEAK_TFLOPS, "TFLOP/s"
+        # algorithmic (fp32) flops per second.  The x3 kernel issues X3_PRODUCTS bf16 MFMA flops per algorithmic flop, so its
+        # matrix-core ceiling in algorithmic flops is the bf16 peak / X3_PRODUCTS: frac = executed bf16 MFMA rate / bf16 peak.
+        ach, unit = work / us / 1e6, "TFLOP/s"
+        peak = MFMA_BF16_PEAK_TFLOPS / X3_PRODUCTS if x3 else MFMA_F32_PEAK_TFLOPS
         key = "algorithmic_flops_per_launch"
     d = {"kernel": name, "bound": bound, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak,
          "traffic": None, "us_per_launch": us, key: work}
+    if bound == "mfma":
+        d["mfma"] = ({"instruction": "v_mfma_f32_32x32x16_bf16", "products_per_fp32_product": X3_PRODUCTS,
+                      "executed_tflops": ach * X3_PRODUCTS, "instruction_peak_tflops": MFMA_BF16_PEAK_TFLOPS,
+                      "fp32_instruction_peak_tflops": MFMA_F32_PEAK_TFLOPS} if x3 else
+                     {"instruction": "v_mfma_f32_16x16x4_f32", "instruction_peak_tflops": MFMA_F32_PEAK_TFLOPS})
     d.update(extra)
     return d
 
@@ -58,7 +74,9 @@ def _nt_entry(label, M, N, K, device):
         check(L.pdgn_gemm_nt(ctypes.c_longlong(M), N, K, ptr(a), K, ptr(w), K, None, None, 0, ptr(c), N, None, stream_of(a)),
               "pdgn_gemm_nt")
     us = _time_us(run)
-    e = _entry("gemm_nt_kernel (%s, M=%d N=%d K=%d)" % (label, M, N, K), "mfma", 2.0 * M * N * K, us, shape=[M, N, K])
+    x3 = gemm_mode() == "x3"
+    e = _entry("%s (%s, M=%d N=%d K=%d)" % ("gemm_x3_kernel" if x3 else "gemm_nt_kernel", label, M, N, K), "mfma", 2.0 * M * N * K, us,
+               x3=x3, shape=[M, N, K])
     e["algorithmic_bytes_per_launch"] = 4.0 * (M * N + M * K + N * K)
     return e
 
@@ -88,8 +106,9 @@ def conv2_dense_dx_stage4(B, base_points, device):
         check(L.pdgn_gemm_nn(ctypes.c_longlong(M), N, K, ptr(dy), K, ptr(wb), N, None, None, 0, ptr(dx), N, None, stream_of(dy)),
               "pdgn_gemm_nn")
     us = _time_us(run)
-    e = _entry("gemm_nt_kernel<WT> = pdgn_gemm_nn (conv2 dense half input gradient, stage 4, M=%d N=%d K=%d)" % (M, N, K),
-               "mfma", 2.0 * M * N * K, us, shape=[M, N, K])
+    x3 = gemm_mode() == "x3"
+    e = _entry("%s<WT> = pdgn_gemm_nn (conv2 dense half input gradient, stage 4, M=%d N=%d K=%d)"
+               % ("gemm_x3_kernel" if x3 else "gemm_nt_kernel", M, N, K), "mfma", 2.0 * M * N * K, us, x3=x3, shape=[M, N, K])
     e["algorithmic_bytes_per_launch"] = 4.0 * (M * N + M * K + N * K)
     return e
 

@@ -41,7 +41,8 @@ def test_bench_prints_one_json_line_with_roofline_and_cpu_baseline():
     assert "host" in c and "samples_s" in c and len(c["samples_s"]) >= 3
     assert d["rccl_ranks"] == 1 and d["ms_per_step_min_rank"] <= d["ms_per_step_max_rank"]
     assert d["executed_flops_per_step"] > 1e12 and 0.0 < d["step_mfma_frac"] < 1.0 and d["algebraic_saving"] > 1.0
-    assert r["kernel"].startswith("gemm_nt_kernel") and "Cijk" not in json.dumps(r)      # the roofline names own kernels only
+    assert r["kernel"].startswith("gemm_x3_kernel") and "Cijk" not in json.dumps(r)      # the roofline names own kernels only
+    assert r["mfma"]["products_per_fp32_product"] == 6 and abs(r["peak"] * 6 - r["mfma"]["instruction_peak_tflops"]) < 1e-6
     c5 = d["eval_c5"]                                            # config C5 rides in the default line
     assert c5["pairs"] == 512 and c5["finite"] is True and c5["pairs_per_s"] > 0 and c5["ms_per_512"] > 0
     assert c5["roofline"]["bound"] == "valu-issue" and 0 < c5["roofline"]["frac"] < 1 and 0 < c5["roofline"]["exp_frac"] < 1
