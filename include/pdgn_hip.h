@@ -228,9 +228,14 @@ int pdgn_bilateral_weighting_backward(long long m, int k, int c, int act, int tr
 int pdgn_softmax_slots_permute_backward(long long m, int k, int c, const float *w, const float *dw,
                                         float *dh, pdgn_stream_t stream);
 
-/* Dense contraction of a point-major layer on the fp32 matrix cores:
+/* Dense contraction of a point-major layer on the matrix cores, fp32 in and out:
  *   C (m x n, row pitch ldc) = A (m x k, pitch lda) W (n x k, pitch ldw)^T (+ bias[n]) (+ addend (m x n, pitch ldadd)),
  * all row-major; n, k and every pitch are multiples of 4 floats, base pointers 16-byte aligned.
+ * Arithmetic (pdgn_gemm_nt / _nn / _nt_ex / _tn_big): every fp32 operand value is split into three bf16 parts
+ * (x = h + m + l to 2^-25 |x|) and a product is six bf16 MFMA products accumulated in fp32 (csrc/gemm_x3.hip) -- per product
+ * an error of <= 2^-23 |a w|, measured against fp64 below that of the fp32 matrix instructions; no scaling, the fp32
+ * exponent range is kept; an infinite operand value yields NaN (inf - inf in the split), where fp32 arithmetic may yield inf.
+ * The environment variable PDGN_GEMM=fp32 selects the fp32 matrix instructions instead (csrc/gemm_nt.hip; 0.6-0.9x the rate).
  * (The reference's Conv2d/Conv1d/Linear forward at models/PDGNet_v2.py:559-625, 835-862, 886-1014 in
  * point-major form; with the transposed weight it is their input gradient dX = dY W.)  stat_part (may be
  * NULL): pdgn_gemm_nt_stat_rows(m, n, k) rows of [3n] floats = per-column sum (x - pv) | sum (x - pv)^2 | pv of blocks of

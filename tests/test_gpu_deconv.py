@@ -439,9 +439,10 @@ def test_gemm_tn_direct(M, N, K):
 
 
 @pytest.mark.parametrize("cfg", [None, 0, 1, 3])
+@pytest.mark.parametrize("gemm", ["x3", "fp32"])
 @pytest.mark.parametrize("M,N,K", [(35840, 12832, 128), (71680, 1024, 256), (358400, 512, 64), (35840, 512, 5120),
                                    (17920, 256, 2560), (100003, 132, 68), (5000, 64, 128), (40, 128, 64), (8960, 3232, 32)])
-def test_gemm_tn_big_direct(M, N, K, cfg, monkeypatch):
+def test_gemm_tn_big_direct(M, N, K, cfg, monkeypatch, gemm):
     """pdgn_gemm_tn_big through the C ABI (weight gradient on the pdgn_gemm_nt kernel with both operands transposed and
     the row reduction split stream-K): dW = dY^T X against fp32 matmul on all rows and fp64 on a row sample, every
     configuration the entry point can pick; dW needs no zero-fill by the caller (poisoned with NaN here)."""
@@ -452,6 +453,7 @@ def test_gemm_tn_big_direct(M, N, K, cfg, monkeypatch):
         monkeypatch.delenv("PDGN_NT_CFG", raising=False)
     else:
         monkeypatch.setenv("PDGN_NT_CFG", str(cfg))
+    monkeypatch.setenv("PDGN_GEMM", gemm)                      # csrc/gemm_x3.hip (the default) | csrc/gemm_nt.hip
     g = torch.Generator(device="cuda").manual_seed(M + N + K)
     x = torch.randn(M, K, device="cuda", generator=g)
     dy = torch.randn(M, N, device="cuda", generator=g)
@@ -772,9 +774,10 @@ def test_config_c4_four_stage_512_to_4096():
 
 
 @pytest.mark.parametrize("cfg", [None, 0, 1, 2, 3])
+@pytest.mark.parametrize("gemm", ["x3", "fp32"])
 @pytest.mark.parametrize("M,N,K", [(35840, 512, 128), (5000, 132, 36), (129, 8, 4), (71680, 1024, 256), (35840, 512, 5120),
                                    (17920, 64, 6432), (8960, 3232, 32), (1000, 36, 20), (358400, 64, 16)])
-def test_gemm_nt_with_epilogues(M, N, K, cfg, monkeypatch):
+def test_gemm_nt_with_epilogues(M, N, K, cfg, monkeypatch, gemm):
     """pdgn_gemm_nt through the C ABI, every tile configuration (PDGN_NT_CFG) and the launch model's own pick:
     C = A W^T (plain: the stream-K tail may run), and C = A W^T + bias + addend with the column-statistics partials."""
     import ctypes
@@ -785,6 +788,7 @@ def test_gemm_nt_with_epilogues(M, N, K, cfg, monkeypatch):
         monkeypatch.delenv("PDGN_NT_CFG", raising=False)
     else:
         monkeypatch.setenv("PDGN_NT_CFG", str(cfg))
+    monkeypatch.setenv("PDGN_GEMM", gemm)                      # csrc/gemm_x3.hip (the default) | csrc/gemm_nt.hip
     L = _lib.lib()
     L.pdgn_gemm_nt_stat_rows.restype = ctypes.c_longlong
     g = torch.Generator(device="cuda").manual_seed(M + N)
@@ -813,9 +817,10 @@ def test_gemm_nt_with_epilogues(M, N, K, cfg, monkeypatch):
 
 
 @pytest.mark.parametrize("cfg", [None, 0, 1, 2, 3])
+@pytest.mark.parametrize("gemm", ["x3", "fp32"])
 @pytest.mark.parametrize("M,N,K", [(35840, 128, 512), (5000, 132, 36), (129, 8, 4), (17920, 2560, 256), (35840, 5120, 512),
                                    (17920, 64, 6432), (1000, 36, 20), (71680, 256, 1024)])
-def test_gemm_nn_input_gradient_form(M, N, K, cfg, monkeypatch):
+def test_gemm_nn_input_gradient_form(M, N, K, cfg, monkeypatch, gemm):
     """pdgn_gemm_nn through the C ABI: C = A (M x K) Wt (K x N), the second operand row-major as the layer's own
     (C_out x C_in) weight -- every tile configuration and the launch model's pick; plain and with bias + addend + statistics."""
     import ctypes
@@ -825,6 +830,7 @@ def test_gemm_nn_input_gradient_form(M, N, K, cfg, monkeypatch):
         monkeypatch.delenv("PDGN_NT_CFG", raising=False)
     else:
         monkeypatch.setenv("PDGN_NT_CFG", str(cfg))
+    monkeypatch.setenv("PDGN_GEMM", gemm)                      # csrc/gemm_x3.hip (the default) | csrc/gemm_nt.hip
     L = _lib.lib()
     L.pdgn_gemm_nt_stat_rows.restype = ctypes.c_longlong
     g = torch.Generator(device="cuda").manual_seed(M + N + 1)
@@ -848,6 +854,46 @@ def test_gemm_nn_input_gradient_form(M, N, K, cfg, monkeypatch):
     c64 = C2.double()
     tot = _raw_sums(part, M, L.pdgn_gemm_nt_stat_block_rows(ctypes.c_longlong(M), N, K), N)
     np.testing.assert_allclose(tot[:N], c64.sum(0).cpu().numpy(), rtol=1e-4, atol=1e-4 * float(c64.abs().sum(0).max()))
+
+
+@pytest.mark.parametrize("scale", [1.0, 1e15, 1e-15])
+@pytest.mark.parametrize("M,N,K", [(4099, 132, 100), (35840, 512, 5120), (35840, 256, 128), (8960, 3232, 32)])
+def test_gemm_x3_is_as_accurate_as_the_fp32_matrix_instructions(M, N, K, scale, monkeypatch):
+    """csrc/gemm_x3.hip multiplies fp32 operands as three bf16 parts each (six bf16 MFMA products per fp32 product, fp32
+    accumulation).  Against fp64, relative to sum_k |a| |w|: its error stays below 1e-6 and within 1.25x of the error of the
+    fp32 matrix instructions (csrc/gemm_nt.hip, PDGN_GEMM=fp32) on the same operands -- measured 0.7-0.95x -- for all three
+    operand layouts, and over the fp32 exponent range (bf16 shares it: no scaling of the operands is involved)."""
+    import ctypes
+    from pdgn_amd import _lib
+    from pdgn_amd._lib import ptr, stream_of
+    L = _lib.lib()
+    g = torch.Generator(device="cuda").manual_seed(M + K)
+    rows = min(M, 8192)
+    A = torch.randn(M, K, device="cuda", generator=g) * torch.rand(M, 1, device="cuda", generator=g) * 3 * scale
+    W = torch.randn(N, K, device="cuda", generator=g)
+    dY = torch.randn(M, N, device="cuda", generator=g) * scale
+    a64, w64, d64 = A[:rows].double(), W.double(), dY[:rows].double()
+    ref = {"nt": a64 @ w64.t(), "nn": d64 @ w64, "tn": d64.t() @ a64}
+    mag = {"nt": a64.abs() @ w64.abs().t(), "nn": d64.abs() @ w64.abs(), "tn": d64.abs().t() @ a64.abs()}
+    err = {}
+    for mode in ("x3", "fp32"):
+        monkeypatch.setenv("PDGN_GEMM", mode)
+        C = torch.empty(M, N, device="cuda")
+        assert L.pdgn_gemm_nt(ctypes.c_longlong(M), N, K, ptr(A), K, ptr(W), K, None, None, 0, ptr(C), N, None, stream_of(A)) == 0
+        dX = torch.empty(M, K, device="cuda")
+        assert L.pdgn_gemm_nn(ctypes.c_longlong(M), K, N, ptr(dY), N, ptr(W), K, None, None, 0, ptr(dX), K, None, stream_of(A)) == 0
+        out = {"nt": C[:rows], "nn": dX[:rows]}
+        if N >= 64 and K >= 64:
+            dW = torch.empty(N, K, device="cuda")
+            assert L.pdgn_gemm_tn_big(ctypes.c_longlong(rows), N, K, ptr(dY), N, ptr(A), K, ptr(dW), stream_of(A)) == 0
+            out["tn"] = dW
+        for kind, o in out.items():
+            assert torch.isfinite(o).all()
+            err[mode, kind] = ((o.double() - ref[kind]).abs() / mag[kind].clamp_min(1e-300)).max().item()
+    for (mode, kind), e in err.items():
+        assert e < 1e-6, (mode, kind, e)
+        if mode == "x3":
+            assert e <= 1.25 * err["fp32", kind] + 2e-8, (kind, e, err["fp32", kind])
 
 
 @pytest.mark.parametrize("ratio", [30.0, 300.0, 1000.0])
@@ -1052,8 +1098,9 @@ def test_point_max_forward_backward(B, N, C):
 
 
 @pytest.mark.parametrize("cfg", [None, 0, 1, 2, 3])
+@pytest.mark.parametrize("gemm", ["x3", "fp32"])
 @pytest.mark.parametrize("M,N,K,rpg", [(35840, 256, 128, 1024), (5000, 132, 36, 250), (8960, 64, 256, 8960), (1000, 36, 20, 1)])
-def test_gemm_nt_extended_epilogue(M, N, K, rpg, cfg, monkeypatch):
+def test_gemm_nt_extended_epilogue(M, N, K, rpg, cfg, monkeypatch, gemm):
     """pdgn_gemm_nt_ex through the C ABI, every tile configuration: bias per group of rows + LeakyReLU on the result (the
     heads' first layer), and the LeakyReLU-derivative gate on the transposed-weight form (their backward), against fp64."""
     import ctypes
@@ -1063,6 +1110,7 @@ def test_gemm_nt_extended_epilogue(M, N, K, rpg, cfg, monkeypatch):
         monkeypatch.delenv("PDGN_NT_CFG", raising=False)
     else:
         monkeypatch.setenv("PDGN_NT_CFG", str(cfg))
+    monkeypatch.setenv("PDGN_GEMM", gemm)                      # csrc/gemm_x3.hip (the default) | csrc/gemm_nt.hip
     L = _lib.lib()
     g = torch.Generator(device="cuda").manual_seed(M + N + K)
     A = torch.randn(M, K, device="cuda", generator=g)

@@ -19,12 +19,12 @@ for r in sel:
     c[n] += 1
     t[n] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
 print("steps %d  wall %.2f ms/step  kernels/step %.0f  sum of kernel time %.2f ms/step" % (steps, wall, len(sel) / steps, sum(t.values()) / 1e3 / steps))
-groups = {"gemm_nt": 0.0, "gemm_tn": 0.0, "Cijk": 0.0, "at::native": 0.0, "wgs": 0.0, "cl_": 0.0, "bn_softmax|bilateral": 0.0, "knn": 0.0}
+groups = {"gemm_x3": 0.0, "gemm_nt": 0.0, "gemm_tn": 0.0, "Cijk": 0.0, "at::native": 0.0, "wgs": 0.0, "cl_": 0.0, "bn_softmax|bilateral": 0.0, "knn": 0.0}
 for n, v in t.items():
     for g in groups:
         if any(x in n for x in g.split("|")):
             groups[g] += v
             break
 print("  " + "  ".join("%s %.2f" % (g, v / 1e3 / steps) for g, v in groups.items()))
-for n, v in t.most_common(45):
+for n, v in t.most_common(70):
     print("  %6.1f x %9.1f us/step  %s" % (c[n] / steps, v / steps, n))
