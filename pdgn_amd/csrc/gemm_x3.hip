@@ -6,27 +6,41 @@
 // once activations are point-major; with the weight transposed, their input gradients; with both, their weight gradients.)
 //
 // gfx950 multiplies fp32 on the matrix cores at 157 TFLOP/s (v_mfma_f32_16x16x4_f32: gemm_nt.hip runs at 85-88 % of that)
-// and bf16 at 2.5 PFLOP/s.  Every fp32 operand value is split IN REGISTERS, after the fragment read from LDS, into three bf16
-// parts by round-to-nearest conversions of successive remainders,
+// and bf16 at 2.5 PFLOP/s.  Every fp32 operand value is split into three bf16 parts by round-to-nearest conversions of
+// successive remainders,
 //       x = h + m + l (+ e),   |m| <= 2^-8 |x|,  |l| <= 2^-16 |x|,  |e| <= 2^-25 |x|  (less than half an fp32 ulp),
-// and a product is the six partial products of weight <= 2^-16, each exact in the fp32 accumulator's input:
+// and a product is the six partial products of weight >= 2^-16, each exact in the fp32 accumulator's input:
 //       a w ~= al wh + am wm + ah wl + am wh + ah wm + ah wh          (v_mfma_f32_32x32x16_bf16, smallest terms first)
 // The three dropped ones (am wl, al wm, al wl) are <= 2^-23 |a w| together: the error per product is about that of ONE
-// rounded fp32 multiply (2^-24), and the accumulation is the matrix core's fp32 one, as in gemm_nt.hip.  Six bf16
-// instructions of 32 cycles do the work of sixteen fp32 ones of 32 cycles (tools/split_mfma_probe.hip: 2.4 PFLOP/s of bf16
-// MFMA = 400 TFLOP/s fp32-equivalent before the splitting).  tests/test_gpu_deconv.py compares both kernels with fp64.
+// rounded fp32 multiply (2^-24), and the accumulation is the matrix core's fp32 one, as in gemm_nt.hip -- against fp64 the
+// results are closer than the fp32 instructions' (tests/test_gpu_deconv.py::test_gemm_x3_is_as_accurate_as_...: 0.7-0.95x
+// their error).  Six bf16 instructions of 32 cycles do the work of sixteen fp32 ones of 32 cycles: a ceiling of
+// 2.5 PFLOP/s / 6 = 417 TFLOP/s of fp32 products (tools/split_mfma_probe.hip measures 2.4 PFLOP/s of bare bf16 MFMA).
 //
-// Everything around the products is gemm_nt.hip's: persistent workgroups walking (tile, k range) items with ONE continuous
-// sequence of 32-deep k chunks through a two-stage LDS ring, operands global -> LDS by LDS-DMA in fp32 (the same swizzled
-// [rows][32 floats] image), counted waits, XCD-aware tile order, data-parallel launch + stream-K tail with fp32 atomics,
-// the epilogues (bias, addend, per-group row bias, LeakyReLU, gate, block-shifted BatchNorm partial sums).  What differs:
-//   * a chunk is two 16-deep k steps of 32 x 32 fragments; lane (i, g) of a fragment holds k = 8g .. 8g + 7 of row i: two
-//     ds_read_b128 (the 16-B columns 2g, 2g + 1 of the step, conflict-free in the swizzled image);
-//   * the fragments of the NEXT k step are read and split (11 vector instructions per pair of values) in the issue slots the
-//     running MFMAs leave free: a 32 x 32 x 16 bf16 MFMA holds the SIMD's vector issue for 8 of its 32 cycles
-//     (MI355X_MICROARCH.md, cycle constants), so ~5 single-issue instructions per MFMA hide;
-//   * D row (8q + 4g + r) = weight row, D column i = activation row: a lane holds four runs of 4 consecutive output
-//     columns per 32 x 32 block: 16-B stores, issued inside the next item's first k step as in gemm_nt.hip.
+// Around the products the kernel is gemm_nt.hip's: persistent workgroups walking (tile, k range) items as ONE continuous
+// sequence of 32-deep k chunks, XCD-aware tile order, data-parallel launch + stream-K tail with fp32 atomics, the epilogues
+// (bias, addend, per-group row bias, LeakyReLU, gate, block-shifted BatchNorm partial sums), the result's 16-B stores issued
+// inside the next item's first chunk.  The operand path is its own, because the split is vector-ALU work (11 instructions
+// per pair of values) that must be done ONCE per value and hidden between the MFMAs:
+//   * loaders: every thread reads 16 B (4 consecutive k of one row; a wave instruction = whole 128-B lines) of the chunk
+//     AFTER NEXT into registers -- no LDS staging of fp32 data;
+//   * conversion: the values loaded one chunk ago are split and written as three bf16 parts, [rows][32 k] each, 64 B per
+//     row, into the LDS stage the products will read NEXT (two stages); each quad's registers are reloaded as soon as it is
+//     written.  The 16-B column c of row r sits at c ^ ((r >> 2) & 3): conflict-free for the b128 fragment reads' lane
+//     groups and for the 8-B writes;
+//   * products: a chunk is two 16-deep k steps of 6 TM TN MFMAs; the six partial products run in turn over ALL the wave's
+//     32 x 32 blocks (consecutive MFMAs are independent); lane (i, g) of a fragment holds k = 8g .. 8g + 7 of row i: one
+//     ds_read_b128 per part, the fragments of the next k step read during the current one;
+//   * the conversion tasks, the reloads and the fragment reads sit at fixed places between the MFMAs (a 32 x 32 x 16 bf16
+//     MFMA holds the SIMD's vector issue for 8 of its 32 cycles: ~5 single-issue instructions per MFMA hide,
+//     MI355X_MICROARCH.md, cycle constants); one barrier per chunk, placed so that the last MFMAs of the chunk cover the
+//     first fragment reads of the next; the item's first chunk is peeled off the loop so that the loop body is one code
+//     path and the loop-carried registers (values in flight, accumulators) need no copies;
+//   * operands given transposed (K x rows: the input- and weight-gradient forms) differ in the loader only: 4 k rows x 4
+//     columns per thread, transposed in registers.
+// Measured (MI355X, tools/x3_check.py, tools/x3_pmc.sh): 190-200 TFLOP/s on 35840 x 512 x 5120 (gemm_nt.hip: 135) with the
+// matrix pipe busy 68 % of the cycles at the 1.77 GHz the chip holds under this load (2.4 GHz nominal: the bf16 peak at
+// that clock is 1.84 PFLOP/s = 307 TFLOP/s of fp32 products).
 #include <type_traits>
 
 #include "gemm_shared.h"
@@ -610,7 +624,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_x3_kernel(const NtArgs
 template <int TM, int TN, int WM, int WN, int OCC, int RATE>      // RATE: fp32-equivalent kflop / us a CU sustains on this tile's loop
 struct X3Cfg {
     static constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
-    static constexpr int LDS = 2 * ((BM + BN) * NT_BK + (BM / 8 + BN / 8) * 16) * 4;        // with both operands' piece padding
+    static constexpr int LDS = 2 * 3 * (BM + BN) * 64;              // two stages of three bf16 parts of [rows][32 k]
     static constexpr int WG_PER_CU = OCC;
 
     struct Plan {
@@ -703,9 +717,9 @@ struct X3Cfg {
     }
 };
 
-typedef X3Cfg<2, 2, 2, 2, 1, 660> X3Square;   // 128 x 128, 4 waves of 64 x 64 (64 KB): one per CU (the parts of two k steps + accumulators exceed 256 registers)
-typedef X3Cfg<4, 2, 2, 2, 1, 760> X3Big;      // 256 x 128, 4 waves of 128 x 64 (96 KB): one per CU, one wave per SIMD
-typedef X3Cfg<2, 1, 2, 2, 2, 590> X3Narrow;   // 128 x 64, 4 waves of 64 x 32 (48 KB): two per CU
+typedef X3Cfg<2, 2, 2, 2, 1, 660> X3Square;   // 128 x 128, 4 waves of 64 x 64 (96 KB of LDS): one per CU
+typedef X3Cfg<4, 2, 2, 2, 1, 760> X3Big;      // 256 x 128, 4 waves of 128 x 64 (144 KB of LDS): one per CU, one wave per SIMD
+typedef X3Cfg<2, 1, 2, 2, 2, 540> X3Narrow;   // 128 x 64, 4 waves of 64 x 32 (72 KB of LDS): two per CU
 
 static int x3_mode() {                   // PDGN_GEMM: "x3" (default) or "fp32" (gemm_nt.hip: the fp32 matrix instructions)
     const char *e = getenv("PDGN_GEMM");

@@ -33,8 +33,25 @@ def t(fn, it=10):
         best = min(best, s.elapsed_time(e) / it * 1e3)
     return best
 
+NCFG = 4 if os.environ.get("PDGN_GEMM", "x3").startswith("f") else 3
 tot_own = tot_lib = 0.0
 extra = {}
+
+
+def all_cfgs(run, key, cfg):
+    """ALL_CFGS=1: the problem under every tile configuration (PDGN_NT_CFG), against the launch model's pick."""
+    if os.environ.get("ALL_CFGS") != "1":
+        return
+    per = []
+    for c_ in range(NCFG):
+        os.environ["PDGN_NT_CFG"] = str(c_)
+        per.append(t(run, it=5))
+    del os.environ["PDGN_NT_CFG"]
+    best = min(range(NCFG), key=lambda i: per[i])
+    extra[key] = extra.get(key, "") + " | cfgs " + " ".join("%.1f" % v for v in per) + (" | best %d %s" % (
+        best, "" if per[cfg & 15] <= 1.03 * per[best] else "<-- pick %d is %.0f%% slower" % (cfg & 15, 100 * (per[cfg & 15] / per[best] - 1))))
+
+
 rows = []
 for (kind, m, n, k), cnt in log.items():
     if kind.startswith("thin"):
@@ -42,31 +59,28 @@ for (kind, m, n, k), cnt in log.items():
     pad = lambda v: (v + 3) // 4 * 4
     if kind == "nn":
         a = torch.randn(m, pad(k), device="cuda"); w = torch.randn(pad(k), pad(n), device="cuda"); c = torch.empty(m, pad(n), device="cuda")
-        own = t(lambda: L.pdgn_gemm_nn(ctypes.c_longlong(m), pad(n), pad(k), ptr(a), pad(k), ptr(w), pad(n), None, None, 0, ptr(c), pad(n), None, stream_of(a)))
+        run = lambda: L.pdgn_gemm_nn(ctypes.c_longlong(m), pad(n), pad(k), ptr(a), pad(k), ptr(w), pad(n), None, None, 0, ptr(c), pad(n), None, stream_of(a))
+        own = t(run)
         lib = t(lambda: a.matmul(w))
         cfg = L.pdgn_gemm_nt_config(ctypes.c_longlong(m), pad(n), pad(k), 0)
+        all_cfgs(run, (kind, m, n, k), cfg)
     elif kind == "nt":
         a = torch.randn(m, pad(k), device="cuda"); w = torch.randn(pad(n), pad(k), device="cuda"); c = torch.empty(m, pad(n), device="cuda")
         run = lambda: L.pdgn_gemm_nt(ctypes.c_longlong(m), pad(n), pad(k), ptr(a), pad(k), ptr(w), pad(k), None, None, 0, ptr(c), pad(n), None, stream_of(a))
         own = t(run)
         lib = t(lambda: torch.nn.functional.linear(a, w))
         cfg = L.pdgn_gemm_nt_config(ctypes.c_longlong(m), pad(n), pad(k), 0)
-        if os.environ.get("ALL_CFGS") == "1":
-            per = []
-            for c_ in range(4):
-                os.environ["PDGN_NT_CFG"] = str(c_)
-                per.append(t(run, it=5))
-            del os.environ["PDGN_NT_CFG"]
-            best = min(range(4), key=lambda i: per[i])
-            extra[(kind, m, n, k)] = " | cfgs " + " ".join("%.1f" % v for v in per) + (" | best %d %s" % (best, "" if per[cfg & 15] <= 1.03 * per[best] else "<-- pick %d is %.0f%% slower" % (cfg & 15, 100 * (per[cfg & 15] / per[best] - 1))))
+        all_cfgs(run, (kind, m, n, k), cfg)
     else:
         dy = torch.randn(m, pad(n), device="cuda"); x = torch.randn(m, pad(k), device="cuda"); dw = torch.zeros(pad(n), pad(k), device="cuda")
         own = t(lambda: L.pdgn_gemm_tn(ctypes.c_longlong(m), pad(n), pad(k), ptr(dy), ptr(x), ptr(dw), stream_of(dy)))
         lib = t(lambda: dy.t().matmul(x))
         cfg = -1
         if pad(n) >= 64 and pad(k) >= 64:
-            big = t(lambda: L.pdgn_gemm_tn_big(ctypes.c_longlong(m), pad(n), pad(k), ptr(dy), pad(n), ptr(x), pad(k), ptr(dw), stream_of(dy)))
+            runb = lambda: L.pdgn_gemm_tn_big(ctypes.c_longlong(m), pad(n), pad(k), ptr(dy), pad(n), ptr(x), pad(k), ptr(dw), stream_of(dy))
+            big = t(runb)
             extra[(kind, m, n, k)] = " | tn_big %8.1f us %6.1f TF (x%.2f of gemm_tn)" % (big, 2.0 * m * n * k / big / 1e6, big / own)
+            all_cfgs(runb, (kind, m, n, k), L.pdgn_gemm_nt_config(ctypes.c_longlong(pad(n)), pad(k), min(m, 0x7fffffff), 0))
     rows.append((own * cnt, kind, m, n, k, cnt, cfg, own, lib))
     tot_own += own * cnt; tot_lib += lib * cnt
 rows.sort(reverse=True)
