@@ -114,13 +114,22 @@ def conv2_dense_dx_stage4(B, base_points, device):
 
 
 def weight_grad_stage4(B, base_points, device):
-    """conv2's dense half weight gradient at stage 4, dW (512 x 5120) = dY^T (inte*w) over M = B * 8*base rows, on
-    pdgn_gemm_tn (split row reduction)."""
+    """conv2's dense half weight gradient at stage 4, dW (512 x 5120) = dY^T (inte*w) over M = B * 8*base rows, on the entry
+    point the step launches for it: pdgn_gemm_tn_big (the x3 kernel with both operands transposed, stream-K over the rows;
+    the launch zero-fills dW itself) -- or, with PDGN_GEMM=fp32, pdgn_gemm_tn (split row reduction, fp32 instructions)."""
     M, N, K = B * 8 * base_points, 512, 5120
     dy = torch.randn(M, N, device=device)
     x = torch.randn(M, K, device=device)
     dw = torch.zeros(N, K, device=device)
     L = _lib.lib()
+    if gemm_mode() == "x3":
+        def run():
+            check(L.pdgn_gemm_tn_big(ctypes.c_longlong(M), N, K, ptr(dy), N, ptr(x), K, ptr(dw), stream_of(dy)), "pdgn_gemm_tn_big")
+        us = _time_us(run)
+        e = _entry("gemm_x3_kernel<AT,WT> = pdgn_gemm_tn_big (dW of conv2's dense half, stage 4, M=%d N=%d K=%d)" % (M, N, K), "mfma",
+                   2.0 * M * N * K, us, x3=True, shape=[M, N, K])
+        e["algorithmic_bytes_per_launch"] = 4.0 * (M * N + M * K + N * K)
+        return e
 
     def run():
         dw.zero_()

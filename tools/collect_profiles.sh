@@ -17,7 +17,10 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_eval -- python3 
 cp $(find $OUT/kt_eval -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_eval_kernel_stats.csv
 bash tools/run_pmc_roofline.sh $OUT/pmc > /dev/null 2>&1
 python3 tools/pmc_roofline.py $OUT/pmc $OUT/${TAG}_pmc_mfma.csv $OUT/traffic.json > $OUT/${TAG}_pmc_summary.txt
-python3 tools/gemm_shapes.py > $OUT/${TAG}_gemm_shapes.txt 2>&1
+ALL_CFGS=1 python3 tools/gemm_shapes.py > $OUT/${TAG}_gemm_shapes.txt 2>&1
+python3 tools/x3_check.py 2>&1 | grep -v amdgpu.ids > $OUT/${TAG}_x3_check.txt
+PDGN_GEMM=fp32 python3 tools/x3_check.py 2>&1 | grep -v amdgpu.ids >> $OUT/${TAG}_x3_check.txt
+bash tools/x3_pmc.sh $OUT/x3pmc 2>&1 | grep -E "^[abc] \(" > $OUT/${TAG}_x3_pmc.txt
 python3 tools/host_time.py > $OUT/${TAG}_host_time.txt 2>&1
-rm -rf $OUT/kt_bench $OUT/kt_roof $OUT/kt_eval $OUT/pmc $OUT/pmc.*.log
+rm -rf $OUT/kt_bench $OUT/kt_roof $OUT/kt_eval $OUT/pmc $OUT/pmc.*.log $OUT/x3pmc
 ls -la $OUT

@@ -15,7 +15,7 @@ ENTRIES = {   # entry function -> (kernel-name substrings whose dispatches belon
     "conv2_dense_stage4": (["gemm_x3_kernel", "gemm_nt_kernel"], 2.0, "gemm_x3_kernel (conv2 dense half forward"),
     "per_point_stage4": (["gemm_x3_kernel", "gemm_nt_kernel"], 2.0, "gemm_x3_kernel (per-point GEMM"),
     "conv2_dense_dx_stage4": (["gemm_x3_kernel", "gemm_nt_kernel"], 2.0, "gemm_x3_kernel<WT> = pdgn_gemm_nn (conv2 dense half input gradient"),
-    "weight_grad_stage4": (["gemm_tn_kernel"], 2.0, "gemm_tn_kernel"),
+    "weight_grad_stage4": (["gemm_x3_kernel", "gemm_tn_kernel"], 2.0, "gemm_x3_kernel<AT,WT> = pdgn_gemm_tn_big"),
     "bn_act_backward_stage4": (["cl_bwd_reduce_kernel", "cl_bwd_apply_kernel"], 2.0, "cl_bwd_reduce + cl_bwd_apply"),
     "window_gather_sum_stage4": (["wgs_fwd_xcd_kernel"], 2.0, "wgs_fwd_xcd_kernel"),
     "feature_knn_stage4": (["feat_knn_pc_kernel"], 2.0, "feat_knn_pc_kernel<128>"),
