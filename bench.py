@@ -28,6 +28,10 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 matrix peak (v_mfma_f32_32x32x2_f32 / 16x16x4_f32)
+GEMM_ARITHMETIC = ("fp32 matrix instructions (PDGN_GEMM=fp32)" if os.environ.get("PDGN_GEMM", "x3").startswith("f") else
+                   "fp32 operands, results and accumulation; each product = six bf16 MFMA partial products of the operands' "
+                   "three-way bf16 splits (csrc/gemm_x3.hip): error per product <= 2^-23, against fp64 below the fp32 matrix "
+                   "instructions' (tests/test_gpu_deconv.py); PDGN_GEMM=fp32 selects those instructions")
 # SURVEY.md section 8-d / BASELINE.md section 2: the reference's direct form costs ~222 GFLOP per sample and G+D step
 DIRECT_FORM_FLOPS_PER_SAMPLE = 222e9
 
@@ -441,7 +445,9 @@ def measure_and_report(args, trainer, reals, zs, world, rank, device, res):
                                    "synthetic batch, per-GPU batch %d, %d->%d pts, random-init weights"
                                    % (B, res[0], res[3]),
                        "global_batch": world * B, "points_all_resolutions_per_s": world * B * sum(res) / (dt / args.steps),
-                       "parallelism": "dp%d" % world, "losses_finite": finite, "hipgraph": graphed},
+                       "parallelism": "dp%d" % world, "losses_finite": finite, "hipgraph": graphed,
+                       # how one fp32 product of the dense contractions is formed
+                       "gemm_arithmetic": GEMM_ARITHMETIC},
         }
         if flops is not None and "error" in flops:
             line["executed_flops_per_step"] = flops
