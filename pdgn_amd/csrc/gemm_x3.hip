@@ -81,6 +81,23 @@ __device__ __forceinline__ f32x16 x3_mfma(const u32x4 a, const u32x4 b, const f3
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
+// v + (v of the lane CTRL says), 0 where that lane is outside the row / the row is masked: one v_add_f32 with a DPP operand
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float x3_dpp_add(float v) {
+    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, true));
+}
+
+// Sum over the 32 lanes of each half of the wave, valid in lanes 31 and 63: an inclusive scan inside each row of 16 lanes
+// (row_shr 1, 2, 4, 8: lane 15 of a row holds the row's sum), then lane 15 of rows 0 / 2 added into rows 1 / 3 (row_bcast:15).
+// Five vector instructions; the ds_bpermute butterfly of __shfl_xor costs an LDS round trip per step.
+__device__ __forceinline__ float x3_half_wave_sum(float v) {
+    v = x3_dpp_add<0x111, 0xf>(v);
+    v = x3_dpp_add<0x112, 0xf>(v);
+    v = x3_dpp_add<0x114, 0xf>(v);
+    v = x3_dpp_add<0x118, 0xf>(v);
+    return x3_dpp_add<0x142, 0xa>(v);
+}
+
 // TM x TN blocks of 32 x 32 per wave, WM x WN waves, OCC workgroups per CU.
 template <int TM, int TN, int WM, int WN, int OCC, bool ATOMIC, bool WT, bool AT, bool EPI = false>
 __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_x3_kernel(const NtArgs p) {
@@ -442,7 +459,11 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_x3_kernel(const NtArgs
                     float cs[4] = {0.f, 0.f, 0.f, 0.f}, cq[4] = {0.f, 0.f, 0.f, 0.f}, pv[4];
                     const f32x4 x0 = get4(0, bb);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) pv[r] = __shfl(x0[r], lane & 32, 64);            // row li = 0 of block a = 0
+                    for (int r = 0; r < 4; ++r) {                  // row li = 0 of block a = 0: lanes 0 / 32
+                        const float p0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x0[r]), 0));
+                        const float p1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x0[r]), 32));
+                        pv[r] = lg ? p1 : p0;
+                    }
 #pragma unroll
                     for (int a = 0; a < TM; ++a)
                         if (mloc0 + 32 * a < mrows) {
@@ -455,14 +476,12 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_x3_kernel(const NtArgs
                             }
                         }
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-#pragma unroll
-                        for (int d = 1; d < 32; d <<= 1) {
-                            cs[r] += __shfl_xor(cs[r], d, 64);
-                            cq[r] += __shfl_xor(cq[r], d, 64);
-                        }
+                    for (int r = 0; r < 4; ++r) {                  // DPP adds: the sums end up in lanes 31 / 63
+                        cs[r] = x3_half_wave_sum(cs[r]);
+                        cq[r] = x3_half_wave_sum(cq[r]);
+                    }
                     const int nl = nloc0 + coloff(bb);
-                    if (li == 0 && nl < ncols) {
+                    if (li == 31 && nl < ncols) {
                         *reinterpret_cast<float4 *>(P + n0 + nl) = make_float4(cs[0], cs[1], cs[2], cs[3]);
                         *reinterpret_cast<float4 *>(P + p.N + n0 + nl) = make_float4(cq[0], cq[1], cq[2], cq[3]);
                         *reinterpret_cast<float4 *>(P + 2 * p.N + n0 + nl) = make_float4(pv[0], pv[1], pv[2], pv[3]);
