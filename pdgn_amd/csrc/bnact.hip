@@ -194,16 +194,18 @@ __global__ __launch_bounds__(FIN_CH * FIN_PL) void cl_finalize_blocks_kernel(
     const int c = blockIdx.x * FIN_CH + cl;
     const bool ok = c < C;
     double a = 0, b = 0;
+    const double inv_full = 1.0 / (double)rpp;                     // every block but the last is full: no fp64 division per block
     if (ok)
         for (int p = pl; p < nparts; p += FIN_PL) {
             const long long left = R - (long long)p * rpp;
             if (left <= 0) break;
-            const double n = (double)(left < rpp ? left : rpp);
+            const bool full = left >= rpp;
+            const double n = (double)(full ? rpp : left), inv = full ? inv_full : 1.0 / (double)left;
             const float *q = part + (size_t)p * 3 * C + c;
             const double s = (double)q[0], sq = (double)q[C], pv = (double)q[2 * C];
-            const double mb = pv + s / n;
+            const double mb = pv + s * inv;
             a += n * mb;
-            b += (sq - s * s / n) + n * mb * mb;
+            b += (sq - s * s * inv) + n * mb * mb;
         }
     red[pl][cl] = a;
     red2[pl][cl] = b;
