@@ -195,10 +195,11 @@ __global__ __launch_bounds__(FIN_CH * FIN_PL) void cl_finalize_blocks_kernel(
     const bool ok = c < C;
     double a = 0, b = 0;
     const double inv_full = 1.0 / (double)rpp;                     // every block but the last is full: no fp64 division per block
+    const int pmax = (int)min((long long)nparts, (R + rpp - 1) / rpp);      // blocks that hold rows
     if (ok)
-        for (int p = pl; p < nparts; p += FIN_PL) {
+#pragma unroll 4
+        for (int p = pl; p < pmax; p += FIN_PL) {                 // (no exit inside: the loads of four blocks go out together)
             const long long left = R - (long long)p * rpp;
-            if (left <= 0) break;
             const bool full = left >= rpp;
             const double n = (double)(full ? rpp : left), inv = full ? inv_full : 1.0 / (double)left;
             const float *q = part + (size_t)p * 3 * C + c;

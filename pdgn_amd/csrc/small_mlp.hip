@@ -25,18 +25,43 @@ __global__ __launch_bounds__(SM_THREADS) void small_mlp_fwd_kernel(
     const float *__restrict__ W, const float *__restrict__ bias, const float *__restrict__ gamma,
     const float *__restrict__ beta, float *__restrict__ running_mean, float *__restrict__ running_var,
     float *__restrict__ y, float *__restrict__ pre, float *__restrict__ stat) {
-    extern __shared__ float xs[];                               // [R][K + 1]
-    const int ld = K + 1;
-    for (int i = threadIdx.x; i < R * K; i += SM_THREADS) xs[(i / K) * ld + i % K] = x[i];
+    extern __shared__ __attribute__((aligned(16))) float xs[];  // [R][ld]
+    // rows padded to a multiple of 4 floats + 4: 16-B aligned rows (ds_read_b128) whose lane stride is 4 banks off a multiple
+    // of 64 (conflict-free); K % 4 != 0 (never on the model's layers) keeps the scalar form
+    const bool vec = (K & 3) == 0;
+    const int ld = vec ? K + 4 : K + 1;
+    if (vec) {
+        const int K4 = K >> 2;
+        for (int i = threadIdx.x; i < R * K4; i += SM_THREADS) {
+            const int r = i / K4, c = i - r * K4;
+            *reinterpret_cast<float4 *>(xs + r * ld + 4 * c) = *reinterpret_cast<const float4 *>(x + (size_t)r * K + 4 * c);
+        }
+    } else {
+        for (int i = threadIdx.x; i < R * K; i += SM_THREADS) xs[(i / K) * ld + i % K] = x[i];
+    }
     __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // uniform: W[n, :] becomes a scalar-load stream
     const int n = blockIdx.x * (SM_THREADS / 64) + wave;
     if (n >= N) return;
     const bool live = lane < R;
     const float *w = W + (size_t)n * K;
     const float *xr = xs + (live ? lane : 0) * ld;
     float acc = bias ? bias[n] : 0.f;
-    for (int k = 0; k < K; ++k) acc = __fmaf_rn(xr[k], w[k], acc);
+    if (vec) {
+#pragma unroll 8
+        for (int k = 0; k < K; k += 4) {                         // the same fma chain, k ascending: bit-identical to the scalar form
+                                                                 // (unrolled x8: 32 k of LDS / scalar loads in flight per wait)
+            const float4 xv = *reinterpret_cast<const float4 *>(xr + k);
+            const float4 wv = *reinterpret_cast<const float4 *>(w + k);
+            acc = __fmaf_rn(xv.x, wv.x, acc);
+            acc = __fmaf_rn(xv.y, wv.y, acc);
+            acc = __fmaf_rn(xv.z, wv.z, acc);
+            acc = __fmaf_rn(xv.w, wv.w, acc);
+        }
+    } else {
+        for (int k = 0; k < K; ++k) acc = __fmaf_rn(xr[k], w[k], acc);
+    }
     if (pre && live) pre[(size_t)lane * N + n] = acc;
     float z = acc;
     if (bn_mode) {
@@ -109,7 +134,7 @@ __global__ __launch_bounds__(SM_THREADS) void small_mlp_bwd_kernel(
 
 static bool sm_ok(int r, int k, int n, int act, int bn_mode) {
     return r >= 1 && r <= 64 && k >= 1 && k <= SM_MAXK && n >= 1 && act >= 0 && act <= 2 && bn_mode >= 0 && bn_mode <= 2 &&
-           (size_t)r * (k + 1) * 4 + 1024 <= 160 * 1024;
+           (size_t)r * (k + 4) * 4 + 1024 <= 160 * 1024;
 }
 
 extern "C" int pdgn_small_mlp_forward(int r, int k, int n, int act, int bn_mode, float eps, float momentum, const float *x,
@@ -117,7 +142,7 @@ extern "C" int pdgn_small_mlp_forward(int r, int k, int n, int act, int bn_mode,
                                       float *running_mean, float *running_var, float *y, float *pre, float *stat,
                                       pdgn_stream_t stream) {
     if (!sm_ok(r, k, n, act, bn_mode) || (bn_mode == 2 && (!running_mean || !running_var))) return PDGN_ERR_INVALID;
-    const size_t lds = (size_t)r * (k + 1) * sizeof(float);
+    const size_t lds = (size_t)r * (k + 4) * sizeof(float);
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void *)small_mlp_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return (int)e;
