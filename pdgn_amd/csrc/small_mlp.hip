@@ -92,12 +92,21 @@ __global__ __launch_bounds__(SM_THREADS) void small_mlp_bwd_kernel(
     const float *__restrict__ pre, const float *__restrict__ stat, const float *__restrict__ gamma,
     const float *__restrict__ beta, float *__restrict__ dpre, float *__restrict__ dgamma, float *__restrict__ dbeta,
     float *__restrict__ dbias, float *__restrict__ dW) {
-    extern __shared__ float sm[];                               // xs [R][K+1] | dp [4][64]
-    const int ld = K + 1;
+    extern __shared__ __attribute__((aligned(16))) float sm[];  // xs [R][ld] | dp [4][64]
+    const bool vec = (K & 3) == 0;                              // 16-B rows as in the forward kernel
+    const int ld = vec ? K + 4 : K + 1;
     float *xs = sm, *dps = sm + (size_t)R * ld;
-    for (int i = threadIdx.x; i < R * K; i += SM_THREADS) xs[(i / K) * ld + i % K] = x[i];
+    if (vec) {
+        const int K4 = K >> 2;
+        for (int i = threadIdx.x; i < R * K4; i += SM_THREADS) {
+            const int r = i / K4, c = i - r * K4;
+            *reinterpret_cast<float4 *>(xs + r * ld + 4 * c) = *reinterpret_cast<const float4 *>(x + (size_t)r * K + 4 * c);
+        }
+    } else {
+        for (int i = threadIdx.x; i < R * K; i += SM_THREADS) xs[(i / K) * ld + i % K] = x[i];
+    }
     __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int n = blockIdx.x * (SM_THREADS / 64) + wave;
     if (n >= N) return;
     const bool live = lane < R;
@@ -124,10 +133,26 @@ __global__ __launch_bounds__(SM_THREADS) void small_mlp_bwd_kernel(
     if (dW) {
         dps[wave * 64 + lane] = dp;
         __builtin_amdgcn_wave_barrier();
-        for (int k = lane; k < K; k += 64) {
-            float s = 0.f;
-            for (int r = 0; r < R; ++r) s = __fmaf_rn(dps[wave * 64 + r], xs[r * ld + k], s);
-            dW[(size_t)n * K + k] = s;
+        if (vec) {                                               // four columns per lane: one 16-B LDS read per row (same sums, same order)
+            for (int k = 4 * lane; k < K; k += 256) {
+                float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 5
+                for (int r = 0; r < R; ++r) {
+                    const float d = dps[wave * 64 + r];
+                    const float4 xv = *reinterpret_cast<const float4 *>(xs + r * ld + k);
+                    s.x = __fmaf_rn(d, xv.x, s.x);
+                    s.y = __fmaf_rn(d, xv.y, s.y);
+                    s.z = __fmaf_rn(d, xv.z, s.z);
+                    s.w = __fmaf_rn(d, xv.w, s.w);
+                }
+                *reinterpret_cast<float4 *>(dW + (size_t)n * K + k) = s;
+            }
+        } else {
+            for (int k = lane; k < K; k += 64) {
+                float s = 0.f;
+                for (int r = 0; r < R; ++r) s = __fmaf_rn(dps[wave * 64 + r], xs[r * ld + k], s);
+                dW[(size_t)n * K + k] = s;
+            }
         }
     }
 }
@@ -157,7 +182,7 @@ extern "C" int pdgn_small_mlp_backward(int r, int k, int n, int act, int bn_mode
                                        float *dpre, float *dgamma, float *dbeta, float *dbias, float *dW,
                                        pdgn_stream_t stream) {
     if (!sm_ok(r, k, n, act, bn_mode) || (bn_mode && !stat)) return PDGN_ERR_INVALID;
-    const size_t lds = ((size_t)r * (k + 1) + 4 * 64) * sizeof(float);
+    const size_t lds = ((size_t)r * (k + 4) + 4 * 64) * sizeof(float);
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void *)small_mlp_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return (int)e;
