@@ -49,7 +49,7 @@
 #define X3_FENCE 2                    // MFMAs per scheduling region of the main loop
 #endif
 #ifndef X3_ABLATE
-#define X3_ABLATE 0                   // tools/x3_bench.hip (measurement only): 1 no conversion tasks, 2 no operand loads, 4 no stores, 8 no barrier, 16 no fragment reads, 32 no split arithmetic, 64 one LDS write per group
+#define X3_ABLATE 0                   // tools/x3_bench.hip (measurement only): 1 no conversion tasks, 2 no operand loads, 4 no stores, 8 no barrier, 16 no fragment reads, 32 no split arithmetic, 64 one LDS write per group, 128 direct (unstaged) result stores
 #endif
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -107,7 +107,10 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_x3_kernel(const NtArgs
     // {4-11, 16-19, 28-31} (+32) of MI355X_MICROARCH.md's LDS table: the four rows with equal r & 3 of a group differ in
     // (r >> 2) & 3 -- and the b64 writes of the row-major loaders (16 lanes = 2 rows x 64 B) are bank-conflict-free.
     constexpr int PART_A = BM * 64, PART_W = BN * 64, STAGE = 3 * (PART_A + PART_W);
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * STAGE];
+    // STG: the result leaves through a per-wave LDS staging block (32 rows x 128 B) so that a store instruction covers whole
+    // 128-B lines (8 rows) instead of 32 B of each of 32 rows -- for the one-workgroup-per-CU tiles, whose LDS has the room
+    constexpr bool STG = OCC == 1 && !ATOMIC && !(X3_ABLATE & 128);
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * STAGE + (STG ? NW * 4096 : 0)];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -371,7 +374,33 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_x3_kernel(const NtArgs
     unsigned st_off[NBB];                                          // byte offset of (row mloc0, sub-block bb), or out of range
 #pragma unroll
     for (int bb = 0; bb < NBB; ++bb) st_off[bb] = NT_OOB;
+    // staged form: lane l stores row 8 j + (l >> 3), columns 4 (l & 7) .. + 3 of a 32 x 32 block (j = 0 .. 3)
+    unsigned stg_off[TN];                                          // byte offset of (row wm 32 TM + (l >> 3), column block b), or out of range
+#pragma unroll
+    for (int b = 0; b < TN; ++b) stg_off[b] = NT_OOB;
+    unsigned char *const stg = smem + 2 * STAGE + wave * 4096;
+    const unsigned stg_wr = (unsigned)(li * 128), stg_sw = (unsigned)(li & 7);      // writer: row li, 16-B column (2 q + lg) ^ (li & 7)
+    const unsigned stg_rd = (unsigned)((lane >> 3) * 128 + (((lane & 7) ^ (lane >> 3)) * 16));
+    u32x4 pend[4];                                                 // a block on its way out: read back from the staging block
+    auto stage_block = [&](int a, int b) {                         // accumulators -> LDS -> pend (LDS operations are in order)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            *reinterpret_cast<u32x4 *>(stg + stg_wr + (((unsigned)(2 * q + lg) ^ stg_sw) * 16)) = __builtin_bit_cast(u32x4, get4(a, 4 * b + q));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pend[j] = *reinterpret_cast<const u32x4 *>(stg + stg_rd + j * 1024);
+    };
+    auto flush_block = [&](int a, int b) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (!(X3_ABLATE & 4))
+                __builtin_amdgcn_raw_buffer_store_b128(pend[j], rsC, stg_off[b] + (unsigned)((a * 32 + 8 * j) * p.ldc) * 4u, 0, 0);
+    };
     auto store_block = [&](int a, int b) {
+        if (STG) {
+            stage_block(a, b);
+            flush_block(a, b);
+            return;
+        }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const unsigned off = st_off[4 * b + q] + (unsigned)(a * 32 * p.ldc) * 4u;
@@ -390,6 +419,11 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_x3_kernel(const NtArgs
 #pragma unroll
             for (int bb = 0; bb < NBB; ++bb)
                 st_off[bb] = (nloc0 + coloff(bb) < ncols && !(p.dbg & 1)) ? (unsigned)(mloc0 * p.ldc + nloc0 + coloff(bb)) * 4u : NT_OOB;
+#pragma unroll
+            for (int b = 0; b < TN; ++b) {
+                const int nl = wn * 32 * TN + 32 * b + 4 * (lane & 7);
+                stg_off[b] = (nl < ncols && !(p.dbg & 1)) ? (unsigned)((wm * 32 * TM + (lane >> 3)) * p.ldc + nl) * 4u : NT_OOB;
+            }
             if (p.addend) {                                        // out of range reads 0
                 __amdgpu_buffer_rsrc_t rsD = __builtin_amdgcn_make_buffer_rsrc((void *)(p.addend + m0 * p.ldadd + n0), 0,
                                                                                (int)(mrows * p.ldadd * 4), 0x00020000);
@@ -560,10 +594,18 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_x3_kernel(const NtArgs
                         }
                         f32x16 c = acc[a][b];
                         if (FIRST && s == 0 && t == 0) {           // the pending stores of the block, then its restart from zero
-                            if (!ATOMIC) store_block(a, b);
+                            if (STG) {
+                                // staged: the previous block's lines go out (read back one MFMA ago), then this block enters the
+                                // staging block; the last one is flushed after the first MFMA of the second product
+                                if (a + b > 0) flush_block(b ? a : a - 1, b ? b - 1 : TN - 1);
+                                stage_block(a, b);
+                            } else if (!ATOMIC) {
+                                store_block(a, b);
+                            }
 #pragma unroll
                             for (int r = 0; r < 16; ++r) c[r] = 0.f;
                         }
+                        if (FIRST && STG && s == 0 && t == 1 && a == 0 && b == 0) flush_block(TM - 1, TN - 1);
                         const X3Parts &A = fa[s][a], &W = fw[s][b];
                         const u32x4 ap = t == 0 ? A.l : (t == 1 || t == 3) ? A.m : A.h;      // al wh, am wm, ah wl, am wh, ah wm, ah wh
                         const u32x4 wp = t == 2 ? W.l : (t == 1 || t == 4) ? W.m : W.h;

@@ -22,5 +22,7 @@ python3 tools/x3_check.py 2>&1 | grep -v amdgpu.ids > $OUT/${TAG}_x3_check.txt
 PDGN_GEMM=fp32 python3 tools/x3_check.py 2>&1 | grep -v amdgpu.ids >> $OUT/${TAG}_x3_check.txt
 bash tools/x3_pmc.sh $OUT/x3pmc 2>&1 | grep -E "^[abc] \(" > $OUT/${TAG}_x3_pmc.txt
 python3 tools/host_time.py > $OUT/${TAG}_host_time.txt 2>&1
+python3 tools/phase_events.py > $OUT/${TAG}_phases_overlapped.txt 2>&1
+python3 bench.py --base-points 256 --steps 10 --warmup 3 --no-cpu-baseline --no-eval-c5 > $OUT/${TAG}_bench_c4.json 2>> $OUT/bench.err
 rm -rf $OUT/kt_bench $OUT/kt_roof $OUT/kt_eval $OUT/pmc $OUT/pmc.*.log $OUT/x3pmc
 ls -la $OUT
