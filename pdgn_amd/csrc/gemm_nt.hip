@@ -565,7 +565,7 @@ struct NtCfg {
         a.A = A; a.W = W; a.bias = bias; a.addend = addend; a.C = C; a.stat_part = stat_part;
         a.row_bias = epi.row_bias; a.ld_rb = epi.ld_rb; a.rows_per_group = epi.rows_per_group > 0 ? epi.rows_per_group : 1;
         a.rpg_magic = a.rows_per_group > 1 ? (unsigned)(0x100000000ULL / (unsigned)a.rows_per_group) + 1u : 0u;
-        a.act = epi.act; a.gate = epi.gate; a.ldgate = epi.ldgate;
+        a.act = epi.act; a.gate = epi.gate; a.ldgate = epi.ldgate; a.sk_split = 0;
         a.tiles_m = pl.tiles_m; a.tiles_n = pl.tiles_n; a.kchunks = pl.kchunks;
         { const char *e = getenv("PDGN_NT_DBG"); a.dbg = e ? atoi(e) : 0; }
         const long long T = (long long)pl.tiles_m * pl.tiles_n;

@@ -43,6 +43,8 @@ struct NtArgs {
     float *C, *stat_part;
     int tiles_m, tiles_n, tile_begin, tile_end, kchunks;
     long long sk_per_wg;              // stream-K launch: (tile, chunk) iterations per workgroup
+    int sk_split;                     // > 0 (gemm_x3 only): split-K launch over sk_split tiles: workgroup v takes tile v % sk_split,
+                                      // chunks [v / sk_split * sk_per_wg, + sk_per_wg) -- workgroups that run together share panels
     int dbg;                          // PDGN_NT_DBG (measurement only): 1 = stores dropped (out-of-range offsets)
     // extended epilogue (pdgn_gemm_nt_ex), applied in this order after bias / addend:
     const float *row_bias;            // + row_bias[(row / rows_per_group) * ld_rb + col]: a bias per GROUP of rows (per sample)

@@ -139,7 +139,14 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_x3_kernel(const NtArgs
         bool valid;
     };
     auto next_item = [&](Cur &c) {
-        if (ATOMIC) {
+        if (ATOMIC && p.sk_split) {                                // split-K: one item per workgroup
+            const int slice = v / p.sk_split;
+            c.tile = p.tile_begin + v % p.sk_split;
+            c.kc = c.kb = (int)(slice * p.sk_per_wg);
+            c.ke = min(KC, c.kb + (int)p.sk_per_wg);
+            c.valid = c.j == 0 && c.kb < KC;
+            c.j++;
+        } else if (ATOMIC) {
             c.valid = c.f < c.f1;
             if (c.valid) {
                 c.tile = p.tile_begin + (int)(c.f / KC);
@@ -757,10 +764,22 @@ struct X3Cfg {
         a.A = A; a.W = W; a.bias = bias; a.addend = addend; a.C = C; a.stat_part = stat_part;
         a.row_bias = epi.row_bias; a.ld_rb = epi.ld_rb; a.rows_per_group = epi.rows_per_group > 0 ? epi.rows_per_group : 1;
         a.rpg_magic = a.rows_per_group > 1 ? (unsigned)(0x100000000ULL / (unsigned)a.rows_per_group) + 1u : 0u;
-        a.act = epi.act; a.gate = epi.gate; a.ldgate = epi.ldgate;
+        a.act = epi.act; a.gate = epi.gate; a.ldgate = epi.ldgate; a.sk_split = 0;
         a.tiles_m = pl.tiles_m; a.tiles_n = pl.tiles_n; a.kchunks = pl.kchunks;
         { const char *e = getenv("PDGN_NT_DBG"); a.dbg = e ? atoi(e) : 0; }
         const long long T = (long long)pl.tiles_m * pl.tiles_n;
+        if (AT && T <= nt_cus() * WG_PER_CU && !(getenv("PDGN_X3_SPLITK") && getenv("PDGN_X3_SPLITK")[0] == '0')) {
+            // weight gradients: few output tiles, a reduction of 10^4 .. 10^5.5 rows.  Split-K: the workgroups that run at the same
+            // time work on the SAME row range of different tiles (tile = v % T), so the XCD's L2 serves the operand panels they
+            // share; the flattened stream-K order gives neighbouring workgroups neighbouring row ranges of one tile and every
+            // panel is fetched from HBM once per tile (conv2's dense half: 4.4 GB for 0.8 GB of operands).
+            const int slots = nt_cus() * WG_PER_CU;
+            const int S = (int)(slots / T) < pl.kchunks ? (int)(slots / T) : pl.kchunks;
+            if (hipMemsetAsync(C, 0, (size_t)m * ldc * sizeof(float), s) != hipSuccess) return pdgn_launch_status();
+            a.tile_begin = 0; a.tile_end = (int)T; a.sk_split = (int)T; a.sk_per_wg = (pl.kchunks + S - 1) / S;
+            go<true, WT, AT, false>((int)T * S, s, a);
+            return pdgn_launch_status();
+        }
         if (pl.grid_sk) {
             const long long r0 = (long long)(pl.dp_tiles / (NT_GROUP_M * pl.tiles_n)) * NT_GROUP_M * BM;
             if (hipMemsetAsync(C + r0 * ldc, 0, (size_t)(m - r0) * ldc * sizeof(float), s) != hipSuccess) return pdgn_launch_status();
