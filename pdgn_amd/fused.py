@@ -702,7 +702,7 @@ def small_sequential(seq, x, training):
     fusable = x.is_cuda and x.dim() == 2 and x.shape[0] <= 64 and all(
         isinstance(m, (torch.nn.Linear, torch.nn.BatchNorm1d, torch.nn.LeakyReLU, torch.nn.ReLU)) for m in mods)
     if fusable:
-        fusable = all(m.in_features <= 1024 and x.shape[0] * (m.in_features + 1) * 4 + 1024 <= 160 * 1024
+        fusable = all(m.in_features <= 1024 and x.shape[0] * (m.in_features + 4) * 4 + 1024 <= 160 * 1024
                       for m in mods if isinstance(m, torch.nn.Linear))
     if not fusable:
         return seq(x)
