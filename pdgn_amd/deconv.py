@@ -23,7 +23,7 @@ import ctypes
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
-from torch.autograd import Function
+from ._fn import Function
 
 from . import _lib
 from . import streams as _streams

@@ -3,7 +3,7 @@ shape-preserving local-statistics loss (models/PDGNet_v2.py:127-155), on fused H
 (csrc/localpair.hip): no (B,M,N) distance matrix, no (B,3,M,20) grouped tensor, no bmm."""
 import torch
 import torch.nn as nn
-from torch.autograd import Function
+from ._fn import Function
 
 from . import _lib, pointops
 from ._lib import check, ptr, require, stream_of

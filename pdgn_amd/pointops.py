@@ -16,7 +16,7 @@ from typing import Tuple
 import numpy as np
 import torch
 import torch.nn as nn
-from torch.autograd import Function
+from ._fn import Function
 
 from . import _lib
 from ._lib import check, ptr, require, stream_of

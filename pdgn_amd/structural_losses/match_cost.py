@@ -4,7 +4,7 @@
 import ctypes
 
 import torch
-from torch.autograd import Function
+from .._fn import Function
 
 from .. import _lib
 from .._lib import check, ptr, require, stream_of

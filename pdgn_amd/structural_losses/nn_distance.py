@@ -2,7 +2,7 @@
 evaluation/pytorch_structural_losses/nn_distance.py:7-41 (NNDistanceFunction) and the pybind
 entry points NNDistance / NNDistanceGrad (src/structural_loss.cpp:80-124)."""
 import torch
-from torch.autograd import Function
+from .._fn import Function
 
 from .. import _lib
 from .._lib import check, ptr, require, stream_of

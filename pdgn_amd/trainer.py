@@ -245,9 +245,11 @@ class PDGNTrainer:
         return w
 
     def _freeze_D(self, frozen):
-        for d in self.D:
-            for p in d.parameters():
-                p.requires_grad_(not frozen)
+        params = self.__dict__.get("_d_params")
+        if params is None:                                       # (module.parameters() walks the module tree: 0.4 ms per call)
+            params = self.__dict__["_d_params"] = [p for d in self.D for p in d.parameters()]
+        for p in params:
+            p.requires_grad_(not frozen)
 
     def similar_terms(self, clouds, pairs, own=None):
         """{(a, b): (like_mu, like_cov)} of get_local_pair (:232-237) for the given resolution pairs.  `own` caches
