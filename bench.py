@@ -39,8 +39,8 @@ DIRECT_FORM_FLOPS_PER_SAMPLE = 222e9
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=35, help="per-GPU batch (BASELINE.json: 35)")
     ap.add_argument("--base-points", type=int, default=128, help="128: 256->2048 (reference); 256: 512->4096")
     ap.add_argument("--no-cpu-baseline", action="store_true")
