@@ -317,6 +317,20 @@ int pdgn_chamfer_gram(int b, int m, int n, int d, const float *x, const float *y
 int pdgn_chamfer_gram_grad(int b, int m, int n, int d, const float *x, const float *y,
                            const float *gminx, const int32_t *argx, const float *gminy,
                            const int32_t *argy, float *gx, float *gy, pdgn_stream_t stream);
+/* The same for the loss scale * (sum minx + sum miny) (utils/chamfer_loss.py:16-20) with upstream gradient g[0] (a device
+ * scalar): every minimum's gradient is g[0] * scale, no expanded gradient tensor.  When gy == gx + b*m*d one fill zeroes both. */
+int pdgn_chamfer_gram_grad_uniform(int b, int m, int n, int d, const float *x, const float *y, const float *g,
+                                   float scale, const int32_t *argx, const int32_t *argy, float *gx, float *gy,
+                                   pdgn_stream_t stream);
+/* Scalar ends of the step's losses, one launch each way (csrc/loss_small.hip; fixed summation order):
+ * pdgn_scaled_sum: out[0] = scale * sum_i x[i] (the Chamfer minima, chamfer_loss.py:16-20);
+ * pdgn_mse_const: out[0] = scale * mean_i (x[i] - target)^2 -- nn.MSELoss against a constant, the adversarial terms
+ * mse(D(x), 1) / mse(D(x), 0) of models/PDGNet_v2.py:186-190, 246-250 (scale: their 1/2);
+ * pdgn_mse_const_backward: dx[i] = g[0] * scale * 2 (x[i] - target) / n. */
+int pdgn_scaled_sum(long long n, const float *x, float scale, float *out, pdgn_stream_t stream);
+int pdgn_mse_const(long long n, const float *x, float target, float scale, float *out, pdgn_stream_t stream);
+int pdgn_mse_const_backward(long long n, const float *x, float target, float scale, const float *g, float *dx,
+                            pdgn_stream_t stream);
 
 /* All-pairs evaluation (evaluation/evaluation_metrics.py:85-121 expands every sample against every
  * reference batch): the same kernels over explicit pair lists, pair p = (cloud ia[p] of the first

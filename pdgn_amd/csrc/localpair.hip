@@ -164,7 +164,7 @@ __global__ __launch_bounds__(LP_THREADS) void chamfer_gram_kernel(
 __global__ __launch_bounds__(LP_THREADS) void chamfer_gram_grad_kernel(
     int m, int n, int d, const float *__restrict__ x, const float *__restrict__ y,
     const float *__restrict__ gminx, const int32_t *__restrict__ argx, const float *__restrict__ gminy,
-    const int32_t *__restrict__ argy, float *__restrict__ gx, float *__restrict__ gy) {
+    const int32_t *__restrict__ argy, float *__restrict__ gx, float *__restrict__ gy, const float *__restrict__ guni, float gscale) {
     const int bs = blockIdx.y;
     const bool rev = blockIdx.z != 0;
     const int nq = rev ? n : m, nc = rev ? m : n;
@@ -173,7 +173,8 @@ __global__ __launch_bounds__(LP_THREADS) void chamfer_gram_grad_kernel(
     const float *Q = (rev ? y : x) + ((size_t)bs * nq + i) * d;
     const int j = (rev ? argy : argx)[(size_t)bs * nq + i];
     const float *C = (rev ? x : y) + ((size_t)bs * nc + j) * d;
-    const float g = 2.0f * (rev ? gminy : gminx)[(size_t)bs * nq + i];
+    // upstream gradient of the minima: per element, or (guni) ONE device scalar times gscale (the minima were summed)
+    const float g = 2.0f * (guni ? guni[0] * gscale : (rev ? gminy : gminx)[(size_t)bs * nq + i]);
     float *GQ = (rev ? gy : gx) + ((size_t)bs * nq + i) * d;
     float *GC = (rev ? gx : gy) + ((size_t)bs * nc + j) * d;
     for (int c = 0; c < d; ++c) {
@@ -236,17 +237,37 @@ extern "C" int pdgn_chamfer_gram_indexed(int npairs, int m, int n, int d, const 
     return chamfer_launch(grid, (hipStream_t)stream, m, n, d, x, y, minx, argx, miny, argy, ia, ib);
 }
 
+static int chamfer_grad_launch(int b, int m, int n, int d, const float *x, const float *y, const float *gminx, const int32_t *argx,
+                               const float *gminy, const int32_t *argy, float *gx, float *gy, const float *guni, float gscale,
+                               hipStream_t s) {
+    hipError_t e;
+    const size_t nx = (size_t)b * m * d, ny = (size_t)b * n * d;
+    if (gy == gx + nx) {                                           // one buffer (the callers here allocate it so): one fill
+        if ((e = hipMemsetAsync(gx, 0, (nx + ny) * sizeof(float), s)) != hipSuccess) return (int)e;
+    } else {
+        if ((e = hipMemsetAsync(gx, 0, nx * sizeof(float), s)) != hipSuccess) return (int)e;
+        if ((e = hipMemsetAsync(gy, 0, ny * sizeof(float), s)) != hipSuccess) return (int)e;
+    }
+    dim3 grid(cdiv(m > n ? m : n, LP_THREADS), b, 2);
+    hipLaunchKernelGGL(chamfer_gram_grad_kernel, grid, dim3(LP_THREADS), 0, s, m, n, d, x, y, gminx, argx, gminy, argy, gx, gy,
+                       guni, gscale);
+    return pdgn_launch_status();
+}
+
 extern "C" int pdgn_chamfer_gram_grad(int b, int m, int n, int d, const float *x, const float *y,
                                       const float *gminx, const int32_t *argx, const float *gminy,
                                       const int32_t *argy, float *gx, float *gy, pdgn_stream_t stream) {
     if (b < 0 || m < 1 || n < 1 || d < 1 || d > CH_MAXD || b > 65535) return PDGN_ERR_INVALID;
     if (b == 0) return 0;
-    hipStream_t s = (hipStream_t)stream;
-    hipError_t e;
-    if ((e = hipMemsetAsync(gx, 0, (size_t)b * m * d * sizeof(float), s)) != hipSuccess) return (int)e;
-    if ((e = hipMemsetAsync(gy, 0, (size_t)b * n * d * sizeof(float), s)) != hipSuccess) return (int)e;
-    dim3 grid(cdiv(m > n ? m : n, LP_THREADS), b, 2);
-    hipLaunchKernelGGL(chamfer_gram_grad_kernel, grid, dim3(LP_THREADS), 0, s, m, n, d, x, y, gminx, argx, gminy, argy,
-                       gx, gy);
-    return pdgn_launch_status();
+    return chamfer_grad_launch(b, m, n, d, x, y, gminx, argx, gminy, argy, gx, gy, nullptr, 0.f, (hipStream_t)stream);
+}
+
+// The same with a uniform upstream gradient g[0] * scale for every minimum (the loss is scale * sum of the minima,
+// utils/chamfer_loss.py:16-20): no expanded gradient tensor.
+extern "C" int pdgn_chamfer_gram_grad_uniform(int b, int m, int n, int d, const float *x, const float *y, const float *g,
+                                              float scale, const int32_t *argx, const int32_t *argy, float *gx, float *gy,
+                                              pdgn_stream_t stream) {
+    if (b < 0 || m < 1 || n < 1 || d < 1 || d > CH_MAXD || b > 65535 || !g) return PDGN_ERR_INVALID;
+    if (b == 0) return 0;
+    return chamfer_grad_launch(b, m, n, d, x, y, nullptr, argx, nullptr, argy, gx, gy, g, scale, (hipStream_t)stream);
 }

@@ -1,6 +1,8 @@
 """Losses of the PDGN training step: Chamfer (utils/chamfer_loss.py:13-38) and the
 shape-preserving local-statistics loss (models/PDGNet_v2.py:127-155), on fused HIP kernels
 (csrc/localpair.hip): no (B,M,N) distance matrix, no (B,3,M,20) grouped tensor, no bmm."""
+import ctypes
+
 import torch
 import torch.nn as nn
 from ._fn import Function
@@ -68,19 +70,55 @@ class ChamferSum(Function):
                                            stream_of(x)), "pdgn_chamfer_gram")
         ctx.save_for_backward(x, y, args)
         ctx.scale = float(scale)
-        return mins.sum() * ctx.scale
+        out = torch.empty((), dtype=F32, device=x.device)
+        check(_lib.lib().pdgn_scaled_sum(ctypes.c_longlong(b * (m + n)), ptr(mins), ctypes.c_float(ctx.scale), ptr(out),
+                                         stream_of(x)), "pdgn_scaled_sum")
+        return out
 
     @staticmethod
     def backward(ctx, g):
         x, y, args = ctx.saved_tensors
         b, m, d = x.shape
         n = y.shape[1]
-        gfull = (g * ctx.scale).expand(b * (m + n)).contiguous()
-        gx, gy = torch.empty_like(x), torch.empty_like(y)
-        check(_lib.lib().pdgn_chamfer_gram_grad(b, m, n, d, ptr(x), ptr(y), ptr(gfull[:b * m]), ptr(args[:b * m]),
-                                                ptr(gfull[b * m:]), ptr(args[b * m:]), ptr(gx), ptr(gy), stream_of(x)),
-              "pdgn_chamfer_gram_grad")
+        gbuf = torch.empty((b * (m + n) * d,), dtype=F32, device=x.device)      # gx | gy: one zero-fill inside the call
+        gx, gy = gbuf[:b * m * d].view(b, m, d), gbuf[b * m * d:].view(b, n, d)
+        g = g.contiguous()
+        check(_lib.lib().pdgn_chamfer_gram_grad_uniform(b, m, n, d, ptr(x), ptr(y), ptr(g), ctypes.c_float(ctx.scale),
+                                                        ptr(args[:b * m]), ptr(args[b * m:]), ptr(gx), ptr(gy), stream_of(x)),
+              "pdgn_chamfer_gram_grad_uniform")
         return gx, gy, None
+
+
+class MseConst(Function):
+    """scale * nn.MSELoss()(x, target * ones_like(x)) -- the adversarial terms mse(D(x), 1) / mse(D(x), 0) with their 1/2
+    (models/PDGNet_v2.py:186-190, 246-250) -- as one launch forward and one backward (csrc/loss_small.hip)."""
+
+    @staticmethod
+    def forward(ctx, x, target, scale):
+        x = x.contiguous()
+        require(x, "x", F32)
+        out = torch.empty((), dtype=F32, device=x.device)
+        check(_lib.lib().pdgn_mse_const(ctypes.c_longlong(x.numel()), ptr(x), ctypes.c_float(target), ctypes.c_float(scale),
+                                        ptr(out), stream_of(x)), "pdgn_mse_const")
+        ctx.save_for_backward(x)
+        ctx.cfg = (float(target), float(scale))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, = ctx.saved_tensors
+        target, scale = ctx.cfg
+        dx = torch.empty_like(x)
+        g = g.contiguous()
+        check(_lib.lib().pdgn_mse_const_backward(ctypes.c_longlong(x.numel()), ptr(x), ctypes.c_float(target),
+                                                 ctypes.c_float(scale), ptr(g), ptr(dx), stream_of(x)),
+              "pdgn_mse_const_backward")
+        return dx, None, None
+
+
+def mse_const(x, target, scale=1.0):
+    """scale * mean((x - target)^2) (MseConst)."""
+    return MseConst.apply(x, float(target), float(scale))
 
 
 def chamfer_sum(x, y, scale=1.0):

@@ -11,11 +11,11 @@ import os
 import torch
 import torch.distributed as dist
 import torch.nn as nn
-import torch.nn.functional as F
 
 from . import streams as _streams
 from .fused import clear_zero_colsum, flush_bn_counters, release_zero_arena, reset_zero_arena
 from .generator import PointDiscriminator, PointGenerator
+from . import losses
 from .losses import LocalPairLoss
 
 PAIRS = ((0, 1), (0, 2), (0, 3), (1, 2), (1, 3), (2, 3))   # get_local_pair calls :232-237
@@ -279,7 +279,7 @@ class PDGNTrainer:
     def _seg_d(self, st, i):
         D = self.D[i]
         self.gradD[i].begin()
-        lossD = (F.mse_loss(D(st["reals"][i]), st["ones"]) + F.mse_loss(D(st["fakes"][i]), st["zeros"])) / 2.0
+        lossD = losses.mse_const(D(st["reals"][i]), 1.0, 0.5) + losses.mse_const(D(st["fakes"][i]), 0.0, 0.5)
         lossD.backward()
         st["out"]["d_loss%d" % (i + 1)] = lossD.detach()
 
@@ -293,14 +293,14 @@ class PDGNTrainer:
         D = self.D[i]
         self.gradD[i].begin()
         params = self.gradD[i].params
-        loss_r = F.mse_loss(D(st["reals"][i]), st["ones"]) / 2.0
+        loss_r = losses.mse_const(D(st["reals"][i]), 1.0, 0.5)
         st["d_half"][i] = (loss_r.detach(), torch.autograd.grad(loss_r, params))
 
     def _seg_d_fake(self, st, i):
         D = self.D[i]
         fg = self.gradD[i]
         fg.resume()
-        loss_f = F.mse_loss(D(st["fakes"][i]), st["zeros"]) / 2.0
+        loss_f = losses.mse_const(D(st["fakes"][i]), 0.0, 0.5)
         loss_r, g_real = st["d_half"][i]
         g_fake = torch.autograd.grad(loss_f, fg.params)
         torch._foreach_add_(g_real, g_fake)
@@ -327,7 +327,7 @@ class PDGNTrainer:
             self._freeze_D(True)
             gen = self.G(self._z(st, "z2"), feature_hook=self._early_bucket_hook)
             similar = self.similar_loss(gen)
-            g_loss = [F.mse_loss(self.D[i](gen[i]), st["ones"]) for i in range(4)]
+            g_loss = [losses.mse_const(self.D[i](gen[i]), 1.0) for i in range(4)]
             adv = 1.2 * g_loss[0] + 1.2 * g_loss[1] + 1.2 * g_loss[2] + g_loss[3]
             lossG = adv + 0.1 * similar
             # MSE is a batch MEAN, the shape loss a batch SUM (chamfer_loss.py:16-20): to reproduce
@@ -364,8 +364,7 @@ class PDGNTrainer:
 
     def _state(self, reals, z1, z2):
         B = reals[0].shape[0]
-        return {"reals": reals, "z1": z1, "z2": z2, "B": B, "out": {}, "ws": world_size() if self.distributed else 1,
-                "ones": torch.ones(B, 1, device=self.device), "zeros": torch.zeros(B, 1, device=self.device)}
+        return {"reals": reals, "z1": z1, "z2": z2, "B": B, "out": {}, "ws": world_size() if self.distributed else 1}
 
     def step(self, reals, z1, z2):
         """reals: four tensors (B,3,N_k); z1 / z2: noise (B,128) of the two generator passes
@@ -462,7 +461,7 @@ class PDGNTrainer:
             side = self._side[level]
             side.wait_stream(main)
             with torch.cuda.stream(side):
-                g_loss[level] = F.mse_loss(self.D[level](cloud), st["ones"])
+                g_loss[level] = losses.mse_const(self.D[level](cloud), 1.0)
 
         gen = self.G(self._z(st, "z2"), stage_hook=tail if early else None, feature_hook=self._early_bucket_hook)
         mark("G(z2) forward")
@@ -473,7 +472,7 @@ class PDGNTrainer:
             for i, side in enumerate(self._side):
                 side.wait_stream(main)
                 with torch.cuda.stream(side):
-                    g_loss[i] = F.mse_loss(self.D[i](gen[i]), st["ones"])
+                    g_loss[i] = losses.mse_const(self.D[i](gen[i]), 1.0)
         for side in self._side:
             main.wait_stream(side)
         main.wait_stream(self._side_lp)

@@ -93,3 +93,38 @@ def test_local_pair_vs_oracle():
     np.testing.assert_allclose(cov.item(), rcov.item(), rtol=1e-4)
     np.testing.assert_allclose(a.grad.cpu().numpy(), ar.grad.numpy(), rtol=1e-3, atol=1e-4)
     np.testing.assert_allclose(b.grad.cpu().numpy(), br.grad.numpy(), rtol=1e-3, atol=1e-4)
+
+
+@pytest.mark.parametrize("shape,target,scale", [((35, 1), 1.0, 0.5), ((35, 1), 0.0, 0.5), ((7, 3), 1.0, 1.0), ((5000,), -0.25, 2.0)])
+def test_mse_against_a_constant_fwd_bwd(shape, target, scale):
+    """losses.mse_const (pdgn_mse_const[_backward]) == scale * nn.MSELoss()(x, target): the adversarial terms of
+    models/PDGNet_v2.py:186-190, 246-250, value and gradient, with a non-unit upstream gradient."""
+    from pdgn_amd import losses
+    g = torch.Generator(device="cuda").manual_seed(3)
+    x = torch.randn(*shape, device="cuda", generator=g).requires_grad_(True)
+    xr = x.detach().clone().requires_grad_(True)
+    out = losses.mse_const(x, target, scale)
+    ref = torch.nn.functional.mse_loss(xr, torch.full_like(xr, target)) * scale
+    np.testing.assert_allclose(out.item(), ref.item(), rtol=1e-6)
+    (out * 1.7).backward()
+    (ref * 1.7).backward()
+    np.testing.assert_allclose(x.grad.cpu().numpy(), xr.grad.cpu().numpy(), rtol=1e-6, atol=1e-9)
+
+
+@pytest.mark.parametrize("b,m,n,d", [(3, 100, 70, 3), (2, 257, 512, 9), (35, 256, 128, 3)])
+def test_chamfer_sum_fwd_bwd_vs_torch(b, m, n, d):
+    """losses.chamfer_sum (one node: pdgn_chamfer_gram + pdgn_scaled_sum forward, pdgn_chamfer_gram_grad_uniform backward with
+    the upstream scalar read on the device) against the torch stand-in, value and both gradients."""
+    from pdgn_amd import losses
+    from torch_standins import chamfer_sum_torch
+    g = torch.Generator(device="cuda").manual_seed(b * m + n)
+    x = torch.randn(b, m, d, device="cuda", generator=g).requires_grad_(True)
+    y = torch.randn(b, n, d, device="cuda", generator=g).requires_grad_(True)
+    xr, yr = x.detach().clone().requires_grad_(True), y.detach().clone().requires_grad_(True)
+    out = losses.chamfer_sum(x, y, 0.25)
+    ref = chamfer_sum_torch(xr, yr, 0.25)
+    np.testing.assert_allclose(out.item(), ref.item(), rtol=2e-5)
+    (out * 3.0).backward()
+    (ref * 3.0).backward()
+    np.testing.assert_allclose(x.grad.cpu().numpy(), xr.grad.cpu().numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(y.grad.cpu().numpy(), yr.grad.cpu().numpy(), rtol=1e-4, atol=1e-5)

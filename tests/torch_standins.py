@@ -74,11 +74,16 @@ def chamfer_sum_torch(x, y, scale=1.0):
     return (minx.sum() + miny.sum()) * scale
 
 
+def mse_const_torch(x, target, scale=1.0):
+    """Same contract as pdgn_amd.losses.mse_const: scale * nn.MSELoss against a constant, in torch ops."""
+    return torch.nn.functional.mse_loss(x, torch.full_like(x, float(target))) * scale
+
+
 def patch_losses(monkeypatch_or_module):
-    """Route pdgn_amd.losses' three HIP entry points to the stand-ins above."""
+    """Route pdgn_amd.losses' HIP entry points to the stand-ins above."""
     from pdgn_amd import losses
     for name, fn in (("knnquery", knnquery_oracle), ("local_stats", local_stats_torch), ("chamfer_min", chamfer_min_torch),
-                     ("chamfer_sum", chamfer_sum_torch)):
+                     ("chamfer_sum", chamfer_sum_torch), ("mse_const", mse_const_torch)):
         if hasattr(monkeypatch_or_module, "setattr"):
             monkeypatch_or_module.setattr(losses, name, fn)
         else:
