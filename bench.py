@@ -462,6 +462,7 @@ def measure_and_report(args, trainer, reals, zs, world, rank, device, res):
             try:
                 from pdgn_amd import roofline
                 line["roofline"] = roofline.measure(args.batch, args.base_points, device)
+                line["gemm_accuracy"] = roofline.gemm_accuracy(device)        # both kernels against fp64, same operands
             except Exception as e:                               # never lose the headline number
                 line["roofline"] = {"error": repr(e)}
         if world == 1 and not args.no_eval_c5:               # BASELINE.json configs[4], ~0.3 s: Chamfer + EMD, 512 pairs

@@ -64,6 +64,32 @@ def _entry(name, bound, work, us, x3=False, **extra):
     return d
 
 
+def gemm_accuracy(device, M=8192, N=512, K=2560):
+    """Largest error of pdgn_gemm_nt against fp64, relative to sum_k |a| |w|, for the kernel in use (x3: six bf16 MFMA products
+    per fp32 product) and for the fp32 matrix instructions on the same operands (PDGN_GEMM is read per call by the C entry
+    points): the live form of tests/test_gpu_deconv.py::test_gemm_x3_is_as_accurate_as_the_fp32_matrix_instructions."""
+    g = torch.Generator(device=device).manual_seed(1234)
+    a = torch.randn(M, K, device=device, generator=g) * (torch.rand(M, 1, device=device, generator=g) * 3)
+    w = torch.randn(N, K, device=device, generator=g)
+    ref = a.double() @ w.double().t()
+    mag = a.double().abs() @ w.double().abs().t()
+    c = torch.empty(M, N, device=device)
+    L = _lib.lib()
+    out, saved = {"shape": [M, N, K], "relative_to": "sum_k |a| |w|"}, os.environ.get("PDGN_GEMM")
+    try:
+        for mode in ("x3", "fp32"):
+            os.environ["PDGN_GEMM"] = mode
+            check(L.pdgn_gemm_nt(ctypes.c_longlong(M), N, K, ptr(a), K, ptr(w), K, None, None, 0, ptr(c), N, None, stream_of(a)),
+                  "pdgn_gemm_nt")
+            out["max_error_vs_fp64_" + mode] = ((c.double() - ref).abs() / mag).max().item()
+    finally:
+        if saved is None:
+            os.environ.pop("PDGN_GEMM", None)
+        else:
+            os.environ["PDGN_GEMM"] = saved
+    return out
+
+
 def _nt_entry(label, M, N, K, device):
     a = torch.randn(M, K, device=device)
     w = torch.randn(N, K, device=device)

@@ -43,6 +43,8 @@ def test_bench_prints_one_json_line_with_roofline_and_cpu_baseline():
     assert d["executed_flops_per_step"] > 1e12 and 0.0 < d["step_mfma_frac"] < 1.0 and d["algebraic_saving"] > 1.0
     assert r["kernel"].startswith("gemm_x3_kernel") and "Cijk" not in json.dumps(r)      # the roofline names own kernels only
     assert r["mfma"]["products_per_fp32_product"] == 6 and abs(r["peak"] * 6 - r["mfma"]["instruction_peak_tflops"]) < 1e-6
+    acc = d["gemm_accuracy"]                                     # the arithmetic of the contractions, measured in the same run
+    assert 0.0 < acc["max_error_vs_fp64_x3"] < 1e-6 and acc["max_error_vs_fp64_x3"] <= 1.25 * acc["max_error_vs_fp64_fp32"]
     c5 = d["eval_c5"]                                            # config C5 rides in the default line
     assert c5["pairs"] == 512 and c5["finite"] is True and c5["pairs_per_s"] > 0 and c5["ms_per_512"] > 0
     assert c5["roofline"]["bound"] == "valu-issue" and 0 < c5["roofline"]["frac"] < 1 and 0 < c5["roofline"]["exp_frac"] < 1
