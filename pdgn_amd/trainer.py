@@ -117,6 +117,53 @@ def world_size():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
 
+class LeanAdamStep:
+    """`optimizer.step()` of a fused, capturable `torch.optim.Adam` without its per-call Python (profile hooks, `_init_group`,
+    grouping by device and dtype: ~0.3 ms of host time per call, five calls per training step -- tools/host_prof.py): after the
+    first, ordinary step the same two calls torch makes -- `_foreach_add_` on the step counters, `_fused_adam_` on the parameter /
+    gradient / moment lists -- are issued on lists cached here.  The state stays the optimizer's own (checkpoints, broadcasts and
+    `state_dict()` are untouched); anything unusual (a parameter without gradient, several groups, amsgrad, weight decay, a
+    non-fused optimizer) keeps calling `optimizer.step()`."""
+
+    def __init__(self, opt):
+        self.opt, self.lists = opt, None
+
+    def reset(self):
+        """The optimizer's state tensors were replaced (load_state_dict): rebuild the lists after the next ordinary step."""
+        self.lists = None
+
+    def step(self):
+        opt = self.opt
+        if self.lists is None:
+            opt.step()
+            g = opt.param_groups[0]
+            ok = (len(opt.param_groups) == 1 and g.get("fused") and g.get("capturable") and not g.get("amsgrad")
+                  and not g.get("maximize") and not g.get("differentiable") and g.get("weight_decay", 0) == 0
+                  and not isinstance(g["lr"], torch.Tensor) and all(p.grad is not None for p in g["params"])
+                  and os.environ.get("PDGN_LEAN_ADAM", "1") == "1")
+            if ok:
+                ps, st = list(g["params"]), opt.state
+                self.lists = (ps, [st[p]["exp_avg"] for p in ps], [st[p]["exp_avg_sq"] for p in ps], [st[p]["step"] for p in ps])
+            else:
+                self.lists = False
+            return
+        if self.lists is False:
+            opt.step()
+            return
+        ps, exp_avgs, exp_avg_sqs, steps = self.lists
+        grads = [p.grad for p in ps]
+        for gr in grads:
+            if gr is None:
+                opt.step()
+                return
+        g = opt.param_groups[0]
+        with torch.no_grad():
+            torch._foreach_add_(steps, 1)
+            torch._fused_adam_(ps, grads, exp_avgs, exp_avg_sqs, [], steps, amsgrad=False, lr=g["lr"], beta1=g["betas"][0],
+                               beta2=g["betas"][1], weight_decay=0.0, eps=g["eps"], maximize=False, grad_scale=None,
+                               found_inf=None)
+
+
 class PDGNTrainer:
     """Generator + D1..D4 + their Adam optimisers (lr 1e-4, betas (0.5, 0.999), :121-125) and the
     op sequence of one iteration.  ``step`` returns the six logged losses (:259-261) as 0-dim
@@ -139,6 +186,7 @@ class PDGNTrainer:
         cap = self.device.type == "cuda"                     # device-side step counter: graph-capturable
         adam = lambda m: torch.optim.Adam(m.parameters(), lr=lr, betas=(0.5, 0.999), capturable=cap, fused=cap and os.environ.get("PDGN_FUSED_ADAM", "1") == "1")
         self.optG, self.optD = adam(self.G), [adam(d) for d in self.D]
+        self._stepG, self._stepD = LeanAdamStep(self.optG), [LeanAdamStep(o) for o in self.optD]
         # stream-overlapped schedule of the eager step (see _step_overlapped); PDGN_OVERLAP=0 turns it off
         self.overlap = cap and os.environ.get("PDGN_OVERLAP", "1") == "1"
         self._side = None
@@ -233,6 +281,8 @@ class PDGNTrainer:
         for i, (m, o) in enumerate(zip(self.D, self.optD), 1):
             load_reference_state_dict(m, d["D_model%d" % i])
             self._load_optim(o, d["D_optimizer%d" % i])
+        for st in [self._stepG] + self._stepD:                   # the optimizers' state tensors are new objects now
+            st.reset()
         self.sync_replicas()
         return g["G_epoch"]
 
@@ -317,10 +367,10 @@ class PDGNTrainer:
                 st["fakes"] = self.G(self._z(st, "z1"))
             self._seg_d(st, 0)
         elif k in (1, 2, 3):
-            self.optD[k - 1].step()
+            self._stepD[k - 1].step()
             self._seg_d(st, k)
         elif k == 4:
-            self.optD[3].step()
+            self._stepD[3].step()
             self.gradG.begin()
             # The reference lets lossG.backward() also fill the discriminators' .grad and throws
             # that away at the next zero_grad (:183); freezing D skips those weight-gradient GEMMs.
@@ -338,7 +388,7 @@ class PDGNTrainer:
             self._freeze_D(False)
             st["out"]["g_loss"], st["out"]["similar_loss"] = lossG.detach(), similar.detach()
         else:
-            self.optG.step()
+            self._stepG.step()
 
     def _early_bucket_hook(self, lvl, xt):
         """PointGenerator feature hook: the gradient of the deepest block's input is the point of the backward at which
@@ -422,7 +472,7 @@ class PDGNTrainer:
                 else:
                     self._seg_d(st, level)
                 self._comm(level)
-                self.optD[level].step()
+                self._stepD[level].step()
 
         if split:
             st["d_half"] = [None] * 4
@@ -488,7 +538,7 @@ class PDGNTrainer:
         self._freeze_D(False)
         st["out"]["g_loss"], st["out"]["similar_loss"] = lossG.detach(), similar.detach()
         self._comm(4)
-        self.optG.step()
+        self._stepG.step()
         release_zero_arena()                                # no later backward may receive slices of this step's arena
         mark("all-reduce + Adam G")
         return st["out"]

@@ -144,3 +144,37 @@ def test_split_discriminator_updates_equal_whole_updates():
                 torch.testing.assert_close(va, vb, rtol=2e-2, atol=2e-3, msg=ka)
             if "num_batches_tracked" in ka:
                 assert int(va) == int(vb) == 3, ka
+
+
+def test_lean_adam_step_is_the_optimizers_own_step():
+    """trainer.LeanAdamStep (the two calls of torch's fused Adam on cached lists) against optimizer.step() itself: parameters and
+    both moments bit-identical after six steps, the optimizer's state_dict() usable as ever, and the fall-back when a parameter
+    has no gradient."""
+    import copy
+    from pdgn_amd.trainer import LeanAdamStep
+    torch.manual_seed(0)
+    net_a = torch.nn.Sequential(torch.nn.Linear(37, 64), torch.nn.BatchNorm1d(64), torch.nn.Linear(64, 5)).cuda()
+    net_b = copy.deepcopy(net_a)
+    mk = lambda m: torch.optim.Adam(m.parameters(), lr=1e-3, betas=(0.5, 0.999), capturable=True, fused=True)
+    opt_a, opt_b = mk(net_a), mk(net_b)
+    lean = LeanAdamStep(opt_a)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    for it in range(6):
+        for pa, pb in zip(net_a.parameters(), net_b.parameters()):
+            pa.grad = torch.randn(pa.shape, device="cuda", generator=g)
+            pb.grad = pa.grad.clone()
+        lean.step()
+        opt_b.step()
+    assert lean.lists not in (None, False)
+    for pa, pb in zip(net_a.parameters(), net_b.parameters()):
+        assert torch.equal(pa, pb)
+        for key in ("exp_avg", "exp_avg_sq", "step"):
+            assert torch.equal(opt_a.state[pa][key], opt_b.state[pb][key])
+    sd = opt_a.state_dict()
+    assert len(sd["state"]) == len(list(net_a.parameters()))
+    # a parameter without gradient: the ordinary step takes over (and skips it, as torch does)
+    first = next(net_a.parameters())
+    before = first.detach().clone()
+    first.grad = None
+    lean.step()
+    assert torch.equal(first, before)
