@@ -51,6 +51,10 @@ def parse():
                          "faster on MI355X (DESIGN.md section 6), and on ROCm 7.2 graph launches are not reliably "
                          "ordered against RCCL / eager kernels on the same stream")
     ap.add_argument("--no-graph", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--issue", default="list", choices=("list", "eager"),
+                    help="list (default, one process): the iteration is captured once and every step re-issues its launches "
+                         "from C on the eager schedule's streams (trainer.capture_list, csrc/replay.hip); eager: every "
+                         "launch issued from Python (always under data parallelism: collectives cannot be captured)")
     ap.add_argument("--no-roofline", action="store_true", help="skip the roofline kernels (for clean rocprof traces)")
     ap.add_argument("--eval", action="store_true", help="time config C5 (Chamfer + EMD, 512 pairs of 2048 points)")
     ap.add_argument("--eval-pairs", type=int, default=512)
@@ -402,6 +406,16 @@ def measure_and_report(args, trainer, reals, zs, world, rank, device, res):
     # never land in the timed region, whatever W the caller asks for.
     for _ in range(2):
         step(reals, *zs[0])
+    issue = "hipgraph" if graphed else "eager"
+    if not graphed and args.issue == "list" and not trainer.distributed and getattr(trainer, "overlap", False):
+        try:                                   # the SAME launches as the eager step, re-issued from a recorded list
+            trainer.capture_list(reals, *zs[0])
+            step, issue = (lambda reals, z1, z2: trainer.step_list(None, z1, z2)), "list"
+            step(reals, *zs[0])
+        except Exception as e:                 # a capture problem must not lose the measurement
+            print("launch-list capture failed (%r): issuing eagerly" % (e,), file=sys.stderr)
+            torch.cuda.synchronize()
+            step = trainer.step
     for i in range(args.warmup):
         step(reals, *zs[i])
     barrier()
@@ -446,6 +460,8 @@ def measure_and_report(args, trainer, reals, zs, world, rank, device, res):
                                    % (B, res[0], res[3]),
                        "global_batch": world * B, "points_all_resolutions_per_s": world * B * sum(res) / (dt / args.steps),
                        "parallelism": "dp%d" % world, "losses_finite": finite, "hipgraph": graphed,
+                       # list: every launch of the iteration re-issued from C (csrc/replay.hip), one iteration in flight
+                       "issue": issue,
                        # how one fp32 product of the dense contractions is formed
                        "gemm_arithmetic": GEMM_ARITHMETIC},
         }

@@ -423,6 +423,24 @@ int pdgn_point_max_backward(int b, int n, int c, const float *grad_out, const in
  * queue to itself. */
 int pdgn_spin(unsigned int microseconds, pdgn_stream_t stream);
 
+/* ------------------------------------------------------------------ launch-list replay (csrc/replay.hip)
+ * No reference counterpart (the reference issues its iteration op by op from Python, models/PDGNet_v2.py:171-256).
+ * A captured hipGraph_t of the iteration is read back node by node and re-issued with plain launches on caller-chosen
+ * streams: pdgn_replay_marker(id, stream) inside the capture tags a stream; pdgn_replay_build turns the graph into a plan
+ * (kernel / memset / flat device-to-device memcpy / empty nodes only: anything else returns a negative code); chains =
+ * runs of nodes that were captured on one stream (pdgn_replay_chains: marker id or -1, and length, per chain);
+ * pdgn_replay_set_stream binds a chain to a hipStream_t; pdgn_replay_launch issues every node once, in capture order,
+ * with event pairs for the dependencies that cross chains.  counts8 = nodes, kernels, memsets, memcpys, empty nodes,
+ * chains, events, labelled chains.  The graph (and the memory its launches address) must outlive the plan. */
+int pdgn_replay_marker(int id, pdgn_stream_t stream);
+int pdgn_replay_build(void *hip_graph, void **plan_out);
+int pdgn_replay_info(void *plan, int *counts8);
+int pdgn_replay_chains(void *plan, int *labels, int *nodes_per_chain);
+int pdgn_replay_set_stream(void *plan, int chain, pdgn_stream_t stream);
+int pdgn_replay_launch(void *plan);
+int pdgn_replay_launch_timed(void *plan, double *us32); /* measurement: host microseconds per call kind / chain */
+int pdgn_replay_destroy(void *plan);
+
 #ifdef __cplusplus
 }
 #endif

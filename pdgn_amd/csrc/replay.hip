@@ -1,0 +1,298 @@
+// Launch-list replay of a captured G+D iteration.
+//
+// The iteration (models/PDGNet_v2.py:171-256; pdgn_amd/trainer.py) is ~1300 kernel launches spread over seven HIP streams.
+// Issued eagerly from Python the HOST needs 25-27 ms for them (autograd nodes, allocations, ctypes marshalling: ~20 us per
+// launch), which is within 2-4 ms of what the DEVICE needs; hipGraphLaunch of the captured iteration is slower than the eager
+// step on this ROCm (34.0 vs 31.2 ms: its executor re-derives streams and barriers on its own).  This file takes the third
+// route: the iteration is CAPTURED once (stream capture, so every launch parameter and every cross-stream dependency is
+// recorded by the runtime), the captured graph is read back node by node, and every later iteration RE-ISSUES the same
+// launches with plain hipModuleLaunchKernel calls on the streams the capture used -- same kernels, same arguments, same
+// streams and hardware queues as the eager step, at ~4 us of host time per launch and no Python in between.
+//
+// Stream identity is not part of a captured graph, so the capture tags its streams: pdgn_replay_marker(id, stream) launches an
+// empty kernel whose argument is the stream's id.  Nodes are walked in capture order (a topological order: a captured node
+// depends only on earlier ones); a node continues the chain of its first dependency that is still the tail of a chain, a
+// marker node opens the chain of its id, anything else opens an anonymous chain (replayed on a spare stream).  Dependencies
+// inside a chain are stream order; dependencies across chains become hipEventRecord / hipStreamWaitEvent pairs.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstring>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/pdgn_hip.h"
+
+namespace {
+
+__global__ void replay_marker_kernel(int id) { (void)id; }
+
+enum NodeKind { NK_KERNEL = 0, NK_MEMSET = 1, NK_MEMCPY = 2, NK_EMPTY = 3 };
+
+struct RNode {
+    int kind = NK_EMPTY;
+    int chain = -1;
+    int record = -1;                 // event to record after this node (another chain waits for it), or -1
+    std::vector<int> waits;          // events this node's chain must wait for before the node
+    // kernel
+    hipFunction_t func = nullptr;
+    unsigned gx = 1, gy = 1, gz = 1, bx = 1, by = 1, bz = 1, shmem = 0;
+    void **params = nullptr;
+    void **extra = nullptr;
+    // memset / memcpy
+    void *dst = nullptr;
+    const void *src = nullptr;
+    size_t bytes = 0;
+    unsigned value = 0, elem = 1;
+    size_t width = 0;
+};
+
+struct RPlan {
+    std::vector<RNode> nodes;
+    std::vector<int> chain_label;    // marker id of a chain, or -1
+    std::vector<hipStream_t> chain_stream;
+    std::vector<hipEvent_t> events;
+    int counts[8] = {0};             // nodes, kernels, memsets, memcpys, empties, chains, events, labelled chains
+    hipStream_t origin = nullptr;    // the capture's origin stream: chain of marker 0
+};
+
+bool is_marker(const hipKernelNodeParams &p) { return p.func == (void *)replay_marker_kernel; }
+
+}  // namespace
+
+extern "C" int pdgn_replay_marker(int id, pdgn_stream_t stream) {
+    hipLaunchKernelGGL(replay_marker_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, id);
+    return (int)hipGetLastError();
+}
+
+extern "C" int pdgn_replay_build(void *graph_, void **plan_out) {
+    hipGraph_t graph = (hipGraph_t)graph_;
+    if (!graph || !plan_out) return PDGN_ERR_INVALID;
+    size_t n = 0;
+    hipError_t e = hipGraphGetNodes(graph, nullptr, &n);
+    if (e != hipSuccess) return (int)e;
+    std::vector<hipGraphNode_t> gn(n);
+    if (n && (e = hipGraphGetNodes(graph, gn.data(), &n)) != hipSuccess) return (int)e;
+    std::unordered_map<hipGraphNode_t, int> index;
+    for (size_t i = 0; i < n; ++i) index[gn[i]] = (int)i;
+    // dependencies per node, in the order the capture recorded them (own stream first, waited events after)
+    std::vector<std::vector<int>> deps(n);
+    for (size_t i = 0; i < n; ++i) {
+        size_t nd = 0;
+        if ((e = hipGraphNodeGetDependencies(gn[i], nullptr, &nd)) != hipSuccess) return (int)e;
+        std::vector<hipGraphNode_t> d(nd);
+        if (nd && (e = hipGraphNodeGetDependencies(gn[i], d.data(), &nd)) != hipSuccess) return (int)e;
+        for (size_t j = 0; j < nd; ++j) {
+            auto it = index.find(d[j]);
+            if (it == index.end()) return PDGN_ERR_INVALID;
+            deps[i].push_back(it->second);
+        }
+    }
+    // a topological order that stays as close to capture order as the dependencies allow
+    std::vector<int> order, indeg(n, 0), pos(n, -1);
+    std::vector<std::vector<int>> succ(n);
+    for (size_t i = 0; i < n; ++i)
+        for (int d : deps[i]) { succ[d].push_back((int)i); ++indeg[i]; }
+    {
+        std::vector<int> heap;
+        auto cmp = [](int a, int b) { return a > b; };
+        for (size_t i = 0; i < n; ++i) if (!indeg[i]) heap.push_back((int)i);
+        std::make_heap(heap.begin(), heap.end(), cmp);
+        while (!heap.empty()) {
+            std::pop_heap(heap.begin(), heap.end(), cmp);
+            int u = heap.back(); heap.pop_back();
+            pos[u] = (int)order.size();
+            order.push_back(u);
+            for (int v : succ[u]) if (--indeg[v] == 0) { heap.push_back(v); std::push_heap(heap.begin(), heap.end(), cmp); }
+        }
+        if (order.size() != n) return PDGN_ERR_INVALID;       // a cycle: not a captured graph
+    }
+    RPlan *plan = new RPlan();
+    plan->nodes.resize(n);
+    std::vector<int> tail;                                    // tail[c] = node (original index) at the end of chain c
+    std::vector<int> chain_of(n, -1);
+    std::vector<int> record_of(n, -1);
+    for (int u : order) {
+        RNode &r = plan->nodes[pos[u]];
+        hipGraphNodeType t;
+        if ((e = hipGraphNodeGetType(gn[u], &t)) != hipSuccess) { delete plan; return (int)e; }
+        int marker = -1;
+        if (t == hipGraphNodeTypeKernel) {
+            hipKernelNodeParams p;
+            memset(&p, 0, sizeof(p));
+            if ((e = hipGraphKernelNodeGetParams(gn[u], &p)) != hipSuccess) { delete plan; return (int)e; }
+            r.kind = NK_KERNEL;
+            r.gx = p.gridDim.x; r.gy = p.gridDim.y; r.gz = p.gridDim.z;
+            r.bx = p.blockDim.x; r.by = p.blockDim.y; r.bz = p.blockDim.z;
+            r.shmem = p.sharedMemBytes;
+            r.params = p.kernelParams;
+            r.extra = p.extra;
+            hipFunction_t f = nullptr;
+            if (hipGetFuncBySymbol(&f, p.func) == hipSuccess && f) r.func = f;      // a __global__ function's host stub
+            else { (void)hipGetLastError(); r.func = (hipFunction_t)p.func; }       // launched through the module API
+            if (is_marker(p) && p.kernelParams) marker = *(int *)p.kernelParams[0];
+            ++plan->counts[1];
+        } else if (t == hipGraphNodeTypeMemset) {
+            hipMemsetParams p;
+            memset(&p, 0, sizeof(p));
+            if ((e = hipGraphMemsetNodeGetParams(gn[u], &p)) != hipSuccess) { delete plan; return (int)e; }
+            if (p.height > 1) { delete plan; return PDGN_ERR_INVALID; }
+            r.kind = NK_MEMSET;
+            r.dst = p.dst; r.value = p.value; r.elem = p.elementSize; r.width = p.width;
+            ++plan->counts[2];
+        } else if (t == hipGraphNodeTypeMemcpy) {
+            hipMemcpy3DParms p;
+            memset(&p, 0, sizeof(p));
+            if ((e = hipGraphMemcpyNodeGetParams(gn[u], &p)) != hipSuccess) { delete plan; return (int)e; }
+            // only flat device-to-device copies are re-issued (what torch's copy_ of a contiguous tensor records)
+            if (p.extent.height > 1 || p.extent.depth > 1 || !p.dstPtr.ptr || !p.srcPtr.ptr || p.srcArray || p.dstArray ||
+                p.srcPos.x || p.srcPos.y || p.srcPos.z || p.dstPos.x || p.dstPos.y || p.dstPos.z ||
+                !(p.kind == hipMemcpyDeviceToDevice || p.kind == hipMemcpyDefault)) { delete plan; return -2; }
+            r.kind = NK_MEMCPY;
+            r.dst = p.dstPtr.ptr; r.src = p.srcPtr.ptr; r.bytes = p.extent.width;
+            ++plan->counts[3];
+        } else if (t == hipGraphNodeTypeEmpty) {
+            r.kind = NK_EMPTY;
+            ++plan->counts[4];
+        } else {
+            delete plan;
+            return -3 - (int)t;                                  // host / event / child-graph nodes: not part of this iteration
+        }
+        // chain assignment
+        int c = -1;
+        if (marker < 0)
+            for (int d : deps[u]) { int cd = chain_of[d]; if (tail[cd] == d) { c = cd; break; } }
+        if (c < 0) {
+            c = (int)tail.size();
+            tail.push_back(u);
+            plan->chain_label.push_back(marker);
+        }
+        tail[c] = u;
+        chain_of[u] = c;
+        r.chain = c;
+        for (int d : deps[u]) {
+            if (chain_of[d] == c) continue;                       // stream order covers it (d is earlier in the same chain)
+            if (record_of[d] < 0) {
+                record_of[d] = (int)plan->events.size();
+                plan->events.push_back(nullptr);
+                plan->nodes[pos[d]].record = record_of[d];
+            }
+            if (std::find(r.waits.begin(), r.waits.end(), record_of[d]) == r.waits.end()) r.waits.push_back(record_of[d]);
+        }
+    }
+    for (auto &ev : plan->events)
+        if ((e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) != hipSuccess) { delete plan; return (int)e; }
+    plan->chain_stream.assign(tail.size(), nullptr);
+    plan->counts[0] = (int)n;
+    plan->counts[5] = (int)tail.size();
+    plan->counts[6] = (int)plan->events.size();
+    for (int l : plan->chain_label) if (l >= 0) ++plan->counts[7];
+    *plan_out = plan;
+    return 0;
+}
+
+extern "C" int pdgn_replay_info(void *plan_, int *counts8) {
+    RPlan *plan = (RPlan *)plan_;
+    if (!plan || !counts8) return PDGN_ERR_INVALID;
+    memcpy(counts8, plan->counts, sizeof(plan->counts));
+    return 0;
+}
+
+// labels[c] = marker id of chain c (or -1), nodes_per_chain[c] = its length; both arrays of counts[5] ints.
+extern "C" int pdgn_replay_chains(void *plan_, int *labels, int *nodes_per_chain) {
+    RPlan *plan = (RPlan *)plan_;
+    if (!plan) return PDGN_ERR_INVALID;
+    size_t nc = plan->chain_label.size();
+    for (size_t c = 0; c < nc; ++c) { if (labels) labels[c] = plan->chain_label[c]; if (nodes_per_chain) nodes_per_chain[c] = 0; }
+    if (nodes_per_chain) for (auto &r : plan->nodes) ++nodes_per_chain[r.chain];
+    return 0;
+}
+
+extern "C" int pdgn_replay_set_stream(void *plan_, int chain, pdgn_stream_t stream) {
+    RPlan *plan = (RPlan *)plan_;
+    if (!plan || chain < 0 || chain >= (int)plan->chain_stream.size()) return PDGN_ERR_INVALID;
+    plan->chain_stream[chain] = (hipStream_t)stream;
+    return 0;
+}
+
+extern "C" int pdgn_replay_launch(void *plan_) {
+    RPlan *plan = (RPlan *)plan_;
+    if (!plan) return PDGN_ERR_INVALID;
+    hipError_t e = hipSuccess;
+    for (RNode &r : plan->nodes) {
+        hipStream_t s = plan->chain_stream[r.chain];
+        for (int w : r.waits)
+            if ((e = hipStreamWaitEvent(s, plan->events[w], 0)) != hipSuccess) return (int)e;
+        switch (r.kind) {
+        case NK_KERNEL:
+            e = hipModuleLaunchKernel(r.func, r.gx, r.gy, r.gz, r.bx, r.by, r.bz, r.shmem, s, r.params, r.extra);
+            break;
+        case NK_MEMSET:
+            if (r.elem == 4) e = hipMemsetD32Async((hipDeviceptr_t)r.dst, (int)r.value, r.width, s);
+            else if (r.elem == 2) e = hipMemsetD16Async((hipDeviceptr_t)r.dst, (unsigned short)r.value, r.width, s);
+            else e = hipMemsetAsync(r.dst, (int)r.value, r.width, s);
+            break;
+        case NK_MEMCPY:
+            e = hipMemcpyAsync(r.dst, r.src, r.bytes, hipMemcpyDeviceToDevice, s);
+            break;
+        default:
+            break;
+        }
+        if (e != hipSuccess) return (int)e;
+        if (r.record >= 0 && (e = hipEventRecord(plan->events[r.record], s)) != hipSuccess) return (int)e;
+    }
+    return 0;
+}
+
+// Measurement only: pdgn_replay_launch with the host time of every call accumulated per kind -- us[0..3] = kernel launches,
+// memsets + copies, event waits, event records; us[4 + c] = everything issued for chain c (c < 28).
+extern "C" int pdgn_replay_launch_timed(void *plan_, double *us32) {
+    RPlan *plan = (RPlan *)plan_;
+    if (!plan || !us32) return PDGN_ERR_INVALID;
+    for (int i = 0; i < 32; ++i) us32[i] = 0.0;
+    using clk = std::chrono::steady_clock;
+    auto since = [](clk::time_point t0) { return std::chrono::duration<double, std::micro>(clk::now() - t0).count(); };
+    hipError_t e = hipSuccess;
+    for (RNode &r : plan->nodes) {
+        hipStream_t s = plan->chain_stream[r.chain];
+        auto t0 = clk::now();
+        for (int w : r.waits)
+            if ((e = hipStreamWaitEvent(s, plan->events[w], 0)) != hipSuccess) return (int)e;
+        double tw = since(t0);
+        auto t1 = clk::now();
+        int slot = 1;
+        switch (r.kind) {
+        case NK_KERNEL:
+            e = hipModuleLaunchKernel(r.func, r.gx, r.gy, r.gz, r.bx, r.by, r.bz, r.shmem, s, r.params, r.extra);
+            slot = 0;
+            break;
+        case NK_MEMSET:
+            if (r.elem == 4) e = hipMemsetD32Async((hipDeviceptr_t)r.dst, (int)r.value, r.width, s);
+            else if (r.elem == 2) e = hipMemsetD16Async((hipDeviceptr_t)r.dst, (unsigned short)r.value, r.width, s);
+            else e = hipMemsetAsync(r.dst, (int)r.value, r.width, s);
+            break;
+        case NK_MEMCPY:
+            e = hipMemcpyAsync(r.dst, r.src, r.bytes, hipMemcpyDeviceToDevice, s);
+            break;
+        default:
+            break;
+        }
+        if (e != hipSuccess) return (int)e;
+        double tl = since(t1);
+        auto t2 = clk::now();
+        if (r.record >= 0 && (e = hipEventRecord(plan->events[r.record], s)) != hipSuccess) return (int)e;
+        double tr = since(t2);
+        us32[slot] += tl; us32[2] += tw; us32[3] += tr;
+        if (r.chain < 28) us32[4 + r.chain] += tl + tw + tr;
+    }
+    return 0;
+}
+
+extern "C" int pdgn_replay_destroy(void *plan_) {
+    RPlan *plan = (RPlan *)plan_;
+    if (!plan) return 0;
+    for (auto ev : plan->events) if (ev) (void)hipEventDestroy(ev);
+    delete plan;
+    return 0;
+}

@@ -1,0 +1,71 @@
+"""Launch-list replay of a captured iteration (csrc/replay.hip).
+
+`torch.cuda.CUDAGraph(keep_graph=True)` records the iteration once (stream capture: every kernel's launch parameters and
+every cross-stream dependency); the recorded graph is never instantiated or launched.  `LaunchList` reads it back and
+re-issues its launches with plain HIP calls on the streams the eager schedule uses -- no autograd nodes, allocations or
+ctypes marshalling per launch, and none of hipGraphLaunch's own scheduling (measured slower than the eager step on ROCm 7.2,
+DESIGN.md section 10b).  There is no reference counterpart: models/PDGNet_v2.py issues its iteration op by op from Python.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import check
+
+MAIN, D0, LP, KNN = 0, 1, 5, 6            # marker ids of the overlapped schedule's streams (D1..D4 = 1..4)
+
+
+def mark(stream_id, stream):
+    """Tag `stream` inside a capture: the chain of nodes that follows on it is replayed on the stream given for this id."""
+    check(_lib.lib().pdgn_replay_marker(int(stream_id), ctypes.c_void_p(stream.cuda_stream)), "pdgn_replay_marker")
+
+
+class LaunchList:
+    """The launches of one captured graph.  `graph` must have been created with keep_graph=True and stay alive as long
+    as this object (its memory pool holds every buffer the launches address)."""
+
+    def __init__(self, graph):
+        self.graph = graph
+        self._plan = ctypes.c_void_p()
+        L = _lib.lib()
+        raw = graph.raw_cuda_graph()
+        rc = L.pdgn_replay_build(ctypes.c_void_p(raw), ctypes.byref(self._plan))
+        if rc != 0:
+            raise _lib.PdgnHipError("pdgn_replay_build failed with %d (a node type or copy shape the launch list does not re-issue)" % rc)
+        counts = (ctypes.c_int * 8)()
+        check(L.pdgn_replay_info(self._plan, counts), "pdgn_replay_info")
+        self.info = dict(zip(("nodes", "kernels", "memsets", "memcpys", "empties", "chains", "events", "labelled"), counts))
+        nc = self.info["chains"]
+        labels, sizes = (ctypes.c_int * nc)(), (ctypes.c_int * nc)()
+        check(L.pdgn_replay_chains(self._plan, labels, sizes), "pdgn_replay_chains")
+        self.labels, self.sizes = list(labels), list(sizes)
+        self._bound = None
+
+    def bind(self, streams, spare):
+        """streams: {marker id: torch stream}; spare: streams for chains without a marker (dealt out round-robin)."""
+        key = tuple(sorted((k, s.cuda_stream) for k, s in streams.items())) + tuple(s.cuda_stream for s in spare)
+        if key == self._bound:
+            return
+        L = _lib.lib()
+        nxt = 0
+        for c, lab in enumerate(self.labels):
+            if lab in streams:
+                s = streams[lab]
+            else:
+                s = spare[nxt % len(spare)]
+                nxt += 1
+            check(L.pdgn_replay_set_stream(self._plan, c, ctypes.c_void_p(s.cuda_stream)), "pdgn_replay_set_stream")
+        self._keep = (dict(streams), list(spare))
+        self._bound = key
+
+    def launch(self):
+        check(_lib.lib().pdgn_replay_launch(self._plan), "pdgn_replay_launch")
+
+    def __del__(self):
+        try:
+            if self._plan:
+                _lib.lib().pdgn_replay_destroy(self._plan)
+                self._plan = ctypes.c_void_p()
+        except Exception:
+            pass

@@ -444,6 +444,14 @@ class PDGNTrainer:
         st["fakes"] = [None] * 4
         mark = st.get("mark") or (lambda name: None)        # tools/phase_events.py: HIP events on the default stream
         mark("start")
+        if st.get("tag_streams"):
+            # capture for a launch list (capture_list): a captured graph does not say which stream a node was recorded
+            # on, so every stream of the schedule opens with a marker node carrying its id (csrc/replay.hip)
+            from . import replay as _replay
+            _replay.mark(_replay.MAIN, main)
+            for sid, s in enumerate(list(pl.d) + [pl.lp, pl.knn], 1):
+                s.wait_stream(main)
+                _replay.mark(sid, s)
 
         # D_k's update starts on the DEVICE when level k exists (an event recorded in the stage hook), but its ~150
         # launches are issued by the host only after the whole generator pass has been issued: with a host that runs
@@ -595,6 +603,68 @@ class PDGNTrainer:
             self._comm(group[-1])
         release_zero_arena()
         return self
+
+    # ---------------------------------------------------------------- launch-list replay (csrc/replay.hip)
+    def capture_list(self, reals, z1, z2, warmup=2):
+        """Record the stream-overlapped iteration ONCE (stream capture into a hipGraph that is kept but never instantiated)
+        and turn it into a launch list: `step_list` then re-issues the same ~1300 launches with plain HIP calls on the
+        streams the eager schedule uses -- ~4 us of host time per launch instead of ~20 (autograd nodes, allocations,
+        ctypes), and none of hipGraphLaunch's own scheduling (slower than eager here).  Single
+        process only: a collective cannot be captured (the data-parallel path stays eager)."""
+        from . import replay
+        if self.distributed or not self.overlap:
+            raise RuntimeError("capture_list: single-process, stream-overlapped schedule only")
+        self._static = self._state([r.clone() for r in reals], z1.clone(), z2.clone())
+        side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(side):
+            for _ in range(warmup):                          # allocator pools, the optimizers' lean lists, arena sizes
+                self._step_overlapped(None, None, None, st=self._state(self._static["reals"], self._static["z1"], self._static["z2"]))
+        torch.cuda.current_stream(self.device).wait_stream(side)
+        torch.cuda.synchronize(self.device)
+        g = torch.cuda.CUDAGraph(keep_graph=True)            # the recorded graph is read back, never launched
+        defer, self._defer_d = self._defer_d, False           # capture order = issue order of the replay: D_k's launches
+        self._static["tag_streams"] = True                   # next to the level that feeds them
+        try:
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                self._step_overlapped(None, None, None, st=self._static)
+        finally:
+            self._defer_d = defer
+            self._static.pop("tag_streams", None)
+        release_zero_arena()                                # the capture's arena lives in the graph's private pool
+        self._list = replay.LaunchList(g)
+        self._list_spare = [torch.cuda.Stream(device=self.device) for _ in range(2)]
+        self._list_done = None
+        return self
+
+    def step_list(self, reals=None, z1=None, z2=None):
+        """One iteration from the launch list of `capture_list`.  Inputs, when given, are copied into the static buffers
+        first (ordinary launches on the current stream: plain stream order, no synchronisation needed)."""
+        from . import replay
+        st = self._static
+        if reals is not None:
+            for d, s in zip(st["reals"], reals):
+                if d.data_ptr() != s.data_ptr():
+                    d.copy_(s)
+        if z1 is not None:
+            st["z1"].copy_(z1)
+            st["z2"].copy_(z2)
+        pl = _streams.plan(self.device)                      # the eager schedule's streams for the current stream
+        streams = {replay.MAIN: torch.cuda.current_stream(self.device), replay.LP: pl.lp, replay.KNN: pl.knn}
+        for i, s in enumerate(pl.d):
+            streams[replay.D0 + i] = s
+        self._list.bind(streams, self._list_spare)
+        # One iteration in flight: the list is issued in ~5 ms, the device needs ~6x that.  A host that runs several
+        # iterations ahead fills the runtime's queues, blocks inside a launch for ONE stream and starves the others
+        # (measured: 30.5 ms/step unbounded, 30.7 with two iterations in flight, 29.2 with one; the eager host's 25 ms
+        # per iteration paced it by accident).  The wait is on the END of the previous iteration, recorded below.
+        if self._list_done is not None:
+            self._list_done.synchronize()
+        self._list.launch()
+        if self._list_done is None:
+            self._list_done = torch.cuda.Event()
+        self._list_done.record(streams[replay.MAIN])
+        return st["out"]
 
     def _sync(self):
         torch.cuda.current_stream(self.device).synchronize()

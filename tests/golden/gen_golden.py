@@ -79,6 +79,34 @@ def gen_knn():
     save("pointops_knn.npz", **cases)
 
 
+# ------------------------------------------------------------------ 1b. 3-NN (NearestNeighbor's indices / distances)
+def gen_nn3():
+    """pointops.py:61-83: nearestneighbor(unknown, known) -> (sqrt(dist2), idx) of the three nearest `known` points.
+    The CUDA kernel cannot run here; the same contract is what KNNQueryNaive.forward(None, 3, known, unknown)
+    (pointops.py:368-405) returns, so its indices on lattice inputs (top-4 distances pairwise distinct: no tie, no
+    dependence on FMA contraction) pin idx, and the squared distances follow exactly (lattice: exact in fp32).
+    `dist` is torch's CPU sqrt of them, which is NOT correctly rounded on every element (vectorised sqrt, 1 ulp off
+    in ~0.5 % of them): tests compare dist2 exactly and dist to 2 ulp."""
+    cases = {}
+    for tag, (b, n, m) in {"a": (2, 20, 11), "b": (2, 128, 64), "c": (1, 257, 300), "d": (3, 64, 3)}.items():
+        salt = 0
+        while True:
+            unknown = lattice_points("nn3_u_" + tag, (b, n, 3), salt=salt)
+            known = lattice_points("nn3_k_" + tag, (b, m, 3), salt=salt + 100)
+            d = ((unknown[:, :, None, :].astype(np.float64) - known[:, None, :, :]) ** 2).sum(-1)
+            ds = np.sort(d, axis=2)[:, :, :4]
+            if (np.diff(ds, axis=2) > 0).all():
+                break
+            salt += 1
+        idx = ref_pointops.KNNQueryNaive.forward(None, 3, torch.from_numpy(known), torch.from_numpy(unknown))
+        tu, tk = torch.from_numpy(unknown), torch.from_numpy(known)
+        dist2 = (tu[:, :, None, :] - tk[:, None, :, :]).pow(2).sum(-1)          # the reference expression's values
+        d2 = torch.gather(dist2, 2, idx.long())
+        cases.update({tag + "_unknown": unknown, tag + "_known": known, tag + "_idx": idx.numpy(),
+                      tag + "_dist2": d2.numpy(), tag + "_dist": torch.sqrt(d2).numpy()})
+    save("pointops_nn3.npz", **cases)
+
+
 # ------------------------------------------------------------------ 2. edge features
 def gen_edges():
     x = hash_tensor("edge_x", (2, 6, 24))
@@ -455,6 +483,14 @@ def gen_step(G, Ds, B, record_graphs=False):
 
 if __name__ == "__main__":
     cref.build()
+    if "--nn3" in sys.argv:                     # round 4: only the 3-NN pin
+        gen_nn3()
+        sys.exit(0)
+    if "--graphs35" in sys.argv:                # round 4: config C2's own batch (BASELINE.json configs[1])
+        G = ref.PointGenerator(2048, 20)
+        Ds = [ref.PointDiscriminator_1(), ref.PointDiscriminator_2(), ref.PointDiscriminator_3(), ref.PointDiscriminator_4()]
+        gen_step(G, Ds, 35, record_graphs=True)
+        sys.exit(0)
     if "--graphs" in sys.argv:
         G = ref.PointGenerator(2048, 20)
         Ds = [ref.PointDiscriminator_1(), ref.PointDiscriminator_2(), ref.PointDiscriminator_3(), ref.PointDiscriminator_4()]
@@ -468,6 +504,7 @@ if __name__ == "__main__":
         gen_step(G, Ds, 8, record_graphs=True)
         sys.exit(0)
     gen_knn()
+    gen_nn3()
     gen_edges()
     gen_deconv()
     gen_losses()

@@ -24,7 +24,8 @@ def test_library_builds_and_exports_every_declared_symbol():
     assert len(names) >= 13
     for name in names:
         assert hasattr(handle, name), "missing export: " + name
-    assert handle.pdgn_abi_version() == 13
+    from pdgn_amd import _lib
+    assert handle.pdgn_abi_version() == _lib.ABI_VERSION
 
 
 def test_no_cpu_fallback():

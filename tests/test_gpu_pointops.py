@@ -90,6 +90,17 @@ def test_gen_query_and_group_xyz(po):
     np.testing.assert_array_equal(out.cpu().numpy(), ref)
 
 
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d"])
+def test_nearestneighbor_golden(po, golden, tag):
+    """The reference's own answer (KNNQueryNaive with nsample 3 on lattice inputs, gen_golden.py::gen_nn3)."""
+    g = golden("pointops_nn3.npz")
+    dist, idx = po.nearestneighbor(dev(g[tag + "_unknown"]), dev(g[tag + "_known"]))
+    assert idx.dtype == torch.int32
+    np.testing.assert_array_equal(idx.cpu().numpy(), g[tag + "_idx"])
+    np.testing.assert_array_equal(dist.cpu().numpy(), np.sqrt(g[tag + "_dist2"]))   # exact squares, rounded sqrt
+    np.testing.assert_allclose(dist.cpu().numpy(), g[tag + "_dist"], rtol=2.4e-7, atol=0)
+
+
 @pytest.mark.parametrize("b,n,m", [(2, 300, 100), (1, 2048, 512), (2, 5, 2), (1, 64, 3000)])
 def test_nearestneighbor(po, b, n, m):
     rng = np.random.default_rng(3)

@@ -49,6 +49,17 @@ def test_grouping_fwd_bwd_vs_torch_gather():
                                rtol=1e-6, atol=1e-6)
 
 
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d"])
+def test_nearestneighbor_matches_reference_naive(golden, tag):
+    """3-NN pinned to the imported reference: KNNQueryNaive.forward(None, 3, known, unknown) on lattice inputs
+    (lib/pointops/functions/pointops.py:368-405 <-> :61-83); gen_golden.py::gen_nn3."""
+    g = golden("pointops_nn3.npz")
+    d2, idx = cref.nearestneighbor(g[tag + "_unknown"], g[tag + "_known"])
+    np.testing.assert_array_equal(idx, g[tag + "_idx"])
+    np.testing.assert_array_equal(d2, g[tag + "_dist2"])                # lattice: exact in fp32
+    np.testing.assert_allclose(np.sqrt(d2), g[tag + "_dist"], rtol=2.4e-7, atol=0)   # torch's CPU sqrt: <= 1 ulp off
+
+
 def test_three_nn_and_interpolation():
     unknown = lattice_points("nn_u", (2, 20, 3))
     known = lattice_points("nn_k", (2, 11, 3))
