@@ -407,7 +407,7 @@ def measure_and_report(args, trainer, reals, zs, world, rank, device, res):
     for _ in range(2):
         step(reals, *zs[0])
     issue = "hipgraph" if graphed else "eager"
-    if not graphed and args.issue == "list" and not trainer.distributed and getattr(trainer, "overlap", False):
+    if not graphed and getattr(args, "issue", "eager") == "list" and not trainer.distributed and getattr(trainer, "overlap", False):
         try:                                   # the SAME launches as the eager step, re-issued from a recorded list
             trainer.capture_list(reals, *zs[0])
             step, issue = (lambda reals, z1, z2: trainer.step_list(None, z1, z2)), "list"

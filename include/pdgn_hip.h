@@ -176,16 +176,22 @@ int pdgn_bn_stats_from_partials(long long rows, int c, float eps, float momentum
 int pdgn_bn_stats_from_gemm_partials(long long rows, int c, long long nparts, int block_rows, float eps, float momentum,
                                      const float *gamma, const float *beta, const float *pre_bias,
                                      float *running_mean, float *running_var, const float *partials,
-                                     float *stats, pdgn_stream_t stream);
+                                     float *stats, double *scratch, pdgn_stream_t stream);
+/* scratch: pdgn_bn_blocks_scratch_doubles(c, nparts) fp64 elements (may be NULL, and is unused for short lists): long
+ * lists are summed by several workgroups per channel group in a first launch and joined, in order, by a second. */
+long long pdgn_bn_blocks_scratch_doubles(int c, long long nparts);
 /* y = act(x*scale + shift) [* mul]   (mul may be NULL; same shape as x) */
 int pdgn_bn_act_forward(long long rows, int c, int act, const float *x, const float *stats,
-                        const float *mul, float *y, pdgn_stream_t stream);
+                        const float *mul, float *y, int interleave_n, pdgn_stream_t stream);
 /* dz = dy [* mul] * act'(z);  bsums (2c floats out): [0:c] = sum dz (= dbeta), [c:2c] = sum dz*xhat (= dgamma);
  * dx = scale*(dz - mean(dz) - xhat*mean(dz*xhat)) if training else scale*dz;
  * dmul (may be NULL) = dy * act(z). */
 int pdgn_bn_act_backward(long long rows, int c, int act, int training, const float *x,
                          const float *dy, const float *mul, const float *stats, float *scratch,
-                         float *bsums, float *dx, float *dmul, pdgn_stream_t stream);
+                         float *bsums, float *dx, float *dmul, int interleave_n, pdgn_stream_t stream);
+/* interleave_n = N > 0 (c even... a multiple of 4, mul NULL, rows % N == 0): y / dy are stored INTERLEAVED -- x row b*N + n, channel
+ * 2c + j  <->  y row b*2N + j*N + n, channel c ((rows * 2) x (c / 2)): the (B,2Fout,N,1) -> (B,Fout,2N) regrouping of a
+ * deconvolution block's result (models/PDGNet_v2.py:645-647) in point-major form, without a separate permute copy. */
 
 /* BatchNorm + activation + max-pool over the n rows of each sample (the tail of the PointNet-style
  * discriminators, models/PDGNet_v2.py:886-911): x (b*n, c) -> ymax / yarg (b, c); the activated tensor
@@ -275,8 +281,10 @@ int pdgn_gemm_nn(long long m, int n, int k, const float *A, int lda, const float
 /* Weight gradient on the same kernel (both operands transposed, reduction over the m rows split over the workgroups):
  * dW (n x k) = dY (m x n, pitch ldy)^T X (m x k, pitch ldx); dW is zero-filled by the call.  Meant for outputs of at
  * least one 128 x 64 tile (pdgn_gemm_tn keeps the small ones). */
-int pdgn_gemm_tn_big(long long m, int n, int k, const float *dY, int ldy, const float *X, int ldx, float *dW,
+int pdgn_gemm_tn_big(long long m, int n, int k, const float *dY, int ldy, const float *X, int ldx, float *dW, int dw_is_zero,
                      pdgn_stream_t stream);
+/* dw_is_zero != 0: the caller hands over an all-zero dW (e.g. a slice of one zero-filled arena per backward pass): the
+ * split-K launch then adds into it without a zero-fill launch of its own. */
 /* pdgn_gemm_nt / pdgn_gemm_nn (transposed_w != 0) with an extended epilogue, applied after bias / addend in this order:
  *   + row_bias[(row / rows_per_group) * ld_rb + col]   a bias per group of rows (the per-sample term of the generator's heads:
  *                                                      mlp1..4 on cat([g broadcast, x]), models/PDGNet_v2.py:835-862, 868-876)
@@ -438,6 +446,8 @@ int pdgn_replay_info(void *plan, int *counts8);
 int pdgn_replay_chains(void *plan, int *labels, int *nodes_per_chain);
 int pdgn_replay_set_stream(void *plan, int chain, pdgn_stream_t stream);
 int pdgn_replay_launch(void *plan);
+int pdgn_replay_launch_range(void *plan, int lo, int hi); /* nodes [lo, hi) of the list */
+int pdgn_replay_position(void *plan, int chain, int nth); /* list position of a chain's n-th node, or -1 */
 int pdgn_replay_launch_timed(void *plan, double *us32); /* measurement: host microseconds per call kind / chain */
 int pdgn_replay_destroy(void *plan);
 

@@ -237,6 +237,83 @@ __global__ __launch_bounds__(FIN_CH * FIN_PL) void cl_finalize_blocks_kernel(
     }
 }
 
+// The same in two launches for long partial lists (a 358400-row GEMM leaves 2800-5600 partial rows; one workgroup per four
+// channels walking all of them took 35-60 us on the issuing stream, twice per block and pass): slice s of FB_SLICES(nparts)
+// sums its share of the blocks in fp64 into scratch[s][2][C]; the second kernel adds the slices in order (deterministic)
+// and finalises.
+__global__ __launch_bounds__(FIN_CH * FIN_PL) void cl_finalize_blocks_slice_kernel(
+    long long R, int C, int nparts, int rpp, int per_slice, const float *__restrict__ part, double *__restrict__ scratch) {
+    __shared__ double red[FIN_PL][FIN_CH], red2[FIN_PL][FIN_CH];
+    const int cl = threadIdx.x % FIN_CH, pl = threadIdx.x / FIN_CH;
+    const int c = blockIdx.x * FIN_CH + cl;
+    const bool ok = c < C;
+    double a = 0, b = 0;
+    const double inv_full = 1.0 / (double)rpp;
+    const int pmax_all = (int)min((long long)nparts, (R + rpp - 1) / rpp);
+    const int p0 = blockIdx.y * per_slice, pmax = min(pmax_all, p0 + per_slice);
+    if (ok)
+#pragma unroll 4
+        for (int p = p0 + pl; p < pmax; p += FIN_PL) {
+            const long long left = R - (long long)p * rpp;
+            const bool full = left >= rpp;
+            const double n = (double)(full ? rpp : left), inv = full ? inv_full : 1.0 / (double)left;
+            const float *q = part + (size_t)p * 3 * C + c;
+            const double s = (double)q[0], sq = (double)q[C], pv = (double)q[2 * C];
+            const double mb = pv + s * inv;
+            a += n * mb;
+            b += (sq - s * s * inv) + n * mb * mb;
+        }
+    red[pl][cl] = a;
+    red2[pl][cl] = b;
+    __syncthreads();
+    for (int h = FIN_PL / 2; h > 0; h >>= 1) {
+        if (pl < h) {
+            red[pl][cl] += red[pl + h][cl];
+            red2[pl][cl] += red2[pl + h][cl];
+        }
+        __syncthreads();
+    }
+    if (!ok || threadIdx.x >= FIN_CH) return;
+    scratch[((size_t)blockIdx.y * 2) * C + c] = red[0][cl];
+    scratch[((size_t)blockIdx.y * 2 + 1) * C + c] = red2[0][cl];
+}
+
+__global__ void cl_finalize_blocks_join_kernel(long long R, int C, int slices, float eps, float momentum,
+                                               const double *__restrict__ scratch, const float *__restrict__ gamma,
+                                               const float *__restrict__ beta, const float *__restrict__ pre_bias,
+                                               float *__restrict__ running_mean, float *__restrict__ running_var,
+                                               float *__restrict__ stats) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double a = 0, b = 0;
+    for (int s = 0; s < slices; ++s) {
+        a += scratch[((size_t)s * 2) * C + c];
+        b += scratch[((size_t)s * 2 + 1) * C + c];
+    }
+    const double mean = a / (double)R;
+    double var = b / (double)R - mean * mean;
+    var = var < 0 ? 0 : var;
+    const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float g = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
+    const float scale = g * invstd;
+    stats[c] = scale;
+    stats[C + c] = be - (float)mean * scale;
+    stats[2 * C + c] = (float)mean;
+    stats[3 * C + c] = invstd;
+    if (running_mean) {
+        const double unbiased = R > 1 ? var * (double)R / (double)(R - 1) : var;
+        const float mb = (float)mean + (pre_bias ? pre_bias[c] : 0.f);
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mb;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+    }
+}
+
+static inline int fb_slices(long long nparts) {                  // 0: the one-launch form
+    if (nparts < 512) return 0;
+    long long s = nparts / 128;
+    return (int)(s > 32 ? 32 : s);
+}
+
 // eval mode: scale/shift from the running statistics
 __global__ void cl_eval_stats_kernel(int C, float eps, const float *__restrict__ gamma, const float *__restrict__ beta,
                                      const float *__restrict__ pre_bias, const float *__restrict__ running_mean,
@@ -254,10 +331,19 @@ __global__ void cl_eval_stats_kernel(int C, float eps, const float *__restrict__
 
 // y = act(x*scale + shift) [* mul].  Same geometry as the reductions: a thread owns one float4
 // column group (its scale/shift live in registers) and streams its rows four at a time.
+// pn > 0 (INTERLEAVED y / dy): x row b*pn + n, channel 2c + j  <->  y row b*2pn + j*pn + n, channel c -- the reference's
+// (B,2Fout,N,1) -> view(B,Fout,2,N) -> (B,Fout,2N) of a deconvolution block's result (models/PDGNet_v2.py:645-647) in
+// point-major form, written / read here instead of by a separate permute copy.
+__device__ __forceinline__ void cl_interleaved_rows(long long r, int pn, long long &ra, long long &rb) {
+    const long long b = r / pn;
+    ra = b * 2 * pn + (r - b * pn);
+    rb = ra + pn;
+}
+
 __global__ __launch_bounds__(BN_THREADS) void cl_apply_kernel(long long R, int C, int cgb, int rows_per_block, int act,
                                                               const float *__restrict__ x,
                                                               const float *__restrict__ stats,
-                                                              const float *__restrict__ mul, float *__restrict__ y) {
+                                                              const float *__restrict__ mul, float *__restrict__ y, int pn) {
     const int cgl = threadIdx.x % cgb, rlane = threadIdx.x / cgb, rl = BN_THREADS / cgb;
     const int cgi = blockIdx.x * cgb + cgl;
     if (cgi * 4 >= C) return;
@@ -284,7 +370,14 @@ __global__ __launch_bounds__(BN_THREADS) void cl_apply_kernel(long long R, int C
                 o.x = act_fwd(__fmaf_rn(v[u].x, sc.x, sh.x), act); o.y = act_fwd(__fmaf_rn(v[u].y, sc.y, sh.y), act);
                 o.z = act_fwd(__fmaf_rn(v[u].z, sc.z, sh.z), act); o.w = act_fwd(__fmaf_rn(v[u].w, sc.w, sh.w), act);
                 if (has_mul) { o.x *= m[u].x; o.y *= m[u].y; o.z *= m[u].z; o.w *= m[u].w; }
-                *reinterpret_cast<float4 *>(y + rr * C + cgi * 4) = o;
+                if (pn) {
+                    long long ra, rb;
+                    cl_interleaved_rows(rr, pn, ra, rb);
+                    *reinterpret_cast<float2 *>(y + ra * (C / 2) + cgi * 2) = make_float2(o.x, o.z);
+                    *reinterpret_cast<float2 *>(y + rb * (C / 2) + cgi * 2) = make_float2(o.y, o.w);
+                } else {
+                    *reinterpret_cast<float4 *>(y + rr * C + cgi * 4) = o;
+                }
             }
         }
     }
@@ -296,7 +389,7 @@ __global__ __launch_bounds__(BN_THREADS) void cl_bwd_reduce_kernel(long long R, 
                                                                    const float *__restrict__ dy,
                                                                    const float *__restrict__ mul,
                                                                    const float *__restrict__ stats,
-                                                                   float *__restrict__ part) {
+                                                                   float *__restrict__ part, int pn) {
     __shared__ float4 red[2][BN_THREADS];
     const int cgl = threadIdx.x % cgb, rlane = threadIdx.x / cgb, rl = BN_THREADS / cgb;
     const int cgi = blockIdx.x * cgb + cgl;
@@ -317,7 +410,15 @@ __global__ __launch_bounds__(BN_THREADS) void cl_bwd_reduce_kernel(long long R, 
                 const long long r = rb + (long long)u * rl;
                 if (r < r1) {
                     v[u] = *reinterpret_cast<const float4 *>(x + r * C + cgi * 4);
-                    g[u] = *reinterpret_cast<const float4 *>(dy + r * C + cgi * 4);
+                    if (pn) {
+                        long long ra, rbb;
+                        cl_interleaved_rows(r, pn, ra, rbb);
+                        const float2 ga = *reinterpret_cast<const float2 *>(dy + ra * (C / 2) + cgi * 2);
+                        const float2 gb = *reinterpret_cast<const float2 *>(dy + rbb * (C / 2) + cgi * 2);
+                        g[u] = make_float4(ga.x, gb.x, ga.y, gb.y);
+                    } else {
+                        g[u] = *reinterpret_cast<const float4 *>(dy + r * C + cgi * 4);
+                    }
                     if (has_mul) m[u] = *reinterpret_cast<const float4 *>(mul + r * C + cgi * 4);
                 }
             }
@@ -382,7 +483,7 @@ __global__ __launch_bounds__(BN_THREADS) void cl_bwd_apply_kernel(long long R, i
                                                                   const float *__restrict__ mul,
                                                                   const float *__restrict__ stats,
                                                                   const float *__restrict__ coef,
-                                                                  float *__restrict__ dx, float *__restrict__ dmul) {
+                                                                  float *__restrict__ dx, float *__restrict__ dmul, int pn) {
     const int cgl = threadIdx.x % cgb, rlane = threadIdx.x / cgb, rl = BN_THREADS / cgb;
     const int cgi = blockIdx.x * cgb + cgl;
     if (cgi * 4 >= C) return;
@@ -401,7 +502,15 @@ __global__ __launch_bounds__(BN_THREADS) void cl_bwd_apply_kernel(long long R, i
             const long long rr = r + (long long)u * rl;
             if (rr < r1) {
                 *reinterpret_cast<float4 *>(v[u]) = *reinterpret_cast<const float4 *>(x + rr * C + cgi * 4);
-                *reinterpret_cast<float4 *>(g[u]) = *reinterpret_cast<const float4 *>(dy + rr * C + cgi * 4);
+                if (pn) {
+                    long long ra, rb;
+                    cl_interleaved_rows(rr, pn, ra, rb);
+                    const float2 ga = *reinterpret_cast<const float2 *>(dy + ra * (C / 2) + cgi * 2);
+                    const float2 gb = *reinterpret_cast<const float2 *>(dy + rb * (C / 2) + cgi * 2);
+                    g[u][0] = ga.x; g[u][1] = gb.x; g[u][2] = ga.y; g[u][3] = gb.y;
+                } else {
+                    *reinterpret_cast<float4 *>(g[u]) = *reinterpret_cast<const float4 *>(dy + rr * C + cgi * 4);
+                }
                 if (has_mul) *reinterpret_cast<float4 *>(m[u]) = *reinterpret_cast<const float4 *>(mul + rr * C + cgi * 4);
             }
         }
@@ -465,13 +574,28 @@ extern "C" int pdgn_bn_stats_from_partials(long long rows, int c, float eps, flo
 extern "C" int pdgn_bn_stats_from_gemm_partials(long long rows, int c, long long nparts, int block_rows, float eps,
                                                 float momentum, const float *gamma, const float *beta, const float *pre_bias,
                                                 float *running_mean, float *running_var, const float *partials,
-                                                float *stats, pdgn_stream_t stream) {
+                                                float *stats, double *scratch, pdgn_stream_t stream) {
     if (rows < 1 || c < 4 || c % 4 || nparts < 1 || nparts > 0x7fffffffLL || block_rows < 1 ||
         nparts * (long long)block_rows < rows)
         return PDGN_ERR_INVALID;
+    const int slices = scratch ? fb_slices(nparts) : 0;
+    if (slices > 1) {
+        const int per = (int)((nparts + slices - 1) / slices);
+        hipLaunchKernelGGL(cl_finalize_blocks_slice_kernel, dim3(cdiv(c, FIN_CH), slices), dim3(FIN_CH * FIN_PL), 0,
+                           (hipStream_t)stream, rows, c, (int)nparts, block_rows, per, partials, scratch);
+        hipLaunchKernelGGL(cl_finalize_blocks_join_kernel, dim3(cdiv(c, 64)), dim3(64), 0, (hipStream_t)stream, rows, c, slices,
+                           eps, momentum, (const double *)scratch, gamma, beta, pre_bias, running_mean, running_var, stats);
+        return pdgn_launch_status();
+    }
     hipLaunchKernelGGL(cl_finalize_blocks_kernel, dim3(cdiv(c, FIN_CH)), dim3(FIN_CH * FIN_PL), 0, (hipStream_t)stream, rows, c,
                        (int)nparts, block_rows, eps, momentum, partials, gamma, beta, pre_bias, running_mean, running_var, stats);
     return pdgn_launch_status();
+}
+
+// fp64 scratch elements pdgn_bn_stats_from_gemm_partials wants for `nparts` partial rows of c channels (0: none needed).
+extern "C" long long pdgn_bn_blocks_scratch_doubles(int c, long long nparts) {
+    if (c < 1 || nparts < 1) return PDGN_ERR_INVALID;
+    return (long long)fb_slices(nparts) * 2 * c;
 }
 
 extern "C" int pdgn_bn_eval_stats(int c, float eps, const float *gamma, const float *beta, const float *pre_bias,
@@ -484,29 +608,31 @@ extern "C" int pdgn_bn_eval_stats(int c, float eps, const float *gamma, const fl
 }
 
 extern "C" int pdgn_bn_act_forward(long long rows, int c, int act, const float *x, const float *stats, const float *mul,
-                                   float *y, pdgn_stream_t stream) {
+                                   float *y, int interleave_n, pdgn_stream_t stream) {
     if (rows < 1 || c < 4 || c % 4 || act < 0 || act > 2) return PDGN_ERR_INVALID;
+    if (interleave_n < 0 || (interleave_n > 0 && (rows % interleave_n || mul))) return PDGN_ERR_INVALID;
     int cgb, gx, gy, rpb;
     cl_geometry(rows, c, &cgb, &gx, &gy, &rpb);
     hipLaunchKernelGGL(cl_apply_kernel, dim3(gx, gy), dim3(BN_THREADS), 0, (hipStream_t)stream, rows, c, cgb, rpb, act,
-                       x, stats, mul, y);
+                       x, stats, mul, y, interleave_n);
     return pdgn_launch_status();
 }
 
 extern "C" int pdgn_bn_act_backward(long long rows, int c, int act, int training, const float *x, const float *dy,
                                     const float *mul, const float *stats, float *scratch, float *bsums, float *dx,
-                                    float *dmul, pdgn_stream_t stream) {
+                                    float *dmul, int interleave_n, pdgn_stream_t stream) {
     if (rows < 1 || c < 4 || c % 4 || act < 0 || act > 2) return PDGN_ERR_INVALID;
+    if (interleave_n < 0 || (interleave_n > 0 && (rows % interleave_n || mul))) return PDGN_ERR_INVALID;
     hipStream_t s = (hipStream_t)stream;
     int cgb, gx, gy, rpb;
     cl_geometry(rows, c, &cgb, &gx, &gy, &rpb);
     hipLaunchKernelGGL(cl_bwd_reduce_kernel, dim3(gx, gy), dim3(BN_THREADS), 0, s, rows, c, cgb, rpb, act, x, dy, mul,
-                       stats, scratch);
+                       stats, scratch, interleave_n);
     float *coef = scratch + (size_t)gy * 2 * c;                // [ca | cb], behind the partials
     hipLaunchKernelGGL(cl_bwd_finalize_kernel, dim3(cdiv(c, FIN_CH)), dim3(FIN_CH * FIN_PL), 0, s, rows, c, gy, training,
                        scratch, stats, bsums, coef);
     hipLaunchKernelGGL(cl_bwd_apply_kernel, dim3(gx, gy), dim3(BN_THREADS), 0, s, rows, c, cgb, rpb, act, x, dy, mul,
-                       stats, coef, dx, dmul);
+                       stats, coef, dx, dmul, interleave_n);
     return pdgn_launch_status();
 }
 

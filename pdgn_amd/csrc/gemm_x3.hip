@@ -756,7 +756,7 @@ struct X3Cfg {
     template <bool WT, bool AT = false>
     static int launch(long long m, int n, int k, const float *A, int lda, const float *W, int ldw, const float *bias,
                       const float *addend, int ldadd, float *C, int ldc, float *stat_part, hipStream_t s,
-                      const NtEpi &epi = NtEpi()) {
+                      const NtEpi &epi = NtEpi(), bool prezeroed = false) {
         const bool allow_sk = stat_part == nullptr && ldc == n && !epi.any();
         const Plan pl = plan(m, n, k, allow_sk);
         NtArgs a;
@@ -775,14 +775,14 @@ struct X3Cfg {
             // panel is fetched from HBM once per tile (conv2's dense half: 4.4 GB for 0.8 GB of operands).
             const int slots = nt_cus() * WG_PER_CU;
             const int S = (int)(slots / T) < pl.kchunks ? (int)(slots / T) : pl.kchunks;
-            if (hipMemsetAsync(C, 0, (size_t)m * ldc * sizeof(float), s) != hipSuccess) return pdgn_launch_status();
+            if (!prezeroed && hipMemsetAsync(C, 0, (size_t)m * ldc * sizeof(float), s) != hipSuccess) return pdgn_launch_status();
             a.tile_begin = 0; a.tile_end = (int)T; a.sk_split = (int)T; a.sk_per_wg = (pl.kchunks + S - 1) / S;
             go<true, WT, AT, false>((int)T * S, s, a);
             return pdgn_launch_status();
         }
         if (pl.grid_sk) {
             const long long r0 = (long long)(pl.dp_tiles / (NT_GROUP_M * pl.tiles_n)) * NT_GROUP_M * BM;
-            if (hipMemsetAsync(C + r0 * ldc, 0, (size_t)(m - r0) * ldc * sizeof(float), s) != hipSuccess) return pdgn_launch_status();
+            if (!prezeroed && hipMemsetAsync(C + r0 * ldc, 0, (size_t)(m - r0) * ldc * sizeof(float), s) != hipSuccess) return pdgn_launch_status();
         }
         if (pl.grid_dp) {
             a.tile_begin = 0; a.tile_end = pl.dp_tiles; a.sk_per_wg = 0;
@@ -884,17 +884,17 @@ extern "C" int pdgn_gemm_nt_ex(long long m, int n, int k, const float *A, int ld
 // which the launch zero-fills itself).  For outputs of at least one 128 x 64 tile; pdgn_gemm_tn (gemm_tn.hip) keeps the
 // small ones.
 extern "C" int pdgn_gemm_tn_big(long long m, int n, int k, const float *dY, int ldy, const float *X, int ldx, float *dW,
-                                pdgn_stream_t stream) {
-    if (!x3_mode()) return fp32_gemm_tn_big(m, n, k, dY, ldy, X, ldx, dW, stream);
+                                int dw_is_zero, pdgn_stream_t stream) {
+    if (!x3_mode()) return fp32_gemm_tn_big(m, n, k, dY, ldy, X, ldx, dW, stream);       // (zero-fills dW itself in any case)
     if (m < 1 || n < 4 || k < 4 || n % 4 || k % 4 || ldy % 4 || ldx % 4 || ldy < n || ldx < k || ldy >= (1 << 19) ||
         ldx >= (1 << 19) || m > 0x7fffffffLL * 16)
         return PDGN_ERR_INVALID;
     hipStream_t s = (hipStream_t)stream;
     // kernel roles: output rows = n (columns of dY), output columns = k (columns of X), reduction = m
     switch (x3_pick(n, k, (int)(m > 0x7fffffff ? 0x7fffffff : m), false)) {
-        case 0: return X3Big::launch<true, true>(n, k, (int)m, dY, ldy, X, ldx, nullptr, nullptr, 0, dW, k, nullptr, s);
-        case 2: return X3Narrow::launch<true, true>(n, k, (int)m, dY, ldy, X, ldx, nullptr, nullptr, 0, dW, k, nullptr, s);
-        default: return X3Square::launch<true, true>(n, k, (int)m, dY, ldy, X, ldx, nullptr, nullptr, 0, dW, k, nullptr, s);
+        case 0: return X3Big::launch<true, true>(n, k, (int)m, dY, ldy, X, ldx, nullptr, nullptr, 0, dW, k, nullptr, s, NtEpi(), dw_is_zero != 0);
+        case 2: return X3Narrow::launch<true, true>(n, k, (int)m, dY, ldy, X, ldx, nullptr, nullptr, 0, dW, k, nullptr, s, NtEpi(), dw_is_zero != 0);
+        default: return X3Square::launch<true, true>(n, k, (int)m, dY, ldy, X, ldx, nullptr, nullptr, 0, dW, k, nullptr, s, NtEpi(), dw_is_zero != 0);
     }
 }
 

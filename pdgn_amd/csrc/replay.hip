@@ -18,6 +18,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cstdlib>
 #include <cstring>
 #include <unordered_map>
 #include <vector>
@@ -181,6 +182,50 @@ extern "C" int pdgn_replay_build(void *graph_, void **plan_out) {
             if (std::find(r.waits.begin(), r.waits.end(), record_of[d]) == r.waits.end()) r.waits.push_back(record_of[d]);
         }
     }
+    // Issue order.  Capture order issues whatever the Python schedule enqueued first -- e.g. the ~240 launches of the four
+    // discriminators' real halves before the issuing stream's first kernel.  With PDGN_REPLAY_BURST = R > 0 the list is
+    // re-ordered (still topologically): up to R nodes of the issuing stream's chain (marker 0) per node of any other chain
+    // whenever both are ready, other chains in capture order among themselves.
+    {
+        const char *env = getenv("PDGN_REPLAY_BURST");
+        const int burst = env ? atoi(env) : 0;
+        int main_chain = -1;
+        for (size_t c = 0; c < plan->chain_label.size(); ++c) if (plan->chain_label[c] == 0) main_chain = (int)c;
+        if (burst > 0 && main_chain >= 0) {
+            const int N = (int)n;
+            // dependencies in list positions
+            std::vector<std::vector<int>> pdeps(N), psucc(N);
+            for (int u = 0; u < N; ++u)
+                for (int d : deps[u]) { pdeps[pos[u]].push_back(pos[d]); psucc[pos[d]].push_back(pos[u]); }
+            std::vector<int> left(N);
+            for (int i = 0; i < N; ++i) left[i] = (int)pdeps[i].size();
+            std::vector<char> done(N, 0);
+            std::vector<int> neworder;
+            neworder.reserve(N);
+            int run = 0;
+            size_t scan_main = 0, scan_side = 0;
+            auto next_ready = [&](bool want_main, size_t &scan) {
+                while (scan < (size_t)N && (done[scan] || (plan->nodes[scan].chain == main_chain) != want_main)) ++scan;
+                for (size_t i = scan; i < (size_t)N; ++i)
+                    if (!done[i] && (plan->nodes[i].chain == main_chain) == want_main && left[i] == 0) return (int)i;
+                return -1;
+            };
+            while ((int)neworder.size() < N) {
+                int m = next_ready(true, scan_main), sd = next_ready(false, scan_side);
+                int pick = (m >= 0 && (run < burst || sd < 0)) ? m : sd;
+                if (pick < 0) pick = m;
+                if (pick < 0) { delete plan; return PDGN_ERR_INVALID; }
+                run = (pick == m) ? run + 1 : 0;
+                done[pick] = 1;
+                neworder.push_back(pick);
+                for (int v : psucc[pick]) --left[v];
+            }
+            std::vector<RNode> nn;
+            nn.reserve(N);
+            for (int i : neworder) nn.push_back(plan->nodes[i]);
+            plan->nodes.swap(nn);
+        }
+    }
     for (auto &ev : plan->events)
         if ((e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) != hipSuccess) { delete plan; return (int)e; }
     plan->chain_stream.assign(tail.size(), nullptr);
@@ -216,11 +261,14 @@ extern "C" int pdgn_replay_set_stream(void *plan_, int chain, pdgn_stream_t stre
     return 0;
 }
 
-extern "C" int pdgn_replay_launch(void *plan_) {
+// Nodes [lo, hi) of the list, in order (the whole list: 0 .. counts[0]).  A caller that issues the list in two ranges can
+// record an event of its own between them (pdgn_amd/trainer.py paces the next iteration's issue on one).
+extern "C" int pdgn_replay_launch_range(void *plan_, int lo, int hi) {
     RPlan *plan = (RPlan *)plan_;
-    if (!plan) return PDGN_ERR_INVALID;
+    if (!plan || lo < 0 || hi > (int)plan->nodes.size() || lo > hi) return PDGN_ERR_INVALID;
     hipError_t e = hipSuccess;
-    for (RNode &r : plan->nodes) {
+    for (int i = lo; i < hi; ++i) {
+        RNode &r = plan->nodes[i];
         hipStream_t s = plan->chain_stream[r.chain];
         for (int w : r.waits)
             if ((e = hipStreamWaitEvent(s, plan->events[w], 0)) != hipSuccess) return (int)e;
@@ -243,6 +291,23 @@ extern "C" int pdgn_replay_launch(void *plan_) {
         if (r.record >= 0 && (e = hipEventRecord(plan->events[r.record], s)) != hipSuccess) return (int)e;
     }
     return 0;
+}
+
+extern "C" int pdgn_replay_launch(void *plan_) {
+    RPlan *plan = (RPlan *)plan_;
+    if (!plan) return PDGN_ERR_INVALID;
+    return pdgn_replay_launch_range(plan_, 0, (int)plan->nodes.size());
+}
+
+// Position in the list of the n-th node (0-based) of chain `chain`, or -1: lets a caller cut the list at a point of one
+// stream's progress (e.g. "after 60 % of the issuing stream's launches").
+extern "C" int pdgn_replay_position(void *plan_, int chain, int nth) {
+    RPlan *plan = (RPlan *)plan_;
+    if (!plan || nth < 0) return -1;
+    int seen = 0;
+    for (size_t i = 0; i < plan->nodes.size(); ++i)
+        if (plan->nodes[i].chain == chain && seen++ == nth) return (int)i;
+    return -1;
 }
 
 // Measurement only: pdgn_replay_launch with the host time of every call accumulated per kind -- us[0..3] = kernel launches,

@@ -70,19 +70,26 @@ def start_feature_knn(xt, const, k, x_cf=None):
     gather-sum, AFTER the per-point GEMM; its selection phase is vector-ALU work next to the GEMM's matrix-core work --
     together with the transposed graph a backward pass will want.  Returns (idx, event to wait for | None)."""
     want_csr = torch.is_grad_enabled() and xt.requires_grad
+
+    def channel_major():                                       # (B, Fin, N): what pdgn_feature_knn reads
+        if x_cf is not None:
+            return x_cf.detach().contiguous()
+        x = xt.detach().transpose(1, 2)
+        if const is not None:
+            x = torch.cat((const.detach().unsqueeze(2).expand(-1, -1, xt.shape[1]), x), 1)
+        return x.contiguous()
+
     with torch.no_grad():
-        if x_cf is None:
-            x_cf = xt.transpose(1, 2)
-            if const is not None:
-                x_cf = torch.cat((const.unsqueeze(2).expand(-1, -1, xt.shape[1]), x_cf), 1)
-        x_knn = x_cf.detach().contiguous()
-        if not (x_knn.is_cuda and _KNN_OVERLAP):
-            return feature_knn(x_knn, k), None
-        cur = torch.cuda.current_stream(x_knn.device)
-        side = _knn_stream(x_knn.device)
+        if not (xt.is_cuda and _KNN_OVERLAP):
+            return feature_knn(channel_major(), k), None
+        cur = torch.cuda.current_stream(xt.device)
+        side = _knn_stream(xt.device)
         side.wait_stream(cur)
-        x_knn.record_stream(side)
+        for t in (xt, const, x_cf):                            # read on the side stream: the transpose / cat that lay the
+            if t is not None:                                  # kNN input out belong to the graph's chain, not to the
+                t.record_stream(side)                          # issuing stream's (2 launches per block off its queue)
         with torch.cuda.stream(side):
+            x_knn = channel_major()
             idx = feature_knn(x_knn, k)
             ready = torch.cuda.Event()
             ready.record(side)                                # the consumer waits for the graph only ...
@@ -410,10 +417,11 @@ class PointDeconv(nn.Module):
             # inte = LeakyReLU(BN(inte_pre))  (:637)
             inte = bn_act(inte_pre.view(-1, 4 * Fi), self.inte_conv_hk[1], training, partials=part_i)
         out_pre = linear_cl(inte.view(B * N, P * 4 * Fi), Wb, None, a_pre.view(B * N, 2 * Fo))    # sum in the GEMM's epilogue
-        out = bn_act(out_pre, self.conv2.bn, training, act="relu")     # (B*N, 2Fo): channel 2c+j
-        # (B,2Fout,N,1) -> view(B,Fout,2,N) -> (B,Fout,2N) (:645-647): point j*N+n of channel c is conv
-        # channel 2c+j at point n; in point-major form that is (B, 2, N, Fout) -> (B, 2N, Fout)
-        return out.view(B, N, Fo, 2).permute(0, 3, 1, 2).reshape(B, 2 * N, Fo)
+        # (B,2Fout,N,1) -> view(B,Fout,2,N) -> (B,Fout,2N) (:645-647): point j*N+n of channel c is conv channel 2c+j at
+        # point n; in point-major form that is (B, 2, N, Fout) -> (B, 2N, Fout), which the BatchNorm + ReLU pass stores
+        # directly (interleave_n) instead of a permute copy behind it
+        out = bn_act(out_pre, self.conv2.bn, training, act="relu", interleave_n=N)     # (B*2N, Fo)
+        return out.view(B, 2 * N, Fo)
 
 
 def upsample_edgeConv(Fin, Fout, k, num=None):

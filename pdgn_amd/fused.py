@@ -99,9 +99,13 @@ def _bn_stats(L, x, rows, C, g, b, pre_bias, running_mean, running_var, training
         block = getattr(partials, "_pdgn_block", None)          # set by gemm_nt / thin_nt on the tensor they return
         if block is None:                           # (lost on the way: the kernels' block sizes are 64, 80, 128 and 256 rows)
             block = next(bs for bs in (64, 80, 128, 256) if -(-rows // bs) <= nparts < -(-rows // bs) + 4 and bs * nparts >= rows)
+        L.pdgn_bn_blocks_scratch_doubles.restype = ctypes.c_longlong
+        nd = L.pdgn_bn_blocks_scratch_doubles(C, ctypes.c_longlong(nparts))
+        scr = torch.empty(nd, dtype=torch.float64, device=x.device) if nd > 0 else None
         check(L.pdgn_bn_stats_from_gemm_partials(ctypes.c_longlong(rows), C, ctypes.c_longlong(nparts), block,
                                                  ctypes.c_float(eps), ctypes.c_float(momentum), ptr(g), ptr(b), ptr(pb),
-                                                 ptr(running_mean), ptr(running_var), ptr(partials), ptr(stats), stream_of(x)),
+                                                 ptr(running_mean), ptr(running_var), ptr(partials), ptr(stats), ptr(scr),
+                                                 stream_of(x)),
               "pdgn_bn_stats_from_gemm_partials")
     elif training and partials is not None:                     # first stage done by x's producer (its epilogue)
         check(L.pdgn_bn_stats_from_partials(ctypes.c_longlong(rows), C, ctypes.c_float(eps), ctypes.c_float(momentum),
@@ -141,7 +145,7 @@ class BNActCL(Function):
 
     @staticmethod
     def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, act, mul, pre_bias=None,
-                partials=None):
+                partials=None, interleave_n=0):
         rows, C = x.shape
         x = x.contiguous()
         L = _lib.lib()
@@ -149,17 +153,18 @@ class BNActCL(Function):
         stats = _bn_stats(L, x, rows, C, g, b, pre_bias, running_mean, running_var, training, momentum, eps, partials)
         ctx.has_pre_bias = pre_bias is not None
         mul_c = mul.contiguous() if mul is not None else None
-        y = torch.empty_like(x)
-        check(L.pdgn_bn_act_forward(ctypes.c_longlong(rows), C, act, ptr(x), ptr(stats), ptr(mul_c), ptr(y),
+        # interleave_n = N: y is (rows * 2, C / 2), x row b*N + n / channel 2c + j at y row b*2N + j*N + n / channel c
+        y = torch.empty((rows * 2, C // 2), dtype=F32, device=x.device) if interleave_n else torch.empty_like(x)
+        check(L.pdgn_bn_act_forward(ctypes.c_longlong(rows), C, act, ptr(x), ptr(stats), ptr(mul_c), ptr(y), int(interleave_n),
                                     stream_of(x)), "pdgn_bn_act_forward")
         ctx.save_for_backward(x, stats, mul_c)
-        ctx.cfg = (rows, C, act, bool(training), mul is not None and mul.requires_grad)
+        ctx.cfg = (rows, C, act, bool(training), mul is not None and mul.requires_grad, int(interleave_n))
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, stats, mul = ctx.saved_tensors
-        rows, C, act, training, need_dmul = ctx.cfg
+        rows, C, act, training, need_dmul, inter = ctx.cfg
         dy = dy.contiguous()
         L = _lib.lib()
         scratch = torch.empty(_scratch_floats(L, rows, C), dtype=F32, device=x.device)
@@ -167,12 +172,12 @@ class BNActCL(Function):
         dx = torch.empty_like(x)
         dmul = torch.empty_like(x) if need_dmul else None
         check(L.pdgn_bn_act_backward(ctypes.c_longlong(rows), C, act, int(training), ptr(x), ptr(dy), ptr(mul),
-                                     ptr(stats), ptr(scratch), ptr(bs), ptr(dx), ptr(dmul), stream_of(x)),
+                                     ptr(stats), ptr(scratch), ptr(bs), ptr(dx), ptr(dmul), inter, stream_of(x)),
               "pdgn_bn_act_backward")
         if training:
             mark_zero_colsum(dx)
         return (dx, bs[C:], bs[:C], None, None, None, None, None, None, dmul, _pre_bias_grad(ctx.has_pre_bias, C, x.device),
-                None)
+                None, None)
 
 
 # nn.BatchNorm's num_batches_tracked bookkeeping: one tiny int64 add per layer per forward would be
@@ -188,7 +193,7 @@ def flush_bn_counters():
         _PENDING_COUNTS.clear()
 
 
-def bn_act(x2d, bn, training, act="leaky_relu", mul=None, pre_bias=None, partials=None):
+def bn_act(x2d, bn, training, act="leaky_relu", mul=None, pre_bias=None, partials=None, interleave_n=0):
     """Apply an nn.BatchNorm{1,2}d module's parameters/buffers to a channels-last (rows, C) view,
     followed by `act` (and an optional elementwise product).  `pre_bias`: the bias of the layer that produced
     x2d, when the caller did not add it (it cancels inside the BatchNorm; only the running mean sees it)."""
@@ -201,9 +206,19 @@ def bn_act(x2d, bn, training, act="leaky_relu", mul=None, pre_bias=None, partial
         y = torch.nn.functional.batch_norm(x2d, bn.running_mean, bn.running_var, bn.weight, bn.bias, training,
                                            bn.momentum, bn.eps)
         y = {"none": lambda t: t, "relu": torch.relu, "leaky_relu": torch.nn.functional.leaky_relu}[act](y)
-        return y * mul if mul is not None else y
+        y = y * mul if mul is not None else y
+        return interleave_rows(y, interleave_n) if interleave_n else y
+    if interleave_n and (mul is not None or not x2d.is_cuda):
+        return interleave_rows(bn_act(x2d, bn, training, act, mul, pre_bias, partials), interleave_n)
     return BNActCL.apply(x2d, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, bn.momentum, bn.eps,
-                         ACT[act], mul, pre_bias, partials)
+                         ACT[act], mul, pre_bias, partials, interleave_n)
+
+
+def interleave_rows(y2d, n):
+    """(B*n, 2F) -> (B*2n, F): row b*n + p, channel 2c + j  ->  row b*2n + j*n + p, channel c (models/PDGNet_v2.py:645-647 in
+    point-major form; the torch form of what BNActCL's interleave_n store does)."""
+    rows, c2 = y2d.shape
+    return y2d.view(rows // n, n, c2 // 2, 2).permute(0, 3, 1, 2).reshape(rows * 2, c2 // 2)
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -282,14 +297,16 @@ def gemm_tn(dy, x):
     if GEMM_LOG is not None:
         GEMM_LOG.append(("tn", m, n, k))
     dyp, xp = _pad_cols(dy), _pad_cols(x)
-    if _TN_BIG and dyp.shape[1] >= 64 and xp.shape[1] >= 64 and 65536 <= dyp.shape[1] * xp.shape[1] <= _TN_BIG_MAX:
+    nk = dyp.shape[1] * xp.shape[1]
+    # (long reductions -- >= 150 k rows -- also with 16 K .. 64 K outputs: 0.85-0.88x pdgn_gemm_tn's time, r03_gemm_shapes.txt)
+    if _TN_BIG and dyp.shape[1] >= 64 and xp.shape[1] >= 64 and (65536 if (m < 150000 or not _GEMM_X3) else 16384) <= nk <= _TN_BIG_MAX:
         # mid-sized outputs (4 .. 64 tiles of 128 x 128): the stream-K launch of the pdgn_gemm_nt kernel with both operands
         # transposed balances them better than pdgn_gemm_tn's split (measured, tools/gemm_shapes.py: 0.70-0.94x its time);
         # smaller outputs (and, on the fp32 kernels, the two largest ones: conv2's dense half, the per-point GEMM) stay on
         # pdgn_gemm_tn
-        dwp = torch.empty((dyp.shape[1], xp.shape[1]), dtype=F32, device=dy.device)
+        dwp = _zeros((dyp.shape[1], xp.shape[1]), dy.device)       # a slice of the backward pass's zero arena: no fill launch here
         check(_lib.lib().pdgn_gemm_tn_big(ctypes.c_longlong(m), dyp.shape[1], xp.shape[1], ptr(dyp), dyp.stride(0), ptr(xp),
-                                          xp.stride(0), ptr(dwp), stream_of(dy)), "pdgn_gemm_tn_big")
+                                          xp.stride(0), ptr(dwp), 1, stream_of(dy)), "pdgn_gemm_tn_big")
         return dwp if (dyp.shape[1] == n and xp.shape[1] == k) else dwp[:n, :k]
     if dyp.stride(0) != dyp.shape[1]:
         dyp = dyp.contiguous()
@@ -546,7 +563,7 @@ class BNSoftmaxSlotsPermute(Function):
         bs = torch.empty(2 * C, dtype=F32, device=x.device)
         dx = torch.empty_like(x)
         check(L.pdgn_bn_act_backward(ctypes.c_longlong(rows), C, act, int(training), ptr(x), ptr(dh), ptr(None),
-                                     ptr(stats), ptr(scratch), ptr(bs), ptr(dx), ptr(None), stream_of(x)),
+                                     ptr(stats), ptr(scratch), ptr(bs), ptr(dx), ptr(None), 0, stream_of(x)),
               "pdgn_bn_act_backward")
         if training:
             mark_zero_colsum(dx)
@@ -616,7 +633,7 @@ class BilateralWeighting(Function):
             bsu = torch.empty(2 * Cu, dtype=F32, device=x.device)
             du, dw = torch.empty_like(u), torch.empty_like(u)
             check(L.pdgn_bn_act_backward(ctypes.c_longlong(rows_u), Cu, act, int(training), ptr(u), ptr(dy), ptr(w),
-                                         ptr(stats_u), ptr(scr), ptr(bsu), ptr(du), ptr(dw), stream_of(x)),
+                                         ptr(stats_u), ptr(scr), ptr(bsu), ptr(du), ptr(dw), 0, stream_of(x)),
                   "pdgn_bn_act_backward")
             # w = softmax_slots_permute(act(BN(x)))
             dh = torch.empty((rows, C), dtype=F32, device=x.device)
@@ -626,7 +643,7 @@ class BilateralWeighting(Function):
             bsx = torch.empty(2 * C, dtype=F32, device=x.device)
             dx = torch.empty_like(x)
             check(L.pdgn_bn_act_backward(ctypes.c_longlong(rows), C, act, int(training), ptr(x), ptr(dh), ptr(None),
-                                         ptr(stats_x), ptr(scr), ptr(bsx), ptr(dx), ptr(None), stream_of(x)),
+                                         ptr(stats_x), ptr(scr), ptr(bsx), ptr(dx), ptr(None), 0, stream_of(x)),
                   "pdgn_bn_act_backward")
         if training:
             mark_zero_colsum(du)

@@ -59,8 +59,17 @@ class LaunchList:
         self._keep = (dict(streams), list(spare))
         self._bound = key
 
-    def launch(self):
-        check(_lib.lib().pdgn_replay_launch(self._plan), "pdgn_replay_launch")
+    def launch(self, lo=0, hi=None):
+        """Issue nodes [lo, hi) of the list (all of it by default)."""
+        check(_lib.lib().pdgn_replay_launch_range(self._plan, int(lo), self.info["nodes"] if hi is None else int(hi)),
+              "pdgn_replay_launch_range")
+
+    def position(self, label, fraction):
+        """List position right after `fraction` of the launches of the chain with marker id `label`."""
+        c = self.labels.index(label)
+        nth = max(0, min(self.sizes[c] - 1, int(self.sizes[c] * fraction)))
+        pos = _lib.lib().pdgn_replay_position(self._plan, c, nth)
+        return pos + 1 if pos >= 0 else self.info["nodes"]
 
     def __del__(self):
         try:

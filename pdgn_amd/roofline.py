@@ -150,7 +150,7 @@ def weight_grad_stage4(B, base_points, device):
     L = _lib.lib()
     if gemm_mode() == "x3":
         def run():
-            check(L.pdgn_gemm_tn_big(ctypes.c_longlong(M), N, K, ptr(dy), N, ptr(x), K, ptr(dw), stream_of(dy)), "pdgn_gemm_tn_big")
+            check(L.pdgn_gemm_tn_big(ctypes.c_longlong(M), N, K, ptr(dy), N, ptr(x), K, ptr(dw), 0, stream_of(dy)), "pdgn_gemm_tn_big")
         us = _time_us(run)
         e = _entry("gemm_x3_kernel<AT,WT> = pdgn_gemm_tn_big (dW of conv2's dense half, stage 4, M=%d N=%d K=%d)" % (M, N, K), "mfma",
                    2.0 * M * N * K, us, x3=True, shape=[M, N, K])
@@ -187,7 +187,7 @@ def bn_act_backward_stage4(B, base_points, device):
 
     def run():
         check(L.pdgn_bn_act_backward(ctypes.c_longlong(rows), C, 2, 1, ptr(x), ptr(dy), ptr(mul), ptr(stats),
-                                     ptr(scratch), ptr(bs), ptr(dx), ptr(dmul), stream_of(x)), "pdgn_bn_act_backward")
+                                     ptr(scratch), ptr(bs), ptr(dx), ptr(dmul), 0, stream_of(x)), "pdgn_bn_act_backward")
     us = _time_us(run)
     return _entry("cl_bwd_reduce + cl_bwd_apply (BN+LeakyReLU*w backward, rows=%d C=%d)" % (rows, C), "hbm",
                   8.0 * rows * C * 4, us)

@@ -13,8 +13,9 @@ grouped that way once per (device, issuing stream) and the roles are dealt out s
   * the issuing (default) stream's queue carries nothing else,
   * the feature-kNN stream and the local-pair-loss stream share a queue (the kNN runs inside the generator passes, the
     loss after them),
-  * D1 + D3 and D2 + D4 take the remaining queues (the pairing of light with heavy that the un-probed layout happened
-    to have in the single-process case).
+  * D1 + D2 + D3 share one of the remaining queues and D4 has the other to itself: the backward of D4(G(z2)) is what the
+    generator's backward waits for, and behind another discriminator's kernels in a shared queue it waited longer (round 4,
+    launch-list step: 28.75 vs 29.0 ms; rounds 1-3 paired D1 + D3 / D2 + D4).
 
 There is no reference counterpart: models/PDGNet_v2.py runs on one CUDA stream.
 """
@@ -96,9 +97,9 @@ def plan(device):
         return g.pop() if len(g) > 1 else g[0]
 
     if len(groups) >= 3:
-        # D1 and D3 on one queue, D2 and D4 on another, local-pair loss + feature kNN on the third; PDGN_STREAM_LAYOUT
+        # D1-D3 on one queue, D4 alone on another, local-pair loss + feature kNN on the third; PDGN_STREAM_LAYOUT
         # (six letters A-C for D1 D2 D3 D4 lp knn) is the A/B switch the layouts of DESIGN.md section 10b were tried with
-        layout = os.environ.get("PDGN_STREAM_LAYOUT", "BCBCAA")
+        layout = os.environ.get("PDGN_STREAM_LAYOUT", "BBBCAA")
         by = dict(zip("ABC", groups[:3]))
         roles = [take(by[ch]) for ch in layout]
         d, lp, knn = roles[:4], roles[4], roles[5]

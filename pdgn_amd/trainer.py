@@ -635,6 +635,7 @@ class PDGNTrainer:
         self._list = replay.LaunchList(g)
         self._list_spare = [torch.cuda.Stream(device=self.device) for _ in range(2)]
         self._list_done = None
+        self._list_pace = float(os.environ.get("PDGN_LIST_PACE", "1.0"))     # 1.0: the previous iteration's end
         return self
 
     def step_list(self, reals=None, z1=None, z2=None):
@@ -658,12 +659,17 @@ class PDGNTrainer:
         # iterations ahead fills the runtime's queues, blocks inside a launch for ONE stream and starves the others
         # (measured: 30.5 ms/step unbounded, 30.7 with two iterations in flight, 29.2 with one; the eager host's 25 ms
         # per iteration paced it by accident).  The wait is on the END of the previous iteration, recorded below.
+        # The wait is on a point INSIDE the previous iteration (after `_list_pace` of the issuing stream's launches, recorded
+        # below): the next list is then issued underneath the previous iteration's tail, and the device finds its first
+        # kernels queued when that tail ends.
         if self._list_done is not None:
             self._list_done.synchronize()
-        self._list.launch()
+        cut = self._list.position(replay.MAIN, self._list_pace)
+        self._list.launch(0, cut)
         if self._list_done is None:
             self._list_done = torch.cuda.Event()
         self._list_done.record(streams[replay.MAIN])
+        self._list.launch(cut)
         return st["out"]
 
     def _sync(self):

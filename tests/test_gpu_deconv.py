@@ -336,6 +336,38 @@ def test_fused_bn_act_vs_torch(rows, C, act, use_mul, training):
         np.testing.assert_allclose(a, b, rtol=1e-4, atol=1e-4 * max(1.0, np.abs(b).max()), err_msg=name)
 
 
+@pytest.mark.parametrize("B,N,C2,training", [(3, 50, 24, True), (5, 128, 64, True), (2, 1024, 512, True), (4, 33, 16, False)])
+def test_fused_bn_act_interleaved_store(B, N, C2, training):
+    """bn_act(..., interleave_n=N): BatchNorm + ReLU of a block's conv2 output (B*N, 2F) stored as the interleaved (B*2N, F) cloud
+    (models/PDGNet_v2.py:645-647) by the apply pass itself, and its adjoint reading dy in that layout -- against the torch form
+    (BatchNorm, ReLU, then view / permute / reshape) in fp64: values, input gradient, parameter gradients, running statistics."""
+    from pdgn_amd.fused import bn_act
+    from torch_standins import bn_act_torch
+    rng = np.random.default_rng(B * N + C2)
+    x = torch.from_numpy((rng.standard_normal((B * N, C2)) * 1.5 - 0.3).astype(np.float32))
+    gout = torch.from_numpy(rng.standard_normal((B * 2 * N, C2 // 2)).astype(np.float32))
+    res = []
+    for impl, to in ((bn_act, dev), (bn_act_torch, lambda t: t.double())):
+        bn = torch.nn.BatchNorm1d(C2)
+        fill_module(bn, salt=4)
+        bn = bn.cuda() if impl is bn_act else bn.double()
+        bn.train(training)
+        xi = to(x).requires_grad_(True)
+        y = impl(xi, bn, training, act="relu", interleave_n=N)
+        assert tuple(y.shape) == (B * 2 * N, C2 // 2)
+        y.backward(to(gout))
+        res.append([t.detach().cpu().double().numpy() for t in (y, xi.grad, bn.weight.grad, bn.bias.grad, bn.running_mean, bn.running_var)])
+    # and the layout itself, spelled out: row b*2N + j*N + n, channel c  <-  row b*N + n, channel 2c + j
+    for name, a, b in zip(["y", "dx", "dgamma", "dbeta", "running_mean", "running_var"], *res):
+        np.testing.assert_allclose(a, b, rtol=1e-4, atol=1e-4 * max(1.0, np.abs(b).max()), err_msg=name)
+    y_cpu = res[1][0].reshape(B, 2, N, C2 // 2)
+    bn = torch.nn.BatchNorm1d(C2)
+    fill_module(bn, salt=4)
+    bn = bn.double().train(training)
+    plain = torch.relu(bn(x.double())).detach().numpy().reshape(B, N, C2 // 2, 2)
+    np.testing.assert_allclose(y_cpu, plain.transpose(0, 3, 1, 2), rtol=1e-12)
+
+
 @pytest.mark.parametrize("shift", [30.0, 300.0, 1000.0])
 def test_bn_act_large_mean(shift):
     """|mean| >> std (round-1 advice): the statistics pass sums x - x[0] (shifted sums), so that the variance does not
@@ -461,12 +493,12 @@ def test_gemm_tn_big_direct(M, N, K, cfg, monkeypatch, gemm):
     x = torch.randn(M, K, device="cuda", generator=g)
     dy = torch.randn(M, N, device="cuda", generator=g)
     dw = torch.full((N, K), float("nan"), device="cuda")
-    assert _lib.lib().pdgn_gemm_tn_big(ctypes.c_longlong(M), N, K, ptr(dy), N, ptr(x), K, ptr(dw), stream_of(dy)) == 0
+    assert _lib.lib().pdgn_gemm_tn_big(ctypes.c_longlong(M), N, K, ptr(dy), N, ptr(x), K, ptr(dw), 0, stream_of(dy)) == 0
     scale = (dy.abs().t().matmul(x.abs())).clamp_min(1e-6)
     assert ((dw - dy.t().matmul(x)).abs() / scale).max().item() < 2e-5
     rows = min(M, 40000)
     dw2 = torch.full((N, K), float("nan"), device="cuda")
-    assert _lib.lib().pdgn_gemm_tn_big(ctypes.c_longlong(rows), N, K, ptr(dy), N, ptr(x), K, ptr(dw2), stream_of(dy)) == 0
+    assert _lib.lib().pdgn_gemm_tn_big(ctypes.c_longlong(rows), N, K, ptr(dy), N, ptr(x), K, ptr(dw2), 0, stream_of(dy)) == 0
     ref64 = dy[:rows].double().t().matmul(x[:rows].double())
     scale64 = dy[:rows].abs().double().t().matmul(x[:rows].abs().double()).clamp_min(1e-6)
     assert ((dw2.double() - ref64).abs() / scale64).max().item() < 1e-5
@@ -888,7 +920,7 @@ def test_gemm_x3_is_as_accurate_as_the_fp32_matrix_instructions(M, N, K, scale, 
         out = {"nt": C[:rows], "nn": dX[:rows]}
         if N >= 64 and K >= 64:
             dW = torch.empty(N, K, device="cuda")
-            assert L.pdgn_gemm_tn_big(ctypes.c_longlong(rows), N, K, ptr(dY), N, ptr(A), K, ptr(dW), stream_of(A)) == 0
+            assert L.pdgn_gemm_tn_big(ctypes.c_longlong(rows), N, K, ptr(dY), N, ptr(A), K, ptr(dW), 0, stream_of(A)) == 0
             out["tn"] = dW
         for kind, o in out.items():
             assert torch.isfinite(o).all()

@@ -35,9 +35,12 @@ def feature_knn_torch(x, k):
     return dist.sort(dim=2, stable=True)[1][:, :, 1:k + 1].to(torch.int32).contiguous()
 
 
-def bn_act_torch(x2d, bn, training, act="leaky_relu", mul=None, pre_bias=None, partials=None):
+def bn_act_torch(x2d, bn, training, act="leaky_relu", mul=None, pre_bias=None, partials=None, interleave_n=0):
     """Same contract as pdgn_amd.fused.bn_act in plain torch ops."""
     import torch.nn.functional as F
+    if interleave_n:
+        from pdgn_amd.fused import interleave_rows
+        return interleave_rows(bn_act_torch(x2d, bn, training, act, mul, pre_bias, partials), interleave_n)
     if pre_bias is not None:
         x2d = x2d + pre_bias
     if training and bn.track_running_stats:

@@ -23,10 +23,10 @@ for rows, C in ((179200, 1024), (358400, 512), (89600, 512), (358400, 64), (7168
     scr = torch.empty(L.pdgn_bn_scratch_floats(ctypes.c_longlong(rows), C), device="cuda")
     gb = rows * C * 4 / 1e9
     a = t(lambda: L.pdgn_bn_stats(ctypes.c_longlong(rows), C, ctypes.c_float(1e-5), ctypes.c_float(0.1), ptr(x), ptr(g), ptr(b), None, ptr(rm), ptr(rv), ptr(scr), ptr(stats), stream_of(x)))
-    f = t(lambda: L.pdgn_bn_act_forward(ctypes.c_longlong(rows), C, 2, ptr(x), ptr(stats), None, ptr(y), stream_of(x)))
-    fm = t(lambda: L.pdgn_bn_act_forward(ctypes.c_longlong(rows), C, 2, ptr(x), ptr(stats), ptr(mul), ptr(y), stream_of(x)))
-    bw = t(lambda: L.pdgn_bn_act_backward(ctypes.c_longlong(rows), C, 2, 1, ptr(x), ptr(dy), None, ptr(stats), ptr(scr), ptr(bs), ptr(dx), None, stream_of(x)))
-    bm = t(lambda: L.pdgn_bn_act_backward(ctypes.c_longlong(rows), C, 2, 1, ptr(x), ptr(dy), ptr(mul), ptr(stats), ptr(scr), ptr(bs), ptr(dx), ptr(dmul), stream_of(x)))
+    f = t(lambda: L.pdgn_bn_act_forward(ctypes.c_longlong(rows), C, 2, ptr(x), ptr(stats), None, ptr(y), 0, stream_of(x)))
+    fm = t(lambda: L.pdgn_bn_act_forward(ctypes.c_longlong(rows), C, 2, ptr(x), ptr(stats), ptr(mul), ptr(y), 0, stream_of(x)))
+    bw = t(lambda: L.pdgn_bn_act_backward(ctypes.c_longlong(rows), C, 2, 1, ptr(x), ptr(dy), None, ptr(stats), ptr(scr), ptr(bs), ptr(dx), None, 0, stream_of(x)))
+    bm = t(lambda: L.pdgn_bn_act_backward(ctypes.c_longlong(rows), C, 2, 1, ptr(x), ptr(dy), ptr(mul), ptr(stats), ptr(scr), ptr(bs), ptr(dx), ptr(dmul), 0, stream_of(x)))
     print("rows %7d C %5d (%.0f MB): stats %6.1f us %.2f TB/s | apply %6.1f us %.2f | apply*mul %6.1f us %.2f | bwd %6.1f us %.2f | bwd*mul %6.1f us %.2f" % (
         rows, C, gb * 1e3, a, gb / a * 1e3, f, 2 * gb / f * 1e3, fm, 3 * gb / fm * 1e3, bw, 5 * gb / bw * 1e3, bm, 8 * gb / bm * 1e3))
     del x, dy, mul, y, dx, dmul

@@ -77,7 +77,7 @@ for (kind, m, n, k), cnt in log.items():
         lib = t(lambda: dy.t().matmul(x))
         cfg = -1
         if pad(n) >= 64 and pad(k) >= 64:
-            runb = lambda: L.pdgn_gemm_tn_big(ctypes.c_longlong(m), pad(n), pad(k), ptr(dy), pad(n), ptr(x), pad(k), ptr(dw), stream_of(dy))
+            runb = lambda: L.pdgn_gemm_tn_big(ctypes.c_longlong(m), pad(n), pad(k), ptr(dy), pad(n), ptr(x), pad(k), ptr(dw), 0, stream_of(dy))
             big = t(runb)
             extra[(kind, m, n, k)] = " | tn_big %8.1f us %6.1f TF (x%.2f of gemm_tn)" % (big, 2.0 * m * n * k / big / 1e6, big / own)
             all_cfgs(runb, (kind, m, n, k), L.pdgn_gemm_nt_config(ctypes.c_longlong(pad(n)), pad(k), min(m, 0x7fffffff), 0))

@@ -60,7 +60,7 @@ for (m, n, k) in [(1000, 64, 36), (4099, 132, 100), (35840, 512, 5120), (35840, 
         dw = torch.empty(n, k, device=dev)
         L = _lib.lib()
         def tn():
-            _lib.check(L.pdgn_gemm_tn_big(ctypes.c_longlong(m), n, k, _lib.ptr(dy), dy.stride(0), _lib.ptr(a), a.stride(0), _lib.ptr(dw),
+            _lib.check(L.pdgn_gemm_tn_big(ctypes.c_longlong(m), n, k, _lib.ptr(dy), dy.stride(0), _lib.ptr(a), a.stride(0), _lib.ptr(dw), 0,
                                           _lib.stream_of(dy)), "tn_big")
         tn()
         msg += " | tn err %.2e" % err(dw, dy.double().t().contiguous(), a.double().t().contiguous())
