@@ -28,7 +28,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 matrix peak (v_mfma_f32_32x32x2_f32 / 16x16x4_f32)
-GEMM_ARITHMETIC = ("fp32 matrix instructions (PDGN_GEMM=fp32)" if os.environ.get("PDGN_GEMM", "x3").startswith("f") else
+GEMM_ARITHMETIC = ("fp32 matrix instructions (PDGN_GEMM=fp32)" if os.environ.get("PDGN_GEMM", "x3").startswith("f") else   # (the library reads the same variable at first use)
                    "fp32 operands, results and accumulation; each product = six bf16 MFMA partial products of the operands' "
                    "three-way bf16 splits (csrc/gemm_x3.hip): error per product <= 2^-23, against fp64 below the fp32 matrix "
                    "instructions' (tests/test_gpu_deconv.py); PDGN_GEMM=fp32 selects those instructions")
@@ -44,8 +44,9 @@ def parse():
     ap.add_argument("--batch", type=int, default=35, help="per-GPU batch (BASELINE.json: 35)")
     ap.add_argument("--base-points", type=int, default=128, help="128: 256->2048 (reference); 256: 512->4096")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-batch", type=int, default=12,
-                    help="batch of one CPU-baseline sample (three samples are timed; 12 keeps them at ~20 s in all)")
+    ap.add_argument("--cpu-sample-batch", type=int, default=35,
+                    help="batch of the CPU-baseline sample: 35 = the batch the metric is quoted on (one iteration, ~18 s on "
+                         "16 threads); below 24 three iterations are timed and the median reported")
     ap.add_argument("--graph", action="store_true",
                     help="replay the iteration as hipGraphs (trainer.capture).  Off by default: the eager step is "
                          "faster on MI355X (DESIGN.md section 6), and on ROCm 7.2 graph launches are not reliably "
@@ -118,12 +119,13 @@ def host_cpu():
             "logical_cpus": os.cpu_count()}
 
 
-def cpu_baseline(sample_batch, samples=3):
+def cpu_baseline(sample_batch, samples=None):
     """The oracle's torch-CPU/C restatement of the same iteration (oracle/pdgnet_ref.TrainerRef), timed on this box's
     host cores on a bounded sample: `samples` full G+D iterations at a reduced batch, median reported per point."""
     import torch
     from oracle import cref, pdgnet_ref
     from pdgn_amd.trainer import synthetic_batch
+    samples = samples if samples is not None else (1 if sample_batch >= 24 else 3)   # a bounded sample: ~20 s of CPU work
     cref.build()
     # 16 threads is the fastest setting measured on the 2x EPYC 9575F GPU-box host (16 thr: 17.7 s, 32: 20.9 s,
     # 64: 26.3 s, 256: minutes per B=35 iteration -- torch's intra-op pool oversubscribes).
@@ -471,7 +473,15 @@ def measure_and_report(args, trainer, reals, zs, world, rank, device, res):
             total = flops["gemm"] + flops["feature_knn_gram"]                 # per rank = per GPU
             line["executed_flops_per_step"] = total
             line["executed_flops_detail"] = flops
-            line["step_mfma_frac"] = total / (ms * 1e-3) / (MFMA_F32_PEAK_TFLOPS * 1e12)
+            # the iteration's executed contraction flops per second against the roof of the instruction the contractions
+            # run on -- the same roof `roofline` prices the dominant kernel against (bf16 matrix peak / 6 products per fp32
+            # product for the x3 kernels, the fp32 matrix peak for PDGN_GEMM=fp32) -- and, named, against the fp32 peak
+            from pdgn_amd import roofline as _rf
+            x3 = _rf.gemm_mode() == "x3"
+            peak = (_rf.MFMA_BF16_PEAK_TFLOPS / 6.0 if x3 else MFMA_F32_PEAK_TFLOPS) * 1e12
+            line["step_mfma_frac"] = total / (ms * 1e-3) / peak
+            line["step_mfma_frac_peak_tflops"] = peak / 1e12
+            line["step_frac_of_fp32_instruction_peak"] = total / (ms * 1e-3) / (MFMA_F32_PEAK_TFLOPS * 1e12)
             line["direct_form_flops_per_step"] = DIRECT_FORM_FLOPS_PER_SAMPLE * B
             line["algebraic_saving"] = DIRECT_FORM_FLOPS_PER_SAMPLE * B / total if total else None
         if not args.no_roofline:

@@ -241,7 +241,8 @@ int pdgn_softmax_slots_permute_backward(long long m, int k, int c, const float *
  * (x = h + m + l to 2^-25 |x|) and a product is six bf16 MFMA products accumulated in fp32 (csrc/gemm_x3.hip) -- per product
  * an error of <= 2^-23 |a w|, measured against fp64 below that of the fp32 matrix instructions; no scaling, the fp32
  * exponent range is kept; an infinite operand value yields NaN (inf - inf in the split), where fp32 arithmetic may yield inf.
- * The environment variable PDGN_GEMM=fp32 selects the fp32 matrix instructions instead (csrc/gemm_nt.hip; 0.6-0.9x the rate).
+ * PDGN_GEMM=fp32 in the environment at first use, or pdgn_gemm_set_mode(0), selects the fp32 matrix instructions instead
+ * (csrc/gemm_nt.hip; 0.6-0.9x the rate).
  * (The reference's Conv2d/Conv1d/Linear forward at models/PDGNet_v2.py:559-625, 835-862, 886-1014 in
  * point-major form; with the transposed weight it is their input gradient dX = dY W.)  stat_part (may be
  * NULL): pdgn_gemm_nt_stat_rows(m, n, k) rows of [3n] floats = per-column sum (x - pv) | sum (x - pv)^2 | pv of blocks of
@@ -249,6 +250,12 @@ int pdgn_softmax_slots_permute_backward(long long m, int k, int c, const float *
  * pdgn_bn_stats_from_gemm_partials turns into BatchNorm statistics.  Without
  * stat_part and with ldc == n the launch may add partial tiles with fp32 atomics (C is zero-filled by the
  * call itself where needed). */
+/* Process-wide switches of the dense contractions (read from PDGN_GEMM / PDGN_NT_CFG once, at first use).
+ * pdgn_gemm_set_mode: 1 = bf16 matrix cores (default), 0 = fp32 matrix instructions, < 0 = query; returns the previous mode.
+ * pdgn_gemm_set_config: -1 = the launch model's pick (default), 0 .. 3 = force a tile configuration (measurement / tests),
+ * < -1 = query; returns the previous value. */
+int pdgn_gemm_set_mode(int mode);
+int pdgn_gemm_set_config(int cfg);
 int pdgn_gemm_nt(long long m, int n, int k, const float *A, int lda, const float *W, int ldw,
                  const float *bias, const float *addend, int ldadd, float *C, int ldc, float *stat_part,
                  pdgn_stream_t stream);

@@ -63,3 +63,21 @@ def require(t, name, dtype, dim=None):
     if dim is not None and t.dim() != dim:
         raise ValueError("%s must have %d dims, got %d" % (name, dim, t.dim()))
     return t
+
+
+def gemm_mode():
+    """'x3' (fp32 products as six bf16 MFMA products, csrc/gemm_x3.hip -- the default) or 'fp32' (the fp32 matrix instructions,
+    csrc/gemm_nt.hip): what pdgn_gemm_nt / _nn / _nt_ex / _tn_big launch.  PDGN_GEMM in the environment sets the initial value."""
+    return "x3" if lib().pdgn_gemm_set_mode(-1) else "fp32"
+
+
+def set_gemm_mode(mode):
+    """Select the arithmetic of the dense contractions for this process; returns the previous mode's name."""
+    old = lib().pdgn_gemm_set_mode(0 if str(mode).startswith("f") else 1)
+    return "x3" if old else "fp32"
+
+
+def set_gemm_config(cfg):
+    """Force a tile configuration of pdgn_gemm_nt / _nn (0 .. 3; None or -1: the launch model's pick).  Measurement / tests.
+    Returns the previous value (-1: automatic)."""
+    return lib().pdgn_gemm_set_config(-1 if cfg is None else int(cfg))

@@ -567,7 +567,10 @@ struct NtCfg {
         a.rpg_magic = a.rows_per_group > 1 ? (unsigned)(0x100000000ULL / (unsigned)a.rows_per_group) + 1u : 0u;
         a.act = epi.act; a.gate = epi.gate; a.ldgate = epi.ldgate; a.sk_split = 0;
         a.tiles_m = pl.tiles_m; a.tiles_n = pl.tiles_n; a.kchunks = pl.kchunks;
+        a.dbg = 0;
+#ifdef PDGN_NT_DEBUG
         { const char *e = getenv("PDGN_NT_DBG"); a.dbg = e ? atoi(e) : 0; }
+#endif
         const long long T = (long long)pl.tiles_m * pl.tiles_n;
         if (pl.grid_sk) {
             // the tail tiles start in tile-row group dp_tiles / (NT_GROUP_M tiles_n): zero its rows and all below (whole rows; the data-parallel
@@ -597,8 +600,8 @@ typedef NtCfg<4, 2, 2, 2, 3> NtNarrow;   // 128 x 64, 4 waves (48 KB, < 168 regi
 
 // Tile configuration for a problem: PDGN_NT_CFG (0-3, measurement only), else the cheapest by the launch model.
 static int nt_pick(long long m, int n, int k, bool stats, bool no_tall = false) {
-    const char *e = getenv("PDGN_NT_CFG");
-    if (e && *e) return (no_tall && atoi(e) == 2) ? 1 : atoi(e);
+    const int forced = nt_switches().cfg;
+    if (forced >= 0) return (no_tall && forced == 2) ? 1 : forced;
     const bool sk = !stats;
     const double c[4] = {NtBig::plan(m, n, k, sk).cost, NtSquare::plan(m, n, k, sk).cost, NtTall::plan(m, n, k, sk).cost,
                          NtNarrow::plan(m, n, k, sk).cost};

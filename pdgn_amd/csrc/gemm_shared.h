@@ -45,7 +45,7 @@ struct NtArgs {
     long long sk_per_wg;              // stream-K launch: (tile, chunk) iterations per workgroup
     int sk_split;                     // > 0 (gemm_x3 only): split-K launch over sk_split tiles: workgroup v takes tile v % sk_split,
                                       // chunks [v / sk_split * sk_per_wg, + sk_per_wg) -- workgroups that run together share panels
-    int dbg;                          // PDGN_NT_DBG (measurement only): 1 = stores dropped (out-of-range offsets)
+    int dbg;                          // builds with -DPDGN_NT_DEBUG only (ablation: 1 = stores dropped); always 0 otherwise
     // extended epilogue (pdgn_gemm_nt_ex), applied in this order after bias / addend:
     const float *row_bias;            // + row_bias[(row / rows_per_group) * ld_rb + col]: a bias per GROUP of rows (per sample)
     int ld_rb, rows_per_group;
@@ -70,6 +70,15 @@ static inline int nt_cus() {
     }
     return cached;
 }
+
+// Process-wide switches of the dense contractions.  Read from the environment ONCE (first use); tests and tools change them
+// through pdgn_gemm_set_mode / pdgn_gemm_set_config (no getenv per launch, no environment mutation at run time).
+//   mode: 1 = products on the bf16 matrix cores (gemm_x3.hip, default), 0 = fp32 matrix instructions (gemm_nt.hip; PDGN_GEMM=fp32)
+//   cfg:  -1 = the launch model's pick (default), 0 .. 3 = a forced tile configuration (PDGN_NT_CFG; measurement / tests)
+struct NtSwitches {
+    int mode, cfg, splitk;
+};
+NtSwitches &nt_switches();
 
 struct NtEpi {                        // extended epilogue of pdgn_gemm_nt_ex (all optional)
     const float *row_bias = nullptr;

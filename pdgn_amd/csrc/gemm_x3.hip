@@ -766,9 +766,12 @@ struct X3Cfg {
         a.rpg_magic = a.rows_per_group > 1 ? (unsigned)(0x100000000ULL / (unsigned)a.rows_per_group) + 1u : 0u;
         a.act = epi.act; a.gate = epi.gate; a.ldgate = epi.ldgate; a.sk_split = 0;
         a.tiles_m = pl.tiles_m; a.tiles_n = pl.tiles_n; a.kchunks = pl.kchunks;
+        a.dbg = 0;
+#ifdef PDGN_NT_DEBUG
         { const char *e = getenv("PDGN_NT_DBG"); a.dbg = e ? atoi(e) : 0; }
+#endif
         const long long T = (long long)pl.tiles_m * pl.tiles_n;
-        if (AT && T <= nt_cus() * WG_PER_CU && !(getenv("PDGN_X3_SPLITK") && getenv("PDGN_X3_SPLITK")[0] == '0')) {
+        if (AT && T <= nt_cus() * WG_PER_CU && nt_switches().splitk) {
             // weight gradients: few output tiles, a reduction of 10^4 .. 10^5.5 rows.  Split-K: the workgroups that run at the same
             // time work on the SAME row range of different tiles (tile = v % T), so the XCD's L2 serves the operand panels they
             // share; the flattened stream-K order gives neighbouring workgroups neighbouring row ranges of one tile and every
@@ -801,14 +804,41 @@ typedef X3Cfg<2, 2, 2, 2, 1, 660> X3Square;   // 128 x 128, 4 waves of 64 x 64 (
 typedef X3Cfg<4, 2, 2, 2, 1, 760> X3Big;      // 256 x 128, 4 waves of 128 x 64 (144 KB of LDS): one per CU, one wave per SIMD
 typedef X3Cfg<2, 1, 2, 2, 2, 540> X3Narrow;   // 128 x 64, 4 waves of 64 x 32 (72 KB of LDS): two per CU
 
-static int x3_mode() {                   // PDGN_GEMM: "x3" (default) or "fp32" (gemm_nt.hip: the fp32 matrix instructions)
-    const char *e = getenv("PDGN_GEMM");
-    return (e && e[0] == 'f') ? 0 : 1;
+NtSwitches &nt_switches() {
+    static NtSwitches sw = [] {
+        NtSwitches s;
+        const char *e = getenv("PDGN_GEMM");
+        s.mode = (e && e[0] == 'f') ? 0 : 1;
+        e = getenv("PDGN_NT_CFG");
+        s.cfg = (e && *e) ? atoi(e) : -1;
+        e = getenv("PDGN_X3_SPLITK");                 // 0: weight gradients on the flattened stream-K order (A/B arm)
+        s.splitk = !(e && e[0] == '0');
+        return s;
+    }();
+    return sw;
 }
 
+// mode: 1 = bf16 matrix cores (six partial products per fp32 product), 0 = fp32 matrix instructions, < 0 = leave.  Returns
+// the mode in force before the call.
+extern "C" int pdgn_gemm_set_mode(int mode) {
+    const int old = nt_switches().mode;
+    if (mode >= 0) nt_switches().mode = mode ? 1 : 0;
+    return old;
+}
+
+// cfg: -1 = the launch model's pick, 0 .. 3 = force a tile configuration (measurement / tests), < -1 = leave.  Returns the
+// previous value.
+extern "C" int pdgn_gemm_set_config(int cfg) {
+    const int old = nt_switches().cfg;
+    if (cfg >= -1) nt_switches().cfg = cfg > 3 ? 3 : cfg;
+    return old;
+}
+
+static int x3_mode() { return nt_switches().mode; }
+
 static int x3_pick(long long m, int n, int k, bool stats) {
-    const char *e = getenv("PDGN_NT_CFG");          // measurement / tests only: 0 .. 2 (3, the fp32 kernel's fourth, reads as 2)
-    if (e && *e) return atoi(e) < 0 ? 0 : (atoi(e) > 2 ? 2 : atoi(e));
+    const int forced = nt_switches().cfg;          // 0 .. 2 (3, the fp32 kernel's fourth, reads as 2)
+    if (forced >= 0) return forced > 2 ? 2 : forced;
     const bool sk = !stats;
     const double c[3] = {X3Big::plan(m, n, k, sk).cost, X3Square::plan(m, n, k, sk).cost, X3Narrow::plan(m, n, k, sk).cost};
     int best = 0;

@@ -68,7 +68,8 @@ __device__ __forceinline__ unsigned wgs_div(unsigned x, int d, unsigned magic) {
 static unsigned wgs_magic(int d) { return d == 1 ? 0u : (unsigned)(0x100000000ULL / (unsigned)d) + 1u; }   // x / d == umulhi(x, magic) for x * d < 2^32 (d > 1)
 static bool wgs_slabs_ok(int n, int k, int ldy, int P, int C) {
     return (long long)n * ldy * 4 < 0x7fffffffLL && (long long)n * P * C * 4 < 0x7fffffffLL && (long long)n * k * 4 < 0x7fffffffLL &&
-           (long long)n * P * P < 0x100000000LL && ldy * 4LL < (1 << 24) && (long long)P * C * 4 < (1 << 24) && n < (1 << 24);
+           (long long)n * P * P < 0x100000000LL && ldy * 4LL < (1 << 24) && (long long)P * C * 4 < (1 << 24) && n < (1 << 24) &&
+           (long long)n * P < (1 << 24);                    // store offsets: 24-bit multiply of the output row index n * P + p
 }
 
 template <int TT, int CW>   // compile-time tap count (0 = runtime T <= 8), chunk width in float4

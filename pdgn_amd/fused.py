@@ -94,11 +94,11 @@ def _bn_stats(L, x, rows, C, g, b, pre_bias, running_mean, running_var, training
     training, running statistics in eval.  pre_bias: see include/pdgn_hip.h (the producer's bias, left out of x)."""
     stats = torch.empty(4 * C, dtype=F32, device=x.device)
     pb = pre_bias.detach().contiguous() if pre_bias is not None else None
-    if training and partials is not None and partials.dim() == 2:   # (nparts, 3C) block-shifted rows from a GEMM's epilogue
+    block = None
+    if isinstance(partials, tuple):                             # (tensor (nparts, 3C), rows per block): a GEMM / thin-layer epilogue's
+        partials, block = partials                              # block-shifted rows, with the block size linear_cl attached
+    if training and block is not None:
         nparts = partials.shape[0]
-        block = getattr(partials, "_pdgn_block", None)          # set by gemm_nt / thin_nt on the tensor they return
-        if block is None:                           # (lost on the way: the kernels' block sizes are 64, 80, 128 and 256 rows)
-            block = next(bs for bs in (64, 80, 128, 256) if -(-rows // bs) <= nparts < -(-rows // bs) + 4 and bs * nparts >= rows)
         L.pdgn_bn_blocks_scratch_doubles.restype = ctypes.c_longlong
         nd = L.pdgn_bn_blocks_scratch_doubles(C, ctypes.c_longlong(nparts))
         scr = torch.empty(nd, dtype=torch.float64, device=x.device) if nd > 0 else None
@@ -230,8 +230,11 @@ def interleave_rows(y2d, n):
 # default matmul is used as it is.
 _OWN_MIN_ROWS = 1024
 _TN_BIG = os.environ.get("PDGN_TN_BIG", "1") == "1"            # A/B switch: weight gradients of >= 128 x 64 outputs on pdgn_gemm_tn_big
-_GEMM_X3 = not os.environ.get("PDGN_GEMM", "x3").startswith("f")    # pdgn_gemm_* on the bf16 matrix cores (csrc/gemm_x3.hip) | PDGN_GEMM=fp32
-_TN_BIG_MAX = (1 << 22) if _GEMM_X3 else (1 << 20)             # x3: also the two largest outputs (measured 0.88x / 0.90x pdgn_gemm_tn's time)
+
+
+def _tn_big_max():
+    # x3: also the two largest outputs (measured 0.88x / 0.90x pdgn_gemm_tn's time); fp32 instructions: up to 1 M elements
+    return (1 << 22) if _lib.gemm_mode() == "x3" else (1 << 20)
 
 
 def _pad_cols(t, mult=4):
@@ -252,7 +255,7 @@ def gemm_nt(a, w, bias=None, addend=None, want_stats=False, w_transposed=False):
     pdgn_gemm_nn (the input gradient dy @ W straight from the layer's weight).  Channel counts that are not multiples
     of 4 (the xyz layers: k = 3, the heads' last conv: n = 3) are zero-padded for the launch.  want_stats: also returns
     the BatchNorm partials of the result ((parts, 3n) fp32, block-shifted: per-column sum (x - pv) | sum (x - pv)^2 | pv of
-    row blocks, pv = the block's first row)."""
+    row blocks of pdgn_gemm_nt_stat_block_rows(m, n, k) rows, pv = the block's first row)."""
     m, k = a.shape
     n = w.shape[1] if w_transposed else w.shape[0]
     if GEMM_LOG is not None:
@@ -279,7 +282,6 @@ def gemm_nt(a, w, bias=None, addend=None, want_stats=False, w_transposed=False):
     if want_stats:
         L.pdgn_gemm_nt_stat_rows.restype = ctypes.c_longlong
         part = torch.empty((L.pdgn_gemm_nt_stat_rows(ctypes.c_longlong(m), np_, kp), 3 * np_), dtype=F32, device=a.device)
-        part._pdgn_block = int(L.pdgn_gemm_nt_stat_block_rows(ctypes.c_longlong(m), np_, kp))
     b = bias.detach().contiguous() if bias is not None else None
     fn = L.pdgn_gemm_nn if w_transposed else L.pdgn_gemm_nt
     check(fn(ctypes.c_longlong(m), np_, kp, ptr(ap), ap.stride(0), ptr(wp), wp.stride(0), ptr(b), ptr(addend),
@@ -299,7 +301,7 @@ def gemm_tn(dy, x):
     dyp, xp = _pad_cols(dy), _pad_cols(x)
     nk = dyp.shape[1] * xp.shape[1]
     # (long reductions -- >= 150 k rows -- also with 16 K .. 64 K outputs: 0.85-0.88x pdgn_gemm_tn's time, r03_gemm_shapes.txt)
-    if _TN_BIG and dyp.shape[1] >= 64 and xp.shape[1] >= 64 and (65536 if (m < 150000 or not _GEMM_X3) else 16384) <= nk <= _TN_BIG_MAX:
+    if _TN_BIG and dyp.shape[1] >= 64 and xp.shape[1] >= 64 and (65536 if (m < 150000 or _lib.gemm_mode() != "x3") else 16384) <= nk <= _tn_big_max():
         # mid-sized outputs (4 .. 64 tiles of 128 x 128): the stream-K launch of the pdgn_gemm_nt kernel with both operands
         # transposed balances them better than pdgn_gemm_tn's split (measured, tools/gemm_shapes.py: 0.70-0.94x its time);
         # smaller outputs (and, on the fp32 kernels, the two largest ones: conv2's dense half, the per-point GEMM) stay on
@@ -335,7 +337,6 @@ def thin_nt(x, w, wrs, wcs, n, bias=None, want_stats=False):
     if want_stats and k <= 4:
         L.pdgn_thin_stat_rows.restype = ctypes.c_longlong
         part = torch.empty((L.pdgn_thin_stat_rows(ctypes.c_longlong(m)), 3 * n), dtype=F32, device=x.device)
-        part._pdgn_block = int(L.pdgn_thin_stat_block_rows())
     b = bias.detach().contiguous() if bias is not None else None
     check(L.pdgn_thin_nt(ctypes.c_longlong(m), n, k, ptr(x), x.stride(0), ptr(w), wrs, wcs, ptr(b), ptr(out), n, ptr(part),
                          stream_of(x)), "pdgn_thin_nt")
@@ -495,8 +496,19 @@ def linear_cl(x2d, weight, bias=None, addend=None, want_stats=None):
     if want_stats is None:
         return LinearCL.apply(x2d, weight, bias, addend)
     if want_stats:
-        return LinearCL.apply(x2d, weight, bias, addend, True)
+        y, part = LinearCL.apply(x2d, weight, bias, addend, True)
+        return y, ((part, stat_block_rows(x2d, weight, addend)) if part is not None else None)
     return LinearCL.apply(x2d, weight, bias, addend), None
+
+
+def stat_block_rows(x2d, weight, addend=None):
+    """Rows of y = x2d weight^T each partial-statistics row of LinearCL's epilogue covers: the same question the launch asked
+    (the same deterministic launch model on the same padded sizes), so the block size travels with the partials as a value."""
+    L = _lib.lib()
+    n, k = weight.shape
+    if addend is None and weight.is_contiguous() and _thin_ok(x2d, n, k):
+        return int(L.pdgn_thin_stat_block_rows())
+    return int(L.pdgn_gemm_nt_stat_block_rows(ctypes.c_longlong(x2d.shape[0]), (n + 3) // 4 * 4, (k + 3) // 4 * 4))
 
 
 class SoftmaxSlotsPermute(Function):

@@ -145,35 +145,47 @@ class PointGenerator(nn.Module):
         that level's discriminator update on another stream while the deeper levels are still being generated).
         `feature_hook(level, xt)` is called with the input features of every block (the trainer hangs its early gradient
         bucket on the deepest block's)."""
+        s = self.begin(z)
+        for lvl in range(4):
+            self.level(s, lvl, idx, stage_hook, feature_hook)
+        return self.finish(s)
+
+    # The forward in pieces (begin / level x 4 / finish): the trainer interleaves the levels of its two generator passes
+    # on two streams (PDGNTrainer._step_overlapped); forward() above is the plain sequence.
+    def begin(self, z):
         B = z.shape[0]
         xt = _small_seq(self.fc1, z, self.training).view(B, 32, self.base_points).transpose(1, 2).contiguous()    # (B,N0,32)
-        s = {"xt": xt, "pct": None, "const": None, "clouds": [], "pending": (None, None)}
+        return {"B": B, "xt": xt, "pct": None, "const": None, "clouds": [], "pending": (None, None)}
+
+    def level(self, s, lvl, idx=(None, None, None, None), stage_hook=None, feature_hook=None):
+        B = s["B"]
         blocks = (self.bilateral1, self.bilateral2, self.bilateral3, self.bilateral4)
         heads = (self.mlp1, self.mlp2, self.mlp3, self.mlp4)
-        for lvl in range(4):
-            xt, pct, const, clouds = s["xt"], s["pct"], s["const"], s["clouds"]
-            if feature_hook is not None:
-                feature_hook(lvl, xt)
-            lvl_idx, lvl_ready = (idx[lvl], None) if idx[lvl] is not None else s["pending"]
-            xs, x_ec, g = blocks[lvl].forward_cl(xt, pct, idx=lvl_idx, const=const, idx_ready=lvl_ready)
-            s["pending"] = (None, None)
-            if lvl < 3 and idx[lvl + 1] is None and x_ec.is_cuda:
-                # the next block's kNN graph only needs this block's outputs: start it now, underneath this level's
-                # MLP head, the next block's global branch and per-point GEMM
-                nxt = blocks[lvl + 1].upsample_cov
-                s["pending"] = _deconv.start_feature_knn(x_ec, xs, nxt.k)
-            M, Fo = x_ec.shape[1], x_ec.shape[2]
-            rows = x_ec.reshape(B * M, Fo)
-            if lvl < 3:
-                p = _head_rows(heads[lvl], rows, B, g=g, n_const=512)           # head sees cat(g, x_ec)
-            else:
-                p = _head_rows(heads[lvl], rows, B, g=xs, n_const=Fo)           # mlp4 sees cat(xs, x_ec) :875
-            pct = p.view(B, M, 3)
-            clouds.append(pct.transpose(1, 2))                                  # (B,3,M) like the reference
-            if stage_hook is not None:
-                _deconv.flush_bn_counters()
-                stage_hook(lvl, clouds[-1])
-            s["xt"], s["const"], s["pct"] = x_ec, xs, pct   # next block's input is cat(xs broadcast, x_ec) :708
+        xt, pct, const, clouds = s["xt"], s["pct"], s["const"], s["clouds"]
+        if feature_hook is not None:
+            feature_hook(lvl, xt)
+        lvl_idx, lvl_ready = (idx[lvl], None) if idx[lvl] is not None else s["pending"]
+        xs, x_ec, g = blocks[lvl].forward_cl(xt, pct, idx=lvl_idx, const=const, idx_ready=lvl_ready)
+        s["pending"] = (None, None)
+        if lvl < 3 and idx[lvl + 1] is None and x_ec.is_cuda:
+            # the next block's kNN graph only needs this block's outputs: start it now, underneath this level's
+            # MLP head, the next block's global branch and per-point GEMM
+            nxt = blocks[lvl + 1].upsample_cov
+            s["pending"] = _deconv.start_feature_knn(x_ec, xs, nxt.k)
+        M, Fo = x_ec.shape[1], x_ec.shape[2]
+        rows = x_ec.reshape(B * M, Fo)
+        if lvl < 3:
+            p = _head_rows(heads[lvl], rows, B, g=g, n_const=512)           # head sees cat(g, x_ec)
+        else:
+            p = _head_rows(heads[lvl], rows, B, g=xs, n_const=Fo)           # mlp4 sees cat(xs, x_ec) :875
+        pct = p.view(B, M, 3)
+        clouds.append(pct.transpose(1, 2))                                  # (B,3,M) like the reference
+        if stage_hook is not None:
+            _deconv.flush_bn_counters()
+            stage_hook(lvl, clouds[-1])
+        s["xt"], s["const"], s["pct"] = x_ec, xs, pct   # next block's input is cat(xs broadcast, x_ec) :708
+
+    def finish(self, s):
         _deconv.flush_bn_counters()
         return tuple(s["clouds"])
 

@@ -6,7 +6,7 @@ ROCm).  `achieved` = algorithmic bytes (or flops) per launch / average launch du
 per-unit figures are stated in DESIGN.md section 4.  `traffic` (HBM bytes per launch from the
 rocprofv3 PMC counters FETCH_SIZE / WRITE_SIZE, collected in separate passes and corrected as
 /opt/skills/guides/MI355X_MICROARCH.md prescribes) is read from profiles/traffic.json, which
-tools/pmc_traffic.py writes from a rocprofv3 run of tools/roofline_only.py.
+tools/pmc_roofline.py writes from the rocprofv3 --pmc passes of tools/run_pmc_roofline.sh.
 """
 import ctypes
 import json
@@ -40,7 +40,7 @@ def _time_us(fn, iters=20, warm=3):
 def gemm_mode():
     """"x3" (fp32 operands split into three bf16 parts, products on the bf16 matrix cores: csrc/gemm_x3.hip, the default) or
     "fp32" (PDGN_GEMM=fp32: the fp32 matrix instructions, csrc/gemm_nt.hip) -- what pdgn_gemm_nt / nn / tn_big launch."""
-    return "fp32" if os.environ.get("PDGN_GEMM", "x3").startswith("f") else "x3"
+    return _lib.gemm_mode()
 
 
 def _entry(name, bound, work, us, x3=False, **extra):
@@ -66,8 +66,7 @@ def _entry(name, bound, work, us, x3=False, **extra):
 
 def gemm_accuracy(device, M=8192, N=512, K=2560):
     """Largest error of pdgn_gemm_nt against fp64, relative to sum_k |a| |w|, for the kernel in use (x3: six bf16 MFMA products
-    per fp32 product) and for the fp32 matrix instructions on the same operands (PDGN_GEMM is read per call by the C entry
-    points): the live form of tests/test_gpu_deconv.py::test_gemm_x3_is_as_accurate_as_the_fp32_matrix_instructions."""
+    per fp32 product) and for the fp32 matrix instructions on the same operands (selected per process, _lib.set_gemm_mode): the live form of tests/test_gpu_deconv.py::test_gemm_x3_is_as_accurate_as_the_fp32_matrix_instructions."""
     g = torch.Generator(device=device).manual_seed(1234)
     a = torch.randn(M, K, device=device, generator=g) * (torch.rand(M, 1, device=device, generator=g) * 3)
     w = torch.randn(N, K, device=device, generator=g)
@@ -75,18 +74,15 @@ def gemm_accuracy(device, M=8192, N=512, K=2560):
     mag = a.double().abs() @ w.double().abs().t()
     c = torch.empty(M, N, device=device)
     L = _lib.lib()
-    out, saved = {"shape": [M, N, K], "relative_to": "sum_k |a| |w|"}, os.environ.get("PDGN_GEMM")
+    out, saved = {"shape": [M, N, K], "relative_to": "sum_k |a| |w|"}, _lib.gemm_mode()
     try:
         for mode in ("x3", "fp32"):
-            os.environ["PDGN_GEMM"] = mode
+            _lib.set_gemm_mode(mode)
             check(L.pdgn_gemm_nt(ctypes.c_longlong(M), N, K, ptr(a), K, ptr(w), K, None, None, 0, ptr(c), N, None, stream_of(a)),
                   "pdgn_gemm_nt")
             out["max_error_vs_fp64_" + mode] = ((c.double() - ref).abs() / mag).max().item()
     finally:
-        if saved is None:
-            os.environ.pop("PDGN_GEMM", None)
-        else:
-            os.environ["PDGN_GEMM"] = saved
+        _lib.set_gemm_mode(saved)
     return out
 
 
@@ -271,7 +267,7 @@ def measure(B, base_points, device):
     stage 4 on pdgn_gemm_nt -- with the other hand-written kernels under "others"."""
     entries = [f(B, base_points, device) for f in ENTRIES]
     # `traffic` is NOT measured by this run: it is the PMC figure (FETCH_SIZE + WRITE_SIZE, separate rocprofv3 passes,
-    # corrected as the guide prescribes) committed in profiles/traffic.json by tools/pmc_traffic.py, attached only when
+    # corrected as the guide prescribes) committed in profiles/traffic.json by tools/pmc_roofline.py, attached only when
     # that file was recorded at this batch / resolution
     try:
         with open(_TRAFFIC) as f:

@@ -123,7 +123,9 @@ class LeanAdamStep:
     first, ordinary step the same two calls torch makes -- `_foreach_add_` on the step counters, `_fused_adam_` on the parameter /
     gradient / moment lists -- are issued on lists cached here.  The state stays the optimizer's own (checkpoints, broadcasts and
     `state_dict()` are untouched); anything unusual (a parameter without gradient, several groups, amsgrad, weight decay, a
-    non-fused optimizer) keeps calling `optimizer.step()`."""
+    non-fused optimizer, step hooks, replaced state tensors) keeps calling `optimizer.step()`; the invariants are re-checked on
+    every call.  `torch._fused_adam_` / `torch._foreach_add_` are private torch entry points (written against torch 2.10): a
+    changed signature falls back to `optimizer.step()` for good."""
 
     def __init__(self, opt):
         self.opt, self.lists = opt, None
@@ -152,16 +154,26 @@ class LeanAdamStep:
             return
         ps, exp_avgs, exp_avg_sqs, steps = self.lists
         grads = [p.grad for p in ps]
-        for gr in grads:
-            if gr is None:
-                opt.step()
-                return
         g = opt.param_groups[0]
-        with torch.no_grad():
-            torch._foreach_add_(steps, 1)
-            torch._fused_adam_(ps, grads, exp_avgs, exp_avg_sqs, [], steps, amsgrad=False, lr=g["lr"], beta1=g["betas"][0],
-                               beta2=g["betas"][1], weight_decay=0.0, eps=g["eps"], maximize=False, grad_scale=None,
-                               found_inf=None)
+        # cheap invariants, every call: one group over the same parameters, no weight decay / amsgrad / maximize, a Python float
+        # learning rate, the optimizer's own state tensors still the cached ones, no step hooks, every gradient present
+        st0 = opt.state.get(ps[0]) if ps else None
+        if (len(opt.param_groups) != 1 or len(g["params"]) != len(ps) or g.get("weight_decay", 0) != 0 or g.get("amsgrad")
+                or g.get("maximize") or isinstance(g["lr"], torch.Tensor) or st0 is None or st0.get("exp_avg") is not exp_avgs[0]
+                or opt._optimizer_step_pre_hooks or opt._optimizer_step_post_hooks or any(gr is None for gr in grads)):
+            self.lists = None                                    # re-validated after the next ordinary step
+            opt.step()
+            return
+        try:
+            with torch.no_grad():
+                torch._foreach_add_(steps, 1)
+                torch._fused_adam_(ps, grads, exp_avgs, exp_avg_sqs, [], steps, amsgrad=False, lr=g["lr"], beta1=g["betas"][0],
+                                   beta2=g["betas"][1], weight_decay=0.0, eps=g["eps"], maximize=False, grad_scale=None,
+                                   found_inf=None)
+        except TypeError:                                        # the private op's signature changed (another torch version):
+            torch._foreach_sub_(steps, 1)                        # undo the counter and take the public path from now on
+            self.lists = False
+            opt.step()
 
 
 class PDGNTrainer:

@@ -21,3 +21,14 @@ def golden():
     def load(name):
         return dict(np.load(os.path.join(GOLDEN, name)))
     return load
+
+
+@pytest.fixture(autouse=True)
+def _reset_gemm_switches(request):
+    """GPU tests select the contraction kernel / tile configuration through pdgn_amd._lib.set_gemm_mode / set_gemm_config
+    (process-wide switches of libpdgn_hip.so): put the defaults back after every such test."""
+    yield
+    if request.node.get_closest_marker("gpu") is not None:
+        from pdgn_amd import _lib
+        _lib.set_gemm_mode(os.environ.get("PDGN_GEMM", "x3"))
+        _lib.set_gemm_config(int(os.environ["PDGN_NT_CFG"]) if os.environ.get("PDGN_NT_CFG") else None)

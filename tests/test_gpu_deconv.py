@@ -484,11 +484,9 @@ def test_gemm_tn_big_direct(M, N, K, cfg, monkeypatch, gemm):
     import ctypes
     from pdgn_amd import _lib
     from pdgn_amd._lib import ptr, stream_of
-    if cfg is None:
-        monkeypatch.delenv("PDGN_NT_CFG", raising=False)
-    else:
-        monkeypatch.setenv("PDGN_NT_CFG", str(cfg))
-    monkeypatch.setenv("PDGN_GEMM", gemm)                      # csrc/gemm_x3.hip (the default) | csrc/gemm_nt.hip
+    from pdgn_amd import _lib as _sw
+    _sw.set_gemm_config(cfg)                                   # forced tile configuration | None: the launch model's pick
+    _sw.set_gemm_mode(gemm)                                    # csrc/gemm_x3.hip (the default) | csrc/gemm_nt.hip; conftest resets both
     g = torch.Generator(device="cuda").manual_seed(M + N + K)
     x = torch.randn(M, K, device="cuda", generator=g)
     dy = torch.randn(M, N, device="cuda", generator=g)
@@ -813,17 +811,15 @@ def test_config_c4_four_stage_512_to_4096():
 @pytest.mark.parametrize("M,N,K", [(35840, 512, 128), (5000, 132, 36), (129, 8, 4), (71680, 1024, 256), (35840, 512, 5120),
                                    (17920, 64, 6432), (8960, 3232, 32), (1000, 36, 20), (358400, 64, 16)])
 def test_gemm_nt_with_epilogues(M, N, K, cfg, monkeypatch, gemm):
-    """pdgn_gemm_nt through the C ABI, every tile configuration (PDGN_NT_CFG) and the launch model's own pick:
+    """pdgn_gemm_nt through the C ABI, every tile configuration (_lib.set_gemm_config) and the launch model's own pick:
     C = A W^T (plain: the stream-K tail may run), and C = A W^T + bias + addend with the column-statistics partials."""
     import ctypes
     import os
     from pdgn_amd import _lib
     from pdgn_amd._lib import ptr, stream_of
-    if cfg is None:
-        monkeypatch.delenv("PDGN_NT_CFG", raising=False)
-    else:
-        monkeypatch.setenv("PDGN_NT_CFG", str(cfg))
-    monkeypatch.setenv("PDGN_GEMM", gemm)                      # csrc/gemm_x3.hip (the default) | csrc/gemm_nt.hip
+    from pdgn_amd import _lib as _sw
+    _sw.set_gemm_config(cfg)                                   # forced tile configuration | None: the launch model's pick
+    _sw.set_gemm_mode(gemm)                                    # csrc/gemm_x3.hip (the default) | csrc/gemm_nt.hip; conftest resets both
     L = _lib.lib()
     L.pdgn_gemm_nt_stat_rows.restype = ctypes.c_longlong
     g = torch.Generator(device="cuda").manual_seed(M + N)
@@ -861,11 +857,9 @@ def test_gemm_nn_input_gradient_form(M, N, K, cfg, monkeypatch, gemm):
     import ctypes
     from pdgn_amd import _lib
     from pdgn_amd._lib import ptr, stream_of
-    if cfg is None:
-        monkeypatch.delenv("PDGN_NT_CFG", raising=False)
-    else:
-        monkeypatch.setenv("PDGN_NT_CFG", str(cfg))
-    monkeypatch.setenv("PDGN_GEMM", gemm)                      # csrc/gemm_x3.hip (the default) | csrc/gemm_nt.hip
+    from pdgn_amd import _lib as _sw
+    _sw.set_gemm_config(cfg)                                   # forced tile configuration | None: the launch model's pick
+    _sw.set_gemm_mode(gemm)                                    # csrc/gemm_x3.hip (the default) | csrc/gemm_nt.hip; conftest resets both
     L = _lib.lib()
     L.pdgn_gemm_nt_stat_rows.restype = ctypes.c_longlong
     g = torch.Generator(device="cuda").manual_seed(M + N + 1)
@@ -896,7 +890,7 @@ def test_gemm_nn_input_gradient_form(M, N, K, cfg, monkeypatch, gemm):
 def test_gemm_x3_is_as_accurate_as_the_fp32_matrix_instructions(M, N, K, scale, monkeypatch):
     """csrc/gemm_x3.hip multiplies fp32 operands as three bf16 parts each (six bf16 MFMA products per fp32 product, fp32
     accumulation).  Against fp64, relative to sum_k |a| |w|: its error stays below 1e-6 and within 1.25x of the error of the
-    fp32 matrix instructions (csrc/gemm_nt.hip, PDGN_GEMM=fp32) on the same operands -- measured 0.7-0.95x -- for all three
+    fp32 matrix instructions (csrc/gemm_nt.hip, _lib.set_gemm_mode('fp32')) on the same operands -- measured 0.7-0.95x -- for all three
     operand layouts, and over the fp32 exponent range (bf16 shares it: no scaling of the operands is involved)."""
     import ctypes
     from pdgn_amd import _lib
@@ -912,7 +906,7 @@ def test_gemm_x3_is_as_accurate_as_the_fp32_matrix_instructions(M, N, K, scale, 
     mag = {"nt": a64.abs() @ w64.abs().t(), "nn": d64.abs() @ w64.abs(), "tn": d64.abs().t() @ a64.abs()}
     err = {}
     for mode in ("x3", "fp32"):
-        monkeypatch.setenv("PDGN_GEMM", mode)
+        _lib.set_gemm_mode(mode)
         C = torch.empty(M, N, device="cuda")
         assert L.pdgn_gemm_nt(ctypes.c_longlong(M), N, K, ptr(A), K, ptr(W), K, None, None, 0, ptr(C), N, None, stream_of(A)) == 0
         dX = torch.empty(M, K, device="cuda")
@@ -1141,11 +1135,9 @@ def test_gemm_nt_extended_epilogue(M, N, K, rpg, cfg, monkeypatch, gemm):
     import ctypes
     from pdgn_amd import _lib
     from pdgn_amd._lib import ptr, stream_of
-    if cfg is None:
-        monkeypatch.delenv("PDGN_NT_CFG", raising=False)
-    else:
-        monkeypatch.setenv("PDGN_NT_CFG", str(cfg))
-    monkeypatch.setenv("PDGN_GEMM", gemm)                      # csrc/gemm_x3.hip (the default) | csrc/gemm_nt.hip
+    from pdgn_amd import _lib as _sw
+    _sw.set_gemm_config(cfg)                                   # forced tile configuration | None: the launch model's pick
+    _sw.set_gemm_mode(gemm)                                    # csrc/gemm_x3.hip (the default) | csrc/gemm_nt.hip; conftest resets both
     L = _lib.lib()
     g = torch.Generator(device="cuda").manual_seed(M + N + K)
     A = torch.randn(M, K, device="cuda", generator=g)

@@ -39,14 +39,14 @@ extra = {}
 
 
 def all_cfgs(run, key, cfg):
-    """ALL_CFGS=1: the problem under every tile configuration (PDGN_NT_CFG), against the launch model's pick."""
+    """ALL_CFGS=1: the problem under every tile configuration (_lib.set_gemm_config), against the launch model's pick."""
     if os.environ.get("ALL_CFGS") != "1":
         return
     per = []
     for c_ in range(NCFG):
-        os.environ["PDGN_NT_CFG"] = str(c_)
+        _lib.set_gemm_config(c_)
         per.append(t(run, it=5))
-    del os.environ["PDGN_NT_CFG"]
+    _lib.set_gemm_config(None)
     best = min(range(NCFG), key=lambda i: per[i])
     extra[key] = extra.get(key, "") + " | cfgs " + " ".join("%.1f" % v for v in per) + (" | best %d %s" % (
         best, "" if per[cfg & 15] <= 1.03 * per[best] else "<-- pick %d is %.0f%% slower" % (cfg & 15, 100 * (per[cfg & 15] / per[best] - 1))))
