@@ -250,6 +250,20 @@ int pdgn_softmax_slots_permute_backward(long long m, int k, int c, const float *
  * pdgn_bn_stats_from_gemm_partials turns into BatchNorm statistics.  Without
  * stat_part and with ldc == n the launch may add partial tiles with fp32 atomics (C is zero-filled by the
  * call itself where needed). */
+/* A weight matrix split ONCE into the three bf16 parts the contractions multiply (x = h + m + l, csrc/split.hip) instead of by
+ * every workgroup's loader: src (rows x cols fp32, pitch ld_src) -> planes (3 x [rows][ld_planes] bf16, plane_stride elements
+ * apart; may be NULL) and / or planes_t, the same for the TRANSPOSE (3 x [cols][ld_planes_t]; may be NULL).
+ * pdgn_gemm_nt_ps = pdgn_gemm_nt_ex with such planes as the second operand (n x k, pitch ldw, wplane elements between planes;
+ * ldw and wplane multiples of 8, the planes 16-byte aligned):
+ * forward y = x W^T with W's planes, input gradient dX = dY W with the planes of W^T.  Bit-identical to the unsplit calls; bf16
+ * matrix-core mode only (PDGN_ERR_INVALID under pdgn_gemm_set_mode(0)).  No reference counterpart. */
+int pdgn_split_bf16x3(int rows, int cols, const float *src, int ld_src, unsigned short *planes, int ld_planes,
+                      long long plane_stride, unsigned short *planes_t, int ld_planes_t, long long plane_stride_t,
+                      pdgn_stream_t stream);
+int pdgn_gemm_nt_ps(long long m, int n, int k, const float *A, int lda, const unsigned short *Wplanes, int ldw, long long wplane,
+                    const float *bias, const float *addend, int ldadd, float *C, int ldc, float *stat_part,
+                    const float *row_bias, int ld_rb, int rows_per_group, int act, const float *gate, int ldgate,
+                    pdgn_stream_t stream);
 /* Process-wide switches of the dense contractions (read from PDGN_GEMM / PDGN_NT_CFG once, at first use).
  * pdgn_gemm_set_mode: 1 = bf16 matrix cores (default), 0 = fp32 matrix instructions, < 0 = query; returns the previous mode.
  * pdgn_gemm_set_config: -1 = the launch model's pick (default), 0 .. 3 = force a tile configuration (measurement / tests),

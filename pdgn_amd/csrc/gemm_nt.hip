@@ -561,6 +561,7 @@ struct NtCfg {
         const bool allow_sk = stat_part == nullptr && ldc == n && !epi.any();
         const Plan pl = plan(m, n, k, allow_sk);
         NtArgs a;
+        a.Wp = nullptr; a.wplane = 0;
         a.M = m; a.N = n; a.K = k; a.lda = lda; a.ldw = ldw; a.ldc = ldc; a.ldadd = ldadd;
         a.A = A; a.W = W; a.bias = bias; a.addend = addend; a.C = C; a.stat_part = stat_part;
         a.row_bias = epi.row_bias; a.ld_rb = epi.ld_rb; a.rows_per_group = epi.rows_per_group > 0 ? epi.rows_per_group : 1;

@@ -53,6 +53,8 @@ struct NtArgs {
     int act;                          // 2: LeakyReLU(0.01) on the result
     const float *gate;                // result *= (gate[row, col] > 0 ? 1 : 0.01): the LeakyReLU derivative of a saved activation
     int ldgate;
+    const unsigned short *Wp;         // gemm_x3, PW instances: the second operand pre-split into three bf16 planes [N][ldw]
+    long long wplane;                 // elements between the planes
 };
 
 // ------------------------------------------------------------------ host side

@@ -99,8 +99,13 @@ __device__ __forceinline__ float x3_half_wave_sum(float v) {
 }
 
 // TM x TN blocks of 32 x 32 per wave, WM x WN waves, OCC workgroups per CU.
-template <int TM, int TN, int WM, int WN, int OCC, bool ATOMIC, bool WT, bool AT, bool EPI = false>
+// PW: the second operand arrives PRE-SPLIT -- three bf16 planes [N][ldw] (p.Wp; plane stride p.wplane elements), written once per
+// weight by pdgn_split_bf16x3 with the same round-to-nearest remainders the loader computes: its quads are loaded part by part
+// (8 B per part and lane) and go to LDS as they are -- none of the 22 vector instructions per quad, a third of the split work
+// of a 256 x 128 tile.  Same parts, same products, same order: results are bit-identical to the unsplit operand's.
+template <int TM, int TN, int WM, int WN, int OCC, bool ATOMIC, bool WT, bool AT, bool EPI = false, bool PW = false>
 __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_x3_kernel(const NtArgs p) {
+    static_assert(!PW || (!WT && !AT), "pre-split second operand: row-major (N x K) planes only");
     constexpr int NW = WM * WN, NTH = 64 * NW, BM = 32 * TM * WM, BN = 32 * TN * WN;
     // A chunk in LDS: per operand three bf16 parts of [rows][32 k] (64 B per row); the 16-B column c (k = 8c .. 8c + 7) of
     // row r is stored at position c ^ ((r >> 2) & 3): the b128 fragment reads -- serviced in the lane groups {0-3, 12-15, 20-27},
@@ -182,11 +187,13 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_x3_kernel(const NtArgs
     //   transposed operand (K x rows in memory): 4 loads = k rows 4 kq .. 4 kq + 3 at the same 4 columns, transposed in
     //   registers into 4 rows x 4 k.
     // Either way a thread ends up with "quads": 4 consecutive k of one row = one 8-B write per part.
-    constexpr int QA = BM * 8 / NTH, QW = BN * 8 / NTH, NQ = QA + QW;        // quads per thread and chunk
-    static_assert(QA * NTH == BM * 8 && QW * NTH == BN * 8, "loader quads must divide over the threads");
+    // (PW: the second operand's units are OCTETS -- 8 k of one row = one 16-B column of a part's LDS image, 16-B loads)
+    constexpr int QA = BM * 8 / NTH, QW = PW ? BN * 4 / NTH : BN * 8 / NTH, NQ = QA + QW;        // quads per thread and chunk
+    static_assert(QA * NTH == BM * 8 && QW * NTH == BN * (PW ? 4 : 8), "loader quads must divide over the threads");
     constexpr int CUA = QA % 4 == 0 ? 4 : 2, CUW = QW % 4 == 0 ? 4 : 2;     // columns per transposed unit (16-B or 8-B loads)
     static_assert((!AT || QA % CUA == 0) && (!WT || QW % CUW == 0), "transposed operand: whole units per thread");
     float raw[NQ][4];
+    unsigned rawp[PW ? QW : 1][12];                                // PW: octet j of W as (h, m, l) x 4 dwords
     // quad q of the thread: row-major: piece (wave + j NW) of 8 rows; transposed: unit (tid + j NTH) = (k quad, column quad)
     unsigned goffA0, goffW0, woffA0, woffW0;                       // byte offsets of quad 0 (global: inside the tile / chunk; LDS: part 0)
     int kqA, kqW;                                                  // k quad of the thread's row-major quads (one per operand)
@@ -202,7 +209,12 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_x3_kernel(const NtArgs
             goffA0 = (unsigned)((4 * kq) * p.lda + CUA * cq) * 4u;
             woffA0 = 0;                                            // (computed per quad in conv_write)
         }
-        if (!WT) {
+        if (PW) {
+            const int row = tid >> 2, col = tid & 3;               // octet j: row + j NTH / 4 (a multiple of 16: swizzle unchanged)
+            kqW = 2 * col;
+            goffW0 = (unsigned)(row * p.ldw + 8 * col) * 2u;
+            woffW0 = (unsigned)(3 * PART_A + row * 64 + ((col ^ ((row >> 2) & 3)) * 16));
+        } else if (!WT) {
             const int row = wave * 8 + r8;
             goffW0 = (unsigned)(row * p.ldw + 4 * c16) * 4u;
             woffW0 = (unsigned)(3 * PART_A + row * 64 + (((c16 >> 1) ^ ((row >> 2) & 3)) * 16) + (c16 & 1) * 8);
@@ -241,7 +253,12 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_x3_kernel(const NtArgs
                                                          ok ? (int)(((long long)(ld_mrows - 1) * p.lda + (p.K - ld_k0)) * 4) : 0, 0x00020000);
         else rsA = __builtin_amdgcn_make_buffer_rsrc((void *)(p.A + (long long)ld_k0 * p.lda + ld_m0), 0,
                                                      ok ? (int)(((long long)(krows - 1) * p.lda + ld_mrows) * 4) : 0, 0x00020000);
-        if (!WT) rsW = __builtin_amdgcn_make_buffer_rsrc((void *)(p.W + (long long)ld_n0 * p.ldw + ld_k0), 0,
+        // PW: ONE descriptor from the tile's start in plane h to the end of plane l (the plane offset of a load is part of the
+        // range check): rows past the tile read the following rows' / plane's parts -- finite values that only reach output
+        // columns which are never stored -- and everything past plane l reads zero; the K tail is masked by kokW as always
+        if (PW) rsW = __builtin_amdgcn_make_buffer_rsrc((void *)(p.Wp + (long long)ld_n0 * p.ldw + ld_k0), 0,
+                                                        ok ? (int)((2 * p.wplane + (long long)(p.N - 1 - ld_n0) * p.ldw + (p.K - ld_k0)) * 2) : 0, 0x00020000);
+        else if (!WT) rsW = __builtin_amdgcn_make_buffer_rsrc((void *)(p.W + (long long)ld_n0 * p.ldw + ld_k0), 0,
                                                          ok ? (int)(((long long)(ld_nrows - 1) * p.ldw + (p.K - ld_k0)) * 4) : 0, 0x00020000);
         else rsW = __builtin_amdgcn_make_buffer_rsrc((void *)(p.W + (long long)ld_k0 * p.ldw + ld_n0), 0,
                                                      ok ? (int)(((long long)(krows - 1) * p.ldw + ld_nrows) * 4) : 0, 0x00020000);
@@ -254,7 +271,16 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_x3_kernel(const NtArgs
         const __amdgpu_buffer_rsrc_t rs = isA ? rsA : rsW;
         const int ld_ = isA ? p.lda : p.ldw;
         const unsigned g0 = isA ? goffA0 : goffW0;
-        if (!tr) {
+        if (PW && !isA) {
+            // parts h, m, l of the quad: the same tile-relative offset in each plane, the plane offset in the scalar offset
+            const unsigned off = g0 + (unsigned)(j * (NTH / 4) * ld_) * 2u;
+#pragma unroll
+            for (int part = 0; part < 3; ++part) {
+                const u32x4 x = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, kokW ? off : NT_OOB, (int)(part * p.wplane * 2), 0));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) rawp[j][4 * part + e] = x[e];
+            }
+        } else if (!tr) {
             const unsigned off = g0 + (unsigned)(j * NW * 8 * ld_) * 4u;
             const f32x4 x = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (isA ? kokA : kokW) ? off : NT_OOB, 0, 0));
 #pragma unroll
@@ -291,6 +317,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_x3_kernel(const NtArgs
     // ---- conversion: the 4 values of quad q -> three 8-B writes into stage `st`
     unsigned cvh[2], cvm[2], cvl[2];
     auto conv_pair = [&](int q, int e) {
+        if (PW && q >= QA) return;                                 // already parts
         const float a = raw[q][2 * e], b = raw[q][2 * e + 1];
         if (X3_ABLATE & 32) {                                      // (measurement: no arithmetic)
             cvh[e] = __float_as_uint(a);
@@ -312,7 +339,9 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_x3_kernel(const NtArgs
         const int j = isA ? q : q - QA;
         const int ps = isA ? PART_A : PART_W;
         unsigned off = isA ? woffA0 : woffW0;
-        if (!tr) {
+        if (PW && !isA) {
+            off += (unsigned)(j * (NTH / 4) * 64);                 // octets: NTH / 4 rows apart
+        } else if (!tr) {
             off += (unsigned)(j * NW * 8 * 64);                    // 8 rows per piece, pieces NW apart (32 rows): (row >> 2) & 3 unchanged
         } else {
             // unit j / CU: k quad kq0 + (j / CU) KQ_STEP: 16-B column (kq >> 1) ^ swizzle, half kq & 1; row CU cq + j % CU
@@ -325,6 +354,12 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_x3_kernel(const NtArgs
         }
         unsigned char *dst = smem + st * STAGE + off;
         typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        if (PW && !isA) {
+#pragma unroll
+            for (int part = 0; part < 3; ++part)
+                *reinterpret_cast<u32x4 *>(dst + part * ps) = (u32x4){rawp[j][4 * part], rawp[j][4 * part + 1], rawp[j][4 * part + 2], rawp[j][4 * part + 3]};
+            return;
+        }
         if (X3_ABLATE & 64) {                                      // (measurement: one write instead of three)
             *reinterpret_cast<u32x2 *>(dst) = (u32x2){cvh[0] ^ cvm[0] ^ cvl[0], cvh[1] ^ cvm[1] ^ cvl[1]};
             return;
@@ -748,15 +783,15 @@ struct X3Cfg {
         return pl;
     }
 
-    template <bool ATOMIC, bool WT, bool AT, bool EPI>
+    template <bool ATOMIC, bool WT, bool AT, bool EPI, bool PW = false>
     static void go(int grid, hipStream_t s, const NtArgs &a) {
-        hipLaunchKernelGGL((gemm_x3_kernel<TM, TN, WM, WN, OCC, ATOMIC, WT, AT, EPI>), dim3(grid), dim3(64 * WM * WN), 0, s, a);
+        hipLaunchKernelGGL((gemm_x3_kernel<TM, TN, WM, WN, OCC, ATOMIC, WT, AT, EPI, PW>), dim3(grid), dim3(64 * WM * WN), 0, s, a);
     }
 
     template <bool WT, bool AT = false>
     static int launch(long long m, int n, int k, const float *A, int lda, const float *W, int ldw, const float *bias,
                       const float *addend, int ldadd, float *C, int ldc, float *stat_part, hipStream_t s,
-                      const NtEpi &epi = NtEpi(), bool prezeroed = false) {
+                      const NtEpi &epi = NtEpi(), bool prezeroed = false, const unsigned short *Wp = nullptr, long long wplane = 0) {
         const bool allow_sk = stat_part == nullptr && ldc == n && !epi.any();
         const Plan pl = plan(m, n, k, allow_sk);
         NtArgs a;
@@ -765,6 +800,7 @@ struct X3Cfg {
         a.row_bias = epi.row_bias; a.ld_rb = epi.ld_rb; a.rows_per_group = epi.rows_per_group > 0 ? epi.rows_per_group : 1;
         a.rpg_magic = a.rows_per_group > 1 ? (unsigned)(0x100000000ULL / (unsigned)a.rows_per_group) + 1u : 0u;
         a.act = epi.act; a.gate = epi.gate; a.ldgate = epi.ldgate; a.sk_split = 0;
+        a.Wp = Wp; a.wplane = wplane;
         a.tiles_m = pl.tiles_m; a.tiles_n = pl.tiles_n; a.kchunks = pl.kchunks;
         a.dbg = 0;
 #ifdef PDGN_NT_DEBUG
@@ -787,14 +823,19 @@ struct X3Cfg {
             const long long r0 = (long long)(pl.dp_tiles / (NT_GROUP_M * pl.tiles_n)) * NT_GROUP_M * BM;
             if (!prezeroed && hipMemsetAsync(C + r0 * ldc, 0, (size_t)(m - r0) * ldc * sizeof(float), s) != hipSuccess) return pdgn_launch_status();
         }
+        constexpr bool CAN_PW = !WT && !AT;
         if (pl.grid_dp) {
             a.tile_begin = 0; a.tile_end = pl.dp_tiles; a.sk_per_wg = 0;
-            if (!AT && epi.any()) go<false, WT, false, true>(pl.grid_dp, s, a);
+            if (CAN_PW && Wp) {
+                if (epi.any()) go<false, false, false, true, CAN_PW>(pl.grid_dp, s, a);
+                else go<false, false, false, false, CAN_PW>(pl.grid_dp, s, a);
+            } else if (!AT && epi.any()) go<false, WT, false, true>(pl.grid_dp, s, a);
             else go<false, WT, AT, false>(pl.grid_dp, s, a);
         }
         if (pl.grid_sk) {
             a.tile_begin = pl.dp_tiles; a.tile_end = (int)T; a.sk_per_wg = pl.sk_per_wg;
-            go<true, WT, AT, false>(pl.grid_sk, s, a);
+            if (CAN_PW && Wp) go<true, false, false, false, CAN_PW>(pl.grid_sk, s, a);
+            else go<true, WT, AT, false>(pl.grid_sk, s, a);
         }
         return pdgn_launch_status();
     }
@@ -857,11 +898,11 @@ static bool x3_args_ok(long long m, int n, int k, int lda, int ldw, int ldadd, i
 template <bool WT>
 static int x3_dispatch(long long m, int n, int k, const float *A, int lda, const float *W, int ldw, const float *bias,
                        const float *addend, int ldadd, float *C, int ldc, float *stat_part, hipStream_t s,
-                       const NtEpi &epi = NtEpi()) {
+                       const NtEpi &epi = NtEpi(), const unsigned short *Wp = nullptr, long long wplane = 0) {
     switch (x3_pick(m, n, k, stat_part != nullptr || epi.any())) {
-        case 0: return X3Big::launch<WT>(m, n, k, A, lda, W, ldw, bias, addend, ldadd, C, ldc, stat_part, s, epi);
-        case 2: return X3Narrow::launch<WT>(m, n, k, A, lda, W, ldw, bias, addend, ldadd, C, ldc, stat_part, s, epi);
-        default: return X3Square::launch<WT>(m, n, k, A, lda, W, ldw, bias, addend, ldadd, C, ldc, stat_part, s, epi);
+        case 0: return X3Big::launch<WT>(m, n, k, A, lda, W, ldw, bias, addend, ldadd, C, ldc, stat_part, s, epi, false, Wp, wplane);
+        case 2: return X3Narrow::launch<WT>(m, n, k, A, lda, W, ldw, bias, addend, ldadd, C, ldc, stat_part, s, epi, false, Wp, wplane);
+        default: return X3Square::launch<WT>(m, n, k, A, lda, W, ldw, bias, addend, ldadd, C, ldc, stat_part, s, epi, false, Wp, wplane);
     }
 }
 
@@ -907,6 +948,28 @@ extern "C" int pdgn_gemm_nt_ex(long long m, int n, int k, const float *A, int ld
     e.row_bias = row_bias; e.ld_rb = ld_rb; e.rows_per_group = rows_per_group; e.act = act; e.gate = gate; e.ldgate = ldgate;
     return transposed_w ? x3_dispatch<true>(m, n, k, A, lda, W, ldw, bias, addend, ldadd, C, ldc, stat_part, (hipStream_t)stream, e)
                         : x3_dispatch<false>(m, n, k, A, lda, W, ldw, bias, addend, ldadd, C, ldc, stat_part, (hipStream_t)stream, e);
+}
+
+// pdgn_gemm_nt / pdgn_gemm_nt_ex with the second operand PRE-SPLIT by pdgn_split_bf16x3: Wplanes = three bf16 planes [n][ldw]
+// (wplane elements apart) of the (n x k) weight -- or of the transpose of a (k' x n') weight, which makes this the input-gradient
+// product dX = dY W as well.  Bit-identical to the unsplit entry points on the bf16 matrix cores (the planes hold exactly the
+// parts the loader would compute); only there: with pdgn_gemm_set_mode(0) in force the call is refused (-1).
+extern "C" int pdgn_gemm_nt_ps(long long m, int n, int k, const float *A, int lda, const unsigned short *Wplanes, int ldw,
+                               long long wplane, const float *bias, const float *addend, int ldadd, float *C, int ldc,
+                               float *stat_part, const float *row_bias, int ld_rb, int rows_per_group, int act, const float *gate,
+                               int ldgate, pdgn_stream_t stream) {
+    if (!x3_mode() || !Wplanes) return PDGN_ERR_INVALID;
+    if (!x3_args_ok(m, n, k, lda, ldw, ldadd, ldc, addend, false)) return PDGN_ERR_INVALID;
+    if (wplane < (long long)(n - 1) * ldw + k || wplane >= (1LL << 28) || ldw % 8 || wplane % 8 || ((uintptr_t)Wplanes & 15))
+        return PDGN_ERR_INVALID;                                  // 16-B loads of 8 bf16: rows and planes start on 16-B boundaries
+    if ((act != 0 && act != 2) || (row_bias && (ld_rb < n || ld_rb % 4 || rows_per_group < 1)) ||
+        (gate && (ldgate < n || ldgate % 4)) || m >= (1LL << 31) || (row_bias && m * rows_per_group >= (1LL << 32)))
+        return PDGN_ERR_INVALID;
+    NtEpi e;
+    e.row_bias = row_bias; e.ld_rb = ld_rb; e.rows_per_group = rows_per_group > 0 ? rows_per_group : 1; e.act = act; e.gate = gate;
+    e.ldgate = ldgate;
+    return x3_dispatch<false>(m, n, k, A, lda, nullptr, ldw, bias, addend, ldadd, C, ldc, stat_part, (hipStream_t)stream, e, Wplanes,
+                              wplane);
 }
 
 // Weight gradient of a point-major dense layer, dW (n x k) = dY (m x n)^T X (m x k): the same kernel with BOTH operands

@@ -1,0 +1,77 @@
+// split.hip -- an fp32 matrix as three bf16 planes (x = h + m + l), once per weight.
+//
+// gemm_x3.hip forms every fp32 product from the operands' three-way bf16 splits and normally splits both operands in its
+// loaders, once per workgroup and k chunk.  A WEIGHT matrix is the same for every row tile of a launch, for both generator
+// passes of an iteration and for the input-gradient product of the backward pass: pdgn_split_bf16x3 writes its parts once --
+// with exactly the loader's arithmetic (round-to-nearest bf16 of the value, of the exact remainder, of the second exact
+// remainder: gemm_x3.hip::x3_split_pair) -- as planes [rows][ld] for the forward form (pdgn_gemm_nt_ps) and, optionally,
+// as planes of the TRANSPOSE [cols][ldt] (the input gradient dX = dY W is the same NT product against W^T).
+// (No reference counterpart: models/PDGNet_v2.py's layers run on cuDNN / cuBLAS.)
+#include "common.h"
+
+typedef float sp_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 sp_bf16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ unsigned sp_cvt_pk(float a, float b) {          // v_cvt_pk_bf16_f32: round to nearest even
+    const sp_f32x2 v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, sp_bf16x2));
+}
+
+__device__ __forceinline__ void sp_split(float a, unsigned short &h, unsigned short &m, unsigned short &l) {
+    const unsigned hh = sp_cvt_pk(a, 0.f);
+    const float ra = a - __uint_as_float(hh << 16);                        // exact
+    const unsigned mm = sp_cvt_pk(ra, 0.f);
+    const float sa = ra - __uint_as_float(mm << 16);                       // exact
+    h = (unsigned short)(hh & 0xffffu);
+    m = (unsigned short)(mm & 0xffffu);
+    l = (unsigned short)(sp_cvt_pk(sa, 0.f) & 0xffffu);
+}
+
+// 32 x 32 tiles, 256 threads (32 x 8): row-major planes straight from the registers, transposed planes through LDS.
+__global__ __launch_bounds__(256) void split_bf16x3_kernel(int rows, int cols, const float *__restrict__ src, int lds_,
+                                                           unsigned short *__restrict__ P, int ldp, long long pstride,
+                                                           unsigned short *__restrict__ PT, int ldpt, long long ptstride) {
+    __shared__ unsigned short tile[3][32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = r0 + ty + 8 * i, c = c0 + tx;
+        unsigned short h = 0, m = 0, l = 0;
+        if (r < rows && c < cols) {
+            sp_split(src[(size_t)r * lds_ + c], h, m, l);
+            if (P) {
+                P[(size_t)r * ldp + c] = h;
+                P[pstride + (size_t)r * ldp + c] = m;
+                P[2 * pstride + (size_t)r * ldp + c] = l;
+            }
+        }
+        tile[0][ty + 8 * i][tx] = h;
+        tile[1][ty + 8 * i][tx] = m;
+        tile[2][ty + 8 * i][tx] = l;
+    }
+    if (!PT) return;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = c0 + ty + 8 * i, r = r0 + tx;                        // output row = source column
+        if (c < cols && r < rows) {
+            PT[(size_t)c * ldpt + r] = tile[0][tx][ty + 8 * i];
+            PT[ptstride + (size_t)c * ldpt + r] = tile[1][tx][ty + 8 * i];
+            PT[2 * ptstride + (size_t)c * ldpt + r] = tile[2][tx][ty + 8 * i];
+        }
+    }
+}
+
+// src (rows x cols, row pitch ld_src floats) -> planes (3 x [rows][ld_planes] bf16, plane_stride elements apart; may be NULL)
+// and / or planes_t (3 x [cols][ld_planes_t], plane_stride_t apart; may be NULL): the parts h | m | l of every value.
+extern "C" int pdgn_split_bf16x3(int rows, int cols, const float *src, int ld_src, unsigned short *planes, int ld_planes,
+                                 long long plane_stride, unsigned short *planes_t, int ld_planes_t, long long plane_stride_t,
+                                 pdgn_stream_t stream) {
+    if (rows < 1 || cols < 1 || ld_src < cols || (!planes && !planes_t)) return PDGN_ERR_INVALID;
+    if (planes && (ld_planes < cols || plane_stride < (long long)(rows - 1) * ld_planes + cols)) return PDGN_ERR_INVALID;
+    if (planes_t && (ld_planes_t < rows || plane_stride_t < (long long)(cols - 1) * ld_planes_t + rows)) return PDGN_ERR_INVALID;
+    hipLaunchKernelGGL(split_bf16x3_kernel, dim3(cdiv(cols, 32), cdiv(rows, 32)), dim3(256), 0, (hipStream_t)stream, rows, cols, src,
+                       ld_src, planes, ld_planes, plane_stride, planes_t, ld_planes_t, plane_stride_t);
+    return pdgn_launch_status();
+}

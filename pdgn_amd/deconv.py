@@ -28,7 +28,7 @@ from ._fn import Function
 from . import _lib
 from . import streams as _streams
 from ._lib import check, ptr, require, stream_of
-from .fused import (_zeros, bilateral_weighting, bn_act,  # noqa: F401
+from .fused import (Planes, split_planes, _zeros, bilateral_weighting, bn_act,  # noqa: F401
                     small_sequential, bn_act_maxpool, bn_softmax_slots_permute, flush_bn_counters,  # noqa: F401
                     has_zero_colsum, linear_cl, softmax_slots_permute)
 
@@ -330,6 +330,45 @@ class PointDeconv(nn.Module):
         Wb = W2b.reshape(2 * Fo, 2 * Fi, 2, P).permute(0, 3, 1, 2).reshape(2 * Fo, P * 4 * Fi)
         return Wcat, Wb, T, P
 
+    # -- the re-associated weights of this block for the current parameter values: (WcatC | None, WcatV, Wb) from one gather
+    # kernel (AssembleWeights), plus -- on the bf16 matrix cores -- the pre-split planes of the two large GEMM operands.
+    # `preassemble` builds them ahead of a pass (the trainer: once per iteration, for BOTH generator passes, off the issuing
+    # stream); forward_cl takes them from there while the parameters' versions still match, else builds them on the spot.
+    def _weights_key(self, Fc):
+        ws = [self.inte_conv_hk[0].weight, self.conv2.conv.weight] + ([self.conv_fea[0].weight] if self.bilateral else [])
+        return (Fc,) + tuple((w.data_ptr(), w._version) for w in ws)
+
+    def _assemble_now(self, Fc):
+        Fi, Fo, k = self.Fin, self.Fout, self.k
+        T = k // 2 + 1
+        WcatC, WcatV, Wb = AssembleWeights.apply(self.inte_conv_hk[0].weight, self.conv2.conv.weight,
+                                                 self.conv_fea[0].weight if self.bilateral else None, Fi, Fo, k, T, Fc)
+        want_t = torch.is_grad_enabled() and WcatV.requires_grad
+        with torch.no_grad():
+            pv = split_planes(WcatV.detach(), want_t)
+            pb = split_planes(Wb.detach(), want_t)
+        return WcatC, WcatV, Wb, pv, pb
+
+    def preassemble(self, Fc, ready=None):
+        """Build the block's GEMM operands now (under the caller's grad mode and stream); `ready`: an event recorded after
+        them when they were issued on another stream than the consumer's."""
+        self._pre = (self._weights_key(Fc), torch.is_grad_enabled(), self._assemble_now(Fc), ready)
+
+    def drop_preassembled(self):
+        self._pre = None
+
+    def assembled(self, Fc):
+        pre = getattr(self, "_pre", None)
+        if pre is not None and pre[0] == self._weights_key(Fc) and (pre[1] or not torch.is_grad_enabled()):
+            if pre[3] is not None:
+                torch.cuda.current_stream(pre[2][1].device).wait_event(pre[3])
+                for t in pre[2]:
+                    for u in ((t.p, t.t) if isinstance(t, Planes) else (t,)):
+                        if u is not None:
+                            u.record_stream(torch.cuda.current_stream(u.device))
+            return pre[2]
+        return self._assemble_now(Fc)
+
     def forward(self, x, pc=None, idx=None):
         """Reference layout: x (B,Fin,N) [, pc (B,3,N)] -> (B,Fout,2N)."""
         out = self.forward_cl(x.transpose(1, 2).contiguous(),
@@ -355,12 +394,11 @@ class PointDeconv(nn.Module):
         elif idx.dtype != I32:
             idx = idx.to(I32)
         idx = idx.contiguous()
+        planes_v = planes_b = None
         if xt.is_cuda:
             T = k // 2 + 1
             P = k - T + 1
-            WcatC, WcatV, Wb = AssembleWeights.apply(self.inte_conv_hk[0].weight, self.conv2.conv.weight,
-                                                     self.conv_fea[0].weight if self.bilateral else None, Fi, Fo, k, T,
-                                                     Fc if const is not None else 0)
+            WcatC, WcatV, Wb, planes_v, planes_b = self.assembled(Fc if const is not None else 0)
         else:                                                          # host tests: the same algebra in torch ops
             Wcat, Wb, T, P = self._assemble()
             WcatC, WcatV = (Wcat[:, :Fc], Wcat[:, Fc:].contiguous()) if const is not None else (None, Wcat)
@@ -384,7 +422,7 @@ class PointDeconv(nn.Module):
                       for sp, bias in zip(specs_full, biases)]       # sp = (T, P, C, off, offc)
         x2d = xt.reshape(B * N, Fv)
         specs = [(T, P, 4 * Fi, o_i, o_ci, fuse_stats)] + specs_full[1:]
-        Y = linear_cl(x2d, WcatV).view(B, N, -1)                       # (B,N,Mw) -- per-point GEMM
+        Y = linear_cl(x2d, WcatV, planes=planes_v).view(B, N, -1)      # (B,N,Mw) -- per-point GEMM
         if knn_side is not None:
             torch.cuda.current_stream(idx.device).wait_event(knn_side)
             idx.record_stream(torch.cuda.current_stream(idx.device))
@@ -416,7 +454,7 @@ class PointDeconv(nn.Module):
         else:
             # inte = LeakyReLU(BN(inte_pre))  (:637)
             inte = bn_act(inte_pre.view(-1, 4 * Fi), self.inte_conv_hk[1], training, partials=part_i)
-        out_pre = linear_cl(inte.view(B * N, P * 4 * Fi), Wb, None, a_pre.view(B * N, 2 * Fo))    # sum in the GEMM's epilogue
+        out_pre = linear_cl(inte.view(B * N, P * 4 * Fi), Wb, None, a_pre.view(B * N, 2 * Fo), planes=planes_b)    # sum in the GEMM's epilogue
         # (B,2Fout,N,1) -> view(B,Fout,2,N) -> (B,Fout,2N) (:645-647): point j*N+n of channel c is conv channel 2c+j at
         # point n; in point-major form that is (B, 2, N, Fout) -> (B, 2N, Fout), which the BatchNorm + ReLU pass stores
         # directly (interleave_n) instead of a permute copy behind it

@@ -250,6 +250,52 @@ def _pad_cols(t, mult=4):
 GEMM_LOG = None            # tools/gemm_shapes.py sets this to a list: every (kind, m, n, k) launched is appended
 
 
+class Planes:
+    """A weight's three bf16 parts (x = h + m + l, csrc/split.hip) as planes [3][rows][ld] (int16 storage), written ONCE per
+    weight instead of by every workgroup's loader of the contraction kernel; `t` = the same for the transpose (the input-gradient
+    product dX = dY W is the NT product against W^T) or None."""
+    __slots__ = ("p", "t", "shape")
+
+    def __init__(self, p, t, shape):
+        self.p, self.t, self.shape = p, t, shape
+
+
+def split_planes(w, want_t):
+    """pdgn_split_bf16x3 of a (rows, cols) fp32 matrix; None where the pre-split path does not apply (fp32-instruction mode,
+    sizes that would need padding)."""
+    if not (w.is_cuda and w.dim() == 2 and _lib.gemm_mode() == "x3") or w.shape[0] % 4 or w.shape[1] % 4 or w.stride(1) != 1:
+        return None
+    n, k = w.shape
+    ldp, ldt = (k + 7) // 8 * 8, (n + 7) // 8 * 8
+    P = torch.empty((3, n, ldp), dtype=torch.int16, device=w.device)
+    PT = torch.empty((3, k, ldt), dtype=torch.int16, device=w.device) if want_t else None
+    check(_lib.lib().pdgn_split_bf16x3(n, k, ptr(w), w.stride(0), ptr(P), ldp, ctypes.c_longlong(n * ldp), ptr(PT), ldt,
+                                       ctypes.c_longlong(k * ldt if want_t else 0), stream_of(w)), "pdgn_split_bf16x3")
+    return Planes(P, PT, (n, k))
+
+
+def gemm_nt_planes(a, P, n, k, bias=None, addend=None, want_stats=False):
+    """a (m, k) @ W^T for a weight given as its planes P [3][n][ld] (Planes.p of W, or Planes.t for the product with W itself:
+    then n, k are W^T's); everything else as gemm_nt."""
+    m = a.shape[0]
+    if GEMM_LOG is not None:
+        GEMM_LOG.append(("nt", m, n, k))
+    ap = _pad_cols(a)
+    L = _lib.lib()
+    out = torch.empty((m, n), dtype=F32, device=a.device)
+    part = None
+    if want_stats:
+        L.pdgn_gemm_nt_stat_rows.restype = ctypes.c_longlong
+        part = torch.empty((L.pdgn_gemm_nt_stat_rows(ctypes.c_longlong(m), n, k), 3 * n), dtype=F32, device=a.device)
+    b = bias.detach().contiguous() if bias is not None else None
+    if addend is not None:
+        addend = _pad_cols(addend)
+    check(L.pdgn_gemm_nt_ps(ctypes.c_longlong(m), n, k, ptr(ap), ap.stride(0), ptr(P), P.shape[2], ctypes.c_longlong(P.shape[1] * P.shape[2]),
+                            ptr(b), ptr(addend), addend.stride(0) if addend is not None else 0, ptr(out), n, ptr(part), None, 0, 1, 0,
+                            None, 0, stream_of(a)), "pdgn_gemm_nt_ps")
+    return (out, part) if want_stats else out
+
+
 def gemm_nt(a, w, bias=None, addend=None, want_stats=False, w_transposed=False):
     """a (m, k) @ w (n, k)^T (+ bias) (+ addend) on pdgn_gemm_nt -- or, with w_transposed, a (m, k) @ w (k, n) on
     pdgn_gemm_nn (the input gradient dy @ W straight from the layer's weight).  Channel counts that are not multiples
@@ -366,11 +412,23 @@ class LinearCL(Function):
     (models/PDGNet_v2.py:559-625, 835-862, 886-1014) as row-matrix products on the hand-written MFMA kernels (see above)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, addend, want_stats=False):
+    def forward(ctx, x, weight, bias, addend, want_stats=False, planes=None):
         ctx.save_for_backward(x, weight)
         ctx.set_materialize_grads(False)          # no zero-filled "gradient" of the statistics partials (a launch per call)
         ctx.has_bias = bias is not None
         ctx.has_addend = addend is not None
+        ctx.planes_t = None
+        if (planes is not None and x.is_cuda and x.shape[0] >= _PLANES_MIN_ROWS and planes.shape == tuple(weight.shape)
+                and x.shape[1] == weight.shape[1] and x.shape[1] % 4 == 0):
+            # the weight arrives pre-split (Planes): no split work for it in the kernel, forward and input gradient
+            n, k = weight.shape
+            ctx.thin = False
+            ctx.planes_t = planes.t
+            if want_stats:
+                y, part = gemm_nt_planes(x, planes.p, n, k, bias, addend, want_stats=True)
+                ctx.mark_non_differentiable(part)
+                return y, part
+            return gemm_nt_planes(x, planes.p, n, k, bias, addend)
         ctx.thin = bool(x.is_cuda and x.shape[0] >= _OWN_MIN_ROWS and addend is None and weight.is_contiguous()
                         and _thin_ok(x, weight.shape[0], weight.shape[1]))
         if ctx.thin:
@@ -396,7 +454,7 @@ class LinearCL(Function):
     def backward(ctx, dy, *unused):
         x, weight = ctx.saved_tensors
         if dy is None:
-            return None, None, None, None, None
+            return None, None, None, None, None, None
         zero_db = ctx.has_bias and ctx.needs_input_grad[2] and has_zero_colsum(dy)
         dy = dy.contiguous()
         own = dy.is_cuda and dy.shape[0] >= _OWN_MIN_ROWS
@@ -413,14 +471,17 @@ class LinearCL(Function):
                     db = _zeros((n,), dy.device)
             elif want_db:
                 db = _zeros((n,), dy.device) if zero_db else dy.sum(dim=0)
-            return dx, dw, db, None, None
+            return dx, dw, db, None, None, None
         if ctx.needs_input_grad[0]:
-            dx = gemm_nt(dy, weight, w_transposed=True) if own else dy.matmul(weight)
+            if ctx.planes_t is not None and own and dy.shape[1] % 4 == 0:
+                dx = gemm_nt_planes(dy, ctx.planes_t, weight.shape[1], weight.shape[0])      # dX = dY W = dY (W^T)^T
+            else:
+                dx = gemm_nt(dy, weight, w_transposed=True) if own else dy.matmul(weight)
         if ctx.needs_input_grad[1]:
             dw = gemm_tn(dy, x) if own else dy.t().matmul(x)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = _zeros((dy.shape[1],), dy.device) if zero_db else dy.sum(dim=0)
-        return dx, dw, db, (dy if ctx.has_addend and ctx.needs_input_grad[3] else None), None
+        return dx, dw, db, (dy if ctx.has_addend and ctx.needs_input_grad[3] else None), None, None
 
 
 def gemm_nt_ex(a, w, ldw, n, bias=None, row_bias=None, rows_per_group=1, act=0, gate=None, w_transposed=False):
@@ -488,17 +549,20 @@ class HeadMLP(Function):
         return dx, dg, dW0, drb.sum(dim=0), dW2, db2, dW3, db3, None
 
 
-def linear_cl(x2d, weight, bias=None, addend=None, want_stats=None):
+_PLANES_MIN_ROWS = 4096        # below this a contraction is a few tiles: the split kernel's launches would cost more than they save
+
+
+def linear_cl(x2d, weight, bias=None, addend=None, want_stats=None, planes=None):
     """Dense layer on point-major rows (see LinearCL); `addend` (M, C_out) is added in the GEMM's epilogue.
     want_stats (True / False, not None): returns the PAIR (y, partials) -- with True the BatchNorm partial sums of y from
     the GEMM's epilogue, for bn_act / bilateral_weighting's `partials` argument (no statistics pass over y); None when
     this call did not produce them."""
     if want_stats is None:
-        return LinearCL.apply(x2d, weight, bias, addend)
+        return LinearCL.apply(x2d, weight, bias, addend, False, planes)
     if want_stats:
-        y, part = LinearCL.apply(x2d, weight, bias, addend, True)
+        y, part = LinearCL.apply(x2d, weight, bias, addend, True, planes)
         return y, ((part, stat_block_rows(x2d, weight, addend)) if part is not None else None)
-    return LinearCL.apply(x2d, weight, bias, addend), None
+    return LinearCL.apply(x2d, weight, bias, addend, False, planes), None
 
 
 def stat_block_rows(x2d, weight, addend=None):

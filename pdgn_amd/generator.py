@@ -189,6 +189,22 @@ class PointGenerator(nn.Module):
         _deconv.flush_bn_counters()
         return tuple(s["clouds"])
 
+    def _deconvs(self):
+        blocks = (self.bilateral1, self.bilateral2, self.bilateral3, self.bilateral4)
+        return [(b.upsample_cov[0] if b.level == 1 else b.upsample_cov) for b in blocks]
+
+    def preassemble(self, ready=None):
+        """The four blocks' re-associated GEMM operands for the current parameters, built ONCE for all the forward passes
+        that follow until the parameters change (the trainer's two generator passes of an iteration).  Block l > 1 sees
+        cat([xs broadcast, x_ec]): its first Fout(l-1) input channels are constant per sample (forward_cl's `const`)."""
+        decs = self._deconvs()
+        for lvl, dec in enumerate(decs):
+            dec.preassemble(0 if lvl == 0 else dec.Fin - decs[lvl - 1].Fout, ready)
+
+    def drop_preassembled(self):
+        for dec in self._deconvs():
+            dec.drop_preassembled()
+
 
 class PointDiscriminator(nn.Module):
     """PointDiscriminator_1..4 :882-1023.  (B,3,N) -> (B,1)."""

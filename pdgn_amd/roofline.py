@@ -91,13 +91,23 @@ def _nt_entry(label, M, N, K, device):
     w = torch.randn(N, K, device=device)
     c = torch.empty(M, N, device=device)
     L = _lib.lib()
+    x3 = gemm_mode() == "x3"
+    # as the step launches it: on the bf16 matrix cores the block's assembled weight arrives pre-split (fused.split_planes, once
+    # per iteration) and the kernel is the PW instance of gemm_x3_kernel (pdgn_gemm_nt_ps)
+    from .fused import split_planes
+    planes = split_planes(w, False) if x3 else None
 
     def run():
-        check(L.pdgn_gemm_nt(ctypes.c_longlong(M), N, K, ptr(a), K, ptr(w), K, None, None, 0, ptr(c), N, None, stream_of(a)),
-              "pdgn_gemm_nt")
+        if planes is not None:
+            P = planes.p
+            check(L.pdgn_gemm_nt_ps(ctypes.c_longlong(M), N, K, ptr(a), K, ptr(P), P.shape[2], ctypes.c_longlong(P.shape[1] * P.shape[2]),
+                                    None, None, 0, ptr(c), N, None, None, 0, 1, 0, None, 0, stream_of(a)), "pdgn_gemm_nt_ps")
+        else:
+            check(L.pdgn_gemm_nt(ctypes.c_longlong(M), N, K, ptr(a), K, ptr(w), K, None, None, 0, ptr(c), N, None, stream_of(a)),
+                  "pdgn_gemm_nt")
     us = _time_us(run)
-    x3 = gemm_mode() == "x3"
-    e = _entry("%s (%s, M=%d N=%d K=%d)" % ("gemm_x3_kernel" if x3 else "gemm_nt_kernel", label, M, N, K), "mfma", 2.0 * M * N * K, us,
+    e = _entry("%s (%s, M=%d N=%d K=%d)" % ("gemm_x3_kernel<PW> = pdgn_gemm_nt_ps, weight pre-split" if planes is not None else
+                                            ("gemm_x3_kernel" if x3 else "gemm_nt_kernel"), label, M, N, K), "mfma", 2.0 * M * N * K, us,
                x3=x3, shape=[M, N, K])
     e["algorithmic_bytes_per_launch"] = 4.0 * (M * N + M * K + N * K)
     return e

@@ -494,6 +494,16 @@ class PDGNTrainer:
                 self._comm(level)
                 self._stepD[level].step()
 
+        # The generator's re-associated GEMM operands (and, on the bf16 matrix cores, their pre-split planes) depend on the
+        # parameters only: built once for both passes, on the kNN stream (idle at this point), behind an event the first
+        # consumer waits for; with grad enabled -- pass #2's backward reaches the conv weights through them.
+        pre_ok = hasattr(self.G, "preassemble")
+        if pre_ok:
+            pre_ev = torch.cuda.Event()
+            pl.knn.wait_stream(main)
+            with torch.cuda.stream(pl.knn), torch.enable_grad():
+                self.G.preassemble(pre_ev)
+                pre_ev.record(pl.knn)
         if split:
             st["d_half"] = [None] * 4
             for level, side in enumerate(self._side):
@@ -559,6 +569,8 @@ class PDGNTrainer:
         st["out"]["g_loss"], st["out"]["similar_loss"] = lossG.detach(), similar.detach()
         self._comm(4)
         self._stepG.step()
+        if pre_ok:
+            self.G.drop_preassembled()
         release_zero_arena()                                # no later backward may receive slices of this step's arena
         mark("all-reduce + Adam G")
         return st["out"]
