@@ -349,10 +349,9 @@ class PointDeconv(nn.Module):
             pb = split_planes(Wb.detach(), want_t)
         return WcatC, WcatV, Wb, pv, pb
 
-    def preassemble(self, Fc, ready=None):
-        """Build the block's GEMM operands now (under the caller's grad mode and stream); `ready`: an event recorded after
-        them when they were issued on another stream than the consumer's."""
-        self._pre = (self._weights_key(Fc), torch.is_grad_enabled(), self._assemble_now(Fc), ready)
+    def preassemble(self, Fc):
+        """Build the block's GEMM operands now (under the caller's grad mode, on the current stream)."""
+        self._pre = (self._weights_key(Fc), torch.is_grad_enabled(), self._assemble_now(Fc))
 
     def drop_preassembled(self):
         self._pre = None
@@ -360,12 +359,6 @@ class PointDeconv(nn.Module):
     def assembled(self, Fc):
         pre = getattr(self, "_pre", None)
         if pre is not None and pre[0] == self._weights_key(Fc) and (pre[1] or not torch.is_grad_enabled()):
-            if pre[3] is not None:
-                torch.cuda.current_stream(pre[2][1].device).wait_event(pre[3])
-                for t in pre[2]:
-                    for u in ((t.p, t.t) if isinstance(t, Planes) else (t,)):
-                        if u is not None:
-                            u.record_stream(torch.cuda.current_stream(u.device))
             return pre[2]
         return self._assemble_now(Fc)
 

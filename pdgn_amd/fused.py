@@ -250,6 +250,9 @@ def _pad_cols(t, mult=4):
 GEMM_LOG = None            # tools/gemm_shapes.py sets this to a list: every (kind, m, n, k) launched is appended
 
 
+_PLANES = os.environ.get("PDGN_PLANES", "1") == "1"            # A/B switch: 0 = every operand split in the kernel's loaders
+
+
 class Planes:
     """A weight's three bf16 parts (x = h + m + l, csrc/split.hip) as planes [3][rows][ld] (int16 storage), written ONCE per
     weight instead of by every workgroup's loader of the contraction kernel; `t` = the same for the transpose (the input-gradient
@@ -263,7 +266,7 @@ class Planes:
 def split_planes(w, want_t):
     """pdgn_split_bf16x3 of a (rows, cols) fp32 matrix; None where the pre-split path does not apply (fp32-instruction mode,
     sizes that would need padding)."""
-    if not (w.is_cuda and w.dim() == 2 and _lib.gemm_mode() == "x3") or w.shape[0] % 4 or w.shape[1] % 4 or w.stride(1) != 1:
+    if not (_PLANES and w.is_cuda and w.dim() == 2 and _lib.gemm_mode() == "x3") or w.shape[0] % 4 or w.shape[1] % 4 or w.stride(1) != 1:
         return None
     n, k = w.shape
     ldp, ldt = (k + 7) // 8 * 8, (n + 7) // 8 * 8

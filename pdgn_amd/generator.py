@@ -193,13 +193,13 @@ class PointGenerator(nn.Module):
         blocks = (self.bilateral1, self.bilateral2, self.bilateral3, self.bilateral4)
         return [(b.upsample_cov[0] if b.level == 1 else b.upsample_cov) for b in blocks]
 
-    def preassemble(self, ready=None):
+    def preassemble(self):
         """The four blocks' re-associated GEMM operands for the current parameters, built ONCE for all the forward passes
         that follow until the parameters change (the trainer's two generator passes of an iteration).  Block l > 1 sees
         cat([xs broadcast, x_ec]): its first Fout(l-1) input channels are constant per sample (forward_cl's `const`)."""
         decs = self._deconvs()
         for lvl, dec in enumerate(decs):
-            dec.preassemble(0 if lvl == 0 else dec.Fin - decs[lvl - 1].Fout, ready)
+            dec.preassemble(0 if lvl == 0 else dec.Fin - decs[lvl - 1].Fout)
 
     def drop_preassembled(self):
         for dec in self._deconvs():

@@ -495,15 +495,13 @@ class PDGNTrainer:
                 self._stepD[level].step()
 
         # The generator's re-associated GEMM operands (and, on the bf16 matrix cores, their pre-split planes) depend on the
-        # parameters only: built once for both passes, on the kNN stream (idle at this point), behind an event the first
-        # consumer waits for; with grad enabled -- pass #2's backward reaches the conv weights through them.
-        pre_ok = hasattr(self.G, "preassemble")
+        # parameters only: built once for both passes, with grad enabled -- pass #2's backward reaches the conv weights through
+        # them.  (On the issuing stream: built on the idle kNN stream behind an event the iteration faulted at B = 35 --
+        # the adjoint of the assembly then runs on that stream too -- and the four launches are ~60 us.)
+        pre_ok = hasattr(self.G, "preassemble") and os.environ.get("PDGN_PREASM", "1") == "1"
         if pre_ok:
-            pre_ev = torch.cuda.Event()
-            pl.knn.wait_stream(main)
-            with torch.cuda.stream(pl.knn), torch.enable_grad():
-                self.G.preassemble(pre_ev)
-                pre_ev.record(pl.knn)
+            with torch.enable_grad():
+                self.G.preassemble()
         if split:
             st["d_half"] = [None] * 4
             for level, side in enumerate(self._side):

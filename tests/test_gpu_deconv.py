@@ -885,6 +885,81 @@ def test_gemm_nn_input_gradient_form(M, N, K, cfg, monkeypatch, gemm):
     np.testing.assert_allclose(tot[:N], c64.sum(0).cpu().numpy(), rtol=1e-4, atol=1e-4 * float(c64.abs().sum(0).max()))
 
 
+@pytest.mark.parametrize("M,N,K", [(9000, 512, 1280), (4100, 132, 260), (20000, 64, 64), (2500, 12832, 128), (3000, 256, 8)])
+def test_gemm_presplit_second_operand(M, N, K):
+    """pdgn_split_bf16x3 + pdgn_gemm_nt_ps (csrc/split.hip, the PW instances of gemm_x3_kernel): the weight split ONCE into its three
+    bf16 parts instead of by every workgroup's loader.  The planes hold exactly the loader's parts, so (i) they reassemble to the
+    fp32 weight up to 2^-24, (ii) the product equals the unsplit entry point's -- bit for bit when no stream-K tail (float
+    atomics) is involved, to rounding otherwise -- with bias, addend and statistics partials, (iii) the planes of the TRANSPOSE
+    give the input gradient dX = dY W of pdgn_gemm_nn, and all of it against fp64."""
+    import ctypes
+    from pdgn_amd import _lib, fused
+    from pdgn_amd._lib import ptr, stream_of
+    L = _lib.lib()
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    a = torch.randn(M, K, device="cuda", generator=g)
+    w = torch.randn(N, K, device="cuda", generator=g) * 0.3
+    bias = torch.randn(N, device="cuda", generator=g)
+    add = torch.randn(M, N, device="cuda", generator=g)
+    pl = fused.split_planes(w, True)
+    assert pl is not None and pl.p.shape[:2] == (3, N) and pl.t.shape[:2] == (3, K)
+    parts = (pl.p[:, :, :K].to(torch.int32) << 16).view(torch.float32)          # bf16 bit patterns -> fp32
+    assert (parts.double().sum(0) - w.double()).abs().max().item() <= 2.0 ** -23 * w.abs().max().item()
+    assert torch.equal(pl.t[:, :, :N], pl.p[:, :, :K].transpose(1, 2))
+    ref = a.double() @ w.double().t() + bias.double() + add.double()
+    mag = a.double().abs() @ w.double().abs().t() + 1.0
+    c0, c1 = torch.empty(M, N, device="cuda"), torch.empty(M, N, device="cuda")
+    L.pdgn_gemm_nt_stat_rows.restype = ctypes.c_longlong
+    nrows = L.pdgn_gemm_nt_stat_rows(ctypes.c_longlong(M), N, K)
+    p0, p1 = torch.zeros(nrows, 3 * N, device="cuda"), torch.zeros(nrows, 3 * N, device="cuda")
+    wp = ctypes.c_longlong(N * pl.p.shape[2])
+    assert L.pdgn_gemm_nt(ctypes.c_longlong(M), N, K, ptr(a), K, ptr(w), K, ptr(bias), ptr(add), N, ptr(c0), N, ptr(p0), stream_of(a)) == 0
+    assert L.pdgn_gemm_nt_ps(ctypes.c_longlong(M), N, K, ptr(a), K, ptr(pl.p), pl.p.shape[2], wp, ptr(bias), ptr(add), N, ptr(c1), N, ptr(p1),
+                             None, 0, 1, 0, None, 0, stream_of(a)) == 0
+    assert torch.equal(c0, c1) and torch.equal(p0, p1)          # launches with statistics have no stream-K tail: identical
+    assert ((c1.double() - ref).abs() / mag).max().item() < 1e-6
+    # plain launch (may carry a stream-K tail with float atomics): equal to rounding
+    assert L.pdgn_gemm_nt_ps(ctypes.c_longlong(M), N, K, ptr(a), K, ptr(pl.p), pl.p.shape[2], wp, None, None, 0, ptr(c1), N, None, None, 0, 1, 0,
+                             None, 0, stream_of(a)) == 0
+    assert ((c1.double() - a.double() @ w.double().t()).abs() / mag).max().item() < 1e-6
+    # input gradient through the planes of W^T against pdgn_gemm_nn
+    dy = torch.randn(M, N, device="cuda", generator=g)
+    d0, d1 = torch.empty(M, K, device="cuda"), torch.empty(M, K, device="cuda")
+    assert L.pdgn_gemm_nn(ctypes.c_longlong(M), K, N, ptr(dy), N, ptr(w), K, None, None, 0, ptr(d0), K, None, stream_of(a)) == 0
+    assert L.pdgn_gemm_nt_ps(ctypes.c_longlong(M), K, N, ptr(dy), N, ptr(pl.t), pl.t.shape[2], ctypes.c_longlong(K * pl.t.shape[2]), None, None, 0,
+                             ptr(d1), K, None, None, 0, 1, 0, None, 0, stream_of(a)) == 0
+    refd = dy.double() @ w.double()
+    magd = dy.double().abs() @ w.double().abs() + 1.0
+    assert ((d1.double() - refd).abs() / magd).max().item() < 1e-6 and ((d0 - d1).abs().double() / magd).max().item() < 1e-6
+    # refused where it cannot be what it says: the fp32-instruction mode
+    _lib.set_gemm_mode("fp32")
+    assert L.pdgn_gemm_nt_ps(ctypes.c_longlong(M), N, K, ptr(a), K, ptr(pl.p), pl.p.shape[2], wp, None, None, 0, ptr(c1), N, None, None, 0, 1, 0,
+                             None, 0, stream_of(a)) == -1
+    _lib.set_gemm_mode("x3")
+
+
+def test_linear_cl_with_planes_equals_without():
+    """LinearCL with a pre-split weight (forward + input gradient through the planes) against the same layer without: the
+    deconvolution blocks' two large contractions take this path (PointDeconv.assembled)."""
+    from pdgn_amd import fused
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.randn(6000, 256, device="cuda", generator=g)
+    w = (torch.randn(384, 256, device="cuda", generator=g) * 0.2).requires_grad_(True)
+    add = torch.randn(6000, 384, device="cuda", generator=g)
+    gout = torch.randn(6000, 384, device="cuda", generator=g)
+    res = []
+    for use in (False, True):
+        xi = x.clone().requires_grad_(True)
+        w.grad = None
+        planes = fused.split_planes(w.detach(), True) if use else None
+        assert (planes is not None) == use
+        y = fused.linear_cl(xi, w, None, add, planes=planes)
+        y.backward(gout)
+        res.append((y.detach().clone(), xi.grad.clone(), w.grad.clone()))
+    for a_, b_ in zip(*res):
+        assert (a_ - b_).abs().max().item() <= 1e-5 * max(1.0, b_.abs().max().item())
+
+
 @pytest.mark.parametrize("scale", [1.0, 1e15, 1e-15])
 @pytest.mark.parametrize("M,N,K", [(4099, 132, 100), (35840, 512, 5120), (35840, 256, 128), (8960, 3232, 32)])
 def test_gemm_x3_is_as_accurate_as_the_fp32_matrix_instructions(M, N, K, scale, monkeypatch):
