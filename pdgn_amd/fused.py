@@ -369,9 +369,14 @@ def gemm_tn(dy, x):
     return dwp if (dyp.shape[1] == n and xp.shape[1] == k) else dwp[:n, :k]
 
 
+_THIN16 = os.environ.get("PDGN_THIN16", "1") == "1"             # A/B switch: 0 = layers with 8 .. 16 input channels on the matrix cores
+
+
 def _thin_ok(x, n, k):
-    """The layer has <= 4 channels on one side and fits pdgn_thin_nt (csrc/thin.hip): no zero-padded copies."""
-    return (k <= 4 and n % 4 == 0 and n <= 1024) or (n <= 4 and k % 4 == 0 and k <= 1024)   # (the backward runs the wide side as n)
+    """The layer has <= 4 channels on one side -- or 8 .. 16 input channels (conv_all.0: half a k chunk of the matrix-core
+    kernel) -- and fits pdgn_thin_nt (csrc/thin.hip): a streaming pass, no zero-padded copies."""
+    return ((k <= 4 and n % 4 == 0 and n <= 1024) or (n <= 4 and k % 4 == 0 and k <= 1024)   # (the backward runs the wide side as n)
+            or (_THIN16 and 4 < k <= 16 and k % 4 == 0 and n % 4 == 0 and n <= 1024))
 
 
 def thin_nt(x, w, wrs, wcs, n, bias=None, want_stats=False):
@@ -383,7 +388,7 @@ def thin_nt(x, w, wrs, wcs, n, bias=None, want_stats=False):
     L = _lib.lib()
     out = torch.empty((m, n), dtype=F32, device=x.device)
     part = None
-    if want_stats and k <= 4:
+    if want_stats and k <= 16 and n > 4:
         L.pdgn_thin_stat_rows.restype = ctypes.c_longlong
         part = torch.empty((L.pdgn_thin_stat_rows(ctypes.c_longlong(m)), 3 * n), dtype=F32, device=x.device)
     b = bias.detach().contiguous() if bias is not None else None
@@ -401,7 +406,7 @@ def thin_tn(dy, x, want_db):
     dw = _zeros((n, k), dy.device)
     db = _zeros((n,), dy.device) if want_db else None
     L = _lib.lib()
-    if k <= 4:                      # A = x (thin), B = dy (wide): O[i = kk, j = n] -> dw[j, i]
+    if k <= 4 or (k <= 16 and n > 4):   # A = x (thin), B = dy (wide): O[i = kk, j = n] -> dw[j, i]
         check(L.pdgn_thin_tn(ctypes.c_longlong(m), k, n, ptr(x), x.stride(0), ptr(dy), dy.stride(0), ptr(dw), 1, k, ptr(None),
                              ptr(db), stream_of(dy)), "pdgn_thin_tn")
     else:                           # A = dy (thin), B = x (wide): O[i = n, j = kk] -> dw[i, j]
@@ -436,7 +441,7 @@ class LinearCL(Function):
                         and _thin_ok(x, weight.shape[0], weight.shape[1]))
         if ctx.thin:
             n, k = weight.shape
-            if want_stats and k <= 4:
+            if want_stats and k <= 16 and n > 4:
                 y, part = thin_nt(x, weight, k, 1, n, bias, want_stats=True)
                 ctx.mark_non_differentiable(part)
                 return y, part
@@ -465,10 +470,13 @@ class LinearCL(Function):
         if ctx.thin:
             n, k = weight.shape
             if ctx.needs_input_grad[0]:
-                dx = thin_nt(dy, weight, 1, k, k)                  # dX = dY W: W'[j, kk] = weight[kk, j]
+                if 4 < k <= 16 and n > 4:                          # 16 outputs from n inputs: the matrix-core kernel (30 us at stage 4)
+                    dx = gemm_nt(dy, weight, w_transposed=True)
+                else:
+                    dx = thin_nt(dy, weight, 1, k, k)              # dX = dY W: W'[j, kk] = weight[kk, j]
             want_db = ctx.has_bias and ctx.needs_input_grad[2]
             if ctx.needs_input_grad[1]:
-                xc = x if (x.stride(1) == 1 and (k <= 4 or (x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0))) else x.contiguous()
+                xc = x if (x.stride(1) == 1 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0) or (x.stride(1) == 1 and k <= 4) else x.contiguous()
                 dw, db = thin_tn(dy, xc, want_db and not zero_db)
                 if want_db and zero_db:
                     db = _zeros((n,), dy.device)

@@ -526,11 +526,11 @@ def test_linear_cl_autograd(M, N, K):
 
 
 @pytest.mark.parametrize("M,N,K", [(71680, 64, 3), (1024, 3, 64), (2049, 32, 3), (5001, 3, 32), (1500, 4, 64), (1030, 64, 4),
-                                   (1024, 128, 1), (3000, 2, 256), (1100, 48, 3)])
+                                   (1024, 128, 1), (3000, 2, 256), (1100, 48, 3), (35840, 64, 16), (3001, 32, 8), (5000, 128, 12)])
 @pytest.mark.parametrize("bias", [True, False])
 def test_thin_layers(M, N, K, bias):
-    """The xyz-in / xyz-out layers (<= 4 channels on one side) on pdgn_thin_nt / pdgn_thin_tn: forward, the BatchNorm partials
-    of the k <= 4 form, input / weight / bias gradients against fp64."""
+    """The xyz-in / xyz-out layers (<= 4 channels on one side) and the 8 .. 16-channel-in layers (conv_all.0) on pdgn_thin_nt /
+    pdgn_thin_tn: forward, the BatchNorm partials of the thin-input form, input / weight / bias gradients against fp64."""
     from pdgn_amd import fused
     g = torch.Generator(device="cuda").manual_seed(M + N + K)
     x = torch.randn(M, K, device="cuda", generator=g)
@@ -545,7 +545,8 @@ def test_thin_layers(M, N, K, bias):
         kinds = [e[0] for e in fused.GEMM_LOG]
     finally:
         fused.GEMM_LOG = None
-    assert kinds == ["thin", "thin", "thin_tn"], kinds                       # no padded launch on the MFMA kernels
+    # no padded launch on the MFMA kernels (8 .. 16 input channels -- conv_all.0 -- take their input gradient, 16 outputs, there)
+    assert kinds == (["thin", "nn", "thin_tn"] if 4 < K <= 16 and N > 4 else ["thin", "thin", "thin_tn"]), kinds
     ref = [t.double().clone().requires_grad_(True) for t in (x, w)] + ([b.double().clone().requires_grad_(True)] if bias else [None])
     yr = torch.nn.functional.linear(*ref)
     yr.backward(dy.double())
@@ -554,8 +555,9 @@ def test_thin_layers(M, N, K, bias):
                                   ("dw", leaves[1].grad, ref[1].grad, 2e-4 * sc)) + \
             ((("db", leaves[2].grad, ref[2].grad, 2e-4 * sc),) if bias else ()):
         np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), rtol=1e-4, atol=atol + 1e-6, err_msg=name)
-    if K <= 4:
-        assert part is not None and part.shape[1] == 3 * N
+    if K <= 16 and N > 4:
+        part, block = part                                                   # (partials, rows per block) as linear_cl hands them on
+        assert part is not None and part.shape[1] == 3 * N and block == 256
         tot = _raw_sums(part, M, 256, N)
         np.testing.assert_allclose(tot[:N], yr.detach().sum(0).cpu().numpy(), rtol=1e-4, atol=1e-3 * sc)
         np.testing.assert_allclose(tot[N:], (yr.detach() ** 2).sum(0).cpu().numpy(), rtol=1e-4, atol=1e-3 * sc)
@@ -1015,7 +1017,7 @@ def test_epilogue_statistics_large_mean(ratio):
         b = None if K > 4 else torch.full((N,), ratio, device="cuda")
         bn = nn.BatchNorm1d(N).cuda().train()
         y, part = fused.linear_cl(x, w, b, add, True)
-        assert part is not None and part.shape[1] == 3 * N
+        assert part is not None and part[0].shape[1] == 3 * N and part[1] in (64, 80, 128, 256)      # (partials, rows per block)
         out = fused.bn_act(y, bn, True, act="none", partials=part)
         y64 = y.double()
         want = (y64 - y64.mean(0)) / torch.sqrt(y64.var(0, unbiased=False) + bn.eps)
