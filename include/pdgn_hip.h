@@ -470,6 +470,7 @@ int pdgn_replay_launch(void *plan);
 int pdgn_replay_launch_range(void *plan, int lo, int hi); /* nodes [lo, hi) of the list */
 int pdgn_replay_position(void *plan, int chain, int nth); /* list position of a chain's n-th node, or -1 */
 int pdgn_replay_launch_timed(void *plan, double *us32); /* measurement: host microseconds per call kind / chain */
+int pdgn_replay_probe_chain(void *plan, int chain, int stride, float *ms_out, int *pos_out, int max_out); /* measurement: device-time progress of one chain */
 int pdgn_replay_destroy(void *plan);
 
 #ifdef __cplusplus

@@ -354,6 +354,63 @@ extern "C" int pdgn_replay_launch_timed(void *plan_, double *us32) {
     return 0;
 }
 
+// Measurement only: one replay with a timing event recorded after every `stride`-th node of chain `chain` (and one before its
+// first node); after a device synchronise, ms_out[i] = milliseconds from the first event to the i-th, pos_out[i] = how many
+// nodes of the chain had been issued by then.  Returns the number of probes written (<= max_out), or a negative / HIP code.
+extern "C" int pdgn_replay_probe_chain(void *plan_, int chain, int stride, float *ms_out, int *pos_out, int max_out) {
+    RPlan *plan = (RPlan *)plan_;
+    if (!plan || stride < 1 || !ms_out || !pos_out || max_out < 2 || chain < 0 || chain >= (int)plan->chain_stream.size())
+        return PDGN_ERR_INVALID;
+    std::vector<hipEvent_t> ev;
+    std::vector<int> at;
+    hipError_t e = hipSuccess;
+    hipStream_t cs = plan->chain_stream[chain];
+    auto probe = [&](int count) {
+        if ((int)ev.size() >= max_out) return;
+        hipEvent_t x;
+        if (hipEventCreate(&x) != hipSuccess) return;
+        (void)hipEventRecord(x, cs);
+        ev.push_back(x);
+        at.push_back(count);
+    };
+    int seen = 0;
+    bool first = true;
+    for (RNode &r : plan->nodes) {
+        hipStream_t s = plan->chain_stream[r.chain];
+        for (int w : r.waits)
+            if ((e = hipStreamWaitEvent(s, plan->events[w], 0)) != hipSuccess) return (int)e;
+        if (r.chain == chain && first) { probe(0); first = false; }
+        switch (r.kind) {
+        case NK_KERNEL:
+            e = hipModuleLaunchKernel(r.func, r.gx, r.gy, r.gz, r.bx, r.by, r.bz, r.shmem, s, r.params, r.extra);
+            break;
+        case NK_MEMSET:
+            if (r.elem == 4) e = hipMemsetD32Async((hipDeviceptr_t)r.dst, (int)r.value, r.width, s);
+            else if (r.elem == 2) e = hipMemsetD16Async((hipDeviceptr_t)r.dst, (unsigned short)r.value, r.width, s);
+            else e = hipMemsetAsync(r.dst, (int)r.value, r.width, s);
+            break;
+        case NK_MEMCPY:
+            e = hipMemcpyAsync(r.dst, r.src, r.bytes, hipMemcpyDeviceToDevice, s);
+            break;
+        default:
+            break;
+        }
+        if (e != hipSuccess) return (int)e;
+        if (r.record >= 0 && (e = hipEventRecord(plan->events[r.record], s)) != hipSuccess) return (int)e;
+        if (r.chain == chain && (++seen % stride) == 0) probe(seen);
+    }
+    probe(seen);
+    if ((e = hipDeviceSynchronize()) != hipSuccess) return (int)e;
+    for (size_t i = 0; i < ev.size(); ++i) {
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, ev[0], ev[i]);
+        ms_out[i] = ms;
+        pos_out[i] = at[i];
+    }
+    for (hipEvent_t x : ev) (void)hipEventDestroy(x);
+    return (int)ev.size();
+}
+
 extern "C" int pdgn_replay_destroy(void *plan_) {
     RPlan *plan = (RPlan *)plan_;
     if (!plan) return 0;

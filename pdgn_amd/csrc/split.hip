@@ -38,13 +38,11 @@ __global__ __launch_bounds__(256) void split_bf16x3_kernel(int rows, int cols, c
     for (int i = 0; i < 4; ++i) {
         const int r = r0 + ty + 8 * i, c = c0 + tx;
         unsigned short h = 0, m = 0, l = 0;
-        if (r < rows && c < cols) {
-            sp_split(src[(size_t)r * lds_ + c], h, m, l);
-            if (P) {
-                P[(size_t)r * ldp + c] = h;
-                P[pstride + (size_t)r * ldp + c] = m;
-                P[2 * pstride + (size_t)r * ldp + c] = l;
-            }
+        if (r < rows && c < cols) sp_split(src[(size_t)r * lds_ + c], h, m, l);
+        if (P && r < rows && c < ldp) {                                    // the pad columns [cols, ld) hold zeros: the contraction's
+            P[(size_t)r * ldp + c] = h;                                    // 16-B loads reach them on a K tail (0 x NaN would poison)
+            P[pstride + (size_t)r * ldp + c] = m;
+            P[2 * pstride + (size_t)r * ldp + c] = l;
         }
         tile[0][ty + 8 * i][tx] = h;
         tile[1][ty + 8 * i][tx] = m;
@@ -55,7 +53,7 @@ __global__ __launch_bounds__(256) void split_bf16x3_kernel(int rows, int cols, c
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int c = c0 + ty + 8 * i, r = r0 + tx;                        // output row = source column
-        if (c < cols && r < rows) {
+        if (c < cols && r < ldpt) {                                        // (rows .. ldpt: zeros, as above)
             PT[(size_t)c * ldpt + r] = tile[0][tx][ty + 8 * i];
             PT[ptstride + (size_t)c * ldpt + r] = tile[1][tx][ty + 8 * i];
             PT[2 * ptstride + (size_t)c * ldpt + r] = tile[2][tx][ty + 8 * i];
