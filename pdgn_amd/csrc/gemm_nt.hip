@@ -276,7 +276,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_nt_kernel(const NtArgs p
                 }
             }
             if (EPI && p.row_bias) {                               // a bias per group of rows: the heads' per-sample term
-                __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc((void *)p.row_bias, 0, 0x7ffffff0, 0x00020000);
+                // (bounded by the table's own extent -- groups x ld_rb floats, < 2^30 bytes by the entry point's check -- so that the
+                // masked lanes' NT_OOB offset is out of range: an unbounded descriptor made them read row_bias + 1 GiB)
+                __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc((void *)p.row_bias, 0, p.rb_bytes, 0x00020000);
 #pragma unroll
                 for (int a = 0; a < TM; ++a) {
                     const unsigned row = (unsigned)(m0 + mloc0 + 16 * a);
@@ -566,6 +568,7 @@ struct NtCfg {
         a.A = A; a.W = W; a.bias = bias; a.addend = addend; a.C = C; a.stat_part = stat_part;
         a.row_bias = epi.row_bias; a.ld_rb = epi.ld_rb; a.rows_per_group = epi.rows_per_group > 0 ? epi.rows_per_group : 1;
         a.rpg_magic = a.rows_per_group > 1 ? (unsigned)(0x100000000ULL / (unsigned)a.rows_per_group) + 1u : 0u;
+        a.rb_bytes = epi.row_bias ? (int)((((m + a.rows_per_group - 1) / a.rows_per_group - 1) * (long long)epi.ld_rb + n) * 4) : 0;
         a.act = epi.act; a.gate = epi.gate; a.ldgate = epi.ldgate; a.sk_split = 0;
         a.tiles_m = pl.tiles_m; a.tiles_n = pl.tiles_n; a.kchunks = pl.kchunks;
         a.dbg = 0;
@@ -662,7 +665,8 @@ int fp32_gemm_nt_ex(long long m, int n, int k, const float *A, int lda, const fl
                                pdgn_stream_t stream) {
     if (!nt_args_ok(m, n, k, lda, ldw, ldadd, ldc, addend, transposed_w != 0)) return PDGN_ERR_INVALID;
     if ((act != 0 && act != 2) || (row_bias && (ld_rb < n || ld_rb % 4 || rows_per_group < 1)) ||
-        (gate && (ldgate < n || ldgate % 4)) || m >= (1LL << 31) || (row_bias && m * rows_per_group >= (1LL << 32)))
+        (gate && (ldgate < n || ldgate % 4)) || m >= (1LL << 31) || (row_bias && m * rows_per_group >= (1LL << 32)) ||
+        (row_bias && rows_per_group >= 1 && ((m + rows_per_group - 1) / rows_per_group) * (long long)ld_rb * 4 >= (long long)NT_OOB))
         return PDGN_ERR_INVALID;
     NtEpi e;
     e.row_bias = row_bias; e.ld_rb = ld_rb; e.rows_per_group = rows_per_group; e.act = act; e.gate = gate; e.ldgate = ldgate;

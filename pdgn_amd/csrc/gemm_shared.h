@@ -50,6 +50,7 @@ struct NtArgs {
     const float *row_bias;            // + row_bias[(row / rows_per_group) * ld_rb + col]: a bias per GROUP of rows (per sample)
     int ld_rb, rows_per_group;
     unsigned rpg_magic;               // row / rows_per_group == umulhi(row, rpg_magic) (rows_per_group > 1)
+    int rb_bytes;                     // extent of the row_bias table in bytes (its buffer descriptor's range, < NT_OOB)
     int act;                          // 2: LeakyReLU(0.01) on the result
     const float *gate;                // result *= (gate[row, col] > 0 ? 1 : 0.01): the LeakyReLU derivative of a saved activation
     int ldgate;

@@ -11,6 +11,7 @@ from oracle import pdgnet_ref
 from torch_standins import EdgeGatherSumTorch
 
 pytestmark = pytest.mark.gpu
+ROOT_DIR = __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__)))
 
 
 def dev(a):
@@ -1201,6 +1202,27 @@ def test_point_max_forward_backward(B, N, C):
             arg[b, c] = int(torch.nonzero(x[b, :, c] == ref[b, c])[0])
     want = torch.zeros_like(x).scatter_(1, arg.unsqueeze(1), g.unsqueeze(1))
     assert torch.equal(xg.grad.cpu(), want)
+
+
+@pytest.mark.parametrize("gemm", ["x3", "fp32"])
+def test_gemm_nt_ex_masked_lanes_in_a_fresh_process(gemm):
+    """The extended epilogue on a tile that is wider than the problem (N = 36 < 64) in a FRESH process: lanes past the last column
+    are masked with an out-of-range offset, which only works against a BOUNDED buffer descriptor -- the per-group bias table's
+    descriptor was unbounded (round 3), the masked lanes read row_bias + 1 GiB, and that faulted exactly when nothing was mapped
+    there, i.e. in a small fresh process and never in the long test run (found in round 4 by running this case alone)."""
+    import subprocess
+    import sys
+    code = (
+        "import ctypes, sys, torch; sys.path.insert(0, %r); from pdgn_amd import _lib; from pdgn_amd._lib import ptr, stream_of;"
+        "_lib.set_gemm_mode(%r); L = _lib.lib(); M, N, K = 1000, 36, 20;"
+        "A = torch.randn(M, K, device='cuda'); W = torch.randn(N, K, device='cuda'); rb = torch.randn(M, N + 4, device='cuda')[:, :N];"
+        "C = torch.empty(M, N, device='cuda');"
+        "rc = L.pdgn_gemm_nt_ex(ctypes.c_longlong(M), N, K, ptr(A), K, ptr(W), K, None, None, 0, ptr(C), N, None, ptr(rb), rb.stride(0), 1, 2,"
+        " None, 0, 0, stream_of(A)); torch.cuda.synchronize();"
+        "ref = torch.nn.functional.leaky_relu(A.double() @ W.double().t() + rb.double());"
+        "assert rc == 0 and (C.double() - ref).abs().max().item() < 1e-4; print('ok')" % (ROOT_DIR, gemm))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-1500:]
 
 
 @pytest.mark.parametrize("cfg", [None, 0, 1, 2, 3])
