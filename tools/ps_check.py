@@ -1,6 +1,6 @@
 """Pre-split second operand (pdgn_split_bf16x3 + pdgn_gemm_nt_ps) against the unsplit entry points: bit-identity and time."""
 import ctypes, os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 from pdgn_amd import _lib
