@@ -308,10 +308,14 @@ __global__ void cl_finalize_blocks_join_kernel(long long R, int C, int slices, f
     }
 }
 
-static inline int fb_slices(long long nparts) {                  // 0: the one-launch form
+static inline int fb_slices(int c, long long nparts) {           // 0: the one-launch form
+    // enough workgroups (c / 4 channel groups x slices ~ 512) with at least two passes of the 64 part lanes each; measured
+    // (tools/finalize_bench.py): 5600 x 64 channels 35 -> 14 us with 32 slices; 2800 x 512 is no faster sliced 32 ways (25 -> 30)
     if (nparts < 512) return 0;
-    long long s = nparts / 128;
-    return (int)(s > 32 ? 32 : s);
+    long long s = 512 / (c / 4 > 0 ? c / 4 : 1);
+    s = s > 32 ? 32 : s;
+    while (s > 1 && nparts / s < 128) s >>= 1;
+    return s < 2 ? 0 : (int)s;
 }
 
 // eval mode: scale/shift from the running statistics
@@ -578,7 +582,7 @@ extern "C" int pdgn_bn_stats_from_gemm_partials(long long rows, int c, long long
     if (rows < 1 || c < 4 || c % 4 || nparts < 1 || nparts > 0x7fffffffLL || block_rows < 1 ||
         nparts * (long long)block_rows < rows)
         return PDGN_ERR_INVALID;
-    const int slices = scratch ? fb_slices(nparts) : 0;
+    const int slices = scratch ? fb_slices(c, nparts) : 0;
     if (slices > 1) {
         const int per = (int)((nparts + slices - 1) / slices);
         hipLaunchKernelGGL(cl_finalize_blocks_slice_kernel, dim3(cdiv(c, FIN_CH), slices), dim3(FIN_CH * FIN_PL), 0,
@@ -595,7 +599,7 @@ extern "C" int pdgn_bn_stats_from_gemm_partials(long long rows, int c, long long
 // fp64 scratch elements pdgn_bn_stats_from_gemm_partials wants for `nparts` partial rows of c channels (0: none needed).
 extern "C" long long pdgn_bn_blocks_scratch_doubles(int c, long long nparts) {
     if (c < 1 || nparts < 1) return PDGN_ERR_INVALID;
-    return (long long)fb_slices(nparts) * 2 * c;
+    return (long long)fb_slices(c, nparts) * 2 * c;
 }
 
 extern "C" int pdgn_bn_eval_stats(int c, float eps, const float *gamma, const float *beta, const float *pre_bias,

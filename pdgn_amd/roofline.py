@@ -106,9 +106,9 @@ def _nt_entry(label, M, N, K, device):
             check(L.pdgn_gemm_nt(ctypes.c_longlong(M), N, K, ptr(a), K, ptr(w), K, None, None, 0, ptr(c), N, None, stream_of(a)),
                   "pdgn_gemm_nt")
     us = _time_us(run)
-    e = _entry("%s (%s, M=%d N=%d K=%d)" % ("gemm_x3_kernel<PW> = pdgn_gemm_nt_ps, weight pre-split" if planes is not None else
-                                            ("gemm_x3_kernel" if x3 else "gemm_nt_kernel"), label, M, N, K), "mfma", 2.0 * M * N * K, us,
-               x3=x3, shape=[M, N, K])
+    e = _entry("%s (%s, M=%d N=%d K=%d%s)" % ("gemm_x3_kernel" if x3 else "gemm_nt_kernel", label, M, N, K,
+                                               "; PW instance = pdgn_gemm_nt_ps, the weight pre-split once per iteration" if planes is not None else ""),
+               "mfma", 2.0 * M * N * K, us, x3=x3, shape=[M, N, K])
     e["algorithmic_bytes_per_launch"] = 4.0 * (M * N + M * K + N * K)
     return e
 
