@@ -250,6 +250,17 @@ int pdgn_softmax_slots_permute_backward(long long m, int k, int c, const float *
  * pdgn_bn_stats_from_gemm_partials turns into BatchNorm statistics.  Without
  * stat_part and with ldc == n the launch may add partial tiles with fp32 atomics (C is zero-filled by the
  * call itself where needed). */
+/* Products with a per-sample operand of R <= 64 rows (csrc/skinny.hip; the 35-row layers of models/PDGNet_v2.py:704-707,
+ * 825-828, 835-862 and the constant-channel contribution of DESIGN.md section 2), fp32 matrix instructions, one pass over the large
+ * operand:
+ *   pdgn_skinny_nt: C (R x N) = A (R x K) B (N x K)^T (+ bias[N])      K % 4 == 0, rows of A / B 16-byte aligned
+ *   pdgn_skinny_nn: C (R x N) += A (R x K) B (K x N)                    C ZERO-FILLED by the caller (K slices add with fp32 atomics); N % 4 == 0
+ *   pdgn_skinny_tn: C (N x K) = A (R x N)^T B (R x K)
+ * every operand with its own row pitch (a column slice of a wider weight needs no copy). */
+int pdgn_skinny_nt(int R, int N, int K, const float *A, int lda, const float *B, int ldb, const float *bias, float *C, int ldc,
+                   pdgn_stream_t stream);
+int pdgn_skinny_nn(int R, int N, int K, const float *A, int lda, const float *B, int ldb, float *C, int ldc, pdgn_stream_t stream);
+int pdgn_skinny_tn(int R, int N, int K, const float *A, int lda, const float *B, int ldb, float *C, int ldc, pdgn_stream_t stream);
 /* A weight matrix split ONCE into the three bf16 parts the contractions multiply (x = h + m + l, csrc/split.hip) instead of by
  * every workgroup's loader: src (rows x cols fp32, pitch ld_src) -> planes (3 x [rows][ld_planes] bf16, plane_stride elements
  * apart; may be NULL) and / or planes_t, the same for the TRANSPOSE (3 x [cols][ld_planes_t]; may be NULL).

@@ -14,10 +14,6 @@
 #define THIN_ROWS 256             // rows per workgroup of thin_k (one partial-statistics row each)
 #define THIN_TN_ROWS 512          // rows per workgroup of thin_tn
 
-// KQ = 1: k <= 4 (scalar loads of X, any alignment); KQ = 4: k <= 16, k % 4 == 0, rows of X 16-byte aligned (float4 loads) --
-// conv_all.0 of the bilateral blocks (Conv2d(16, 64, 1), models/PDGNet_v2.py:611): 358400 x 64 x 16 at stage 4 is 115 MB of
-// traffic and 0.7 GFLOP, a streaming pass, where the matrix-core kernel (half a k chunk per tile) took 110 us.
-template <int KQ>
 __global__ __launch_bounds__(THIN_THREADS) void thin_k_kernel(long long m, int n, int k, const float *__restrict__ X, int ldx,
                                                               const float *__restrict__ W, int wrs, int wcs,
                                                               const float *__restrict__ bias, float *__restrict__ Y, int ldy,
@@ -26,53 +22,41 @@ __global__ __launch_bounds__(THIN_THREADS) void thin_k_kernel(long long m, int n
     const int n4 = n >> 2;                       // threads per row
     const int rpp = THIN_THREADS / n4;           // rows per pass
     const int c4 = threadIdx.x % n4, ro = threadIdx.x / n4;
-    constexpr int KM = 4 * KQ;
-    float w[4][KM], b[4];
+    float w[4][4], b[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         b[j] = bias ? bias[c4 * 4 + j] : 0.f;
 #pragma unroll
-        for (int kk = 0; kk < KM; ++kk) w[j][kk] = kk < k ? W[(size_t)(c4 * 4 + j) * wrs + (size_t)kk * wcs] : 0.f;
+        for (int kk = 0; kk < 4; ++kk) w[j][kk] = kk < k ? W[(size_t)(c4 * 4 + j) * wrs + (size_t)kk * wcs] : 0.f;
     }
-    auto load_x = [&](const float *xr, float *x) {
-        if (KQ == 1) {
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) x[kk] = kk < k ? xr[kk] : 0.f;
-        } else {
-#pragma unroll
-            for (int q = 0; q < KQ; ++q) {
-                const float4 v = 4 * q < k ? *reinterpret_cast<const float4 *>(xr + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
-                x[4 * q] = v.x; x[4 * q + 1] = v.y; x[4 * q + 2] = v.z; x[4 * q + 3] = v.w;
-            }
-        }
-    };
     float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f}, pv[4] = {0.f, 0.f, 0.f, 0.f};
     const long long r0 = (long long)blockIdx.x * THIN_ROWS;
     const long long r1 = r0 + THIN_ROWS < m ? r0 + THIN_ROWS : m;
     if (part) {
         // the statistics are sums of (y - pv), pv = this block's first output row (recomputed by every thread with the
         // row loop's own expression): shifted sums do not cancel when |mean| >> std (see cl_finalize_blocks_kernel)
-        float x0[KM];
-        load_x(X + r0 * ldx, x0);
+        const float *xr = X + r0 * ldx;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             float acc = b[j];
 #pragma unroll
-            for (int kk = 0; kk < KM; ++kk) acc = __fmaf_rn(x0[kk], w[j][kk], acc);
+            for (int kk = 0; kk < 4; ++kk) acc = __fmaf_rn(kk < k ? xr[kk] : 0.f, w[j][kk], acc);
             pv[j] = acc;
         }
     }
     if (ro < rpp) {
         for (long long r = r0 + ro; r < r1; r += rpp) {
-            float x[KM];
-            load_x(X + r * ldx, x);
+            const float *xr = X + r * ldx;
+            float x[4];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) x[kk] = kk < k ? xr[kk] : 0.f;
             float4 o;
             float *ov = &o.x;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 float acc = b[j];
 #pragma unroll
-                for (int kk = 0; kk < KM; ++kk) acc = __fmaf_rn(x[kk], w[j][kk], acc);
+                for (int kk = 0; kk < 4; ++kk) acc = __fmaf_rn(x[kk], w[j][kk], acc);
                 ov[j] = acc;
                 if (gate) ov[j] = acc = acc * (gate[r * ldg + c4 * 4 + j] > 0.f ? 1.f : 0.01f);   // LeakyReLU derivative of a saved activation
                 const float d = acc - pv[j];
@@ -130,23 +114,18 @@ __global__ __launch_bounds__(THIN_THREADS) void thin_n_kernel(long long m, int n
 
 // O[i, j] += sum_r A[r, i] B[r, j] over this workgroup's rows (O zero-filled by the caller); optionally the column sums
 // of A (sum_a[ta]) and of B (sum_b[wb]) -- the bias gradient of the layer, whichever operand is its dY.
-// TQ = 1: ta <= 4; TQ = 4: ta <= 16, ta % 4 == 0, rows of A 16-byte aligned (the weight gradient of a 16-channel layer).
-template <int TQ>
 __global__ __launch_bounds__(THIN_THREADS) void thin_tn_kernel(long long m, int ta, int wb, const float *__restrict__ A, int lda,
                                                                const float *__restrict__ B, int ldb, float *__restrict__ O,
                                                                int osi, int osj, float *__restrict__ sum_a,
                                                                float *__restrict__ sum_b) {
-    constexpr int TM_ = 4 * TQ, NC = (TM_ + 1) * 4;       // components per thread: TM_ rows of 4 products + the column sums of B
-    __shared__ float red[THIN_THREADS * NC];
+    __shared__ float red[THIN_THREADS * 20];
     const int w4 = wb >> 2;
     const int rpp = THIN_THREADS / w4;
     const int c4 = threadIdx.x % w4, ro = threadIdx.x / w4;
-    float acc[TM_ + 1][4];                        // rows 0..TM_-1: A column i times B; last row: column sums of B
-    float sa[TM_];
+    float acc[5][4];                              // rows 0..3: A column i times B; row 4: column sums of B
+    float sa[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int i = 0; i < TM_; ++i) sa[i] = 0.f;
-#pragma unroll
-    for (int i = 0; i < TM_ + 1; ++i)
+    for (int i = 0; i < 5; ++i)
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc[i][e] = 0.f;
     const long long r0 = (long long)blockIdx.x * THIN_TN_ROWS;
@@ -156,40 +135,29 @@ __global__ __launch_bounds__(THIN_THREADS) void thin_tn_kernel(long long m, int 
             const float4 bv = *reinterpret_cast<const float4 *>(B + r * ldb + c4 * 4);
             const float *b = &bv.x;
             const float *ar = A + r * lda;
-            float av[TM_];
-            if (TQ == 1) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) av[i] = i < ta ? ar[i] : 0.f;
-            } else {
-#pragma unroll
-                for (int q = 0; q < TQ; ++q) {
-                    const float4 v = 4 * q < ta ? *reinterpret_cast<const float4 *>(ar + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
-                    av[4 * q] = v.x; av[4 * q + 1] = v.y; av[4 * q + 2] = v.z; av[4 * q + 3] = v.w;
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < TM_; ++i) {
-                const float a = av[i];
+            for (int i = 0; i < 4; ++i) {
+                const float a = i < ta ? ar[i] : 0.f;
                 sa[i] += a;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) acc[i][e] = __fmaf_rn(a, b[e], acc[i][e]);
             }
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc[TM_][e] += b[e];
+            for (int e = 0; e < 4; ++e) acc[4][e] += b[e];
         }
     }
 #pragma unroll
-    for (int i = 0; i < TM_ + 1; ++i)
+    for (int i = 0; i < 5; ++i)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) red[threadIdx.x * NC + i * 4 + e] = acc[i][e];
+        for (int e = 0; e < 4; ++e) red[threadIdx.x * 20 + i * 4 + e] = acc[i][e];
     __syncthreads();
-    // thread t < w4 * NC sums one (column group, component) over the row offsets
-    for (int t = threadIdx.x; t < w4 * NC; t += THIN_THREADS) {
-        const int cc = t / NC, comp = t % NC, i = comp >> 2, e = comp & 3;
+    // thread t < w4 * 20 sums one (column group, component) over the row offsets
+    for (int t = threadIdx.x; t < w4 * 20; t += THIN_THREADS) {
+        const int cc = t / 20, comp = t % 20, i = comp >> 2, e = comp & 3;
         float s = 0.f;
-        for (int q = 0; q < rpp; ++q) s += red[(q * w4 + cc) * NC + comp];
+        for (int q = 0; q < rpp; ++q) s += red[(q * w4 + cc) * 20 + comp];
         const int j = cc * 4 + e;
-        if (i < TM_) {
+        if (i < 4) {
             if (i < ta) atomicAdd(O + (size_t)i * osi + (size_t)j * osj, s);
         } else if (sum_b) {
             atomicAdd(sum_b + j, s);
@@ -200,12 +168,12 @@ __global__ __launch_bounds__(THIN_THREADS) void thin_tn_kernel(long long m, int 
         // every thread of column group 0 saw all of its rows' A values: reduce those over the row offsets
         if (c4 == 0) {
 #pragma unroll
-            for (int i = 0; i < TM_; ++i) red[ro * TM_ + i] = sa[i];
+            for (int i = 0; i < 4; ++i) red[ro * 4 + i] = sa[i];
         }
         __syncthreads();
         if (threadIdx.x < ta) {
             float s = 0.f;
-            for (int q = 0; q < rpp; ++q) s += red[q * TM_ + threadIdx.x];
+            for (int q = 0; q < rpp; ++q) s += red[q * 4 + threadIdx.x];
             atomicAdd(sum_a + threadIdx.x, s);
         }
     }
@@ -225,13 +193,7 @@ extern "C" int pdgn_thin_nt_ex(long long m, int n, int k, const float *X, int ld
     hipStream_t s = (hipStream_t)stream;
     if (k <= 4 && n % 4 == 0 && n <= 4 * THIN_THREADS) {
         if (!thin_aligned(Y, ldy) || (gate && ldgate < n)) return -2;
-        hipLaunchKernelGGL(thin_k_kernel<1>, dim3(cdiv(m, THIN_ROWS)), dim3(THIN_THREADS), 0, s, m, n, k, X, ldx, W, wrs, wcs, bias,
-                           Y, ldy, stat_part, gate, ldgate);
-        return pdgn_launch_status();
-    }
-    if (k <= 16 && k % 4 == 0 && n % 4 == 0 && n <= 4 * THIN_THREADS) {           // 8 .. 16 input channels: float4 loads of X
-        if (!thin_aligned(Y, ldy) || !thin_aligned(X, ldx) || (gate && ldgate < n)) return -2;
-        hipLaunchKernelGGL(thin_k_kernel<4>, dim3(cdiv(m, THIN_ROWS)), dim3(THIN_THREADS), 0, s, m, n, k, X, ldx, W, wrs, wcs, bias,
+        hipLaunchKernelGGL(thin_k_kernel, dim3(cdiv(m, THIN_ROWS)), dim3(THIN_THREADS), 0, s, m, n, k, X, ldx, W, wrs, wcs, bias,
                            Y, ldy, stat_part, gate, ldgate);
         return pdgn_launch_status();
     }
@@ -252,15 +214,9 @@ extern "C" int pdgn_thin_nt(long long m, int n, int k, const float *X, int ldx, 
 
 extern "C" int pdgn_thin_tn(long long m, int ta, int wb, const float *A, int lda, const float *B, int ldb, float *O, int osi,
                             int osj, float *sum_a, float *sum_b, pdgn_stream_t stream) {
-    if (m <= 0 || ta <= 0 || ta > 16 || wb <= 0 || wb % 4 || wb > 4 * THIN_THREADS || !A || !B || !O) return -1;
+    if (m <= 0 || ta <= 0 || ta > 4 || wb <= 0 || wb % 4 || wb > 4 * THIN_THREADS || !A || !B || !O) return -1;
     if (!thin_aligned(B, ldb)) return -2;
-    if (ta <= 4) {
-        hipLaunchKernelGGL(thin_tn_kernel<1>, dim3(cdiv(m, THIN_TN_ROWS)), dim3(THIN_THREADS), 0, (hipStream_t)stream, m, ta, wb, A,
-                           lda, B, ldb, O, osi, osj, sum_a, sum_b);
-    } else {
-        if (ta % 4 || !thin_aligned(A, lda)) return -2;
-        hipLaunchKernelGGL(thin_tn_kernel<4>, dim3(cdiv(m, THIN_TN_ROWS)), dim3(THIN_THREADS), 0, (hipStream_t)stream, m, ta, wb, A,
-                           lda, B, ldb, O, osi, osj, sum_a, sum_b);
-    }
+    hipLaunchKernelGGL(thin_tn_kernel, dim3(cdiv(m, THIN_TN_ROWS)), dim3(THIN_THREADS), 0, (hipStream_t)stream, m, ta, wb, A, lda, B,
+                       ldb, O, osi, osj, sum_a, sum_b);
     return pdgn_launch_status();
 }

@@ -28,7 +28,7 @@ from ._fn import Function
 from . import _lib
 from . import streams as _streams
 from ._lib import check, ptr, require, stream_of
-from .fused import (Planes, split_planes, _zeros, bilateral_weighting, bn_act,  # noqa: F401
+from .fused import (Planes, split_planes, skinny_linear, _zeros, bilateral_weighting, bn_act,  # noqa: F401
                     small_sequential, bn_act_maxpool, bn_softmax_slots_permute, flush_bn_counters,  # noqa: F401
                     has_zero_colsum, linear_cl, softmax_slots_permute)
 
@@ -399,7 +399,7 @@ class PointDeconv(nn.Module):
         o_a = o_ci + 4 * Fi
         o_ca = o_a + k * 2 * Fo
         o_p = o_ca + 2 * Fo
-        Yc = F.linear(const, WcatC) if const is not None else None     # (B,Mw): per-sample contribution
+        Yc = skinny_linear(const, WcatC) if const is not None else None     # (B,Mw): per-sample contribution (csrc/skinny.hip)
         fuse_stats = training and xt.is_cuda and Fi % 4 == 0 and Fv % 4 == 0
         # the full tap layout (rows of Wcat): what the per-sample biases of the constant channels are built from
         specs_full = [(T, P, 4 * Fi, o_i, o_ci), (k, 1, 2 * Fo, o_a, o_ca)]

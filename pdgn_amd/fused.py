@@ -369,14 +369,9 @@ def gemm_tn(dy, x):
     return dwp if (dyp.shape[1] == n and xp.shape[1] == k) else dwp[:n, :k]
 
 
-_THIN16 = os.environ.get("PDGN_THIN16", "1") == "1"             # A/B switch: 0 = layers with 8 .. 16 input channels on the matrix cores
-
-
 def _thin_ok(x, n, k):
-    """The layer has <= 4 channels on one side -- or 8 .. 16 input channels (conv_all.0: half a k chunk of the matrix-core
-    kernel) -- and fits pdgn_thin_nt (csrc/thin.hip): a streaming pass, no zero-padded copies."""
-    return ((k <= 4 and n % 4 == 0 and n <= 1024) or (n <= 4 and k % 4 == 0 and k <= 1024)   # (the backward runs the wide side as n)
-            or (_THIN16 and 4 < k <= 16 and k % 4 == 0 and n % 4 == 0 and n <= 1024))
+    """The layer has <= 4 channels on one side and fits pdgn_thin_nt (csrc/thin.hip): no zero-padded copies."""
+    return (k <= 4 and n % 4 == 0 and n <= 1024) or (n <= 4 and k % 4 == 0 and k <= 1024)   # (the backward runs the wide side as n)
 
 
 def thin_nt(x, w, wrs, wcs, n, bias=None, want_stats=False):
@@ -388,7 +383,7 @@ def thin_nt(x, w, wrs, wcs, n, bias=None, want_stats=False):
     L = _lib.lib()
     out = torch.empty((m, n), dtype=F32, device=x.device)
     part = None
-    if want_stats and k <= 16 and n > 4:
+    if want_stats and k <= 4:
         L.pdgn_thin_stat_rows.restype = ctypes.c_longlong
         part = torch.empty((L.pdgn_thin_stat_rows(ctypes.c_longlong(m)), 3 * n), dtype=F32, device=x.device)
     b = bias.detach().contiguous() if bias is not None else None
@@ -406,7 +401,7 @@ def thin_tn(dy, x, want_db):
     dw = _zeros((n, k), dy.device)
     db = _zeros((n,), dy.device) if want_db else None
     L = _lib.lib()
-    if k <= 4 or (k <= 16 and n > 4):   # A = x (thin), B = dy (wide): O[i = kk, j = n] -> dw[j, i]
+    if k <= 4:                      # A = x (thin), B = dy (wide): O[i = kk, j = n] -> dw[j, i]
         check(L.pdgn_thin_tn(ctypes.c_longlong(m), k, n, ptr(x), x.stride(0), ptr(dy), dy.stride(0), ptr(dw), 1, k, ptr(None),
                              ptr(db), stream_of(dy)), "pdgn_thin_tn")
     else:                           # A = dy (thin), B = x (wide): O[i = n, j = kk] -> dw[i, j]
@@ -441,7 +436,7 @@ class LinearCL(Function):
                         and _thin_ok(x, weight.shape[0], weight.shape[1]))
         if ctx.thin:
             n, k = weight.shape
-            if want_stats and k <= 16 and n > 4:
+            if want_stats and k <= 4:
                 y, part = thin_nt(x, weight, k, 1, n, bias, want_stats=True)
                 ctx.mark_non_differentiable(part)
                 return y, part
@@ -470,13 +465,10 @@ class LinearCL(Function):
         if ctx.thin:
             n, k = weight.shape
             if ctx.needs_input_grad[0]:
-                if 4 < k <= 16 and n > 4:                          # 16 outputs from n inputs: the matrix-core kernel (30 us at stage 4)
-                    dx = gemm_nt(dy, weight, w_transposed=True)
-                else:
-                    dx = thin_nt(dy, weight, 1, k, k)              # dX = dY W: W'[j, kk] = weight[kk, j]
+                dx = thin_nt(dy, weight, 1, k, k)                  # dX = dY W: W'[j, kk] = weight[kk, j]
             want_db = ctx.has_bias and ctx.needs_input_grad[2]
             if ctx.needs_input_grad[1]:
-                xc = x if (x.stride(1) == 1 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0) or (x.stride(1) == 1 and k <= 4) else x.contiguous()
+                xc = x if (x.stride(1) == 1 and (k <= 4 or (x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0))) else x.contiguous()
                 dw, db = thin_tn(dy, xc, want_db and not zero_db)
                 if want_db and zero_db:
                     db = _zeros((n,), dy.device)
@@ -493,6 +485,83 @@ class LinearCL(Function):
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = _zeros((dy.shape[1],), dy.device) if zero_db else dy.sum(dim=0)
         return dx, dw, db, (dy if ctx.has_addend and ctx.needs_input_grad[3] else None), None, None
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Products with a per-sample operand (R <= 64 rows: the batch) on csrc/skinny.hip instead of the BLAS library's skinny solutions.
+_SKINNY = os.environ.get("PDGN_SKINNY", "1") == "1"           # A/B switch: 0 = torch's matmul for the 35-row layers
+
+
+def _sk_ok(a, *others):
+    return (_SKINNY and a.is_cuda and a.dim() == 2 and a.shape[0] <= 64 and a.dtype == F32 and
+            all(t.is_cuda and t.dtype == F32 and t.stride(-1) == 1 and t.stride(0) % 4 == 0 and t.data_ptr() % 16 == 0 for t in (a,) + others))
+
+
+def skinny_nt(a, w, bias=None):
+    """a (R, K) @ w (N, K)^T (+ bias) for R <= 64; w may be a column slice of a wider weight (its row pitch is used)."""
+    R, K = a.shape
+    N = w.shape[0]
+    if not (_sk_ok(a, w) and K % 4 == 0):
+        return torch.addmm(bias, a, w.t()) if bias is not None else a.matmul(w.t())
+    out = torch.empty((R, N), dtype=F32, device=a.device)
+    b = bias.detach().contiguous() if bias is not None else None
+    check(_lib.lib().pdgn_skinny_nt(R, N, K, ptr(a), a.stride(0), ptr(w), w.stride(0), ptr(b), ptr(out), N, stream_of(a)), "pdgn_skinny_nt")
+    return out
+
+
+def skinny_nn(a, w):
+    """a (R, K) @ w (K, N) for R <= 64 (the input gradient of a per-sample layer: a = dy, w = the layer's (out, in) weight)."""
+    R, K = a.shape
+    N = w.shape[1]
+    # long reductions only (dconst = dYc WcatC: K = 6432, 12832: 14-22 us against the library's 25-34); for the short ones
+    # (dx of the small layers, K <= 1024) the library's 32 x 32 tiles take 4-7 us and this kernel's join + atomics 11-12
+    if not (_sk_ok(a, w) and N % 4 == 0 and K >= 2048):
+        return a.matmul(w)
+    out = torch.zeros((R, N), dtype=F32, device=a.device)          # K slices add into it
+    check(_lib.lib().pdgn_skinny_nn(R, N, K, ptr(a), a.stride(0), ptr(w), w.stride(0), ptr(out), N, stream_of(a)), "pdgn_skinny_nn")
+    return out
+
+
+def skinny_tn(a, b, out=None):
+    """a (R, N)^T @ b (R, K) -> (N, K) for R <= 64 (the weight gradient of a per-sample layer); `out`: a (N, K) view to write into
+    (its row pitch is used: a column slice of a wider gradient)."""
+    R, N = a.shape
+    K = b.shape[1]
+    if not (_SKINNY and a.is_cuda and R <= 64 and a.stride(1) == 1 and b.stride(1) == 1 and (out is None or out.stride(1) == 1)):
+        res = a.t().matmul(b)
+        if out is None:
+            return res
+        out.copy_(res)
+        return out
+    if out is None:
+        out = torch.empty((N, K), dtype=F32, device=a.device)
+    check(_lib.lib().pdgn_skinny_tn(R, N, K, ptr(a), a.stride(0), ptr(b), b.stride(0), ptr(out), out.stride(0), stream_of(a)), "pdgn_skinny_tn")
+    return out
+
+
+class SkinnyLinear(Function):
+    """y = x W^T for x (R <= 64, K): forward, input and weight gradient on csrc/skinny.hip (one pass over W each)."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        x, weight = x.contiguous(), weight.contiguous()
+        ctx.save_for_backward(x, weight)
+        return skinny_nt(x, weight)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = skinny_nn(dy, weight) if ctx.needs_input_grad[0] else None
+        dw = skinny_tn(dy, x) if ctx.needs_input_grad[1] else None
+        return dx, dw
+
+
+def skinny_linear(x, weight):
+    """F.linear(x, weight) for a per-sample x (R <= 64 rows) on the GPU; torch's own elsewhere (host tests)."""
+    if x.is_cuda and x.dim() == 2 and x.shape[0] <= 64 and x.shape[1] % 4 == 0 and weight.shape[0] % 4 == 0 and _SKINNY:
+        return SkinnyLinear.apply(x, weight)
+    return torch.nn.functional.linear(x, weight)
 
 
 def gemm_nt_ex(a, w, ldw, n, bias=None, row_bias=None, rows_per_group=1, act=0, gate=None, w_transposed=False):
@@ -524,7 +593,7 @@ class HeadMLP(Function):
         rows, Fo = x.shape
         nc, M = g.shape[1], rows // B
         W0, W2, W3 = W0.contiguous(), W2.contiguous(), W3.contiguous()
-        rb = torch.addmm(b0, g, W0[:, :nc].t())                                   # (B, 256): 35 rows, the library's skinny GEMM
+        rb = skinny_nt(g.contiguous(), W0[:, :nc], b0)                            # (B, 256): the per-sample row (csrc/skinny.hip)
         w0x = W0[:, nc:]                                                          # (256, Fo) view, row pitch nc + Fo
         y1 = gemm_nt_ex(x, w0x, W0.stride(0), W0.shape[0], row_bias=rb, rows_per_group=M, act=2)
         y2 = gemm_nt_ex(y1, W2, W2.stride(0), W2.shape[0], bias=b2, act=2)
@@ -554,9 +623,9 @@ class HeadMLP(Function):
         dx = gemm_nt_ex(dpre1, w0x, W0.stride(0), x.shape[1], w_transposed=True) if ctx.needs_input_grad[0] else None
         drb = dpre1.view(B, M, -1).sum(dim=1)                                      # (B, 256): the per-sample term's gradient
         dW0 = torch.empty_like(W0)
-        dW0[:, :nc].copy_(drb.t().mm(g))
+        skinny_tn(drb, g.contiguous(), out=dW0[:, :nc])                           # drb^T g straight into its column slice
         dW0[:, nc:].copy_(gemm_tn(dpre1, x))
-        dg = drb.mm(W0[:, :nc]) if ctx.needs_input_grad[1] else None
+        dg = skinny_nn(drb, W0[:, :nc]) if ctx.needs_input_grad[1] else None
         return dx, dg, dW0, drb.sum(dim=0), dW2, db2, dW3, db3, None
 
 
@@ -795,7 +864,7 @@ class SmallLinearBNAct(Function):
         check(_lib.lib().pdgn_small_mlp_backward(R, K, N, act, bn_mode, ptr(x), ptr(dy), ptr(pre), ptr(stat), ptr(g), ptr(b),
                                                  ptr(dpre), ptr(dg), ptr(db), ptr(dbias), ptr(dW), stream_of(dy)),
               "pdgn_small_mlp_backward")
-        dx = dpre.matmul(weight) if ctx.needs_input_grad[0] else None
+        dx = skinny_nn(dpre, weight) if ctx.needs_input_grad[0] else None
         return dx, dW, dbias, dg, db, None, None, None, None, None, None
 
 

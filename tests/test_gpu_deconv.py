@@ -527,11 +527,11 @@ def test_linear_cl_autograd(M, N, K):
 
 
 @pytest.mark.parametrize("M,N,K", [(71680, 64, 3), (1024, 3, 64), (2049, 32, 3), (5001, 3, 32), (1500, 4, 64), (1030, 64, 4),
-                                   (1024, 128, 1), (3000, 2, 256), (1100, 48, 3), (35840, 64, 16), (3001, 32, 8), (5000, 128, 12)])
+                                   (1024, 128, 1), (3000, 2, 256), (1100, 48, 3)])
 @pytest.mark.parametrize("bias", [True, False])
 def test_thin_layers(M, N, K, bias):
-    """The xyz-in / xyz-out layers (<= 4 channels on one side) and the 8 .. 16-channel-in layers (conv_all.0) on pdgn_thin_nt /
-    pdgn_thin_tn: forward, the BatchNorm partials of the thin-input form, input / weight / bias gradients against fp64."""
+    """The xyz-in / xyz-out layers (<= 4 channels on one side) on pdgn_thin_nt / pdgn_thin_tn: forward, the BatchNorm partials
+    of the k <= 4 form, input / weight / bias gradients against fp64."""
     from pdgn_amd import fused
     g = torch.Generator(device="cuda").manual_seed(M + N + K)
     x = torch.randn(M, K, device="cuda", generator=g)
@@ -546,8 +546,7 @@ def test_thin_layers(M, N, K, bias):
         kinds = [e[0] for e in fused.GEMM_LOG]
     finally:
         fused.GEMM_LOG = None
-    # no padded launch on the MFMA kernels (8 .. 16 input channels -- conv_all.0 -- take their input gradient, 16 outputs, there)
-    assert kinds == (["thin", "nn", "thin_tn"] if 4 < K <= 16 and N > 4 else ["thin", "thin", "thin_tn"]), kinds
+    assert kinds == ["thin", "thin", "thin_tn"], kinds                       # no padded launch on the MFMA kernels
     ref = [t.double().clone().requires_grad_(True) for t in (x, w)] + ([b.double().clone().requires_grad_(True)] if bias else [None])
     yr = torch.nn.functional.linear(*ref)
     yr.backward(dy.double())
@@ -556,7 +555,7 @@ def test_thin_layers(M, N, K, bias):
                                   ("dw", leaves[1].grad, ref[1].grad, 2e-4 * sc)) + \
             ((("db", leaves[2].grad, ref[2].grad, 2e-4 * sc),) if bias else ()):
         np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), rtol=1e-4, atol=atol + 1e-6, err_msg=name)
-    if K <= 16 and N > 4:
+    if K <= 4:
         part, block = part                                                   # (partials, rows per block) as linear_cl hands them on
         assert part is not None and part.shape[1] == 3 * N and block == 256
         tot = _raw_sums(part, M, 256, N)
@@ -939,6 +938,43 @@ def test_gemm_presplit_second_operand(M, N, K):
     assert L.pdgn_gemm_nt_ps(ctypes.c_longlong(M), N, K, ptr(a), K, ptr(pl.p), pl.p.shape[2], wp, None, None, 0, ptr(c1), N, None, None, 0, 1, 0,
                              None, 0, stream_of(a)) == -1
     _lib.set_gemm_mode("x3")
+
+
+@pytest.mark.parametrize("R,N,K,pitch", [(35, 12832, 128, 0), (35, 256, 512, 768), (35, 3232, 32, 0), (64, 1600, 64, 0), (1, 20, 8, 0),
+                                         (35, 4096, 128, 0), (48, 132, 1024, 0), (35, 8192, 32, 0)])
+def test_skinny_products(R, N, K, pitch):
+    """csrc/skinny.hip: the three products of a per-sample operand (R <= 64 rows) with a large matrix -- y = x W^T (+ b), dx = dy W,
+    dW = dy^T x -- against fp64, with a column slice of a wider weight (row pitch) as the large operand and as the gradient's target."""
+    from pdgn_amd import fused
+    g = torch.Generator(device="cuda").manual_seed(R + N + K)
+    ld = pitch or K
+    Wfull = torch.randn(N, ld, device="cuda", generator=g) * 0.2
+    W = Wfull[:, :K]
+    x = torch.randn(R, K, device="cuda", generator=g)
+    b = torch.randn(N, device="cuda", generator=g)
+    dy = torch.randn(R, N, device="cuda", generator=g)
+    y = fused.skinny_nt(x, W, b)
+    ref = x.double() @ W.double().t() + b.double()
+    assert (y.double() - ref).abs().max().item() < 1e-5 * (x.abs().double() @ W.abs().double().t()).max().item()
+    if N % 4 == 0:
+        import ctypes
+        from pdgn_amd import _lib
+        from pdgn_amd._lib import ptr, stream_of
+        dx = torch.zeros(R, K, device="cuda")                            # straight through the C ABI: every reduction length
+        assert _lib.lib().pdgn_skinny_nn(R, K, N, ptr(dy), N, ptr(W), W.stride(0), ptr(dx), K, stream_of(dy)) == 0
+        refx = dy.double() @ W.double()
+        assert (dx.double() - refx).abs().max().item() < 2e-5 * (dy.abs().double() @ W.abs().double()).max().item()
+    target = torch.full((N, ld), float("nan"), device="cuda")
+    dW = fused.skinny_tn(dy, x, out=target[:, :K])
+    refw = dy.double().t() @ x.double()
+    assert (dW.double() - refw).abs().max().item() < 1e-5 * (dy.abs().double().t() @ x.abs().double()).max().item()
+    assert pitch == 0 or torch.isnan(target[:, K:]).all()              # nothing written outside the slice
+    # and through autograd (PointDeconv's constant-channel contribution)
+    if N % 4 == 0:
+        xi, Wi = x.clone().requires_grad_(True), W.clone().contiguous().requires_grad_(True)
+        fused.skinny_linear(xi, Wi).backward(dy)
+        assert (xi.grad.double() - refx).abs().max().item() < 2e-5 * max(1.0, refx.abs().max().item())
+        assert (Wi.grad.double() - refw).abs().max().item() < 2e-5 * max(1.0, refw.abs().max().item())
 
 
 def test_linear_cl_with_planes_equals_without():
