@@ -902,23 +902,39 @@ __global__ void cl_max_finalize_kernel(int B, int C, const float *__restrict__ p
     yarg[e] = arg;
 }
 
-// per channel: dz[b] = dout[b]*act'(z at the argmax row); bsums = [sum_b dz | sum_b dz*xhat]; coef = [ca | cb]
-__global__ void cl_max_bwd_sums_kernel(int B, int N, int C, int act, int training, const float *__restrict__ x,
-                                       const float *__restrict__ dout, const int32_t *__restrict__ yarg,
-                                       const float *__restrict__ stats, float *__restrict__ dz,
-                                       float *__restrict__ bsums, float *__restrict__ coef) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    const float sc = stats[c], sh = stats[C + c], mu = stats[2 * C + c], is = stats[3 * C + c];
+// per channel: dz[b] = dout[b]*act'(z at the argmax row); bsums = [sum_b dz | sum_b dz*xhat]; coef = [ca | cb].
+// A block is 16 channels x 16 sample lanes (the B gathers of a channel are dependent-latency loads: one thread per channel
+// walking all B of them took 105 us at B = 35, C = 1024).
+__global__ __launch_bounds__(256) void cl_max_bwd_sums_kernel(int B, int N, int C, int act, int training,
+                                                              const float *__restrict__ x, const float *__restrict__ dout,
+                                                              const int32_t *__restrict__ yarg, const float *__restrict__ stats,
+                                                              float *__restrict__ dz, float *__restrict__ bsums,
+                                                              float *__restrict__ coef, float *__restrict__ zero, int nzero) {
+    __shared__ double p1[16][17], p2[16][17];
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < nzero; e += gridDim.x * 256) zero[e] = 0.f;   // side job (cf_gram's output)
+    const int cl = threadIdx.x & 15, bl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
     double s1 = 0, s2 = 0;
-    for (int b = 0; b < B; ++b) {
-        const int n = yarg[b * C + c];
-        const float v = x[((size_t)b * N + n) * C + c];
-        const float g = dout[b * C + c] * act_grad(__fmaf_rn(v, sc, sh), act);
-        dz[b * C + c] = g;
-        s1 += g;
-        s2 += (double)g * (double)((v - mu) * is);
+    float sc = 0.f, mu = 0.f, is = 0.f;
+    if (c < C) {
+        sc = stats[c];
+        mu = stats[2 * C + c];
+        is = stats[3 * C + c];
+        const float sh = stats[C + c];
+        for (int b = bl; b < B; b += 16) {
+            const int n = yarg[b * C + c];
+            const float v = x[((size_t)b * N + n) * C + c];
+            const float g = dout[b * C + c] * act_grad(__fmaf_rn(v, sc, sh), act);
+            dz[b * C + c] = g;
+            s1 += g;
+            s2 += (double)g * (double)((v - mu) * is);
+        }
     }
+    p1[bl][cl] = s1;
+    p2[bl][cl] = s2;
+    __syncthreads();
+    if (bl || c >= C) return;
+    for (int q = 1; q < 16; ++q) { s1 += p1[q][cl]; s2 += p2[q][cl]; }
     bsums[c] = (float)s1;
     bsums[C + c] = (float)s2;
     float ca = 0.f, cb = 0.f;
@@ -992,11 +1008,204 @@ extern "C" int pdgn_bn_act_maxpool_backward(int b, int n, int c, int act, int tr
     if (b < 1 || n < 1 || c < 4 || c % 4 || act < 0 || act > 2 || b > 65535) return PDGN_ERR_INVALID;
     hipStream_t s = (hipStream_t)stream;
     float *dz = scratch, *coef = scratch + (size_t)b * c;
-    hipLaunchKernelGGL(cl_max_bwd_sums_kernel, dim3(cdiv(c, 64)), dim3(64), 0, s, b, n, c, act, training, x, dout, yarg,
-                       stats, dz, bsums, coef);
+    hipLaunchKernelGGL(cl_max_bwd_sums_kernel, dim3(cdiv(c, 16)), dim3(256), 0, s, b, n, c, act, training, x, dout, yarg,
+                       stats, dz, bsums, coef, nullptr, 0);
     int cgb, gx;
     mp_geometry(c, &cgb, &gx);
     hipLaunchKernelGGL(cl_max_bwd_apply_kernel, dim3(gx, MP_SPLIT, b), dim3(BN_THREADS), 0, s, n, c, cgb, x, stats, coef, dz,
                        yarg, dx);
+    return pdgn_launch_status();
+}
+
+// ---------------------------------------------------------------------------- dense -> BN -> act -> max-pool: input gradient
+// The last per-point layer of a discriminator with FROZEN parameters (the generator's update, models/PDGNet_v2.py:330-352:
+// only the gradient with respect to the points is wanted).  With x = h W^T (rows x C; the Conv1d bias cancels in the batch
+// statistics) and the adjoint of the pooled BatchNorm above,  dx = S - 1 ca^T - x diag(cb)  (S non-zero at the B*C arg-max
+// entries only), the input gradient needs neither the dense (rows x C) dx nor a (rows x C x K) product:
+//     dh = dx W = S W  -  1 (ca^T W)  -  h (W^T diag(cb) W)
+// = one (rows x K x K) product with a bias epilogue (G = -W^T diag(cb) W and v = -ca^T W are K x K and K) plus a scatter of
+// B*C scaled rows of W.  At D4 (rows = 71680, C = 1024, K = 256): 9.4 GFLOP and 73 MB written instead of 37.6 GFLOP behind a
+// 293 MB dx that is written and read back.
+#define CF_TILE 32         // G tile edge of a block (each thread 4 x 4 outputs)
+#define CF_CSPLIT 8        // channel groups across blocks (x 4 wavefronts a block = 32 channel slices)
+#define CF_RSPLIT 32       // blocks per sample in the scatter
+
+// Gneg (K x K) -= sum_c cb[c] W[c,i] W[c,j]; vneg (K) -= sum_c ca[c] W[c,j]; both ZERO on entry (cl_max_bwd_sums_kernel's side
+// job).  grid (ceil(K/32), ceil(K/32), CF_CSPLIT) x 4 wavefronts, each a 4 x 4 block of G per thread over its slice of the
+// channels: float4 loads of W's rows, sixteen rows in flight (branch-free: a load behind a branch is a round trip of its own),
+// joined in LDS and added to G with CF_CSPLIT-way atomics.
+__global__ __launch_bounds__(256) void cf_gram_kernel(int C, int K, const float *__restrict__ W, int ldw,
+                                                      const float *__restrict__ coef, float *__restrict__ Gneg,
+                                                      float *__restrict__ vneg) {
+    __shared__ float part[3][64][20];
+    const int t = threadIdx.x, o = t & 63, sl = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int i = blockIdx.y * CF_TILE + (o >> 3) * 4, j = blockIdx.x * CF_TILE + (o & 7) * 4;
+    const bool ok = i < K && j < K, do_v = blockIdx.y == 0 && (o >> 3) == 0 && j < K;
+    const int ii = min(i, K - 4), jj = min(j, K - 4);
+    const int nsl = CF_CSPLIT * 4, per = (C + nsl - 1) / nsl;
+    const int c0 = (blockIdx.z * 4 + sl) * per, c1 = min(C, c0 + per);
+    const float *cb = coef + C;
+    float acc[4][4] = {}, av[4] = {};
+    for (int c = c0; c < c1; c += 8) {
+        float4 wi[8], wj[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const float *w = W + (size_t)min(c + u, c1 - 1) * ldw;
+            wi[u] = *reinterpret_cast<const float4 *>(w + ii);
+            wj[u] = *reinterpret_cast<const float4 *>(w + jj);
+        }
+        __builtin_amdgcn_sched_barrier(0);                           // all sixteen loads issued before the first use
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int cc = min(c + u, c1 - 1);
+            const float live = c + u < c1 ? 1.f : 0.f;
+            const float s = cb[cc] * live, a = coef[cc] * live;
+            const float x[4] = {wi[u].x * s, wi[u].y * s, wi[u].z * s, wi[u].w * s};
+            const float y[4] = {wj[u].x, wj[u].y, wj[u].z, wj[u].w};
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[p][q] = __fmaf_rn(x[p], y[q], acc[p][q]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) av[q] = __fmaf_rn(a, y[q], av[q]);
+        }
+    }
+    if (sl) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) part[sl - 1][o][p * 4 + q] = acc[p][q];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) part[sl - 1][o][16 + q] = av[q];
+    }
+    __syncthreads();
+    if (sl) return;
+#pragma unroll
+    for (int w = 0; w < 3; ++w) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[p][q] += part[w][o][p * 4 + q];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) av[q] += part[w][o][16 + q];
+    }
+    if (ok)
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) atomicAdd(&Gneg[(size_t)(i + p) * K + j + q], -acc[p][q]);
+    if (do_v)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) atomicAdd(&vneg[j + q], -av[q]);
+}
+
+// dh[b*N + n, :] += sum over the channels c whose arg-max row in sample b is n of scale[c] dz[b,c] W[c, :]   (K <= 256).
+// The arg-max rows of a sample are few and repeat (the critical points of a PointNet): each block compacts them in LDS
+// (mark, scan), and wavefront w of block s takes every (CF_RSPLIT*4)-th distinct row: it finds the row's channels by ballot
+// over the LDS copy of the sample's arg-max list, sums their W rows in registers (one float4 per lane = a whole row) and adds
+// the result to dh with one read-modify-write -- no atomics, every access a full row.
+// LDS: uint16 table[N] | uint16 rows[min(N,C)] | uint16 args[C] | (pad) | uint32 cnt[256] | float cf[C]
+__global__ __launch_bounds__(256) void cf_scatter_kernel(int N, int C, int K, const float *__restrict__ W, int ldw,
+                                                         const float *__restrict__ stats, const float *__restrict__ dz,
+                                                         const int32_t *__restrict__ yarg, float *__restrict__ dh) {
+    extern __shared__ unsigned char cf_lds[];
+    __shared__ unsigned int ndist;
+    const int maxd = min(N, C);
+    unsigned short *table = reinterpret_cast<unsigned short *>(cf_lds);
+    unsigned short *rows = table + N;
+    unsigned short *args = rows + maxd;
+    unsigned int *cnt = reinterpret_cast<unsigned int *>(cf_lds + (((size_t)(N + maxd + C) * 2 + 15) & ~(size_t)15));
+    float *cf = reinterpret_cast<float *>(cnt + 256);
+    const int t = threadIdx.x, b = blockIdx.y;
+    const int32_t *arg = yarg + (size_t)b * C;
+    for (int n = t; n < N; n += 256) table[n] = 0;
+    __syncthreads();
+    for (int c = t; c < C; c += 256) {
+        const int a = arg[c];
+        table[a] = 1;
+        args[c] = (unsigned short)a;
+        cf[c] = stats[c] * dz[(size_t)b * C + c];
+    }
+    __syncthreads();
+    const int per = (N + 255) / 256, lo = t * per, hi = min(N, lo + per);   // thread t owns the entries [lo, hi)
+    unsigned int mine = 0;
+    for (int n = lo; n < hi; ++n) mine += table[n];
+    cnt[t] = mine;
+    __syncthreads();
+    if (t < 64) {                                                    // exclusive scan of 256 counts by one wavefront
+        const unsigned int v0 = cnt[4 * t], v1 = cnt[4 * t + 1], v2 = cnt[4 * t + 2], v3 = cnt[4 * t + 3];
+        const unsigned int s = v0 + v1 + v2 + v3;
+        unsigned int incl = s;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned int up = __shfl_up(incl, d, 64);
+            if (t >= d) incl += up;
+        }
+        const unsigned int ex = incl - s;
+        cnt[4 * t] = ex;
+        cnt[4 * t + 1] = ex + v0;
+        cnt[4 * t + 2] = ex + v0 + v1;
+        cnt[4 * t + 3] = ex + v0 + v1 + v2;
+    }
+    __syncthreads();
+    unsigned int at = cnt[t];
+    for (int n = lo; n < hi; ++n)
+        if (table[n]) rows[at++] = (unsigned short)n;
+    if (t == 255) ndist = at;                                       // thread 255's running index ends at the total
+    __syncthreads();
+    const int nd = (int)ndist, lane = t & 63, wv = t >> 6;
+    const bool lok = lane * 4 < K;
+    const int col = min(lane * 4, K - 4);
+    for (int r = blockIdx.x * 4 + wv; r < nd; r += CF_RSPLIT * 4) {
+        const int n = rows[r];
+        float *dst = dh + ((size_t)b * N + n) * K + col;
+        const float4 cur = *reinterpret_cast<const float4 *>(dst);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int c0 = 0; c0 < C; c0 += 64) {
+            unsigned long long m = __ballot(c0 + lane < C && args[min(c0 + lane, C - 1)] == n);
+            while (m) {
+                const int c = c0 + __builtin_ctzll(m);
+                m &= m - 1;
+                const float g = cf[c];
+                const float4 w = *reinterpret_cast<const float4 *>(W + (size_t)c * ldw + col);
+                acc.x = __fmaf_rn(g, w.x, acc.x);
+                acc.y = __fmaf_rn(g, w.y, acc.y);
+                acc.z = __fmaf_rn(g, w.z, acc.z);
+                acc.w = __fmaf_rn(g, w.w, acc.w);
+            }
+        }
+        if (lok) *reinterpret_cast<float4 *>(dst) = make_float4(cur.x + acc.x, cur.y + acc.y, cur.z + acc.z, cur.w + acc.w);
+    }
+}
+
+static size_t cf_scatter_lds(int n, int c) {
+    const int maxd = n < c ? n : c;
+    return (((size_t)(n + maxd + c) * 2 + 15) & ~(size_t)15) + 256 * 4 + (size_t)c * 4;
+}
+
+extern "C" long long pdgn_dense_bn_maxpool_input_grad_scratch(int b, int c, int k) {
+    return (long long)b * c + 4LL * c + (long long)k * k + k;
+}
+
+// dh (b*n, k) contiguous.  x (b*n, c) = the dense layer's raw output, yarg / stats as saved by pdgn_bn_act_maxpool (training
+// statistics), dout (b, c), h (b*n, k) pitch ldh, W (c, k) pitch ldw.  scratch: pdgn_dense_bn_maxpool_input_grad_scratch floats.
+extern "C" int pdgn_dense_bn_maxpool_input_grad(int b, int n, int c, int k, int act, const float *x, const float *dout,
+                                                const int32_t *yarg, const float *stats, const float *h, int ldh,
+                                                const float *W, int ldw, float *scratch, float *dh, pdgn_stream_t stream) {
+    if (b < 1 || n < 1 || n > 65535 || c < 4 || c % 4 || k < 4 || k % 4 || k > 256 || ldw % 4 || ((uintptr_t)W & 15) ||
+        ((uintptr_t)dh & 15) || act < 0 || act > 2 || b > 65535 || cf_scatter_lds(n, c) > 64 * 1024)
+        return PDGN_ERR_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    float *dz = scratch, *coef = dz + (size_t)b * c, *bsums = coef + 2 * (size_t)c, *G = bsums + 2 * (size_t)c, *v = G + (size_t)k * k;
+    hipLaunchKernelGGL(cl_max_bwd_sums_kernel, dim3(cdiv(c, 16)), dim3(256), 0, s, b, n, c, act, 1, x, dout, yarg, stats, dz,
+                       bsums, coef, G, k * k + k);
+    const int gt = cdiv(k, CF_TILE);
+    hipLaunchKernelGGL(cf_gram_kernel, dim3(gt, gt, CF_CSPLIT), dim3(256), 0, s, c, k, W, ldw, coef, G, v);
+    int rc = pdgn_launch_status();
+    if (rc) return rc;
+    rc = pdgn_gemm_nt((long long)b * n, k, k, h, ldh, G, k, v, nullptr, 0, dh, k, nullptr, stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(cf_scatter_kernel, dim3(CF_RSPLIT, b), dim3(256), cf_scatter_lds(n, c), s, n, c, k, W, ldw, stats, dz,
+                       yarg, dh);
     return pdgn_launch_status();
 }

@@ -43,6 +43,35 @@ def has_zero_colsum(dy):
 
 def clear_zero_colsum():
     _ZERO_COLSUM.clear()
+    _INPUT_GRADS.clear()
+
+
+# A second side channel of the same kind: BNActMaxPool's backward, when the dense layer in front of it is frozen, computes
+# that layer's INPUT gradient itself (pdgn_dense_bn_maxpool_input_grad: the dense (rows, C) dx is never formed) and hands
+# LinearCL's backward a zero-stride placeholder of dx's shape; the input gradient travels here, keyed like _ZERO_COLSUM.
+_INPUT_GRADS = {}
+_CLOSED_TAIL = os.environ.get("PDGN_CLOSED_TAIL", "1") == "1"    # A/B switch
+
+
+class DenseInput:
+    """The (input rows, weight) of the LinearCL whose output a bn_act_maxpool consumes -- not an autograd edge."""
+
+    def __init__(self, h, w):
+        self.h, self.w = h, w
+
+
+def _placeholder_with_input_grad(rows, C, dh):
+    tok = torch.empty(1, dtype=F32, device=dh.device).expand(rows, C)
+    _INPUT_GRADS[tok.data_ptr()] = (weakref.ref(tok), dh)
+    return tok
+
+
+def take_input_grad(dy):
+    hit = _INPUT_GRADS.pop(dy.data_ptr(), None) if dy.stride(0) == 0 else None
+    if hit is None:
+        return None
+    src = hit[0]()
+    return hit[1] if src is not None and (src is dy or dy._base is src or dy._base is src._base) and dy.shape == src.shape else None
 
 
 # gemm_tn accumulates split partial sums with atomics, so every weight gradient starts from zeros (and the
@@ -458,6 +487,9 @@ class LinearCL(Function):
         x, weight = ctx.saved_tensors
         if dy is None:
             return None, None, None, None, None, None
+        dx = take_input_grad(dy)
+        if dx is not None:                   # BNActMaxPool's backward already carried the gradient through this layer
+            return dx, None, None, None, None, None
         zero_db = ctx.has_bias and ctx.needs_input_grad[2] and has_zero_colsum(dy)
         dy = dy.contiguous()
         own = dy.is_cuda and dy.shape[0] >= _OWN_MIN_ROWS
@@ -918,7 +950,7 @@ class BNActMaxPool(Function):
 
     @staticmethod
     def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, act, B, N, pre_bias=None,
-                partials=None):
+                partials=None, dense=None):
         x = x.contiguous()
         rows, C = x.shape
         dev = x.device
@@ -934,6 +966,10 @@ class BNActMaxPool(Function):
               "pdgn_bn_act_maxpool")
         ctx.save_for_backward(x, stats, yarg)
         ctx.cfg = (B, N, C, act, bool(training))
+        # frozen layer in front (and frozen BatchNorm parameters): the backward goes straight to that layer's input
+        ctx.dense = dense if (dense is not None and _CLOSED_TAIL and training and not any(ctx.needs_input_grad[1:3])
+                              and not (pre_bias is not None and pre_bias.requires_grad)
+                              and _dense_input_ok(dense, x, rows, C, N)) else None
         return ymax
 
     @staticmethod
@@ -941,6 +977,17 @@ class BNActMaxPool(Function):
         x, stats, yarg = ctx.saved_tensors
         B, N, C, act, training = ctx.cfg
         dout = dout.contiguous()
+        if ctx.dense is not None:
+            h, w = ctx.dense.h, ctx.dense.w
+            K = w.shape[1]
+            L = _lib.lib()
+            L.pdgn_dense_bn_maxpool_input_grad_scratch.restype = ctypes.c_longlong
+            scr = torch.empty(L.pdgn_dense_bn_maxpool_input_grad_scratch(B, C, K), dtype=F32, device=x.device)
+            dh = torch.empty((B * N, K), dtype=F32, device=x.device)
+            check(L.pdgn_dense_bn_maxpool_input_grad(B, N, C, K, act, ptr(x), ptr(dout), ptr(yarg), ptr(stats), ptr(h),
+                                                     h.stride(0), ptr(w), w.stride(0), ptr(scr), ptr(dh), stream_of(x)),
+                  "pdgn_dense_bn_maxpool_input_grad")
+            return (_placeholder_with_input_grad(B * N, C, dh),) + (None,) * 13
         scr = torch.empty(B * C + 2 * C, dtype=F32, device=x.device)
         bs = torch.empty(2 * C, dtype=F32, device=x.device)
         dx = torch.empty_like(x)
@@ -950,18 +997,27 @@ class BNActMaxPool(Function):
         if training:
             mark_zero_colsum(dx)
         return (dx, bs[C:], bs[:C], None, None, None, None, None, None, None, None,
-                _pre_bias_grad(ctx.has_pre_bias, C, x.device), None)
+                _pre_bias_grad(ctx.has_pre_bias, C, x.device), None, None)
 
 
-def bn_act_maxpool(x2d, bn, training, B, N, act="leaky_relu", pre_bias=None, partials=None):
-    """max over the N points of every sample of act(BN(x2d)); x2d (B*N, C) -> (B, C)."""
+def _dense_input_ok(dense, x, rows, C, N):
+    h, w = dense.h, dense.w
+    return (x.is_cuda and h.dim() == 2 and w.dim() == 2 and h.shape[0] == rows and w.shape[0] == C and h.shape[1] == w.shape[1]
+            and w.shape[1] % 4 == 0 and w.shape[1] <= 256 and w.stride(0) % 4 == 0 and w.data_ptr() % 16 == 0 and h.dtype == F32 and w.dtype == F32 and h.stride(1) == 1 and w.stride(1) == 1
+            and not w.requires_grad and h.requires_grad and rows >= _OWN_MIN_ROWS
+            and N <= 65535 and 2 * (N + min(N, C) + C) + 1040 + 4 * C <= 65536)
+
+
+def bn_act_maxpool(x2d, bn, training, B, N, act="leaky_relu", pre_bias=None, partials=None, dense=None):
+    """max over the N points of every sample of act(BN(x2d)); x2d (B*N, C) -> (B, C).  dense = DenseInput(h, W) when x2d is
+    linear_cl(h, W) without bias / addend: with W and the BatchNorm frozen the backward then skips the dense gradient."""
     x2d, pre_bias = _fold_pre_bias(x2d, pre_bias, training)
     if x2d.shape[1] % 4:
         return bn_act(x2d, bn, training, act=act, pre_bias=pre_bias).view(B, N, -1).max(dim=1)[0]
     if training and bn.track_running_stats:
         _PENDING_COUNTS[bn.num_batches_tracked] = _PENDING_COUNTS.get(bn.num_batches_tracked, 0) + 1
     return BNActMaxPool.apply(x2d, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, bn.momentum, bn.eps,
-                              ACT[act], B, N, pre_bias, partials)
+                              ACT[act], B, N, pre_bias, partials, dense)
 
 
 class PointMax(Function):

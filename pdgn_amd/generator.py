@@ -237,8 +237,10 @@ class PointDiscriminator(nn.Module):
             y, part = _linear_stats(h, _deconv._w2d(self.fc1[i]), self.training)
             h = _deconv.bn_act(y, self.fc1[i + 1], self.training, pre_bias=self.fc1[i].bias, partials=part)
         # last layer: BatchNorm1d + LeakyReLU + MaxPool1d(num_point) fused (the activated tensor is not written)
-        y, part = _linear_stats(h, _deconv._w2d(self.fc1[last]), self.training)
-        pooled = _deconv.bn_act_maxpool(y, self.fc1[last + 1], self.training, B, N, pre_bias=self.fc1[last].bias, partials=part)
+        w_last = _deconv._w2d(self.fc1[last])
+        y, part = _linear_stats(h, w_last, self.training)
+        pooled = _deconv.bn_act_maxpool(y, self.fc1[last + 1], self.training, B, N, pre_bias=self.fc1[last].bias, partials=part,
+                                        dense=_deconv.DenseInput(h, w_last))
         _deconv.flush_bn_counters()
         return _small_seq(self.mlp, pooled, self.training)            # Linear + LeakyReLU groups on B rows: one launch each
 

@@ -1108,6 +1108,48 @@ def test_fused_bn_act_maxpool_vs_torch(B, N, C, training):
         np.testing.assert_allclose(a, b, rtol=1e-4, atol=1e-4 * max(1.0, np.abs(b).max()), err_msg=name)
 
 
+@pytest.mark.parametrize("B,N,C,K", [(35, 2048, 1024, 256), (6, 256, 256, 128), (4, 1024, 512, 256), (3, 700, 64, 40)])
+def test_frozen_last_layer_input_grad_without_the_dense_gradient(B, N, C, K):
+    """dense -> BatchNorm1d -> LeakyReLU -> MaxPool1d with frozen parameters (the generator's update through a
+    discriminator): pdgn_dense_bn_maxpool_input_grad (dh = S W - 1 ca^T W - h W^T diag(cb) W) against fp64 torch and against
+    the two-Function path it replaces."""
+    from pdgn_amd import fused
+    from torch_standins import bn_act_maxpool_torch
+    rng = np.random.default_rng(B + N + C + K)
+    h0 = torch.from_numpy(rng.standard_normal((B * N, K)).astype(np.float32))
+    W0 = torch.from_numpy((rng.standard_normal((C, K)) / np.sqrt(K)).astype(np.float32))
+    bias0 = torch.from_numpy(rng.standard_normal(C).astype(np.float32))
+    gout = torch.from_numpy(rng.standard_normal((B, C)).astype(np.float32))
+    res = {}
+    for name in ("closed", "dense", "torch"):
+        to = (lambda t: t.double()) if name == "torch" else dev
+        bn = torch.nn.BatchNorm1d(C)
+        fill_module(bn, salt=7)
+        bn = bn.double() if name == "torch" else bn.cuda()
+        bn.train(True)
+        for p in bn.parameters():
+            p.requires_grad_(False)
+        h = to(h0).requires_grad_(True)
+        W, bias = to(W0), to(bias0)
+        if name == "torch":
+            y = bn_act_maxpool_torch(h @ W.t(), bn, True, B, N, pre_bias=bias)
+        else:
+            x, part = fused.linear_cl(h, W, None, None, True)
+            y = fused.bn_act_maxpool(x, bn, True, B, N, pre_bias=bias, partials=part,
+                                     dense=fused.DenseInput(h, W) if name == "closed" else None)
+            took = type(y.grad_fn).__name__
+            assert "BNActMaxPool" in took
+        y.backward(to(gout))
+        fused.flush_bn_counters()
+        if name != "torch":
+            assert not fused._INPUT_GRADS, "the placeholder was consumed"
+        res[name] = (y.detach().cpu().double().numpy(), h.grad.detach().cpu().double().numpy())
+    scale = max(1e-6, np.abs(res["torch"][1]).max())
+    np.testing.assert_allclose(res["closed"][0], res["torch"][0], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(res["closed"][1], res["torch"][1], rtol=1e-4, atol=1e-4 * scale)
+    np.testing.assert_allclose(res["dense"][1], res["torch"][1], rtol=1e-4, atol=1e-4 * scale)
+
+
 def test_bias_feeding_training_batchnorm_gets_analytic_zero_grad():
     """sum_rows d(BN input) == 0 in training mode: the producer's bias gradient is returned as exact zeros and
     the full pass over dy is skipped; the skipped sum is rounding residue (checked here), eval mode is untouched."""

@@ -121,5 +121,5 @@ def flush_bn_counters_noop():
     pass
 
 
-def bn_act_maxpool_torch(x2d, bn, training, B, N, act="leaky_relu", pre_bias=None, partials=None):
+def bn_act_maxpool_torch(x2d, bn, training, B, N, act="leaky_relu", pre_bias=None, partials=None, dense=None):
     return bn_act_torch(x2d, bn, training, act=act, pre_bias=pre_bias).view(B, N, -1).max(dim=1)[0]
