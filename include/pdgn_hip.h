@@ -271,6 +271,11 @@ int pdgn_softmax_slots_permute_backward(long long m, int k, int c, const float *
 int pdgn_skinny_nt(int R, int N, int K, const float *A, int lda, const float *B, int ldb, const float *bias, float *C, int ldc,
                    pdgn_stream_t stream);
 int pdgn_skinny_nn(int R, int N, int K, const float *A, int lda, const float *B, int ldb, float *C, int ldc, pdgn_stream_t stream);
+/* pdgn_skinny_nn with A[r][k] scaled by act'(P[r][k]) on load (act 1 = ReLU, 2 = LeakyReLU(0.01); P (R x K) the pre-activation a
+ * Linear + activation saved): that layer's input gradient dx = (dy * act'(pre)) W in one launch when its parameters are frozen
+ * (the discriminators' nn.Linear heads during the generator's update, models/PDGNet_v2.py:330-352, :896-911). */
+int pdgn_skinny_nn_masked(int R, int N, int K, const float *A, int lda, const float *P, int ldp, int act, const float *B,
+                          int ldb, float *C, int ldc, pdgn_stream_t stream);
 int pdgn_skinny_tn(int R, int N, int K, const float *A, int lda, const float *B, int ldb, float *C, int ldc, pdgn_stream_t stream);
 /* A weight matrix split ONCE into the three bf16 parts the contractions multiply (x = h + m + l, csrc/split.hip) instead of by
  * every workgroup's loader: src (rows x cols fp32, pitch ld_src) -> planes (3 x [rows][ld_planes] bf16, plane_stride elements

@@ -10,9 +10,11 @@
 //                 argmins, both directions in one launch; the (B,M,N) matrix never exists.
 // Both have hand-written adjoints (scatter through the argmins / neighbour indices).
 #include "common.h"
+#include <stdlib.h>
 
 #define LP_THREADS 256
-#define LP_LDS_FLOATS 12288      // 48 KiB slab for the privatised scatter
+#define LP_LDS_FLOATS 8192       // 32 KiB slab for the privatised scatter (n <= 2730)
+#define LP_PTS_FLOATS 6144       // 24 KiB: the sample's points staged for the adjoint's gathers (n <= 2048)
 
 // ---------------------------------------------------------------------------- local statistics
 // xyz (b,n,3), idx (b,m,K) -> mu (b,m,3), cov (b,m,9);  cov = (1/K) sum_s t_s t_s^T, t_s = p_s - mu
@@ -52,13 +54,16 @@ __global__ __launch_bounds__(LP_THREADS) void local_stats_bwd_kernel(
     int n, int m, int K, int qsplit, const float *__restrict__ xyz, const int32_t *__restrict__ idx,
     const float *__restrict__ dmu, const float *__restrict__ dcov, float *__restrict__ dxyz) {
     __shared__ float slab[LP_LDS_FLOATS];
+    __shared__ float pts[LP_PTS_FLOATS];                           // the sample's points: 2 K gathers per query come from LDS
     const int bs = blockIdx.y;
-    const bool use_lds = n * 3 <= LP_LDS_FLOATS;
-    if (use_lds) {
-        for (int i = threadIdx.x; i < n * 3; i += LP_THREADS) slab[i] = 0.f;
-        __syncthreads();
-    }
+    const bool use_lds = n * 3 <= LP_LDS_FLOATS, use_pts = n * 3 <= LP_PTS_FLOATS;
     const float *P = xyz + (size_t)bs * n * 3;
+    if (use_lds)
+        for (int i = threadIdx.x; i < n * 3; i += LP_THREADS) slab[i] = 0.f;
+    if (use_pts)
+        for (int i = threadIdx.x; i < n * 3; i += LP_THREADS) pts[i] = P[i];
+    if (use_lds || use_pts) __syncthreads();
+    auto pt = [&](int j, int c) { return use_pts ? pts[j * 3 + c] : P[(size_t)j * 3 + c]; };
     float *D = dxyz + (size_t)bs * n * 3;
     const int per = (m + qsplit - 1) / qsplit;
     const int q0 = blockIdx.x * per, q1 = min(m, q0 + per);
@@ -67,8 +72,8 @@ __global__ __launch_bounds__(LP_THREADS) void local_stats_bwd_kernel(
         const int32_t *I = idx + ((size_t)bs * m + q) * K;
         float sx = 0.f, sy = 0.f, sz = 0.f;
         for (int s = 0; s < K; ++s) {
-            const float *p = P + (size_t)I[s] * 3;
-            sx += p[0]; sy += p[1]; sz += p[2];
+            const int j = I[s];
+            sx += pt(j, 0); sy += pt(j, 1); sz += pt(j, 2);
         }
         const float mx = sx * invK, my = sy * invK, mz = sz * invK;
         const float *gm = dmu + ((size_t)bs * m + q) * 3;
@@ -78,8 +83,7 @@ __global__ __launch_bounds__(LP_THREADS) void local_stats_bwd_kernel(
         const float bx = gm[0] * invK, by = gm[1] * invK, bz = gm[2] * invK;
         for (int s = 0; s < K; ++s) {
             const int j = I[s];
-            const float *p = P + (size_t)j * 3;
-            const float tx = p[0] - mx, ty = p[1] - my, tz = p[2] - mz;
+            const float tx = pt(j, 0) - mx, ty = pt(j, 1) - my, tz = pt(j, 2) - mz;
             const float gx = bx + (s00 * tx + s01 * ty + s02 * tz) * invK;
             const float gy = by + (s01 * tx + s11 * ty + s12 * tz) * invK;
             const float gz = bz + (s02 * tx + s12 * ty + s22 * tz) * invK;
@@ -184,6 +188,46 @@ __global__ __launch_bounds__(LP_THREADS) void chamfer_gram_grad_kernel(
     }
 }
 
+// The same gradients with the sums taken in LDS: one workgroup per (sample, cloud) holds that cloud's whole gradient (nq x d
+// floats), writes every point's own term 2 g (q_i - c*) there, adds the terms of the other cloud's points that chose it with LDS
+// atomics (every global access a flat, coalesced sweep; the only gathers are c* and q_target) and stores the result once: no
+// global atomics, no zero-fill.  35 x 1024 x 18 float atomics onto a few popular points took 56 us isolated / 85-130 us in the
+// iteration for the 9-D covariance pairs.  (A per-point gather -- each thread scanning the other direction's arg-min list --
+// was slower: a match is rare per lane but not per wavefront, and every one is a dependent round trip.)
+#define CHL_THREADS 1024
+#define CHL_MAXF 12288      // floats of one cloud's gradient in LDS (48 KB)
+template <int D>
+__global__ __launch_bounds__(CHL_THREADS) void chamfer_gram_grad_lds_kernel(
+    int m, int n, int d, const float *__restrict__ x, const float *__restrict__ y,
+    const float *__restrict__ gminx, const int32_t *__restrict__ argx, const float *__restrict__ gminy,
+    const int32_t *__restrict__ argy, float *__restrict__ gx, float *__restrict__ gy, const float *__restrict__ guni, float gscale) {
+    __shared__ float accs[CHL_MAXF];
+    const int dd = D > 0 ? D : d;
+    const int bs = blockIdx.y;
+    const bool rev = blockIdx.z != 0;                              // rev: this block writes gy
+    const int nq = rev ? n : m, nc = rev ? m : n;                  // own cloud / other cloud
+    const float *Qb = (rev ? y : x) + (size_t)bs * nq * dd, *Cb = (rev ? x : y) + (size_t)bs * nc * dd;
+    const int32_t *own_arg = (rev ? argy : argx) + (size_t)bs * nq, *oth_arg = (rev ? argx : argy) + (size_t)bs * nc;
+    const float *own_g = (rev ? gminy : gminx) + (guni ? 0 : (size_t)bs * nq), *oth_g = (rev ? gminx : gminy) + (guni ? 0 : (size_t)bs * nc);
+    const float uni = guni ? 2.0f * guni[0] * gscale : 0.f;
+    for (int f = threadIdx.x; f < nq * dd; f += CHL_THREADS) {     // own terms: entry f = (point i, coordinate c)
+        const int i = f / dd, c = f - i * dd;
+        const float g = guni ? uni : 2.0f * own_g[i];
+        accs[f] = g * (Qb[f] - Cb[(size_t)own_arg[i] * dd + c]);
+    }
+    __syncthreads();
+    for (int f = threadIdx.x; f < nc * dd; f += CHL_THREADS) {     // the other cloud's points, each to the point it chose
+        const int e = f / dd, c = f - e * dd;
+        const int tgt = oth_arg[e];
+        const float ge = guni ? uni : 2.0f * oth_g[e];
+        __hip_atomic_fetch_add(&accs[tgt * dd + c], ge * (Qb[(size_t)tgt * dd + c] - Cb[f]), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    __syncthreads();
+    float *G = (rev ? gy : gx) + (size_t)bs * nq * dd;
+    for (int f = threadIdx.x; f < nq * dd; f += CHL_THREADS) G[f] = accs[f];
+}
+
 // ---------------------------------------------------------------------------- C ABI
 extern "C" int pdgn_local_stats(int b, int n, int m, int k, const float *xyz, const int32_t *idx, float *mu,
                                 float *cov, pdgn_stream_t stream) {
@@ -242,6 +286,20 @@ static int chamfer_grad_launch(int b, int m, int n, int d, const float *x, const
                                hipStream_t s) {
     hipError_t e;
     const size_t nx = (size_t)b * m * d, ny = (size_t)b * n * d;
+    static const bool in_lds = !(getenv("PDGN_CHAMFER_LDS") && getenv("PDGN_CHAMFER_LDS")[0] == '0');   // A/B switch
+    if (in_lds && (size_t)m * d <= CHL_MAXF && (size_t)n * d <= CHL_MAXF) {   // sums in LDS: plain stores, nothing to clear
+        dim3 grid(1, b, 2);
+        if (d == 3)
+            hipLaunchKernelGGL(chamfer_gram_grad_lds_kernel<3>, grid, dim3(CHL_THREADS), 0, s, m, n, d, x, y, gminx, argx, gminy, argy,
+                               gx, gy, guni, gscale);
+        else if (d == 9)
+            hipLaunchKernelGGL(chamfer_gram_grad_lds_kernel<9>, grid, dim3(CHL_THREADS), 0, s, m, n, d, x, y, gminx, argx, gminy, argy,
+                               gx, gy, guni, gscale);
+        else
+            hipLaunchKernelGGL(chamfer_gram_grad_lds_kernel<0>, grid, dim3(CHL_THREADS), 0, s, m, n, d, x, y, gminx, argx, gminy, argy,
+                               gx, gy, guni, gscale);
+        return pdgn_launch_status();
+    }
     if (gy == gx + nx) {                                           // one buffer (the callers here allocate it so): one fill
         if ((e = hipMemsetAsync(gx, 0, (nx + ny) * sizeof(float), s)) != hipSuccess) return (int)e;
     } else {

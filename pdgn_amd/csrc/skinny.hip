@@ -102,9 +102,13 @@ __global__ __launch_bounds__(SK_THREADS) void skinny_nt_kernel(int R, int N, int
 // A workgroup = 64 columns n0 .. n0 + 63 and one slice of K; its four waves take every fourth 16-deep step of the slice.  Lane
 // (u = l % 16, q = l / 16) loads float4 B[k0 + 4q + s][n0 + 4u ..] (s = 0 .. 3) and float4 A[16 blk + u][k0 + 4q ..]; column block e
 // of the wave's output holds the columns n0 + 4u + e.  Partial sums leave by fp32 atomics (several slices per column block).
+// MASK: A is taken as A[r][k] * act'(P[r][k]) (P = the pre-activation a small layer saved, act 1 = ReLU, 2 = LeakyReLU(0.01)): the
+// input gradient of a frozen Linear + activation in one launch (small_mlp.hip's backward writes that product for the weight
+// gradient; with frozen weights nobody else reads it).
+template <bool MASK>
 __global__ __launch_bounds__(SK_THREADS) void skinny_nn_kernel(int R, int N, int K, int chunks_per_slice, const float *__restrict__ A,
                                                                int lda, const float *__restrict__ B, int ldb, float *__restrict__ C,
-                                                               int ldc) {
+                                                               int ldc, const float *__restrict__ P, int ldp, int act) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int u = lane & 15, q = lane >> 4;
     const int nb = (R + 15) >> 4;
@@ -138,6 +142,12 @@ __global__ __launch_bounds__(SK_THREADS) void skinny_nn_kernel(int R, int N, int
                     } else {
 #pragma unroll
                         for (int s = 0; s < 4; ++s) av[s] = k + s < K ? A[(size_t)r * lda + k + s] : 0.f;
+                    }
+                    if (MASK) {
+                        const float neg = act == 2 ? 0.01f : 0.f;
+#pragma unroll
+                        for (int s = 0; s < 4; ++s)
+                            if (k + s < K && !(P[(size_t)r * ldp + k + s] > 0.f)) av[s] *= neg;
                     }
                 }
 #pragma unroll
@@ -244,8 +254,26 @@ extern "C" int pdgn_skinny_nn(int R, int N, int K, const float *A, int lda, cons
     if (slices > kchunks / 8) slices = kchunks / 8;
     slices = slices < 1 ? 1 : slices;
     const int per = (kchunks + slices - 1) / slices;
-    hipLaunchKernelGGL(skinny_nn_kernel, dim3(gx, cdiv(kchunks, per)), dim3(SK_THREADS), 0, (hipStream_t)stream, R, N, K, per, A, lda, B,
-                       ldb, C, ldc);
+    hipLaunchKernelGGL(skinny_nn_kernel<false>, dim3(gx, cdiv(kchunks, per)), dim3(SK_THREADS), 0, (hipStream_t)stream, R, N, K, per, A,
+                       lda, B, ldb, C, ldc, nullptr, 0, 0);
+    return pdgn_launch_status();
+}
+
+// The same with A[r][k] scaled by act'(P[r][k]) on load (act 1 = ReLU, 2 = LeakyReLU(0.01); P (R x K, pitch ldp) = the layer's
+// pre-activation): dx = (dy * act'(pre)) W of a frozen Linear + activation.  C ZERO-FILLED by the caller.
+extern "C" int pdgn_skinny_nn_masked(int R, int N, int K, const float *A, int lda, const float *P, int ldp, int act, const float *B,
+                                     int ldb, float *C, int ldc, pdgn_stream_t stream) {
+    if (!sk_ok(R, N, K) || N % 4 || lda < K || ldp < K || ldb < N || ldc < N || !A || !B || !C || !P || act < 1 || act > 2)
+        return PDGN_ERR_INVALID;
+    if (!sk_al(A, lda) || !sk_al(B, ldb)) return -2;
+    const int kchunks = (K + 15) / 16, gx = cdiv(N, 64);
+    int slices = 256 / gx;
+    slices = slices < 1 ? 1 : slices;
+    if (slices > kchunks / 8) slices = kchunks / 8;
+    slices = slices < 1 ? 1 : slices;
+    const int per = (kchunks + slices - 1) / slices;
+    hipLaunchKernelGGL(skinny_nn_kernel<true>, dim3(gx, cdiv(kchunks, per)), dim3(SK_THREADS), 0, (hipStream_t)stream, R, N, K, per, A,
+                       lda, B, ldb, C, ldc, P, ldp, act);
     return pdgn_launch_status();
 }
 

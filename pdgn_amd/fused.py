@@ -521,6 +521,7 @@ class LinearCL(Function):
 
 # ---------------------------------------------------------------------------------------------------------------
 # Products with a per-sample operand (R <= 64 rows: the batch) on csrc/skinny.hip instead of the BLAS library's skinny solutions.
+_FROZEN_HEAD = os.environ.get("PDGN_FROZEN_HEAD", "1") == "1"  # A/B switch: frozen small layers' input gradient in one launch
 _SKINNY = os.environ.get("PDGN_SKINNY", "1") == "1"           # A/B switch: 0 = torch's matmul for the 35-row layers
 
 
@@ -551,6 +552,20 @@ def skinny_nn(a, w):
         return a.matmul(w)
     out = torch.zeros((R, N), dtype=F32, device=a.device)          # K slices add into it
     check(_lib.lib().pdgn_skinny_nn(R, N, K, ptr(a), a.stride(0), ptr(w), w.stride(0), ptr(out), N, stream_of(a)), "pdgn_skinny_nn")
+    return out
+
+
+def skinny_nn_masked(a, pre, act, w):
+    """(a * act'(pre)) (R, K) @ w (K, N) for R <= 64: the input gradient of a FROZEN Linear + activation in one launch (a = dy, pre = the
+    saved pre-activation, act 1 = ReLU / 2 = LeakyReLU(0.01), w = the (out, in) weight)."""
+    R, K = a.shape
+    N = w.shape[1]
+    if not (_sk_ok(a, w) and N % 4 == 0 and K % 4 == 0 and pre.stride(1) == 1 and act in (1, 2)):
+        slope = 0.01 if act == 2 else 0.0
+        return (a * torch.where(pre > 0, 1.0, slope)).matmul(w) if act else a.matmul(w)
+    out = _zeros((R, N), a.device)                                 # K slices add into it
+    check(_lib.lib().pdgn_skinny_nn_masked(R, N, K, ptr(a), a.stride(0), ptr(pre), pre.stride(0), act, ptr(w), w.stride(0), ptr(out), N,
+                                           stream_of(a)), "pdgn_skinny_nn_masked")
     return out
 
 
@@ -888,6 +903,12 @@ class SmallLinearBNAct(Function):
         R, K, N, act, bn_mode, has_bias, has_bn = ctx.cfg
         dy = dy.contiguous()
         dev = dy.device
+        if not has_bn and not any(ctx.needs_input_grad[1:3]) and _FROZEN_HEAD:
+            # frozen Linear (+ activation): only the input gradient is wanted -- one launch (no dpre, no second product)
+            if not ctx.needs_input_grad[0]:
+                return (None,) * 11
+            dx = skinny_nn_masked(dy, pre, act, weight) if act else dy.matmul(weight)
+            return (dx,) + (None,) * 10
         dpre = torch.empty((R, N), dtype=F32, device=dev)
         dW = torch.empty((N, K), dtype=F32, device=dev) if ctx.needs_input_grad[1] else None
         dbias = torch.empty(N, dtype=F32, device=dev) if has_bias and ctx.needs_input_grad[2] else None

@@ -1219,6 +1219,34 @@ def test_pre_bias_folded_into_batchnorm(training):
                                        rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("R,dims", [(35, (1024, 512, 256, 64, 1)), (35, (256, 128, 64, 1)), (8, (512, 256, 64, 1)), (3, (20, 12, 1))])
+def test_frozen_head_input_gradient_in_one_launch_per_layer(R, dims):
+    """A discriminator's nn.Linear + LeakyReLU head with FROZEN parameters (the generator's update): the input gradient through
+    pdgn_skinny_nn_masked (dy * act'(pre) applied on load) against torch's own backward of the same nn.Sequential."""
+    import copy
+    import torch.nn as nn
+    from pdgn_amd import fused
+    torch.manual_seed(R + dims[0])
+    layers = []
+    for a, b in zip(dims[:-2], dims[1:-1]):
+        layers += [nn.Linear(a, b), nn.LeakyReLU(inplace=True)]
+    layers.append(nn.Linear(dims[-2], dims[-1]))
+    ref = nn.Sequential(*layers).cuda()
+    mine = copy.deepcopy(ref)
+    for p in mine.parameters():
+        p.requires_grad_(False)
+    x = torch.randn(R, dims[0], device="cuda")
+    xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    t = torch.randn(R, dims[-1], device="cuda")
+    ya = fused.small_sequential(mine, xa, True)
+    yb = ref(xb)
+    torch.testing.assert_close(ya, yb, rtol=2e-4, atol=2e-5)
+    (ya * t).sum().backward()
+    (yb * t).sum().backward()
+    scale = xb.grad.abs().max().item()
+    assert (xa.grad - xb.grad).abs().max().item() <= 1e-4 * scale
+
+
 @pytest.mark.parametrize("R,dims,training", [(35, (128, 256, 256), True), (35, (64, 64, 512), True), (6, (32, 48), True),
                                              (35, (512, 128), False), (64, (1000, 16), True)])
 def test_small_sequential_vs_torch(R, dims, training):

@@ -111,7 +111,7 @@ def test_mse_against_a_constant_fwd_bwd(shape, target, scale):
     np.testing.assert_allclose(x.grad.cpu().numpy(), xr.grad.cpu().numpy(), rtol=1e-6, atol=1e-9)
 
 
-@pytest.mark.parametrize("b,m,n,d", [(3, 100, 70, 3), (2, 257, 512, 9), (35, 256, 128, 3)])
+@pytest.mark.parametrize("b,m,n,d", [(3, 100, 70, 3), (2, 257, 512, 9), (35, 256, 128, 3), (35, 1024, 1024, 9)])
 def test_chamfer_sum_fwd_bwd_vs_torch(b, m, n, d):
     """losses.chamfer_sum (one node: pdgn_chamfer_gram + pdgn_scaled_sum forward, pdgn_chamfer_gram_grad_uniform backward with
     the upstream scalar read on the device) against the torch stand-in, value and both gradients."""
