@@ -205,13 +205,20 @@ int pdgn_bn_act_maxpool(int b, int n, int c, int act, const float *x, const floa
 int pdgn_bn_act_maxpool_backward(int b, int n, int c, int act, int training, const float *x,
                                  const float *dout, const int32_t *yarg, const float *stats,
                                  float *scratch, float *bsums, float *dx, pdgn_stream_t stream);
-/* The same adjoint carried through the dense layer in front of it when that layer's parameters are frozen (the generator's
- * update through a discriminator, models/PDGNet_v2.py:330-352, PointDiscriminator_k.fc1's last Conv1d + BatchNorm1d + LeakyReLU +
- * MaxPool1d :886-911): with x = h W^T the input gradient is  dh = S W - 1 (ca^T W) - h (W^T diag(cb) W)  -- one (b*n, k, k)
- * product, a k x k Gram matrix and a scatter of the b*c arg-max rows; the dense (b*n, c) gradient is never formed.
- * x (b*n, c) the layer's raw output, yarg / stats as saved by pdgn_bn_act_maxpool with training statistics, dout (b, c),
- * h (b*n, k) pitch ldh, W (c, k) pitch ldw (16-byte aligned rows), dh (b*n, k) contiguous; k % 4 == 0, k <= 256, n <= 65535.
- * scratch: pdgn_dense_bn_maxpool_input_grad_scratch(b, c, k) floats. */
+/* The same adjoint carried through the dense layer in front of it (PointDiscriminator_k.fc1's last Conv1d + BatchNorm1d + LeakyReLU +
+ * MaxPool1d, models/PDGNet_v2.py:886-911; training statistics): with x = h W^T and dx = S - 1 ca^T - x diag(cb) (S non-zero at the
+ * b*c arg-max entries only)
+ *     dh = S W - 1 (ca^T W) - h (W^T diag(cb) W)        one (b*n, k, k) product, a k x k Gram matrix, a scatter of b*c rows of W
+ *     dW = S^T h - ca (1^T h) - diag(cb) W (h^T h)      one k x k Gram matrix of h, one (c, k, k) product, a gather of b*c rows of h
+ * -- the dense (b*n, c) gradient is never formed and neither (b*n, c, k) product is computed.
+ * x (b*n, c) the layer's raw output, yarg / stats as saved by pdgn_bn_act_maxpool, dout (b, c), h (b*n, k) pitch ldh, W (c, k) pitch
+ * ldw (16-byte aligned rows); k % 4 == 0, k <= 256, n <= 65535.  Outputs, each may be NULL: dh (b*n, k) contiguous; dW (c, k) pitch
+ * lddw (needs k a power of two >= 16); bsums (2c) = [dbeta | dgamma].  scratch: pdgn_dense_bn_maxpool_backward_scratch floats. */
+long long pdgn_dense_bn_maxpool_backward_scratch(int b, int c, int k);
+int pdgn_dense_bn_maxpool_backward(int b, int n, int c, int k, int act, const float *x, const float *dout, const int32_t *yarg,
+                                   const float *stats, const float *h, int ldh, const float *W, int ldw, float *scratch,
+                                   float *dh, float *dW, int lddw, float *bsums, pdgn_stream_t stream);
+/* The input gradient alone (frozen parameters: the generator's update through a discriminator, models/PDGNet_v2.py:330-352). */
 long long pdgn_dense_bn_maxpool_input_grad_scratch(int b, int c, int k);
 int pdgn_dense_bn_maxpool_input_grad(int b, int n, int c, int k, int act, const float *x, const float *dout,
                                      const int32_t *yarg, const float *stats, const float *h, int ldh,

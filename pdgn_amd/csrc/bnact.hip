@@ -1183,29 +1183,117 @@ static size_t cf_scatter_lds(int n, int c) {
     return (((size_t)(n + maxd + c) * 2 + 15) & ~(size_t)15) + 256 * 4 + (size_t)c * 4;
 }
 
-extern "C" long long pdgn_dense_bn_maxpool_input_grad_scratch(int b, int c, int k) {
-    return (long long)b * c + 4LL * c + (long long)k * k + k;
+// column sums of h (rows x K, K % 4 == 0, pitch ldh) added into hs (zero on entry)
+__global__ __launch_bounds__(256) void cf_colsum_kernel(long long rows, int K, const float *__restrict__ h, int ldh,
+                                                        float *__restrict__ hs) {
+    __shared__ float4 red[256];
+    const int kg = K / 4, cg = threadIdx.x % kg, rl = threadIdx.x / kg, nrl = 256 / kg;   // kg divides 256 (K = 16 .. 256, power of 2)
+    const long long per = (rows + gridDim.x - 1) / gridDim.x, r0 = blockIdx.x * per, r1 = min(rows, r0 + per);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (long long r = r0 + rl; r < r1; r += nrl) {
+        const float4 v = *reinterpret_cast<const float4 *>(h + r * ldh + cg * 4);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    if (rl) return;
+    for (int q = 1; q < nrl; ++q) {
+        const float4 v = red[q * kg + cg];
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    atomicAdd(&hs[cg * 4], acc.x); atomicAdd(&hs[cg * 4 + 1], acc.y); atomicAdd(&hs[cg * 4 + 2], acc.z); atomicAdd(&hs[cg * 4 + 3], acc.w);
 }
 
-// dh (b*n, k) contiguous.  x (b*n, c) = the dense layer's raw output, yarg / stats as saved by pdgn_bn_act_maxpool (training
-// statistics), dout (b, c), h (b*n, k) pitch ldh, W (c, k) pitch ldw.  scratch: pdgn_dense_bn_maxpool_input_grad_scratch floats.
-extern "C" int pdgn_dense_bn_maxpool_input_grad(int b, int n, int c, int k, int act, const float *x, const float *dout,
-                                                const int32_t *yarg, const float *stats, const float *h, int ldh,
-                                                const float *W, int ldw, float *scratch, float *dh, pdgn_stream_t stream) {
+// dW[c, :] = sum_b scale[c] dz[b,c] h[b*N + arg[b,c], :]  -  ca[c] hs  -  cb[c] T[c, :]      (T = W h^T h; K <= 256)
+// one wavefront per channel, a float4 of the row per lane; the B row gathers of a channel are independent loads.
+__global__ __launch_bounds__(256) void cf_dw_kernel(int B, int N, int C, int K, const float *__restrict__ h, int ldh,
+                                                    const int32_t *__restrict__ yarg, const float *__restrict__ stats,
+                                                    const float *__restrict__ dz, const float *__restrict__ coef,
+                                                    const float *__restrict__ hs, const float *__restrict__ T,
+                                                    float *__restrict__ dW, int lddw) {
+    const int lane = threadIdx.x & 63, c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (c >= C || lane * 4 >= K) return;
+    const int col = lane * 4;
+    const float sc = stats[c];
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int b0 = 0; b0 < B; b0 += 8) {
+        float4 v[8];
+        float g[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int b = min(b0 + u, B - 1);
+            g[u] = b0 + u < B ? sc * dz[(size_t)b * C + c] : 0.f;
+            v[u] = *reinterpret_cast<const float4 *>(h + ((size_t)b * N + yarg[(size_t)b * C + c]) * ldh + col);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            acc.x = __fmaf_rn(g[u], v[u].x, acc.x);
+            acc.y = __fmaf_rn(g[u], v[u].y, acc.y);
+            acc.z = __fmaf_rn(g[u], v[u].z, acc.z);
+            acc.w = __fmaf_rn(g[u], v[u].w, acc.w);
+        }
+    }
+    const float ca = coef[c], cb = coef[C + c];
+    const float4 s = *reinterpret_cast<const float4 *>(hs + col), t = *reinterpret_cast<const float4 *>(T + (size_t)c * K + col);
+    *reinterpret_cast<float4 *>(dW + (size_t)c * lddw + col) =
+        make_float4(acc.x - ca * s.x - cb * t.x, acc.y - ca * s.y - cb * t.y, acc.z - ca * s.z - cb * t.z, acc.w - ca * s.w - cb * t.w);
+}
+
+extern "C" long long pdgn_dense_bn_maxpool_backward_scratch(int b, int c, int k) {
+    return (long long)b * c + 2LL * c + 2LL * ((long long)k * k + k) + (long long)c * k;
+}
+
+// The whole adjoint of [dense layer -> BatchNorm (training statistics) -> act -> max-pool over the n points] without the dense
+// (b*n, c) gradient.  x (b*n, c) = the layer's raw output h W^T, yarg / stats as saved by pdgn_bn_act_maxpool, dout (b, c),
+// h (b*n, k) pitch ldh, W (c, k) pitch ldw.  Outputs (each may be NULL): dh (b*n, k) contiguous, dW (c, k) pitch lddw,
+// bsums (2c) = [dbeta | dgamma].  scratch: pdgn_dense_bn_maxpool_backward_scratch floats.
+//   dx = S - 1 ca^T - x diag(cb)   =>   dh = S W - 1 (ca^T W) - h (W^T diag(cb) W),   dW = S^T h - ca (1^T h) - diag(cb) W (h^T h)
+extern "C" int pdgn_dense_bn_maxpool_backward(int b, int n, int c, int k, int act, const float *x, const float *dout,
+                                              const int32_t *yarg, const float *stats, const float *h, int ldh, const float *W,
+                                              int ldw, float *scratch, float *dh, float *dW, int lddw, float *bsums,
+                                              pdgn_stream_t stream) {
     if (b < 1 || n < 1 || n > 65535 || c < 4 || c % 4 || k < 4 || k % 4 || k > 256 || ldw % 4 || ((uintptr_t)W & 15) ||
         ((uintptr_t)dh & 15) || act < 0 || act > 2 || b > 65535 || cf_scatter_lds(n, c) > 64 * 1024)
         return PDGN_ERR_INVALID;
+    if (dW && (k < 16 || (k & (k - 1)) || ldh % 4 || lddw % 4 || ((uintptr_t)h & 15) || ((uintptr_t)dW & 15)))
+        return PDGN_ERR_INVALID;                                    // (the column-sum kernel's geometry: k a power of two)
     hipStream_t s = (hipStream_t)stream;
-    float *dz = scratch, *coef = dz + (size_t)b * c, *bsums = coef + 2 * (size_t)c, *G = bsums + 2 * (size_t)c, *v = G + (size_t)k * k;
-    hipLaunchKernelGGL(cl_max_bwd_sums_kernel, dim3(cdiv(c, 16)), dim3(256), 0, s, b, n, c, act, 1, x, dout, yarg, stats, dz,
-                       bsums, coef, G, k * k + k);
-    const int gt = cdiv(k, CF_TILE);
-    hipLaunchKernelGGL(cf_gram_kernel, dim3(gt, gt, CF_CSPLIT), dim3(256), 0, s, c, k, W, ldw, coef, G, v);
+    const size_t kk = (size_t)k * k;
+    float *dz = scratch, *coef = dz + (size_t)b * c, *G = coef + 2 * (size_t)c, *v = G + kk, *H = v + k, *hs = H + kk, *T = hs + k;
+    float *bs = bsums ? bsums : T;                                  // (T is written later: a scratch home for unwanted sums)
+    hipLaunchKernelGGL(cl_max_bwd_sums_kernel, dim3(cdiv(c, 16)), dim3(256), 0, s, b, n, c, act, 1, x, dout, yarg, stats, dz, bs,
+                       coef, G, (int)(2 * (kk + k)));
     int rc = pdgn_launch_status();
     if (rc) return rc;
-    rc = pdgn_gemm_nt((long long)b * n, k, k, h, ldh, G, k, v, nullptr, 0, dh, k, nullptr, stream);
-    if (rc) return rc;
-    hipLaunchKernelGGL(cf_scatter_kernel, dim3(CF_RSPLIT, b), dim3(256), cf_scatter_lds(n, c), s, n, c, k, W, ldw, stats, dz,
-                       yarg, dh);
-    return pdgn_launch_status();
+    if (dh) {
+        const int gt = cdiv(k, CF_TILE);
+        hipLaunchKernelGGL(cf_gram_kernel, dim3(gt, gt, CF_CSPLIT), dim3(256), 0, s, c, k, W, ldw, coef, G, v);
+        if ((rc = pdgn_launch_status())) return rc;
+        if ((rc = pdgn_gemm_nt((long long)b * n, k, k, h, ldh, G, k, v, nullptr, 0, dh, k, nullptr, stream))) return rc;
+        hipLaunchKernelGGL(cf_scatter_kernel, dim3(CF_RSPLIT, b), dim3(256), cf_scatter_lds(n, c), s, n, c, k, W, ldw, stats, dz,
+                           yarg, dh);
+        if ((rc = pdgn_launch_status())) return rc;
+    }
+    if (dW) {
+        const long long rows = (long long)b * n;
+        hipLaunchKernelGGL(cf_colsum_kernel, dim3(256), dim3(256), 0, s, rows, k, h, ldh, hs);
+        if ((rc = pdgn_launch_status())) return rc;
+        if ((rc = pdgn_gemm_tn_big(rows, k, k, h, ldh, h, ldh, H, 1, stream))) return rc;          // H = h^T h (zeroed above)
+        if ((rc = pdgn_gemm_nt(c, k, k, W, ldw, H, k, nullptr, nullptr, 0, T, k, nullptr, stream))) return rc;   // T = W H
+        hipLaunchKernelGGL(cf_dw_kernel, dim3(cdiv(c, 4)), dim3(256), 0, s, b, n, c, k, h, ldh, yarg, stats, dz, coef, hs, T, dW, lddw);
+        rc = pdgn_launch_status();
+    }
+    return rc;
+}
+
+extern "C" long long pdgn_dense_bn_maxpool_input_grad_scratch(int b, int c, int k) {
+    return pdgn_dense_bn_maxpool_backward_scratch(b, c, k);
+}
+
+// The input gradient alone (frozen parameters): pdgn_dense_bn_maxpool_backward with dW = bsums = NULL.
+extern "C" int pdgn_dense_bn_maxpool_input_grad(int b, int n, int c, int k, int act, const float *x, const float *dout,
+                                                const int32_t *yarg, const float *stats, const float *h, int ldh,
+                                                const float *W, int ldw, float *scratch, float *dh, pdgn_stream_t stream) {
+    return pdgn_dense_bn_maxpool_backward(b, n, c, k, act, x, dout, yarg, stats, h, ldh, W, ldw, scratch, dh, nullptr, 4, nullptr,
+                                          stream);
 }

@@ -51,6 +51,7 @@ def clear_zero_colsum():
 # LinearCL's backward a zero-stride placeholder of dx's shape; the input gradient travels here, keyed like _ZERO_COLSUM.
 _INPUT_GRADS = {}
 _CLOSED_TAIL = os.environ.get("PDGN_CLOSED_TAIL", "1") == "1"    # A/B switch
+_CLOSED_DW = os.environ.get("PDGN_CLOSED_DW", "1") == "1"        # A/B switch: also with a trainable layer (its weight gradient)
 
 
 class DenseInput:
@@ -60,9 +61,9 @@ class DenseInput:
         self.h, self.w = h, w
 
 
-def _placeholder_with_input_grad(rows, C, dh):
-    tok = torch.empty(1, dtype=F32, device=dh.device).expand(rows, C)
-    _INPUT_GRADS[tok.data_ptr()] = (weakref.ref(tok), dh)
+def _placeholder_with_input_grad(rows, C, dh, dw, device):
+    tok = torch.empty(1, dtype=F32, device=device).expand(rows, C)
+    _INPUT_GRADS[tok.data_ptr()] = (weakref.ref(tok), (dh, dw))
     return tok
 
 
@@ -487,9 +488,9 @@ class LinearCL(Function):
         x, weight = ctx.saved_tensors
         if dy is None:
             return None, None, None, None, None, None
-        dx = take_input_grad(dy)
-        if dx is not None:                   # BNActMaxPool's backward already carried the gradient through this layer
-            return dx, None, None, None, None, None
+        carried = take_input_grad(dy)
+        if carried is not None:              # BNActMaxPool's backward already carried the gradient through this layer
+            return carried[0], carried[1], None, None, None, None
         zero_db = ctx.has_bias and ctx.needs_input_grad[2] and has_zero_colsum(dy)
         dy = dy.contiguous()
         own = dy.is_cuda and dy.shape[0] >= _OWN_MIN_ROWS
@@ -987,9 +988,9 @@ class BNActMaxPool(Function):
               "pdgn_bn_act_maxpool")
         ctx.save_for_backward(x, stats, yarg)
         ctx.cfg = (B, N, C, act, bool(training))
-        # frozen layer in front (and frozen BatchNorm parameters): the backward goes straight to that layer's input
-        ctx.dense = dense if (dense is not None and _CLOSED_TAIL and training and not any(ctx.needs_input_grad[1:3])
-                              and not (pre_bias is not None and pre_bias.requires_grad)
+        # dense layer in front known: the backward goes straight to that layer's input (and weight) gradient
+        ctx.dense = dense if (dense is not None and _CLOSED_TAIL and training
+                              and not (pre_bias is not None and pre_bias.requires_grad and not _CLOSED_DW)
                               and _dense_input_ok(dense, x, rows, C, N)) else None
         return ymax
 
@@ -1002,13 +1003,18 @@ class BNActMaxPool(Function):
             h, w = ctx.dense.h, ctx.dense.w
             K = w.shape[1]
             L = _lib.lib()
-            L.pdgn_dense_bn_maxpool_input_grad_scratch.restype = ctypes.c_longlong
-            scr = torch.empty(L.pdgn_dense_bn_maxpool_input_grad_scratch(B, C, K), dtype=F32, device=x.device)
-            dh = torch.empty((B * N, K), dtype=F32, device=x.device)
-            check(L.pdgn_dense_bn_maxpool_input_grad(B, N, C, K, act, ptr(x), ptr(dout), ptr(yarg), ptr(stats), ptr(h),
-                                                     h.stride(0), ptr(w), w.stride(0), ptr(scr), ptr(dh), stream_of(x)),
-                  "pdgn_dense_bn_maxpool_input_grad")
-            return (_placeholder_with_input_grad(B * N, C, dh),) + (None,) * 13
+            want_w, want_bn = w.requires_grad, any(ctx.needs_input_grad[1:3])
+            L.pdgn_dense_bn_maxpool_backward_scratch.restype = ctypes.c_longlong
+            scr = torch.empty(L.pdgn_dense_bn_maxpool_backward_scratch(B, C, K), dtype=F32, device=x.device)
+            dh = torch.empty((B * N, K), dtype=F32, device=x.device) if h.requires_grad else None
+            dw = torch.empty((C, K), dtype=F32, device=x.device) if want_w else None
+            bs = torch.empty(2 * C, dtype=F32, device=x.device) if want_bn else None
+            check(L.pdgn_dense_bn_maxpool_backward(B, N, C, K, act, ptr(x), ptr(dout), ptr(yarg), ptr(stats), ptr(h), h.stride(0),
+                                                   ptr(w), w.stride(0), ptr(scr), ptr(dh), ptr(dw), K, ptr(bs), stream_of(x)),
+                  "pdgn_dense_bn_maxpool_backward")
+            tok = _placeholder_with_input_grad(B * N, C, dh, dw, x.device)
+            return (tok, bs[C:] if want_bn else None, bs[:C] if want_bn else None, None, None, None, None, None, None, None, None,
+                    _pre_bias_grad(ctx.has_pre_bias, C, x.device), None, None)
         scr = torch.empty(B * C + 2 * C, dtype=F32, device=x.device)
         bs = torch.empty(2 * C, dtype=F32, device=x.device)
         dx = torch.empty_like(x)
@@ -1025,7 +1031,9 @@ def _dense_input_ok(dense, x, rows, C, N):
     h, w = dense.h, dense.w
     return (x.is_cuda and h.dim() == 2 and w.dim() == 2 and h.shape[0] == rows and w.shape[0] == C and h.shape[1] == w.shape[1]
             and w.shape[1] % 4 == 0 and w.shape[1] <= 256 and w.stride(0) % 4 == 0 and w.data_ptr() % 16 == 0 and h.dtype == F32 and w.dtype == F32 and h.stride(1) == 1 and w.stride(1) == 1
-            and not w.requires_grad and h.requires_grad and rows >= _OWN_MIN_ROWS
+            and (h.requires_grad or w.requires_grad) and rows >= _OWN_MIN_ROWS
+            and (not w.requires_grad or (_CLOSED_DW and w.shape[1] >= 16 and (w.shape[1] & (w.shape[1] - 1)) == 0
+                                         and h.stride(0) % 4 == 0 and h.data_ptr() % 16 == 0))
             and N <= 65535 and 2 * (N + min(N, C) + C) + 1040 + 4 * C <= 65536)
 
 

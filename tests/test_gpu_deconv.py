@@ -1108,11 +1108,13 @@ def test_fused_bn_act_maxpool_vs_torch(B, N, C, training):
         np.testing.assert_allclose(a, b, rtol=1e-4, atol=1e-4 * max(1.0, np.abs(b).max()), err_msg=name)
 
 
-@pytest.mark.parametrize("B,N,C,K", [(35, 2048, 1024, 256), (6, 256, 256, 128), (4, 1024, 512, 256), (3, 700, 64, 40)])
-def test_frozen_last_layer_input_grad_without_the_dense_gradient(B, N, C, K):
-    """dense -> BatchNorm1d -> LeakyReLU -> MaxPool1d with frozen parameters (the generator's update through a
-    discriminator): pdgn_dense_bn_maxpool_input_grad (dh = S W - 1 ca^T W - h W^T diag(cb) W) against fp64 torch and against
-    the two-Function path it replaces."""
+@pytest.mark.parametrize("B,N,C,K,frozen", [(35, 2048, 1024, 256, True), (6, 256, 256, 128, True), (4, 1024, 512, 256, True),
+                                            (3, 700, 64, 40, True), (35, 2048, 1024, 256, False), (6, 256, 256, 128, False),
+                                            (5, 512, 512, 256, False), (3, 640, 64, 16, False)])
+def test_last_layer_adjoint_without_the_dense_gradient(B, N, C, K, frozen):
+    """dense -> BatchNorm1d -> LeakyReLU -> MaxPool1d (a discriminator's last per-point layer): pdgn_dense_bn_maxpool_backward
+    (dh = S W - 1 ca^T W - h W^T diag(cb) W, dW = S^T h - ca 1^T h - diag(cb) W h^T h) against fp64 torch and against the
+    two-Function path it replaces; frozen = the generator's update (input gradient only)."""
     from pdgn_amd import fused
     from torch_standins import bn_act_maxpool_torch
     rng = np.random.default_rng(B + N + C + K)
@@ -1128,26 +1130,32 @@ def test_frozen_last_layer_input_grad_without_the_dense_gradient(B, N, C, K):
         bn = bn.double() if name == "torch" else bn.cuda()
         bn.train(True)
         for p in bn.parameters():
-            p.requires_grad_(False)
+            p.requires_grad_(not frozen)
         h = to(h0).requires_grad_(True)
-        W, bias = to(W0), to(bias0)
+        W, bias = to(W0).requires_grad_(not frozen), to(bias0).requires_grad_(not frozen)
         if name == "torch":
             y = bn_act_maxpool_torch(h @ W.t(), bn, True, B, N, pre_bias=bias)
         else:
             x, part = fused.linear_cl(h, W, None, None, True)
             y = fused.bn_act_maxpool(x, bn, True, B, N, pre_bias=bias, partials=part,
                                      dense=fused.DenseInput(h, W) if name == "closed" else None)
-            took = type(y.grad_fn).__name__
-            assert "BNActMaxPool" in took
+            assert "BNActMaxPool" in type(y.grad_fn).__name__
+            assert (y.grad_fn.dense is not None) == (name == "closed"), "the closed form was (not) taken"
         y.backward(to(gout))
         fused.flush_bn_counters()
         if name != "torch":
             assert not fused._INPUT_GRADS, "the placeholder was consumed"
-        res[name] = (y.detach().cpu().double().numpy(), h.grad.detach().cpu().double().numpy())
-    scale = max(1e-6, np.abs(res["torch"][1]).max())
-    np.testing.assert_allclose(res["closed"][0], res["torch"][0], rtol=1e-4, atol=1e-4)
-    np.testing.assert_allclose(res["closed"][1], res["torch"][1], rtol=1e-4, atol=1e-4 * scale)
-    np.testing.assert_allclose(res["dense"][1], res["torch"][1], rtol=1e-4, atol=1e-4 * scale)
+        got = [y, h.grad] + ([] if frozen else [W.grad, bn.weight.grad, bn.bias.grad, bias.grad])
+        res[name] = [t.detach().cpu().double().numpy() for t in got]
+    names = ["y", "dh", "dW", "dgamma", "dbeta", "dbias"]
+    for i, ref in enumerate(res["torch"]):
+        scale = max(1e-6, np.abs(ref).max())
+        if names[i] == "dbias":                                       # analytically zero: both sides hold rounding residue
+            wscale = np.abs(res["torch"][2]).max()
+            assert np.abs(res["closed"][i]).max() <= 1e-4 * wscale and np.abs(ref).max() <= 1e-4 * wscale
+            continue
+        np.testing.assert_allclose(res["closed"][i], ref, rtol=1e-4, atol=1e-4 * scale, err_msg=names[i])
+        np.testing.assert_allclose(res["dense"][i], ref, rtol=1e-4, atol=1e-4 * scale, err_msg=names[i] + " (dense path)")
 
 
 def test_bias_feeding_training_batchnorm_gets_analytic_zero_grad():
