@@ -278,6 +278,10 @@ int pdgn_softmax_slots_permute_backward(long long m, int k, int c, const float *
 int pdgn_skinny_nt(int R, int N, int K, const float *A, int lda, const float *B, int ldb, const float *bias, float *C, int ldc,
                    pdgn_stream_t stream);
 int pdgn_skinny_nn(int R, int N, int K, const float *A, int lda, const float *B, int ldb, float *C, int ldc, pdgn_stream_t stream);
+/* pdgn_skinny_nt with an activation after the bias (act 0 none, 1 ReLU, 2 LeakyReLU(0.01)): a discriminator head's nn.Linear +
+ * nn.LeakyReLU on the batch's pooled rows (models/PDGNet_v2.py:896-911) in one launch. */
+int pdgn_skinny_nt_act(int R, int N, int K, const float *A, int lda, const float *B, int ldb, const float *bias, float *C, int ldc,
+                       int act, pdgn_stream_t stream);
 /* pdgn_skinny_nn with A[r][k] scaled by act'(P[r][k]) on load (act 1 = ReLU, 2 = LeakyReLU(0.01); P (R x K) the pre-activation a
  * Linear + activation saved): that layer's input gradient dx = (dy * act'(pre)) W in one launch when its parameters are frozen
  * (the discriminators' nn.Linear heads during the generator's update, models/PDGNet_v2.py:330-352, :896-911). */

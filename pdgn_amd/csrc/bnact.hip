@@ -1190,9 +1190,15 @@ __global__ __launch_bounds__(256) void cf_colsum_kernel(long long rows, int K, c
     const int kg = K / 4, cg = threadIdx.x % kg, rl = threadIdx.x / kg, nrl = 256 / kg;   // kg divides 256 (K = 16 .. 256, power of 2)
     const long long per = (rows + gridDim.x - 1) / gridDim.x, r0 = blockIdx.x * per, r1 = min(rows, r0 + per);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (long long r = r0 + rl; r < r1; r += nrl) {
-        const float4 v = *reinterpret_cast<const float4 *>(h + r * ldh + cg * 4);
-        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    for (long long r = r0 + rl; r < r1; r += 8 * nrl) {            // eight independent loads a round
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const long long rr = r + (long long)u * nrl;
+            v[u] = rr < r1 ? *reinterpret_cast<const float4 *>(h + rr * ldh + cg * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
     }
     red[threadIdx.x] = acc;
     __syncthreads();
@@ -1276,7 +1282,7 @@ extern "C" int pdgn_dense_bn_maxpool_backward(int b, int n, int c, int k, int ac
     }
     if (dW) {
         const long long rows = (long long)b * n;
-        hipLaunchKernelGGL(cf_colsum_kernel, dim3(256), dim3(256), 0, s, rows, k, h, ldh, hs);
+        hipLaunchKernelGGL(cf_colsum_kernel, dim3(rows >= 32768 ? 1024 : 256), dim3(256), 0, s, rows, k, h, ldh, hs);
         if ((rc = pdgn_launch_status())) return rc;
         if ((rc = pdgn_gemm_tn_big(rows, k, k, h, ldh, h, ldh, H, 1, stream))) return rc;          // H = h^T h (zeroed above)
         if ((rc = pdgn_gemm_nt(c, k, k, W, ldw, H, k, nullptr, nullptr, 0, T, k, nullptr, stream))) return rc;   // T = W H

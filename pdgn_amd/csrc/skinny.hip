@@ -32,7 +32,7 @@ __device__ __forceinline__ sk_f32x4 sk_mfma(float a, float b, sk_f32x4 c) {
 template <bool SPLIT>
 __global__ __launch_bounds__(SK_THREADS) void skinny_nt_kernel(int R, int N, int K, const float *__restrict__ A, int lda,
                                                                const float *__restrict__ B, int ldb,
-                                                               const float *__restrict__ bias, float *__restrict__ C, int ldc) {
+                                                               const float *__restrict__ bias, float *__restrict__ C, int ldc, int act) {
     __shared__ float red[SPLIT ? 3 * SK_MAXB * 256 : 1];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 15, q = lane >> 4;
@@ -94,7 +94,10 @@ __global__ __launch_bounds__(SK_THREADS) void skinny_nt_kernel(int R, int N, int
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int r = 16 * b + 4 * q + j;
-            if (b < nb && r < R) C[(size_t)r * ldc + n0 + i] = acc[b][j] + bz;
+            if (b < nb && r < R) {
+                const float z = acc[b][j] + bz;
+                C[(size_t)r * ldc + n0 + i] = act == 2 ? (z > 0.f ? z : 0.01f * z) : (act == 1 ? fmaxf(z, 0.f) : z);
+            }
         }
 }
 
@@ -230,16 +233,22 @@ static bool sk_ok(int R, int N, int K) { return R >= 1 && R <= 16 * SK_MAXB && N
 static bool sk_al(const void *p, int ld) { return ((uintptr_t)p & 15) == 0 && ld % 4 == 0; }
 
 // C (R x N, pitch ldc) = A (R x K, pitch lda) B (N x K, pitch ldb)^T (+ bias[N]); R <= 64, K % 4 == 0, A / B rows 16-byte aligned.
-extern "C" int pdgn_skinny_nt(int R, int N, int K, const float *A, int lda, const float *B, int ldb, const float *bias, float *C,
-                              int ldc, pdgn_stream_t stream) {
-    if (!sk_ok(R, N, K) || K % 4 || lda < K || ldb < K || ldc < N || !A || !B || !C) return PDGN_ERR_INVALID;
+// act: 0 none, 1 ReLU, 2 LeakyReLU(0.01), applied after the bias.
+extern "C" int pdgn_skinny_nt_act(int R, int N, int K, const float *A, int lda, const float *B, int ldb, const float *bias, float *C,
+                                  int ldc, int act, pdgn_stream_t stream) {
+    if (!sk_ok(R, N, K) || K % 4 || lda < K || ldb < K || ldc < N || !A || !B || !C || act < 0 || act > 2) return PDGN_ERR_INVALID;
     if (!sk_al(A, lda) || !sk_al(B, ldb)) return -2;
     hipStream_t s = (hipStream_t)stream;
     if (N < 4096)
-        hipLaunchKernelGGL(skinny_nt_kernel<true>, dim3(cdiv(N, 16)), dim3(SK_THREADS), 0, s, R, N, K, A, lda, B, ldb, bias, C, ldc);
+        hipLaunchKernelGGL(skinny_nt_kernel<true>, dim3(cdiv(N, 16)), dim3(SK_THREADS), 0, s, R, N, K, A, lda, B, ldb, bias, C, ldc, act);
     else
-        hipLaunchKernelGGL(skinny_nt_kernel<false>, dim3(cdiv(N, 64)), dim3(SK_THREADS), 0, s, R, N, K, A, lda, B, ldb, bias, C, ldc);
+        hipLaunchKernelGGL(skinny_nt_kernel<false>, dim3(cdiv(N, 64)), dim3(SK_THREADS), 0, s, R, N, K, A, lda, B, ldb, bias, C, ldc, act);
     return pdgn_launch_status();
+}
+
+extern "C" int pdgn_skinny_nt(int R, int N, int K, const float *A, int lda, const float *B, int ldb, const float *bias, float *C,
+                              int ldc, pdgn_stream_t stream) {
+    return pdgn_skinny_nt_act(R, N, K, A, lda, B, ldb, bias, C, ldc, 0, stream);
 }
 
 // C (R x N, pitch ldc) += A (R x K, pitch lda) B (K x N, pitch ldb): C is ZERO-FILLED by the caller (several K slices add into it

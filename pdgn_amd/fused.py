@@ -922,6 +922,46 @@ class SmallLinearBNAct(Function):
         return dx, dW, dbias, dg, db, None, None, None, None, None, None
 
 
+class SkinnyLinearAct(Function):
+    """act(x W^T + b) for a handful of rows without BatchNorm (the discriminators' heads) on csrc/skinny.hip: one matrix-instruction
+    launch forward; backward = one launch when the layer is frozen (input gradient with act' applied on load), else
+    pdgn_small_mlp_backward (dpre, dW, db) + the dx product.  The activation's derivative is read off y (same sign as the pre-activation)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, act):
+        x = x.contiguous()
+        R, K = x.shape
+        N = weight.shape[0]
+        y = torch.empty((R, N), dtype=F32, device=x.device)
+        b = bias.detach().contiguous() if bias is not None else None
+        check(_lib.lib().pdgn_skinny_nt_act(R, N, K, ptr(x), x.stride(0), ptr(weight), weight.stride(0), ptr(b), ptr(y), N, act,
+                                            stream_of(x)), "pdgn_skinny_nt_act")
+        ctx.save_for_backward(x, weight, y)
+        ctx.cfg = (R, K, N, act, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, y = ctx.saved_tensors
+        R, K, N, act, has_bias = ctx.cfg
+        dy = dy.contiguous()
+        if not any(ctx.needs_input_grad[1:3]):
+            if not ctx.needs_input_grad[0]:
+                return None, None, None, None
+            return (skinny_nn_masked(dy, y, act, weight) if act else dy.matmul(weight)), None, None, None
+        dev = dy.device
+        dpre = torch.empty((R, N), dtype=F32, device=dev)
+        dW = torch.empty((N, K), dtype=F32, device=dev) if ctx.needs_input_grad[1] else None
+        dbias = torch.empty(N, dtype=F32, device=dev) if has_bias and ctx.needs_input_grad[2] else None
+        check(_lib.lib().pdgn_small_mlp_backward(R, K, N, act, 0, ptr(x), ptr(dy), ptr(y), None, None, None, ptr(dpre), None, None,
+                                                 ptr(dbias), ptr(dW), stream_of(dy)), "pdgn_small_mlp_backward")
+        dx = skinny_nn(dpre, weight) if ctx.needs_input_grad[0] else None
+        return dx, dW, dbias, None
+
+
+_SKINNY_HEAD = os.environ.get("PDGN_SKINNY_HEAD", "1") == "1"    # A/B switch
+
+
 def small_sequential(seq, x, training):
     """nn.Sequential of (Linear [, BatchNorm1d] [, LeakyReLU | ReLU]) groups applied to x (R, K): on a GPU, with at
     most 64 rows, every group is one fused launch (SmallLinearBNAct); otherwise the modules run as they are."""
@@ -960,6 +1000,8 @@ def small_sequential(seq, x, training):
                                        bn.running_mean if bn.track_running_stats else None,
                                        bn.running_var if bn.track_running_stats else None, 1 if use_batch else 2,
                                        bn.momentum if bn.momentum is not None else 0.1, bn.eps, act)
+        elif _SKINNY_HEAD and _sk_ok(x, lin.weight) and lin.in_features % 4 == 0:
+            x = SkinnyLinearAct.apply(x, lin.weight, lin.bias, act)
         else:
             x = SmallLinearBNAct.apply(x, lin.weight, lin.bias, None, None, None, None, 0, 0.0, 0.0, act)
     return x

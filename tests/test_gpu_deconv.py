@@ -1227,10 +1227,12 @@ def test_pre_bias_folded_into_batchnorm(training):
                                        rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("frozen", [True, False])
 @pytest.mark.parametrize("R,dims", [(35, (1024, 512, 256, 64, 1)), (35, (256, 128, 64, 1)), (8, (512, 256, 64, 1)), (3, (20, 12, 1))])
-def test_frozen_head_input_gradient_in_one_launch_per_layer(R, dims):
-    """A discriminator's nn.Linear + LeakyReLU head with FROZEN parameters (the generator's update): the input gradient through
-    pdgn_skinny_nn_masked (dy * act'(pre) applied on load) against torch's own backward of the same nn.Sequential."""
+def test_discriminator_head_on_the_skinny_kernels(R, dims, frozen):
+    """A discriminator's nn.Linear + LeakyReLU head (no BatchNorm) through fused.small_sequential: forward on pdgn_skinny_nt_act;
+    with FROZEN parameters (the generator's update) the input gradient is one launch per layer (pdgn_skinny_nn_masked, act' applied
+    on load); trainable, pdgn_small_mlp_backward with the activation's derivative read off y.  Against torch's own nn.Sequential."""
     import copy
     import torch.nn as nn
     from pdgn_amd import fused
@@ -1242,7 +1244,7 @@ def test_frozen_head_input_gradient_in_one_launch_per_layer(R, dims):
     ref = nn.Sequential(*layers).cuda()
     mine = copy.deepcopy(ref)
     for p in mine.parameters():
-        p.requires_grad_(False)
+        p.requires_grad_(not frozen)
     x = torch.randn(R, dims[0], device="cuda")
     xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
     t = torch.randn(R, dims[-1], device="cuda")
@@ -1253,6 +1255,10 @@ def test_frozen_head_input_gradient_in_one_launch_per_layer(R, dims):
     (yb * t).sum().backward()
     scale = xb.grad.abs().max().item()
     assert (xa.grad - xb.grad).abs().max().item() <= 1e-4 * scale
+    if not frozen:
+        for (n1, p1), (n2, p2) in zip(mine.named_parameters(), ref.named_parameters()):
+            scale = max(p2.grad.abs().max().item(), 1e-6)
+            assert (p1.grad - p2.grad).abs().max().item() <= 1e-4 * scale + 1e-7, n1
 
 
 @pytest.mark.parametrize("R,dims,training", [(35, (128, 256, 256), True), (35, (64, 64, 512), True), (6, (32, 48), True),
