@@ -14,6 +14,8 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_bench -- python3
 cp $(find $OUT/kt_bench -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_bench_kernel_stats.csv
 python3 tools/step_kernels.py $OUT/kt_bench 8 > $OUT/${TAG}_step_kernels.txt
 python3 tools/main_chain.py $OUT/kt_bench 6 > $OUT/${TAG}_main_chain.txt
+python3 tools/side_queues.py $OUT/kt_bench 6 22 > $OUT/${TAG}_side_queues.txt 2>&1
+python3 tools/wait_gap.py $OUT/kt_bench 2 > $OUT/${TAG}_wait_gap.txt 2>&1
 MS=$(python3 -c "import json,sys; print(json.load(open(sys.argv[1]))[\"ms_per_step\"])" $OUT/${TAG}_bench_full.json)
 python3 tools/queue_timeline.py $OUT/kt_bench $MS > $OUT/${TAG}_queue_timeline.txt 2>&1
 # the roofline kernels alone
