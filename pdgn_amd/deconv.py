@@ -290,6 +290,23 @@ class _ConvBN(nn.Module):
         self.bn = nn.BatchNorm2d(cout)
 
 
+class _XyzTaps(torch.autograd.Function):
+    """conv_xyz's (16, 6) kernel over cat([p_i, p_j - p_i]) (models/PDGNet_v2.py:559-566) as the two 3-column maps of the
+    re-association: rows 0-15 act on the neighbour p_j (W[:, 3:]), rows 16-31 on the centre p_i (W[:, :3] - W[:, 3:]).  Two launches
+    forward and two backward (torch's cat / slice / sub autograd: eleven)."""
+
+    @staticmethod
+    def forward(ctx, Wx):
+        a = Wx[:, 3:]
+        return torch.cat([a, Wx[:, :3] - a], 0)
+
+    @staticmethod
+    def backward(ctx, g):
+        n = g.shape[0] // 2
+        g1, g2 = g[:n], g[n:]
+        return torch.cat([g2, g1 - g2], 1)
+
+
 class PointDeconv(nn.Module):
     """x (B,Fin,N) [, pc (B,3,N)] -> (B,Fout,2N).  ``bilateral=False``: upsample_edgeConv
     (:547-588); ``bilateral=True``: bilateral_upsample_edgeConv (:590-650)."""
@@ -425,7 +442,7 @@ class PointDeconv(nn.Module):
         w = None
         if self.bilateral:
             Wx = _w2d(self.conv_xyz[0])                   # (16, 6)
-            Yx = linear_cl(pct.reshape(B * N, 3), torch.cat([Wx[:, 3:], Wx[:, :3] - Wx[:, 3:]], 0)).view(B, N, -1)
+            Yx = linear_cl(pct.reshape(B * N, 3), _XyzTaps.apply(Wx)).view(B, N, -1)
             (xyz_pre,) = EdgeGatherSum.apply(Yx, idx, ((1, k, 16, 0, 16),), self.conv_xyz[0].bias)
             xyzf = bn_act(xyz_pre.view(-1, 16), self.conv_xyz[1], training)
             h = bn_act(outs[2].view(-1, 16), self.conv_fea[1], training, mul=xyzf)   # w_fea * w_xyz :632

@@ -523,6 +523,7 @@ class LinearCL(Function):
 # ---------------------------------------------------------------------------------------------------------------
 # Products with a per-sample operand (R <= 64 rows: the batch) on csrc/skinny.hip instead of the BLAS library's skinny solutions.
 _FROZEN_HEAD = os.environ.get("PDGN_FROZEN_HEAD", "1") == "1"  # A/B switch: frozen small layers' input gradient in one launch
+_SK_NN_MIN_K = int(os.environ.get("PDGN_SKINNY_NN_MINK", "2048"))   # shorter reductions of dx = dy W go to the BLAS library
 _SKINNY = os.environ.get("PDGN_SKINNY", "1") == "1"           # A/B switch: 0 = torch's matmul for the 35-row layers
 
 
@@ -549,9 +550,9 @@ def skinny_nn(a, w):
     N = w.shape[1]
     # long reductions only (dconst = dYc WcatC: K = 6432, 12832: 14-22 us against the library's 25-34); for the short ones
     # (dx of the small layers, K <= 1024) the library's 32 x 32 tiles take 4-7 us and this kernel's join + atomics 11-12
-    if not (_sk_ok(a, w) and N % 4 == 0 and K >= 2048):
+    if not (_sk_ok(a, w) and N % 4 == 0 and K >= _SK_NN_MIN_K):
         return a.matmul(w)
-    out = torch.zeros((R, N), dtype=F32, device=a.device)          # K slices add into it
+    out = _zeros((R, N), a.device)                                 # K slices add into it
     check(_lib.lib().pdgn_skinny_nn(R, N, K, ptr(a), a.stride(0), ptr(w), w.stride(0), ptr(out), N, stream_of(a)), "pdgn_skinny_nn")
     return out
 

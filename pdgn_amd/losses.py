@@ -9,6 +9,7 @@ from ._fn import Function
 
 from . import _lib, pointops
 from ._lib import check, ptr, require, stream_of
+from .fused import _zeros
 
 F32, I32 = torch.float32, torch.int32
 
@@ -148,7 +149,7 @@ class LocalStats(Function):
         xyz, idx = ctx.saved_tensors
         b, n, _ = xyz.shape
         _, m, k = idx.shape
-        dxyz = torch.zeros_like(xyz)
+        dxyz = _zeros(tuple(xyz.shape), xyz.device)           # (a slice of the backward pass's zero arena: no fill launch)
         dmu, dcov = dmu.contiguous(), dcov.contiguous()
         check(_lib.lib().pdgn_local_stats_backward(b, n, m, k, ptr(xyz), ptr(idx), ptr(dmu), ptr(dcov), ptr(dxyz),
                                                    stream_of(xyz)), "pdgn_local_stats_backward")
