@@ -224,6 +224,13 @@ int pdgn_dense_bn_maxpool_input_grad(int b, int n, int c, int k, int act, const 
                                      const int32_t *yarg, const float *stats, const float *h, int ldh,
                                      const float *W, int ldw, float *scratch, float *dh, pdgn_stream_t stream);
 
+/* Column sums per group of rows: out[g, c] = sum over rows g*group_rows .. (g+1)*group_rows - 1 of x[r, c]; x (groups*group_rows, c)
+ * pitch ldx (16-byte aligned rows), c a power of two in 16 .. 1024, out (groups, c) contiguous and ZERO on entry.  The bias
+ * gradients torch's autograd takes with sum(dim=...) behind nn.Conv1d / nn.Conv2d layers that no BatchNorm follows
+ * (models/PDGNet_v2.py:835-862 heads, :604-618 per-sample terms of the edge convolutions). */
+int pdgn_group_colsum(long long groups, long long group_rows, int c, const float *x, long long ldx, float *out,
+                      pdgn_stream_t stream);
+
 /* Softmax over the k neighbour slots fused with the slot/channel interleave of
  * models/PDGNet_v2.py:634-641: h (m,k,c) -> w (m, k/2, 2c) with w[m,p,2c'+j] = softmax_s(h[m,:,c'])[s=(k/2)j+p].
  * k even, k <= 32. */

@@ -1303,3 +1303,59 @@ extern "C" int pdgn_dense_bn_maxpool_input_grad(int b, int n, int c, int k, int 
     return pdgn_dense_bn_maxpool_backward(b, n, c, k, act, x, dout, yarg, stats, h, ldh, W, ldw, scratch, dh, nullptr, 4, nullptr,
                                           stream);
 }
+
+// ---------------------------------------------------------------------------- column sums per group of rows
+// out[g, c] += sum over the rows r of group g (rows g*group_rows .. ) of x[r, c]  (out zero on entry; c a power of two, 16 .. 1024;
+// x pitch ldx, 16-byte aligned rows).  The bias gradients that are not analytically zero (layers without a BatchNorm behind them:
+// the heads' convolutions, the per-sample biases of the re-associated edge convolutions, models/PDGNet_v2.py:835-862, :604-618)
+// and the per-sample sums of the heads' adjoint -- 21 at::native reduce kernels per iteration on the issuing stream before.
+__global__ __launch_bounds__(256) void group_colsum_kernel(long long group_rows, int C, const float *__restrict__ x, long long ldx,
+                                                           float *__restrict__ out) {
+    __shared__ float4 red[256];
+    const int kg = C / 4, per_pass = kg < 256 ? kg : 256;            // column groups handled per pass of the block
+    const int cgl = threadIdx.x % per_pass, rl = threadIdx.x / per_pass, nrl = 256 / per_pass;
+    const long long g = blockIdx.y;
+    const long long per = (group_rows + gridDim.x - 1) / gridDim.x, r0 = blockIdx.x * per, r1 = min(group_rows, r0 + per);
+    const float *X = x + g * group_rows * ldx;
+    for (int c0 = 0; c0 < kg; c0 += per_pass) {
+        const int cg = c0 + cgl;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (long long r = r0 + rl; r < r1; r += 8 * nrl) {
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const long long rr = r + (long long)u * nrl;
+                v[u] = rr < r1 ? *reinterpret_cast<const float4 *>(X + rr * ldx + cg * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+        }
+        __syncthreads();
+        red[threadIdx.x] = acc;
+        __syncthreads();
+        if (rl == 0) {
+            for (int q = 1; q < nrl; ++q) {
+                const float4 v = red[q * per_pass + cgl];
+                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            }
+            float *o = out + g * C + cg * 4;
+            if (gridDim.x == 1) *reinterpret_cast<float4 *>(o) = acc;
+            else { atomicAdd(o, acc.x); atomicAdd(o + 1, acc.y); atomicAdd(o + 2, acc.z); atomicAdd(o + 3, acc.w); }
+        }
+    }
+}
+
+// out (groups, c) contiguous, ZERO on entry when a group is split over several workgroups (always pass it zeroed).
+extern "C" int pdgn_group_colsum(long long groups, long long group_rows, int c, const float *x, long long ldx, float *out,
+                                 pdgn_stream_t stream) {
+    if (groups < 1 || group_rows < 1 || c < 16 || c > 1024 || (c & (c - 1)) || ldx < c || ldx % 4 || ((uintptr_t)x & 15) ||
+        ((uintptr_t)out & 15) || groups > 65535)
+        return PDGN_ERR_INVALID;
+    const int kg = c / 4, nrl = kg < 256 ? 256 / kg : 1;
+    long long splits = 1024 / groups;                               // ~1024 workgroups, each at least 8 rounds of its row lanes
+    const long long max_splits = group_rows / (8LL * nrl * 8) > 0 ? group_rows / (8LL * nrl * 8) : 1;
+    splits = splits < 1 ? 1 : (splits > max_splits ? max_splits : splits);
+    hipLaunchKernelGGL(group_colsum_kernel, dim3((unsigned)splits, (unsigned)groups), dim3(256), 0, (hipStream_t)stream, group_rows, c, x,
+                       ldx, out);
+    return pdgn_launch_status();
+}

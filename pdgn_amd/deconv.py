@@ -30,7 +30,7 @@ from . import streams as _streams
 from ._lib import check, ptr, require, stream_of
 from .fused import (Planes, split_planes, skinny_linear, _zeros, bilateral_weighting, bn_act,  # noqa: F401
                     small_sequential, bn_act_maxpool, bn_softmax_slots_permute, flush_bn_counters,  # noqa: F401
-                    has_zero_colsum, linear_cl, softmax_slots_permute, DenseInput)
+                    has_zero_colsum, linear_cl, softmax_slots_permute, DenseInput, group_colsum)
 
 F32, I32 = torch.float32, torch.int32
 _KNN_OVERLAP = __import__("os").environ.get("PDGN_KNN_OVERLAP", "1") == "1"
@@ -167,7 +167,7 @@ class EdgeGatherSum(Function):
                 if hb == 2 and offc >= 0:
                     # per-sample bias: sum over (n, p) of dout = sum over n of the centre columns the kernel just
                     # wrote (dY[b,j,offc+c] = sum_p dout[b,j,p,c]) -- P times less data than dout itself
-                    dbias.append(dY[:, :, offc:offc + C].sum(dim=1))
+                    dbias.append(group_colsum(dY.view(b * n, ldy)[:, offc:offc + C], n))
                 else:
                     dbias.append(_dbias(dout, hb))
             return (dY, None, None) + tuple(dbias)
@@ -186,6 +186,9 @@ def _dbias(dout, kind):
         return None
     if kind == 3:                                  # feeds a training-mode BatchNorm: identically zero (fused.py)
         return _zeros((dout.shape[-1],), dout.device)
+    C = dout.shape[-1]
+    if dout.is_contiguous():
+        return group_colsum(dout.view(-1, C))[0] if kind == 1 else group_colsum(dout.view(-1, C), dout.shape[1] * dout.shape[2])
     return dout.sum(dim=(0, 1, 2)) if kind == 1 else dout.sum(dim=(1, 2))
 
 

@@ -119,6 +119,24 @@ def _zeros(shape, device):
     return v
 
 
+_GROUP_COLSUM = os.environ.get("PDGN_GROUP_COLSUM", "1") == "1"  # A/B switch: 0 = torch's sum(dim=...) for the bias gradients
+
+
+def group_colsum(x2d, group_rows=None):
+    """Column sums of x2d (rows, C) per group of `group_rows` consecutive rows (None: all rows) -> (rows / group_rows, C), on
+    pdgn_group_colsum (one launch into the backward pass's zero arena); torch's reduction for shapes it does not take."""
+    rows, C = x2d.shape
+    gr = rows if group_rows is None else int(group_rows)
+    if not (_GROUP_COLSUM and x2d.is_cuda and x2d.dtype == F32 and x2d.stride(1) == 1 and x2d.stride(0) % 4 == 0
+            and x2d.data_ptr() % 16 == 0 and 16 <= C <= 1024 and (C & (C - 1)) == 0 and gr > 0 and rows % gr == 0
+            and rows // gr <= 65535):
+        return x2d.sum(dim=0, keepdim=True) if gr == rows else x2d.reshape(rows // gr, gr, C).sum(dim=1)
+    out = _zeros((rows // gr, C), x2d.device)
+    check(_lib.lib().pdgn_group_colsum(ctypes.c_longlong(rows // gr), ctypes.c_longlong(gr), C, ptr(x2d), ctypes.c_longlong(x2d.stride(0)),
+                                       ptr(out), stream_of(x2d)), "pdgn_group_colsum")
+    return out
+
+
 def _bn_stats(L, x, rows, C, g, b, pre_bias, running_mean, running_var, training, momentum, eps, partials=None):
     """[scale|shift|mean|invstd] of a BatchNorm over x (rows, C) -- batch statistics (+ running-stat update) in
     training, running statistics in eval.  pre_bias: see include/pdgn_hip.h (the producer's bias, left out of x)."""
@@ -506,7 +524,7 @@ class LinearCL(Function):
                 if want_db and zero_db:
                     db = _zeros((n,), dy.device)
             elif want_db:
-                db = _zeros((n,), dy.device) if zero_db else dy.sum(dim=0)
+                db = _zeros((n,), dy.device) if zero_db else group_colsum(dy)[0]
             return dx, dw, db, None, None, None
         if ctx.needs_input_grad[0]:
             if ctx.planes_t is not None and own and dy.shape[1] % 4 == 0:
@@ -516,7 +534,7 @@ class LinearCL(Function):
         if ctx.needs_input_grad[1]:
             dw = gemm_tn(dy, x) if own else dy.t().matmul(x)
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = _zeros((dy.shape[1],), dy.device) if zero_db else dy.sum(dim=0)
+            db = _zeros((dy.shape[1],), dy.device) if zero_db else group_colsum(dy)[0]
         return dx, dw, db, (dy if ctx.has_addend and ctx.needs_input_grad[3] else None), None, None
 
 
@@ -666,16 +684,16 @@ class HeadMLP(Function):
         check(L.pdgn_thin_nt_ex(ctypes.c_longlong(rows), k3, n3, ptr(dp), dp.stride(0), ptr(W3), 1, k3, None, ptr(dpre2), k3, None,
                                 ptr(y2), y2.stride(0), stream_of(x)), "pdgn_thin_nt_ex")
         dW2 = gemm_tn(dpre2, y1)
-        db2 = dpre2.sum(dim=0)
+        db2 = group_colsum(dpre2)[0]
         dpre1 = gemm_nt_ex(dpre2, W2, W2.stride(0), W2.shape[1], gate=y1, w_transposed=True)     # (dpre2 W2) * lrelu'(y1)
         w0x = W0[:, nc:]
         dx = gemm_nt_ex(dpre1, w0x, W0.stride(0), x.shape[1], w_transposed=True) if ctx.needs_input_grad[0] else None
-        drb = dpre1.view(B, M, -1).sum(dim=1)                                      # (B, 256): the per-sample term's gradient
+        drb = group_colsum(dpre1, M)                                               # (B, 256): the per-sample term's gradient
         dW0 = torch.empty_like(W0)
         skinny_tn(drb, g.contiguous(), out=dW0[:, :nc])                           # drb^T g straight into its column slice
         dW0[:, nc:].copy_(gemm_tn(dpre1, x))
         dg = skinny_nn(drb, W0[:, :nc]) if ctx.needs_input_grad[1] else None
-        return dx, dg, dW0, drb.sum(dim=0), dW2, db2, dW3, db3, None
+        return dx, dg, dW0, group_colsum(drb)[0], dW2, db2, dW3, db3, None
 
 
 _PLANES_MIN_ROWS = 4096        # below this a contraction is a few tiles: the split kernel's launches would cost more than they save

@@ -1227,6 +1227,23 @@ def test_pre_bias_folded_into_batchnorm(training):
                                        rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("groups,group_rows,C,pitch", [(1, 71680, 64, 0), (35, 2048, 256, 0), (1, 35, 256, 0), (35, 512, 128, 6432),
+                                                        (35, 10240, 16, 0), (3, 7, 1024, 0), (2, 100, 48, 0)])
+def test_group_colsum(groups, group_rows, C, pitch):
+    """pdgn_group_colsum (bias gradients / per-sample sums of the adjoints) against fp64 torch, also on a column slice of a wider
+    matrix (the per-sample biases of the edge convolutions) and on a channel count it leaves to torch."""
+    from pdgn_amd import fused
+    g = torch.Generator(device="cuda").manual_seed(groups * group_rows + C)
+    rows = groups * group_rows
+    full = torch.randn(rows, pitch or C, device="cuda", generator=g)
+    x = full[:, 8:8 + C] if pitch else full
+    got = fused.group_colsum(x, group_rows if groups > 1 else None)
+    ref = x.double().view(groups, group_rows, C).sum(dim=1) if not pitch else x.double().reshape(groups, group_rows, C).sum(dim=1)
+    assert got.shape == (groups, C)
+    bound = x.double().abs().reshape(groups, group_rows, C).sum(dim=1).max().item()
+    assert (got.double() - ref).abs().max().item() <= 2e-6 * bound
+
+
 @pytest.mark.parametrize("frozen", [True, False])
 @pytest.mark.parametrize("R,dims", [(35, (1024, 512, 256, 64, 1)), (35, (256, 128, 64, 1)), (8, (512, 256, 64, 1)), (3, (20, 12, 1))])
 def test_discriminator_head_on_the_skinny_kernels(R, dims, frozen):
