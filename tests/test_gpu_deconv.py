@@ -1158,6 +1158,14 @@ def test_last_layer_adjoint_without_the_dense_gradient(B, N, C, K, frozen):
         np.testing.assert_allclose(res["dense"][i], ref, rtol=1e-4, atol=1e-4 * scale, err_msg=names[i] + " (dense path)")
 
 
+def test_last_layer_adjoint_on_the_fp32_matrix_instructions():
+    """The closed-form adjoint issues its three products through pdgn_gemm_nt / pdgn_gemm_tn_big: the same entry under PDGN_GEMM=fp32."""
+    from pdgn_amd import _lib
+    _lib.set_gemm_mode("fp32")
+    test_last_layer_adjoint_without_the_dense_gradient(6, 256, 256, 128, False)
+    test_last_layer_adjoint_without_the_dense_gradient(4, 1024, 512, 256, True)
+
+
 def test_bias_feeding_training_batchnorm_gets_analytic_zero_grad():
     """sum_rows d(BN input) == 0 in training mode: the producer's bias gradient is returned as exact zeros and
     the full pass over dy is skipped; the skipped sum is rounding residue (checked here), eval mode is untouched."""
