@@ -81,7 +81,16 @@ __global__ __launch_bounds__(THIN_THREADS) void thin_k_kernel(long long m, int n
         *reinterpret_cast<float4 *>(part + (size_t)blockIdx.x * 3 * n + 2 * n + c4 * 4) = make_float4(pv[0], pv[1], pv[2], pv[3]);
 }
 
-// 16 lanes per row, each a float4 of the row per step; n <= 4 dot products reduced across the 16 lanes.
+// v + (v of the lane `CTRL` names inside the 16-lane DPP row; 0 where there is none): one v_add_f32 with a DPP operand
+template <int CTRL>
+__device__ __forceinline__ float thin_row_add(float v) {
+    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+
+// 16 lanes per row (= one DPP row), each a float4 of the row per step; the n <= 4 dot products are summed across the 16 lanes by
+// four row_shr adds each (the total lands in the row's last lane) -- as ds_bpermute butterflies they were 16 LDS-crossbar
+// operations per thread, more than the row's own load.  VECW: W has unit column stride and 16-byte aligned rows (float4 loads).
+template <bool VECW>
 __global__ __launch_bounds__(THIN_THREADS) void thin_n_kernel(long long m, int n, int k, const float *__restrict__ X, int ldx,
                                                               const float *__restrict__ W, int wrs, int wcs,
                                                               const float *__restrict__ bias, float *__restrict__ Y, int ldy) {
@@ -96,19 +105,31 @@ __global__ __launch_bounds__(THIN_THREADS) void thin_n_kernel(long long m, int n
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             if (j < n) {
+                if (VECW) {
+                    const float4 wv = *reinterpret_cast<const float4 *>(W + (size_t)j * wrs + k4 * 4);
+                    acc[j] = __fmaf_rn(x[0], wv.x, acc[j]);
+                    acc[j] = __fmaf_rn(x[1], wv.y, acc[j]);
+                    acc[j] = __fmaf_rn(x[2], wv.z, acc[j]);
+                    acc[j] = __fmaf_rn(x[3], wv.w, acc[j]);
+                } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) acc[j] = __fmaf_rn(x[e], W[(size_t)j * wrs + (size_t)(k4 * 4 + e) * wcs], acc[j]);
+                    for (int e = 0; e < 4; ++e) acc[j] = __fmaf_rn(x[e], W[(size_t)j * wrs + (size_t)(k4 * 4 + e) * wcs], acc[j]);
+                }
             }
         }
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-#pragma unroll
-        for (int off = 8; off > 0; off >>= 1) acc[j] += __shfl_xor(acc[j], off, 64);
+        acc[j] = thin_row_add<0x111>(acc[j]);                      // row_shr 1, 2, 4, 8: lane 15 of the row holds the sum
+        acc[j] = thin_row_add<0x112>(acc[j]);
+        acc[j] = thin_row_add<0x114>(acc[j]);
+        acc[j] = thin_row_add<0x118>(acc[j]);
     }
-    if (live && l < n) {
-        const float v = l == 0 ? acc[0] : l == 1 ? acc[1] : l == 2 ? acc[2] : acc[3];
-        Y[row * ldy + l] = v + (bias ? bias[l] : 0.f);
+    if (live && l == 15) {
+        float *y = Y + row * ldy;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (j < n) y[j] = acc[j] + (bias ? bias[j] : 0.f);
     }
 }
 
@@ -200,8 +221,12 @@ extern "C" int pdgn_thin_nt_ex(long long m, int n, int k, const float *X, int ld
     if (gate) return -3;
     if (n <= 4 && k % 4 == 0 && !stat_part) {
         if (!thin_aligned(X, ldx)) return -2;
-        hipLaunchKernelGGL(thin_n_kernel, dim3(cdiv(m, THIN_THREADS / 16)), dim3(THIN_THREADS), 0, s, m, n, k, X, ldx, W, wrs, wcs,
-                           bias, Y, ldy);
+        if (wcs == 1 && wrs % 4 == 0 && ((uintptr_t)W & 15) == 0)
+            hipLaunchKernelGGL(thin_n_kernel<true>, dim3(cdiv(m, THIN_THREADS / 16)), dim3(THIN_THREADS), 0, s, m, n, k, X, ldx, W, wrs,
+                               wcs, bias, Y, ldy);
+        else
+            hipLaunchKernelGGL(thin_n_kernel<false>, dim3(cdiv(m, THIN_THREADS / 16)), dim3(THIN_THREADS), 0, s, m, n, k, X, ldx, W, wrs,
+                               wcs, bias, Y, ldy);
         return pdgn_launch_status();
     }
     return -3;
