@@ -200,6 +200,13 @@ int pdgn_bn_act_backward(long long rows, int c, int act, int training, const flo
 long long pdgn_bn_maxpool_scratch_floats(int b, int c);
 int pdgn_bn_act_maxpool(int b, int n, int c, int act, const float *x, const float *stats, float *scratch,
                         float *ymax, int32_t *yarg, pdgn_stream_t stream);
+/* Training mode without statistics from the producer: batch statistics (stats (4c) out; running statistics updated as by pdgn_bn_stats)
+ * AND the pooled output in one pass over x -- the pass keeps per (sample, split, channel) the largest and the smallest x and picks by
+ * the sign of the channel's scale afterwards (act(scale x + shift) is monotone in x).  scratch: pdgn_bn_stats_maxpool_scratch_floats. */
+long long pdgn_bn_stats_maxpool_scratch_floats(int b, int c);
+int pdgn_bn_stats_act_maxpool(int b, int n, int c, int act, float eps, float momentum, const float *x, const float *gamma,
+                              const float *beta, const float *pre_bias, float *running_mean, float *running_var, float *scratch,
+                              float *stats, float *ymax, int32_t *yarg, pdgn_stream_t stream);
 /* Its adjoint in one streaming pass: dx (b*n, c) from dout (b, c); bsums (2c) = [dbeta | dgamma];
  * scratch: b*c + 2c floats. */
 int pdgn_bn_act_maxpool_backward(int b, int n, int c, int act, int training, const float *x,

@@ -902,6 +902,95 @@ __global__ void cl_max_finalize_kernel(int B, int C, const float *__restrict__ p
     yarg[e] = arg;
 }
 
+// Statistics AND extremes in one streaming pass: when the BatchNorm's statistics do not arrive from the producer's epilogue, the max-pool
+// tail would read x twice (statistics, then apply + max).  act(scale x + shift) is monotone in x with the sign of scale, so the pass
+// that sums x (shifted by row 0, as cl_stats_kernel) also keeps, per (sample, split, channel), the largest and the smallest x and their
+// rows; the finalisation picks one of them once the scale's sign is known.  (For the discriminators' last layer this is also cheaper
+// than statistics in the GEMM's epilogue: 66 us of DPP reductions at 71680 x 1024 x 256 against a pass that is bound by HBM anyway.)
+__global__ __launch_bounds__(BN_THREADS) void cl_stats_max_kernel(int N, int C, int cgb, const float *__restrict__ x,
+                                                                  float *__restrict__ part, float *__restrict__ pmax,
+                                                                  int32_t *__restrict__ pargmax, float *__restrict__ pmin,
+                                                                  int32_t *__restrict__ pargmin) {
+    __shared__ float4 red[4][BN_THREADS];
+    __shared__ int4 redi[2][BN_THREADS];
+    const int cgl = threadIdx.x % cgb, rlane = threadIdx.x / cgb, rl = BN_THREADS / cgb;
+    const int cgi = blockIdx.x * cgb + cgl;
+    const bool cok = cgi * 4 < C;
+    const int b = blockIdx.z, sp = blockIdx.y;
+    const int per = (N + MP_SPLIT - 1) / MP_SPLIT;
+    const int n0 = sp * per, n1 = min(N, n0 + per);
+    float s[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
+    float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}, mn[4] = {INFINITY, INFINITY, INFINITY, INFINITY};
+    int amx[4] = {n0, n0, n0, n0}, amn[4] = {n0, n0, n0, n0};
+    if (cok) {
+        float pv[4];
+        *reinterpret_cast<float4 *>(pv) = *reinterpret_cast<const float4 *>(x + cgi * 4);            // pivot: row 0 of x
+        const float *X = x + ((size_t)b * N) * C + cgi * 4;
+        for (int n = n0 + rlane; n < n1; n += rl) {
+            float v[4];
+            *reinterpret_cast<float4 *>(v) = *reinterpret_cast<const float4 *>(X + (size_t)n * C);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float d = v[j] - pv[j];
+                s[j] += d;
+                q[j] = __fmaf_rn(d, d, q[j]);
+                if (v[j] > mx[j]) { mx[j] = v[j]; amx[j] = n; }
+                if (v[j] < mn[j]) { mn[j] = v[j]; amn[j] = n; }
+            }
+        }
+    }
+    red[0][threadIdx.x] = make_float4(s[0], s[1], s[2], s[3]);
+    red[1][threadIdx.x] = make_float4(q[0], q[1], q[2], q[3]);
+    red[2][threadIdx.x] = make_float4(mx[0], mx[1], mx[2], mx[3]);
+    red[3][threadIdx.x] = make_float4(mn[0], mn[1], mn[2], mn[3]);
+    redi[0][threadIdx.x] = make_int4(amx[0], amx[1], amx[2], amx[3]);
+    redi[1][threadIdx.x] = make_int4(amn[0], amn[1], amn[2], amn[3]);
+    __syncthreads();
+    if (rlane || !cok) return;
+    for (int k = 1; k < rl; ++k) {
+        const int t = k * cgb + cgl;
+        const float *a = &red[0][t].x, *bq = &red[1][t].x, *c2 = &red[2][t].x, *d2 = &red[3][t].x;
+        const int *i2 = &redi[0][t].x, *j2 = &redi[1][t].x;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            s[j] += a[j];
+            q[j] += bq[j];
+            if (c2[j] > mx[j] || (c2[j] == mx[j] && i2[j] < amx[j])) { mx[j] = c2[j]; amx[j] = i2[j]; }
+            if (d2[j] < mn[j] || (d2[j] == mn[j] && j2[j] < amn[j])) { mn[j] = d2[j]; amn[j] = j2[j]; }
+        }
+    }
+    const size_t blk = (size_t)b * MP_SPLIT + sp;
+    float *P = part + blk * 2 * C;
+    *reinterpret_cast<float4 *>(P + cgi * 4) = make_float4(s[0], s[1], s[2], s[3]);
+    *reinterpret_cast<float4 *>(P + C + cgi * 4) = make_float4(q[0], q[1], q[2], q[3]);
+    const size_t o = blk * C + cgi * 4;
+    *reinterpret_cast<float4 *>(pmax + o) = make_float4(mx[0], mx[1], mx[2], mx[3]);
+    *reinterpret_cast<int4 *>(pargmax + o) = make_int4(amx[0], amx[1], amx[2], amx[3]);
+    *reinterpret_cast<float4 *>(pmin + o) = make_float4(mn[0], mn[1], mn[2], mn[3]);
+    *reinterpret_cast<int4 *>(pargmin + o) = make_int4(amn[0], amn[1], amn[2], amn[3]);
+}
+
+// per (sample, channel): the extreme the scale's sign asks for over the MP_SPLIT splits (in row order: the first one wins)
+__global__ void cl_max_pick_kernel(int B, int C, int act, const float *__restrict__ stats, const float *__restrict__ pmax,
+                                   const int32_t *__restrict__ pargmax, const float *__restrict__ pmin,
+                                   const int32_t *__restrict__ pargmin, float *__restrict__ ymax, int32_t *__restrict__ yarg) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= B * C) return;
+    const int b = e / C, c = e - b * C;
+    const float sc = stats[c], sh = stats[C + c];
+    const bool up = sc >= 0.f;
+    const float *pv = up ? pmax : pmin;
+    const int32_t *pa = up ? pargmax : pargmin;
+    float best = pv[((size_t)b * MP_SPLIT) * C + c];
+    int arg = pa[((size_t)b * MP_SPLIT) * C + c];
+    for (int s = 1; s < MP_SPLIT; ++s) {
+        const float v = pv[((size_t)b * MP_SPLIT + s) * C + c];
+        if (up ? v > best : v < best) { best = v; arg = pa[((size_t)b * MP_SPLIT + s) * C + c]; }
+    }
+    ymax[e] = act_fwd(__fmaf_rn(best, sc, sh), act);
+    yarg[e] = arg;
+}
+
 // per channel: dz[b] = dout[b]*act'(z at the argmax row); bsums = [sum_b dz | sum_b dz*xhat]; coef = [ca | cb].
 // A block is 16 channels x 16 sample lanes (the B gathers of a channel are dependent-latency loads: one thread per channel
 // walking all B of them took 105 us at B = 35, C = 1024).
@@ -998,6 +1087,29 @@ extern "C" int pdgn_bn_act_maxpool(int b, int n, int c, int act, const float *x,
     int32_t *parg = reinterpret_cast<int32_t *>(scratch + (size_t)b * MP_SPLIT * c);
     hipLaunchKernelGGL(cl_apply_max_kernel, dim3(gx, MP_SPLIT, b), dim3(BN_THREADS), 0, s, n, c, cgb, act, x, stats, pmax, parg);
     hipLaunchKernelGGL(cl_max_finalize_kernel, dim3(cdiv((long long)b * c, 256)), dim3(256), 0, s, b, c, pmax, parg, ymax, yarg);
+    return pdgn_launch_status();
+}
+
+// The same from x alone, in training mode: batch statistics (+ running-statistics update, as pdgn_bn_stats) and the pooled output
+// in ONE pass over x.  stats (4c) out.  scratch: pdgn_bn_stats_maxpool_scratch_floats(b, c) floats.
+extern "C" long long pdgn_bn_stats_maxpool_scratch_floats(int b, int c) { return 6LL * b * MP_SPLIT * c; }
+
+extern "C" int pdgn_bn_stats_act_maxpool(int b, int n, int c, int act, float eps, float momentum, const float *x, const float *gamma,
+                                         const float *beta, const float *pre_bias, float *running_mean, float *running_var,
+                                         float *scratch, float *stats, float *ymax, int32_t *yarg, pdgn_stream_t stream) {
+    if (b < 1 || n < 1 || c < 4 || c % 4 || act < 0 || act > 2 || b > 65535) return PDGN_ERR_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    int cgb, gx;
+    mp_geometry(c, &cgb, &gx);
+    const size_t bc = (size_t)b * MP_SPLIT * c;
+    float *part = scratch, *pmax = part + 2 * bc, *pmin = pmax + 2 * bc;
+    int32_t *pargmax = reinterpret_cast<int32_t *>(pmax + bc), *pargmin = reinterpret_cast<int32_t *>(pmin + bc);
+    hipLaunchKernelGGL(cl_stats_max_kernel, dim3(gx, MP_SPLIT, b), dim3(BN_THREADS), 0, s, n, c, cgb, x, part, pmax, pargmax, pmin,
+                       pargmin);
+    hipLaunchKernelGGL(cl_finalize_kernel, dim3(cdiv(c, FIN_CH)), dim3(FIN_CH * FIN_PL), 0, s, (long long)b * n, c, b * MP_SPLIT, eps,
+                       momentum, part, gamma, beta, pre_bias, running_mean, running_var, stats, x);
+    hipLaunchKernelGGL(cl_max_pick_kernel, dim3(cdiv((long long)b * c, 256)), dim3(256), 0, s, b, c, act, stats, pmax, pargmax, pmin,
+                       pargmin, ymax, yarg);
     return pdgn_launch_status();
 }
 

@@ -31,6 +31,7 @@ from ._lib import check, ptr, require, stream_of
 from .fused import (Planes, split_planes, skinny_linear, _zeros, bilateral_weighting, bn_act,  # noqa: F401
                     small_sequential, bn_act_maxpool, bn_softmax_slots_permute, flush_bn_counters,  # noqa: F401
                     has_zero_colsum, linear_cl, softmax_slots_permute, DenseInput, group_colsum)
+from .fused import _STATS_MAX as STATS_MAX  # noqa: F401
 
 F32, I32 = torch.float32, torch.int32
 _KNN_OVERLAP = __import__("os").environ.get("PDGN_KNN_OVERLAP", "1") == "1"

@@ -51,6 +51,7 @@ def clear_zero_colsum():
 # LinearCL's backward a zero-stride placeholder of dx's shape; the input gradient travels here, keyed like _ZERO_COLSUM.
 _INPUT_GRADS = {}
 _CLOSED_TAIL = os.environ.get("PDGN_CLOSED_TAIL", "1") == "1"    # A/B switch
+_STATS_MAX = os.environ.get("PDGN_STATS_MAX", "1") == "1"        # A/B switch: statistics + extremes of the max-pool tail in one pass
 _CLOSED_DW = os.environ.get("PDGN_CLOSED_DW", "1") == "1"        # A/B switch: also with a trainable layer (its weight gradient)
 
 
@@ -1039,14 +1040,24 @@ class BNActMaxPool(Function):
         dev = x.device
         L = _lib.lib()
         g, b = gamma.detach().contiguous(), beta.detach().contiguous()
-        stats = _bn_stats(L, x, rows, C, g, b, pre_bias, running_mean, running_var, training, momentum, eps, partials)
         ctx.has_pre_bias = pre_bias is not None
-        L.pdgn_bn_maxpool_scratch_floats.restype = ctypes.c_longlong
-        scr = torch.empty(L.pdgn_bn_maxpool_scratch_floats(B, C), dtype=F32, device=dev)
         ymax = torch.empty((B, C), dtype=F32, device=dev)
         yarg = torch.empty((B, C), dtype=torch.int32, device=dev)
-        check(L.pdgn_bn_act_maxpool(B, N, C, act, ptr(x), ptr(stats), ptr(scr), ptr(ymax), ptr(yarg), stream_of(x)),
-              "pdgn_bn_act_maxpool")
+        if training and partials is None and _STATS_MAX:
+            # no statistics from the producer: ONE pass over x for the statistics and the extremes (the sign of the scale picks later)
+            stats = torch.empty(4 * C, dtype=F32, device=dev)
+            pb = pre_bias.detach().contiguous() if pre_bias is not None else None
+            L.pdgn_bn_stats_maxpool_scratch_floats.restype = ctypes.c_longlong
+            scr = torch.empty(L.pdgn_bn_stats_maxpool_scratch_floats(B, C), dtype=F32, device=dev)
+            check(L.pdgn_bn_stats_act_maxpool(B, N, C, act, ctypes.c_float(eps), ctypes.c_float(momentum), ptr(x), ptr(g), ptr(b), ptr(pb),
+                                              ptr(running_mean), ptr(running_var), ptr(scr), ptr(stats), ptr(ymax), ptr(yarg),
+                                              stream_of(x)), "pdgn_bn_stats_act_maxpool")
+        else:
+            stats = _bn_stats(L, x, rows, C, g, b, pre_bias, running_mean, running_var, training, momentum, eps, partials)
+            L.pdgn_bn_maxpool_scratch_floats.restype = ctypes.c_longlong
+            scr = torch.empty(L.pdgn_bn_maxpool_scratch_floats(B, C), dtype=F32, device=dev)
+            check(L.pdgn_bn_act_maxpool(B, N, C, act, ptr(x), ptr(stats), ptr(scr), ptr(ymax), ptr(yarg), stream_of(x)),
+                  "pdgn_bn_act_maxpool")
         ctx.save_for_backward(x, stats, yarg)
         ctx.cfg = (B, N, C, act, bool(training))
         # dense layer in front known: the backward goes straight to that layer's input (and weight) gradient

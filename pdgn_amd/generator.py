@@ -238,7 +238,8 @@ class PointDiscriminator(nn.Module):
             h = _deconv.bn_act(y, self.fc1[i + 1], self.training, pre_bias=self.fc1[i].bias, partials=part)
         # last layer: BatchNorm1d + LeakyReLU + MaxPool1d(num_point) fused (the activated tensor is not written)
         w_last = _deconv._w2d(self.fc1[last])
-        y, part = _linear_stats(h, w_last, self.training)
+        # (no statistics in this GEMM's epilogue: the max-pool tail takes them in the pass that finds the extremes -- fused.BNActMaxPool)
+        y, part = _linear_stats(h, w_last, self.training and not _deconv.STATS_MAX)
         pooled = _deconv.bn_act_maxpool(y, self.fc1[last + 1], self.training, B, N, pre_bias=self.fc1[last].bias, partials=part,
                                         dense=_deconv.DenseInput(h, w_last))
         _deconv.flush_bn_counters()

@@ -1166,6 +1166,39 @@ def test_last_layer_adjoint_on_the_fp32_matrix_instructions():
     test_last_layer_adjoint_without_the_dense_gradient(4, 1024, 512, 256, True)
 
 
+@pytest.mark.parametrize("B,N,C", [(35, 2048, 1024), (4, 300, 64), (3, 17, 8)])
+def test_maxpool_tail_statistics_and_extremes_in_one_pass(B, N, C):
+    """bn_act_maxpool in training mode WITHOUT statistics from the producer: pdgn_bn_stats_act_maxpool keeps max and min of x per split
+    and picks by the sign of the channel's scale -- channels with negative and zero gamma included -- against the torch stand-in
+    (values, input / parameter gradients, running statistics)."""
+    from pdgn_amd.fused import bn_act_maxpool, flush_bn_counters
+    from torch_standins import bn_act_maxpool_torch
+    rng = np.random.default_rng(B * N + C)
+    x = torch.from_numpy((rng.standard_normal((B * N, C)) * 1.5 + 0.3).astype(np.float32))
+    gout = torch.from_numpy(rng.standard_normal((B, C)).astype(np.float32))
+    gamma = torch.from_numpy(rng.standard_normal(C).astype(np.float32))            # both signs
+    gamma[0] = 0.0
+    res = []
+    for impl, to in ((bn_act_maxpool, dev), (bn_act_maxpool_torch, lambda t: t.double())):
+        bn = torch.nn.BatchNorm1d(C)
+        fill_module(bn, salt=5)
+        with torch.no_grad():
+            bn.weight.copy_(gamma)
+        bn = bn.cuda() if impl is bn_act_maxpool else bn.double()
+        bn.train(True)
+        xi = to(x).requires_grad_(True)
+        y = impl(xi, bn, True, B, N)
+        y.backward(to(gout))
+        flush_bn_counters()
+        res.append([t.detach().cpu().double().numpy() for t in (y, xi.grad, bn.weight.grad, bn.bias.grad, bn.running_mean, bn.running_var)])
+    for name, a, b in zip(["y", "dx", "dgamma", "dbeta", "running_mean", "running_var"], *res):
+        if name == "dx":                                            # channel 0 (gamma = 0): every row ties, any of them may take the
+            a, b = a[:, 1:], b[:, 1:]                               # gradient (and with it dgamma[0] = sum dz * xhat at that row)
+        if name == "dgamma":
+            a, b = a[1:], b[1:]
+        np.testing.assert_allclose(a, b, rtol=1e-4, atol=1e-4 * max(1.0, np.abs(b).max()), err_msg=name)
+
+
 def test_bias_feeding_training_batchnorm_gets_analytic_zero_grad():
     """sum_rows d(BN input) == 0 in training mode: the producer's bias gradient is returned as exact zeros and
     the full pass over dy is skipped; the skipped sum is rounding residue (checked here), eval mode is untouched."""
