@@ -1295,11 +1295,14 @@ static size_t cf_scatter_lds(int n, int c) {
     return (((size_t)(n + maxd + c) * 2 + 15) & ~(size_t)15) + 256 * 4 + (size_t)c * 4;
 }
 
-// column sums of h (rows x K, K % 4 == 0, pitch ldh) added into hs (zero on entry)
-__global__ __launch_bounds__(256) void cf_colsum_kernel(long long rows, int K, const float *__restrict__ h, int ldh,
-                                                        float *__restrict__ hs) {
-    __shared__ float4 red[256];
-    const int kg = K / 4, cg = threadIdx.x % kg, rl = threadIdx.x / kg, nrl = 256 / kg;   // kg divides 256 (K = 16 .. 256, power of 2)
+// column sums of h (rows x K, K % 4 == 0, pitch ldh) added into hs (zero on entry).  1024 threads a workgroup (K / 4 column groups x
+// row lanes, eight loads in flight each) and at most 128 workgroups: every workgroup ends with K atomic adds onto the SAME K floats --
+// with 1024 workgroups those were 1024-deep chains per address and the kernel took 110 us inside the iteration for 73 MB.
+#define CFS_THREADS 1024
+__global__ __launch_bounds__(CFS_THREADS) void cf_colsum_kernel(long long rows, int K, const float *__restrict__ h, int ldh,
+                                                                float *__restrict__ hs) {
+    __shared__ float4 red[CFS_THREADS];
+    const int kg = K / 4, cg = threadIdx.x % kg, rl = threadIdx.x / kg, nrl = CFS_THREADS / kg;   // kg divides 1024 (K a power of two <= 256)
     const long long per = (rows + gridDim.x - 1) / gridDim.x, r0 = blockIdx.x * per, r1 = min(rows, r0 + per);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     for (long long r = r0 + rl; r < r1; r += 8 * nrl) {            // eight independent loads a round
@@ -1394,7 +1397,7 @@ extern "C" int pdgn_dense_bn_maxpool_backward(int b, int n, int c, int k, int ac
     }
     if (dW) {
         const long long rows = (long long)b * n;
-        hipLaunchKernelGGL(cf_colsum_kernel, dim3(rows >= 32768 ? 1024 : 256), dim3(256), 0, s, rows, k, h, ldh, hs);
+        hipLaunchKernelGGL(cf_colsum_kernel, dim3(rows >= 32768 ? 128 : (rows >= 8192 ? 64 : 16)), dim3(CFS_THREADS), 0, s, rows, k, h, ldh, hs);
         if ((rc = pdgn_launch_status())) return rc;
         if ((rc = pdgn_gemm_tn_big(rows, k, k, h, ldh, h, ldh, H, 1, stream))) return rc;          // H = h^T h (zeroed above)
         if ((rc = pdgn_gemm_nt(c, k, k, W, ldw, H, k, nullptr, nullptr, 0, T, k, nullptr, stream))) return rc;   // T = W H
@@ -1464,7 +1467,8 @@ extern "C" int pdgn_group_colsum(long long groups, long long group_rows, int c, 
         ((uintptr_t)out & 15) || groups > 65535)
         return PDGN_ERR_INVALID;
     const int kg = c / 4, nrl = kg < 256 ? 256 / kg : 1;
-    long long splits = 1024 / groups;                               // ~1024 workgroups, each at least 8 rounds of its row lanes
+    long long splits = 1024 / groups;                               // ~1024 workgroups, but <= 128 a group: their sums meet in atomics on
+    splits = splits > 128 ? 128 : splits;                           // the same C floats (1024-deep chains per address were the kernel's time)
     const long long max_splits = group_rows / (8LL * nrl * 8) > 0 ? group_rows / (8LL * nrl * 8) : 1;
     splits = splits < 1 ? 1 : (splits > max_splits ? max_splits : splits);
     hipLaunchKernelGGL(group_colsum_kernel, dim3((unsigned)splits, (unsigned)groups), dim3(256), 0, (hipStream_t)stream, group_rows, c, x,
