@@ -62,10 +62,25 @@ class DenseInput:
         self.h, self.w = h, w
 
 
+_NAN_SLOTS = {}                                                  # per device: (256 NaNs, next slot)
+
+
 def _placeholder_with_input_grad(rows, C, dh, dw, device):
-    tok = torch.empty(1, dtype=F32, device=device).expand(rows, C)
+    """A zero-stride (rows, C) view of ONE NaN: whoever reads it as a gradient -- anything but the LinearCL it is meant for --
+    produces NaNs, not plausible numbers.  The slots rotate so that placeholders pending at the same time (the
+    four discriminators inside one generator backward) have distinct keys."""
+    pool = _NAN_SLOTS.get(device)
+    if pool is None:
+        pool = _NAN_SLOTS[device] = [torch.full((256,), float("nan"), dtype=F32, device=device), 0]
+    i = pool[1]
+    pool[1] = (i + 1) % 256
+    tok = pool[0][i:i + 1].expand(rows, C)
     _INPUT_GRADS[tok.data_ptr()] = (weakref.ref(tok), (dh, dw))
     return tok
+
+
+def is_placeholder(dy):
+    return dy.dim() == 2 and dy.stride(0) == 0 and dy.stride(1) == 0 and dy.numel() > 1
 
 
 def take_input_grad(dy):
@@ -510,6 +525,9 @@ class LinearCL(Function):
         carried = take_input_grad(dy)
         if carried is not None:              # BNActMaxPool's backward already carried the gradient through this layer
             return carried[0], carried[1], None, None, None, None
+        if is_placeholder(dy):
+            raise RuntimeError("LinearCL.backward: received BNActMaxPool's gradient placeholder without the gradient it stands for "
+                               "(another consumer of the layer's output, a hook or a copy sits between the two nodes)")
         zero_db = ctx.has_bias and ctx.needs_input_grad[2] and has_zero_colsum(dy)
         dy = dy.contiguous()
         own = dy.is_cuda and dy.shape[0] >= _OWN_MIN_ROWS
@@ -1099,6 +1117,16 @@ class BNActMaxPool(Function):
                 _pre_bias_grad(ctx.has_pre_bias, C, x.device), None, None)
 
 
+def _is_plain_linear_output(y2d, dense):
+    """y2d is the direct output of LinearCL(dense.h, dense.w) without bias or addend (or needs no gradient at all)."""
+    fn = y2d.grad_fn
+    if fn is None:
+        return not y2d.requires_grad
+    return (type(fn).__name__ == "LinearCLBackward" and not getattr(fn, "has_bias", True) and not getattr(fn, "has_addend", True)
+            and len(fn.saved_tensors) == 2 and fn.saved_tensors[1].data_ptr() == dense.w.data_ptr()
+            and fn.saved_tensors[0].data_ptr() == dense.h.data_ptr())
+
+
 def _dense_input_ok(dense, x, rows, C, N):
     h, w = dense.h, dense.w
     return (x.is_cuda and h.dim() == 2 and w.dim() == 2 and h.shape[0] == rows and w.shape[0] == C and h.shape[1] == w.shape[1]
@@ -1112,7 +1140,10 @@ def _dense_input_ok(dense, x, rows, C, N):
 def bn_act_maxpool(x2d, bn, training, B, N, act="leaky_relu", pre_bias=None, partials=None, dense=None):
     """max over the N points of every sample of act(BN(x2d)); x2d (B*N, C) -> (B, C).  dense = DenseInput(h, W) when x2d is
     linear_cl(h, W) without bias / addend: with W and the BatchNorm frozen the backward then skips the dense gradient."""
+    y2d = x2d
     x2d, pre_bias = _fold_pre_bias(x2d, pre_bias, training)
+    if dense is not None and not (x2d is y2d and _is_plain_linear_output(y2d, dense)):
+        dense = None                         # the closed tail needs x2d to BE h W^T: the unmodified output of that LinearCL
     if x2d.shape[1] % 4:
         return bn_act(x2d, bn, training, act=act, pre_bias=pre_bias).view(B, N, -1).max(dim=1)[0]
     if training and bn.track_running_stats:

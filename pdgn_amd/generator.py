@@ -140,14 +140,12 @@ class PointGenerator(nn.Module):
         self.mlp1, self.mlp2 = _mlp_head(512 + 32), _mlp_head(512 + 64)
         self.mlp3, self.mlp4 = _mlp_head(512 + 128), _mlp_head(512)
 
-    def forward(self, z, idx=(None, None, None, None), stage_hook=None, feature_hook=None):
+    def forward(self, z, idx=(None, None, None, None), stage_hook=None):
         """`stage_hook(level, cloud)`, if given, is called as soon as the cloud of a level exists (the trainer starts
-        that level's discriminator update on another stream while the deeper levels are still being generated).
-        `feature_hook(level, xt)` is called with the input features of every block (the trainer hangs its early gradient
-        bucket on the deepest block's)."""
+        that level's discriminator update on another stream while the deeper levels are still being generated)."""
         s = self.begin(z)
         for lvl in range(4):
-            self.level(s, lvl, idx, stage_hook, feature_hook)
+            self.level(s, lvl, idx, stage_hook)
         return self.finish(s)
 
     # The forward in pieces (begin / level x 4 / finish): the trainer interleaves the levels of its two generator passes
@@ -157,13 +155,11 @@ class PointGenerator(nn.Module):
         xt = _small_seq(self.fc1, z, self.training).view(B, 32, self.base_points).transpose(1, 2).contiguous()    # (B,N0,32)
         return {"B": B, "xt": xt, "pct": None, "const": None, "clouds": [], "pending": (None, None)}
 
-    def level(self, s, lvl, idx=(None, None, None, None), stage_hook=None, feature_hook=None):
+    def level(self, s, lvl, idx=(None, None, None, None), stage_hook=None):
         B = s["B"]
         blocks = (self.bilateral1, self.bilateral2, self.bilateral3, self.bilateral4)
         heads = (self.mlp1, self.mlp2, self.mlp3, self.mlp4)
         xt, pct, const, clouds = s["xt"], s["pct"], s["const"], s["clouds"]
-        if feature_hook is not None:
-            feature_hook(lvl, xt)
         lvl_idx, lvl_ready = (idx[lvl], None) if idx[lvl] is not None else s["pending"]
         xs, x_ec, g = blocks[lvl].forward_cl(xt, pct, idx=lvl_idx, const=const, idx_ready=lvl_ready)
         s["pending"] = (None, None)
@@ -193,13 +189,20 @@ class PointGenerator(nn.Module):
         blocks = (self.bilateral1, self.bilateral2, self.bilateral3, self.bilateral4)
         return [(b.upsample_cov[0] if b.level == 1 else b.upsample_cov) for b in blocks]
 
-    def preassemble(self):
+    def preassemble(self, deepest_without_graph=False):
         """The four blocks' re-associated GEMM operands for the current parameters, built ONCE for all the forward passes
         that follow until the parameters change (the trainer's two generator passes of an iteration).  Block l > 1 sees
-        cat([xs broadcast, x_ec]): its first Fout(l-1) input channels are constant per sample (forward_cl's `const`)."""
+        cat([xs broadcast, x_ec]): its first Fout(l-1) input channels are constant per sample (forward_cl's `const`).
+        deepest_without_graph: the last block's operands are built under no_grad (they serve the no-grad pass; a pass with
+        grad enabled assembles its own inside its forward -- PointDeconv.assembled)."""
         decs = self._deconvs()
         for lvl, dec in enumerate(decs):
-            dec.preassemble(0 if lvl == 0 else dec.Fin - decs[lvl - 1].Fout)
+            Fc = 0 if lvl == 0 else dec.Fin - decs[lvl - 1].Fout
+            if deepest_without_graph and lvl == len(decs) - 1:
+                with torch.no_grad():
+                    dec.preassemble(Fc)
+            else:
+                dec.preassemble(Fc)
 
     def drop_preassembled(self):
         for dec in self._deconvs():

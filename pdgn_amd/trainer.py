@@ -48,12 +48,14 @@ class FlatGrads:
         if self.n_early == len(self.params):
             self.early_numel = off
         self._early_work, self._early_done = None, False
+        self._armed, self._arrived, self._hooks, self._group = False, 0, [], None
 
     def begin(self):
         """Before a backward: drop the old gradients (autograd then writes, never accumulates)."""
         for p in self.params:
             p.grad = None
         self._early_work, self._early_done = None, False
+        self._arrived = 0
         clear_zero_colsum()
         if self.params and self.params[0].is_cuda:
             reset_zero_arena(self.params[0].device, self)
@@ -83,13 +85,36 @@ class FlatGrads:
         for v, p in zip(views, params):
             p.grad = v
 
+    def arm_early(self, on=True, group=None):
+        """Let the backward itself start the early bucket's all-reduce: a post-accumulate-grad hook on every early
+        parameter counts the gradients that HAVE ARRIVED since begin(), and the one that completes the bucket calls
+        reduce_early().  Arrival, not a position in the graph, is the trigger: autograd runs a node created before the
+        forward (the re-associated operands of PointGenerator.preassemble) after everything of higher sequence number
+        that is ready, so "the backward has reached the block's input" does not say that the block's weight gradients
+        exist (the early all-reduce then ran on zero-filled slices while AccumulateGrad was still to write
+        them).  A parameter that receives no gradient in some backward simply leaves the bucket to all_reduce_mean()."""
+        self._armed, self._group = bool(on), group
+        if on and not self._hooks and self.n_early:
+            for p in self.params[:self.n_early]:
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._arrival))
+
+    def _arrival(self, _param):
+        if not self._armed or self._early_done:
+            return
+        self._arrived += 1
+        if self._arrived == self.n_early:
+            self.reduce_early(self._group)
+
     def reduce_early(self, group=None):
-        """Called from inside the backward once the early bucket's gradients exist: pack them and start their
+        """Called from inside the backward once the early bucket's gradients exist (arm_early): pack them and start their
         all-reduce (asynchronous: on RCCL's stream, underneath the rest of the backward).  all_reduce_mean() later
-        reduces the rest and joins.  No-op without a process group or without an early bucket."""
+        reduces the rest and joins.  No-op without a process group or without an early bucket, and REFUSED while a
+        gradient of the bucket is still missing (its slice would be zero-filled under a running collective)."""
         if self._early_done or self.n_early == 0 or not (dist.is_available() and dist.is_initialized()):
             return
         if _capturing(self.buf.device):
+            return
+        if any(p.grad is None for p in self.params[:self.n_early]):
             return
         self._pack(0, self.n_early)
         self._early_done = True
@@ -194,6 +219,8 @@ class PDGNTrainer:
         self._buckets = os.environ.get("PDGN_BUCKETS", "1") == "1"
         deepest = (list(self.G.bilateral4.parameters()) + list(self.G.mlp4.parameters())) if self._buckets and hasattr(self.G, "bilateral4") else None
         self.gradG = FlatGrads(self.G.parameters(), first=deepest)
+        if self.distributed and self._buckets:
+            self.gradG.arm_early()
         self.gradD = [FlatGrads(d.parameters()) for d in self.D]
         cap = self.device.type == "cuda"                     # device-side step counter: graph-capturable
         adam = lambda m: torch.optim.Adam(m.parameters(), lr=lr, betas=(0.5, 0.999), capturable=cap, fused=cap and os.environ.get("PDGN_FUSED_ADAM", "1") == "1")
@@ -387,7 +414,7 @@ class PDGNTrainer:
             # The reference lets lossG.backward() also fill the discriminators' .grad and throws
             # that away at the next zero_grad (:183); freezing D skips those weight-gradient GEMMs.
             self._freeze_D(True)
-            gen = self.G(self._z(st, "z2"), feature_hook=self._early_bucket_hook)
+            gen = self.G(self._z(st, "z2"))
             similar = self.similar_loss(gen)
             g_loss = [losses.mse_const(self.D[i](gen[i]), 1.0) for i in range(4)]
             adv = 1.2 * g_loss[0] + 1.2 * g_loss[1] + 1.2 * g_loss[2] + g_loss[3]
@@ -401,14 +428,6 @@ class PDGNTrainer:
             st["out"]["g_loss"], st["out"]["similar_loss"] = lossG.detach(), similar.detach()
         else:
             self._stepG.step()
-
-    def _early_bucket_hook(self, lvl, xt):
-        """PointGenerator feature hook: the gradient of the deepest block's input is the point of the backward at which
-        that block's (and its head's) parameter gradients are complete -- start their all-reduce there."""
-        if lvl == 3 and self.distributed and self._buckets and xt.requires_grad and not _capturing(self.device):
-            # (never inside a hipGraph capture: a collective cannot be captured, and the Python bookkeeping of the
-            # early bucket would not re-run on replay -- the graphed path reduces the whole buffer between its graphs)
-            xt.register_hook(lambda g: self.gradG.reduce_early())
 
     def _z(self, st, name):
         """Noise of a generator pass: the caller's tensor, or -- when it is None -- drawn on the
@@ -498,10 +517,14 @@ class PDGNTrainer:
         # parameters only: built once for both passes, with grad enabled -- pass #2's backward reaches the conv weights through
         # them.  (On the issuing stream: built on the idle kNN stream behind an event the iteration faulted at B = 35 --
         # the adjoint of the assembly then runs on that stream too -- and the four launches are ~60 us.)
+        # Under data parallelism with the early gradient bucket the DEEPEST block's operands are pre-assembled for pass #1
+        # only (no graph): pass #2 assembles them inside its forward, so that the adjoint of that assembly -- the conv
+        # weights' gradients, 69 % of the early bucket -- runs right behind the block's backward instead of at the very end
+        # (autograd orders ready nodes by creation: a node made before the forward goes last).
         pre_ok = hasattr(self.G, "preassemble") and os.environ.get("PDGN_PREASM", "1") == "1"
         if pre_ok:
             with torch.enable_grad():
-                self.G.preassemble()
+                self.G.preassemble(deepest_without_graph=self.distributed and self._buckets)
         if split:
             st["d_half"] = [None] * 4
             for level, side in enumerate(self._side):
@@ -541,7 +564,7 @@ class PDGNTrainer:
             with torch.cuda.stream(side):
                 g_loss[level] = losses.mse_const(self.D[level](cloud), 1.0)
 
-        gen = self.G(self._z(st, "z2"), stage_hook=tail if early else None, feature_hook=self._early_bucket_hook)
+        gen = self.G(self._z(st, "z2"), stage_hook=tail if early else None)
         mark("G(z2) forward")
         if not early:
             self._side_lp.wait_stream(main)

@@ -48,3 +48,21 @@ def test_pointdeconv_matches_reference(golden, deconv, name):
     mod.eval()
     with torch.no_grad():
         np.testing.assert_allclose(mod(x, pc, idx=idx).numpy(), g["y_eval"], rtol=1e-4, atol=2e-5)
+
+
+def test_linear_cl_refuses_a_bare_gradient_placeholder():
+    """BNActMaxPool's closed tail hands the dense layer a zero-stride placeholder and the real gradient through a side
+    table; a placeholder that arrives WITHOUT its entry (consumed elsewhere, another node in between) must raise, not be used."""
+    from pdgn_amd import fused
+    x = torch.randn(6, 4, requires_grad=True)
+    w = torch.randn(3, 4, requires_grad=True)
+    y = fused.LinearCL.apply(x, w, None, None, False, None)
+    tok = torch.full((1,), float("nan")).expand(6, 3)
+    with pytest.raises(RuntimeError, match="placeholder"):
+        y.backward(tok)
+    # ... and with its entry the carried gradients come out untouched
+    fused.clear_zero_colsum()
+    y = fused.LinearCL.apply(x, w, None, None, False, None)
+    dh, dw = torch.ones(6, 4), torch.ones(3, 4)
+    y.backward(fused._placeholder_with_input_grad(6, 3, dh, dw, x.device))
+    assert torch.equal(x.grad, dh) and torch.equal(w.grad, dw) and not fused._INPUT_GRADS

@@ -294,3 +294,53 @@ def test_bench_measurement_with_two_ranks_gloo():
     assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and line["config"]["global_batch"] == 8
     assert line["config"]["losses_finite"] is True and line["ms_per_step_min_rank"] <= line["ms_per_step_max_rank"]
     assert "error" not in json.dumps(line.get("executed_flops_per_step"))
+
+
+def _worker_late_gradient(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    from pdgn_amd.trainer import FlatGrads
+    res = {}
+    for mode in ("bucketed", "flat"):
+        torch.manual_seed(3)
+        w0 = torch.nn.Parameter(torch.randn(5, 6))          # a shallow layer (late gradients)
+        w1 = torch.nn.Parameter(torch.randn(6, 4))          # deepest block, reached through an operand made BEFORE the forward
+        w2 = torch.nn.Parameter(torch.randn(6, 4))          # deepest block, used directly
+        fg = FlatGrads([w0, w1, w2], first=[w1, w2] if mode == "bucketed" else None)
+        if mode == "bucketed":
+            fg.arm_early()
+        fg.begin()
+        wa = w1 * 2.0                                        # the "pre-assembled" operand: lowest sequence number of the graph
+        x = torch.randn(7, 5, generator=torch.Generator().manual_seed(50 + rank))
+        h = torch.tanh(x @ w0)
+        seen = {}
+        # what the round-4 trigger did: fire when the backward reaches the deepest block's input
+        h.register_hook(lambda g: seen.update(at_input=[p.grad is not None for p in (w1, w2)]))
+        ((h @ wa).sum() + (h @ w2).pow(2).sum()).backward()
+        res[mode + "_early"] = bool(fg._early_done)
+        fg.pack()
+        fg.all_reduce_mean()
+        res[mode] = torch.cat([p.grad.reshape(-1) for p in (w0, w1, w2)]).numpy()
+        res[mode + "_at_input"] = np.array(seen["at_input"])
+    np.savez(os.path.join(out_dir, "late%d.npz" % rank), **res)
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_early_bucket_waits_for_gradients_that_arrive_late_gloo():
+    """a weight reached through a node created before the forward (PointGenerator.preassemble) gets its
+    gradient AFTER the backward has passed its block's input.  The early bucket is started by the arrival of its last
+    gradient (FlatGrads.arm_early), so it equals the flat all-reduce whatever order autograd picks."""
+    world = 2
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker_late_gradient, args=(world, _free_port(), d), nprocs=world, join=True)
+        r = [dict(np.load(os.path.join(d, "late%d.npz" % i))) for i in range(world)]
+    for x in r:
+        assert bool(x["bucketed_early"]) and not bool(x["flat_early"])
+        # the situation the test is about: at the block's input w1's gradient does not exist yet
+        assert not bool(x["bucketed_at_input"][0])
+        np.testing.assert_array_equal(x["bucketed"], x["flat"])
+    np.testing.assert_array_equal(r[0]["bucketed"], r[1]["bucketed"])
+    assert not np.array_equal(r[0]["bucketed"], np.zeros_like(r[0]["bucketed"]))

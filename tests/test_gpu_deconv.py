@@ -1158,6 +1158,61 @@ def test_last_layer_adjoint_without_the_dense_gradient(B, N, C, K, frozen):
         np.testing.assert_allclose(res["dense"][i], ref, rtol=1e-4, atol=1e-4 * scale, err_msg=names[i] + " (dense path)")
 
 
+@pytest.mark.parametrize("case", ["no_fold", "bias_in_gemm", "other_producer", "second_consumer"])
+def test_closed_tail_is_refused_when_its_input_is_not_the_plain_dense_output(case, monkeypatch):
+    """the closed-form tail hands LinearCL a placeholder instead of dx, which is only right when the
+    max-pool's input IS h W^T, straight from that LinearCL.  With a bias added in between (PDGN_FOLD_BIAS=0), a bias or
+    addend inside the GEMM, or another producer, the dense path must be taken; every gradient then equals fp64 torch.
+    A second consumer of the GEMM's output would receive the placeholder: LinearCL raises instead of using NaNs."""
+    from pdgn_amd import fused
+    from torch_standins import bn_act_maxpool_torch
+    B, N, C, K = 4, 512, 128, 64
+    rng = np.random.default_rng(11)
+    h0 = torch.from_numpy(rng.standard_normal((B * N, K)).astype(np.float32))
+    W0 = torch.from_numpy((rng.standard_normal((C, K)) / np.sqrt(K)).astype(np.float32))
+    bias0 = torch.from_numpy(rng.standard_normal(C).astype(np.float32))
+    gout = torch.from_numpy(rng.standard_normal((B, C)).astype(np.float32))
+    if case == "no_fold":
+        monkeypatch.setattr(fused, "_NO_FOLD", True)
+    res = {}
+    for name in ("hip", "torch"):
+        to = (lambda t: t.double()) if name == "torch" else dev
+        bn = torch.nn.BatchNorm1d(C)
+        fill_module(bn, salt=7)
+        bn = (bn.double() if name == "torch" else bn.cuda()).train(True)
+        h = to(h0).requires_grad_(True)
+        W, bias = to(W0).requires_grad_(True), to(bias0).requires_grad_(True)
+        if name == "torch":
+            x = h @ W.t() + (bias if case == "bias_in_gemm" else 0.0)
+            y = bn_act_maxpool_torch(x * (2.0 if case == "other_producer" else 1.0), bn, True, B, N,
+                                     pre_bias=None if case == "bias_in_gemm" else bias)
+            extra = x.sum() if case == "second_consumer" else 0.0
+        else:
+            x = fused.linear_cl(h, W, bias if case == "bias_in_gemm" else None)
+            xin = x * 2.0 if case == "other_producer" else x
+            y = fused.bn_act_maxpool(xin, bn, True, B, N, pre_bias=None if case == "bias_in_gemm" else bias,
+                                     dense=fused.DenseInput(h, W))
+            if case != "second_consumer":
+                assert y.grad_fn.dense is None, "the closed form must be refused here"
+            extra = x.sum() if case == "second_consumer" else 0.0
+        if case == "second_consumer" and name == "hip":
+            # x feeds the max-pool tail (closed form: placeholder) AND a sum: autograd adds both gradients -> not the placeholder
+            # any more, the NaN spreads into the sum instead of a plausible number -- or LinearCL sees the bare placeholder and raises
+            try:
+                (y * to(gout)).sum().add(extra).backward()
+            except RuntimeError as e:
+                assert "placeholder" in str(e)
+            else:
+                assert not torch.isfinite(h.grad).all(), "a mis-routed placeholder must not produce finite gradients"
+            fused.clear_zero_colsum()
+            return
+        (y * to(gout)).sum().add(extra).backward()
+        fused.flush_bn_counters()
+        res[name] = [t.detach().cpu().double().numpy() for t in (y, h.grad, W.grad, bn.weight.grad, bn.bias.grad)]
+    for i, (a, ref) in enumerate(zip(res["hip"], res["torch"])):
+        np.testing.assert_allclose(a, ref, rtol=1e-4, atol=1e-4 * max(1e-6, np.abs(ref).max()), err_msg=str(i))
+
+
 def test_last_layer_adjoint_on_the_fp32_matrix_instructions():
     """The closed-form adjoint issues its three products through pdgn_gemm_nt / pdgn_gemm_tn_big: the same entry under PDGN_GEMM=fp32."""
     from pdgn_amd import _lib
