@@ -256,7 +256,8 @@ int pdgn_bn_softmax_slots_permute_mul(long long m, int k, int c, int act, const 
 /* Adjoint of pdgn_bn_softmax_slots_permute_mul in two passes over (x, u, w, dy): BatchNorm_u backward, slot-softmax
  * backward and BatchNorm_x backward with dW / dh kept in registers.  scratch: pdgn_bilateral_scratch_floats(m,k,c)
  * floats; bsums_x (2c) = [sum dz_x | sum dz_x*xhat] (= dbeta, dgamma of BN_x), bsums_u (4c) likewise for BN_u;
- * training = 0: running-statistics BatchNorms (no batch terms in dx / du).  c % 4 == 0. */
+ * training = 0: running-statistics BatchNorms (no batch terms in dx / du).  c % 4 == 0, k even, k <= 16 (all k slots of a
+ * channel pair live in registers; wider neighbourhoods: pdgn_bn_softmax_slots_permute + pdgn_bn_act_backward). */
 long long pdgn_bilateral_scratch_floats(long long m, int k, int c);
 int pdgn_bilateral_weighting_backward(long long m, int k, int c, int act, int training, const float *x,
                                       const float *stats_x, const float *u, const float *stats_u, const float *w,
@@ -319,9 +320,14 @@ int pdgn_gemm_nt_ps(long long m, int n, int k, const float *A, int lda, const un
 /* Process-wide switches of the dense contractions (read from PDGN_GEMM / PDGN_NT_CFG once, at first use).
  * pdgn_gemm_set_mode: 1 = bf16 matrix cores (default), 0 = fp32 matrix instructions, < 0 = query; returns the previous mode.
  * pdgn_gemm_set_config: -1 = the launch model's pick (default), 0 .. 3 = force a tile configuration (measurement / tests),
- * < -1 = query; returns the previous value. */
+ * < -1 = query; returns the previous value.
+ * pdgn_gemm_set_shape: the bf16 matrix instruction of the matrix-core mode: 32 = v_mfma_f32_32x32x16_bf16 for every launch, 16 =
+ * v_mfma_f32_16x16x32_bf16 for every launch (same tiles, same operands; results differ in the last bits), -1 = the built-in choice
+ * per instance class, 0x1000 | mask = a per-class mask (bit 4 * tile + class; gemm_x3.hip), anything else = query; returns the
+ * previous mask.  PDGN_X3_SHAPE / PDGN_X3_SHAPE16_MASK set the process default. */
 int pdgn_gemm_set_mode(int mode);
 int pdgn_gemm_set_config(int cfg);
+int pdgn_gemm_set_shape(int shape);
 int pdgn_gemm_nt(long long m, int n, int k, const float *A, int lda, const float *W, int ldw,
                  const float *bias, const float *addend, int ldadd, float *C, int ldc, float *stat_part,
                  pdgn_stream_t stream);

@@ -10,7 +10,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "libpdgn_hip.so")
-ABI_VERSION = 19
+ABI_VERSION = 20
 _lib = None
 
 
@@ -72,9 +72,20 @@ def gemm_mode():
 
 
 def set_gemm_mode(mode):
-    """Select the arithmetic of the dense contractions for this process; returns the previous mode's name."""
-    old = lib().pdgn_gemm_set_mode(0 if str(mode).startswith("f") else 1)
+    """Select the arithmetic of the dense contractions for this process: "x3" (bf16 matrix cores, the process default's matrix
+    instruction per instance class), "x3_16" / "x3_32" (every class on v_mfma_f32_16x16x32_bf16 / _32x32x16_bf16), "fp32" (fp32
+    matrix instructions); returns the previous mode's name ("x3" | "fp32")."""
+    m = str(mode)
+    old = lib().pdgn_gemm_set_mode(0 if m.startswith("f") else 1)
+    if not m.startswith("f"):
+        lib().pdgn_gemm_set_shape(16 if m.endswith("_16") else 32 if m.endswith("_32") else -1)
     return "x3" if old else "fp32"
+
+
+def set_gemm_shape(shape):
+    """Select the bf16 matrix instruction of the dense contractions (32: v_mfma_f32_32x32x16_bf16, 16: v_mfma_f32_16x16x32_bf16)
+    for this process; returns the previous shape.  Measurement / tests (PDGN_X3_SHAPE sets the process default)."""
+    return lib().pdgn_gemm_set_shape(int(shape))
 
 
 def set_gemm_config(cfg):

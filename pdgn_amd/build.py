@@ -15,6 +15,9 @@ ARCH = "gfx950"
 # __fmaf_rn chains that reproduce the reference's contracted arithmetic bit for bit.
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-ffp-contract=off",
          "-Wall", "-Wno-unused-function"]
+# gemm_x3.hip: a k chunk is ONE fully unrolled straight line of up to 192 matrix instructions with the conversion, load and LDS
+# work placed between them; the default budget of `#pragma unroll` (16 K IR instructions) refuses the 16x16x32 form's chunk
+EXTRA_FLAGS = {"gemm_x3.hip": ["-mllvm", "-pragma-unroll-threshold=200000"]}
 
 
 def sources():
@@ -45,7 +48,7 @@ def build(force=False, verbose=False):
                                          for h in os.listdir(CSRC) if h.endswith(".h")),
                 os.path.getmtime(os.path.join(os.path.dirname(HERE), "include", "pdgn_hip.h"))):
             continue
-        cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
+        cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(os.path.basename(src), []) + ["-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd))
         procs.append((src, subprocess.Popen(cmd)))

@@ -647,7 +647,8 @@ extern "C" int pdgn_bn_act_backward(long long rows, int c, int act, int training
 // owns one channel pair of x (= four interleaved channels of u) and walks points: it holds all k slots of the pair,
 // so dW, the softmax dot product and dh live in registers.  Two launches (batch sums, then the gradients) read
 // x, u, w, dy twice and write dx, du once: 10 passes instead of 16, nothing intermediate in HBM.
-#define BW_MAXK 32
+#define BW_MAXK 16                      // runtime-k instance: 16 slots in registers (32 needed 62 spilled registers); wider
+                                        // neighbourhoods take the unfused route (fused.bilateral_weighting)
 
 template <int KT, bool APPLY>
 __global__ __launch_bounds__(BN_THREADS) void bilateral_bwd_kernel(

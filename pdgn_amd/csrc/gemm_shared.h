@@ -78,8 +78,10 @@ static inline int nt_cus() {
 // through pdgn_gemm_set_mode / pdgn_gemm_set_config (no getenv per launch, no environment mutation at run time).
 //   mode: 1 = products on the bf16 matrix cores (gemm_x3.hip, default), 0 = fp32 matrix instructions (gemm_nt.hip; PDGN_GEMM=fp32)
 //   cfg:  -1 = the launch model's pick (default), 0 .. 3 = a forced tile configuration (PDGN_NT_CFG; measurement / tests)
+//   shape16: per instance class of gemm_x3.hip, which bf16 matrix instruction it runs on (PDGN_X3_SHAPE / PDGN_X3_SHAPE16_MASK;
+//   pdgn_gemm_set_shape)
 struct NtSwitches {
-    int mode, cfg, splitk;
+    int mode, cfg, splitk, shape16, shape16_default;
 };
 NtSwitches &nt_switches();
 

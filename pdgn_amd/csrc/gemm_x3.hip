@@ -48,6 +48,12 @@
 #ifndef X3_FENCE
 #define X3_FENCE 2                    // MFMAs per scheduling region of the main loop
 #endif
+#ifndef X3_DEFAULT_MASK
+#define X3_DEFAULT_MASK 0x000         // instance classes on v_mfma_f32_16x16x32_bf16 (nt_switches); PDGN_X3_SHAPE[16_MASK] / pdgn_gemm_set_shape override
+#endif
+#ifndef X3_FENCE16
+#define X3_FENCE16 2                  // the same for the 16x16x32 form
+#endif
 #ifndef X3_ABLATE
 #define X3_ABLATE 0                   // tools/x3_bench.hip (measurement only): 1 no conversion tasks, 2 no operand loads, 4 no stores, 8 no barrier, 16 no fragment reads, 32 no split arithmetic, 64 one LDS write per group, 128 direct (unstaged) result stores
 #endif
@@ -81,6 +87,23 @@ __device__ __forceinline__ f32x16 x3_mfma(const u32x4 a, const u32x4 b, const f3
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
+typedef float f32x4a __attribute__((ext_vector_type(4)));
+// the other bf16 shape, K = 32 in one instruction of 16 cycles: lane (i = l & 15, g = l >> 4) holds k = 8 g .. 8 g + 7 of row i of
+// either operand, D[row 4 g + r][column i] in register r
+__device__ __forceinline__ f32x4a x3_mfma16(const u32x4 a, const u32x4 b, const f32x4a c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+// XOR pattern of the LDS image's 16-B columns for row r.  MS = 32: (r >> 2) & 3, conflict-free for the 32-row fragment reads
+// (lanes of a ds_read_b128 group: rows 0-3, 12-15, 20-27 of ONE column).  MS = 16: the groups mix two columns (rows 0-3 and 12-15
+// of column g, rows 4-11 of column g ^ 1), which wants f(0), f(3), f(1) ^ 1, f(2) ^ 1 all different: f = (0, 2, 3, 1).  The
+// writers (b64: two whole rows per 16 lanes; b128: eight 16-B columns of two rows) are conflict-free under any row pattern.
+template <int MS>
+__device__ __forceinline__ unsigned x3_sw(unsigned r) {
+    const unsigned x = (r >> 2) & 3u;
+    return MS == 32 ? x : ((0x78u >> (2u * x)) & 3u);
+}
+
 // v + (v of the lane CTRL says), 0 where that lane is outside the row / the row is masked: one v_add_f32 with a DPP operand
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ float x3_dpp_add(float v) {
@@ -98,14 +121,33 @@ __device__ __forceinline__ float x3_half_wave_sum(float v) {
     return x3_dpp_add<0x142, 0xa>(v);
 }
 
+// Sum over the 16 lanes of each DPP row, valid in lanes 15, 31, 47, 63.
+__device__ __forceinline__ float x3_row_sum(float v) {
+    v = x3_dpp_add<0x111, 0xf>(v);
+    v = x3_dpp_add<0x112, 0xf>(v);
+    v = x3_dpp_add<0x114, 0xf>(v);
+    return x3_dpp_add<0x118, 0xf>(v);
+}
+
 // TM x TN blocks of 32 x 32 per wave, WM x WN waves, OCC workgroups per CU.
+// MS: the matrix instruction.  32: v_mfma_f32_32x32x16_bf16, two 16-deep k steps per chunk, fragments of step s + 1 read during
+// step s.  16: v_mfma_f32_16x16x32_bf16 on the SAME wave tile ((2 TM) x (2 TN) blocks of 16 x 16, a chunk is one k step of
+// 6 x 4 TM TN instructions of 16 cycles): same LDS image, same number of fragment reads and registers; under the chip's power
+// limit this shape holds a higher clock (MI355X_MICROARCH.md, DVFS give-back item 7; cdna_hip_programming.md rule 28).  The six
+// partial products of a chunk run in the order  ah wh, ah wm, ah wl, am wh, al wh, am wm  so that every fragment part is
+// re-read for the next chunk right after its last use in this one and is back before its first use there -- no second set
+// of fragment registers: Wm, Wl, Am during the first product, Al during the next two, and behind the barrier Ah and (when the
+// fifth product has issued) Wh of the next chunk.  The k sum of a chunk is taken by one instruction instead of two, and the
+// parts are added largest first: results differ from MS = 32 in the last bits (same error bound; tests/test_gpu_deconv.py
+// runs both against fp64).
 // PW: the second operand arrives PRE-SPLIT -- three bf16 planes [N][ldw] (p.Wp; plane stride p.wplane elements), written once per
 // weight by pdgn_split_bf16x3 with the same round-to-nearest remainders the loader computes: its quads are loaded part by part
 // (8 B per part and lane) and go to LDS as they are -- none of the 22 vector instructions per quad, a third of the split work
 // of a 256 x 128 tile.  Same parts, same products, same order: results are bit-identical to the unsplit operand's.
-template <int TM, int TN, int WM, int WN, int OCC, bool ATOMIC, bool WT, bool AT, bool EPI = false, bool PW = false>
+template <int TM, int TN, int WM, int WN, int OCC, bool ATOMIC, bool WT, bool AT, bool EPI = false, bool PW = false, int MS = 32>
 __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_x3_kernel(const NtArgs p) {
     static_assert(!PW || (!WT && !AT), "pre-split second operand: row-major (N x K) planes only");
+    static_assert(MS == 32 || MS == 16, "matrix instruction: 32x32x16 or 16x16x32");
     constexpr int NW = WM * WN, NTH = 64 * NW, BM = 32 * TM * WM, BN = 32 * TN * WN;
     // A chunk in LDS: per operand three bf16 parts of [rows][32 k] (64 B per row); the 16-B column c (k = 8c .. 8c + 7) of
     // row r is stored at position c ^ ((r >> 2) & 3): the b128 fragment reads -- serviced in the lane groups {0-3, 12-15, 20-27},
@@ -120,7 +162,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_x3_kernel(const NtArgs
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
-    const int li = lane & 31, lg = lane >> 5;
+    const int li = MS == 32 ? lane & 31 : lane & 15, lg = MS == 32 ? lane >> 5 : lane >> 4;   // fragment row, 16-B k column of the lane
 
     // XCD-aware decode of the 1-D grid: ids are dealt round-robin to the 8 XCDs; XCD x takes a contiguous range
     const int G = gridDim.x, pid = blockIdx.x;
@@ -203,7 +245,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_x3_kernel(const NtArgs
         if (!AT) {
             const int row = wave * 8 + r8;
             goffA0 = (unsigned)(row * p.lda + 4 * c16) * 4u;
-            woffA0 = (unsigned)(row * 64 + (((c16 >> 1) ^ ((row >> 2) & 3)) * 16) + (c16 & 1) * 8);
+            woffA0 = (unsigned)(row * 64 + (((c16 >> 1) ^ x3_sw<MS>(row)) * 16) + (c16 & 1) * 8);
         } else {
             const int cq = tid % (BM / CUA), kq = tid / (BM / CUA);          // units per chunk: 8 k quads x BM / CUA column groups
             goffA0 = (unsigned)((4 * kq) * p.lda + CUA * cq) * 4u;
@@ -213,11 +255,11 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_x3_kernel(const NtArgs
             const int row = tid >> 2, col = tid & 3;               // octet j: row + j NTH / 4 (a multiple of 16: swizzle unchanged)
             kqW = 2 * col;
             goffW0 = (unsigned)(row * p.ldw + 8 * col) * 2u;
-            woffW0 = (unsigned)(3 * PART_A + row * 64 + ((col ^ ((row >> 2) & 3)) * 16));
+            woffW0 = (unsigned)(3 * PART_A + row * 64 + ((col ^ x3_sw<MS>(row)) * 16));
         } else if (!WT) {
             const int row = wave * 8 + r8;
             goffW0 = (unsigned)(row * p.ldw + 4 * c16) * 4u;
-            woffW0 = (unsigned)(3 * PART_A + row * 64 + (((c16 >> 1) ^ ((row >> 2) & 3)) * 16) + (c16 & 1) * 8);
+            woffW0 = (unsigned)(3 * PART_A + row * 64 + (((c16 >> 1) ^ x3_sw<MS>(row)) * 16) + (c16 & 1) * 8);
         } else {
             const int cq = tid % (BN / CUW), kq = tid / (BN / CUW);
             goffW0 = (unsigned)((4 * kq) * p.ldw + CUW * cq) * 4u;
@@ -350,7 +392,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_x3_kernel(const NtArgs
             const int kq0 = isA ? (int)(tid / (BM / CUA)) : (int)(tid / (BN / CUW));
             const int cq = isA ? (int)(tid % (BM / CUA)) : (int)(tid % (BN / CUW));
             const int row = CU * cq + (j % CU), kq = kq0 + d;
-            off = (unsigned)((isA ? 0 : 3 * PART_A) + row * 64 + (((kq >> 1) ^ ((row >> 2) & 3)) * 16) + (kq & 1) * 8);
+            off = (unsigned)((isA ? 0 : 3 * PART_A) + row * 64 + (((kq >> 1) ^ x3_sw<MS>(row)) * 16) + (kq & 1) * 8);
         }
         unsigned char *dst = smem + st * STAGE + off;
         typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
@@ -369,27 +411,36 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_x3_kernel(const NtArgs
         *reinterpret_cast<u32x2 *>(dst + 2 * ps) = (u32x2){cvl[0], cvl[1]};
     };
 
-    // ---- fragments: lane (li, lg) of k step s holds k = 16 s + 8 lg .. + 7 of row li of a 32-row block: column 2 s + lg
-    const unsigned a_rd = (unsigned)((wm * 32 * TM + li) * 64 + ((lg ^ ((li >> 2) & 3)) * 16));
-    const unsigned w_rd = (unsigned)(3 * PART_A + (wn * 32 * TN + li) * 64 + ((lg ^ ((li >> 2) & 3)) * 16));
-    X3Parts fa[2][TM], fw[2][TN];                                  // [parity of the k step]
+    // ---- fragments.  MS = 32: lane (li, lg) of k step s holds k = 16 s + 8 lg .. + 7 of row li of a 32-row block: column
+    // 2 s + lg.  MS = 16: lane (li, lg) holds k = 8 lg .. + 7 of row li of a 16-row block: column lg, the whole chunk.
+    constexpr int FR = MS == 32 ? 32 : 16;                         // rows of a fragment / of an output block
+    constexpr int FA = 32 * TM / FR, FW = 32 * TN / FR, NPAR = MS == 32 ? 2 : 1;
+    const unsigned a_rd = (unsigned)((wm * 32 * TM + li) * 64 + ((lg ^ x3_sw<MS>(li)) * 16));
+    const unsigned w_rd = (unsigned)(3 * PART_A + (wn * 32 * TN + li) * 64 + ((lg ^ x3_sw<MS>(li)) * 16));
+    X3Parts fa[NPAR][FA], fw[NPAR][FW];                            // MS = 32: [parity of the k step]
     // fragment read r of k step s (A blocks first, 3 parts each) from stage st into parity `par`
     auto read_frag = [&](int st, int s, int par, int r) {
         const int f = r / 3, part = r % 3;
-        if (f < TM) {
-            const u32x4 x = *reinterpret_cast<const u32x4 *>(smem + st * STAGE + ((a_rd ^ (unsigned)(32 * s)) + f * 32 * 64 + part * PART_A));
+        if (f < FA) {
+            const u32x4 x = *reinterpret_cast<const u32x4 *>(smem + st * STAGE + ((a_rd ^ (unsigned)(32 * s)) + f * FR * 64 + part * PART_A));
             if (part == 0) fa[par][f].h = x;
             else if (part == 1) fa[par][f].m = x;
             else fa[par][f].l = x;
         } else {
-            const int b = f - TM;
-            const u32x4 x = *reinterpret_cast<const u32x4 *>(smem + st * STAGE + ((w_rd ^ (unsigned)(32 * s)) + b * 32 * 64 + part * PART_W));
+            const int b = f - FA;
+            const u32x4 x = *reinterpret_cast<const u32x4 *>(smem + st * STAGE + ((w_rd ^ (unsigned)(32 * s)) + b * FR * 64 + part * PART_W));
             if (part == 0) fw[par][b].h = x;
             else if (part == 1) fw[par][b].m = x;
             else fw[par][b].l = x;
         }
     };
+    // MS = 16: one part (0 h, 1 m, 2 l) of fragment f of operand A / W
+    auto read_part = [&](int st, bool isA, int part, int f) {
+        read_frag(st, 0, 0, 3 * (isA ? f : FA + f) + part);
+    };
 
+    // accumulators: MS = 32: acc[a][b] = 32 x 32 block (a, b), 16 registers; MS = 16: the same registers as four 16 x 16 blocks
+    // (2 a + ar, 2 b + bc) -> acc[a][b][4 (2 ar + bc) .. + 3]
     f32x16 acc[TM][TN];
 #pragma unroll
     for (int a = 0; a < TM; ++a)
@@ -398,19 +449,21 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_x3_kernel(const NtArgs
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    // ---- output of a finished item.  Sub-block bb = 4 b + q of a lane's accumulators: output row 32 a + li, output columns
-    // 32 b + 8 q + 4 lg + (0 .. 3).  The 16-B stores of item t are issued from inside the first k step of item t + 1 (before
-    // the MFMA that restarts the block from zero), in the shadow of running MFMAs.
-    constexpr int NBB = 4 * TN;
+    // ---- output of a finished item.  A lane holds 4 consecutive output columns of one output row per "sub-block":
+    //   MS = 32: sub-block bb = 4 b + q of block row a: row 32 a + li, columns 32 b + 8 q + 4 lg + (0 .. 3);
+    //   MS = 16: sub-block bb (= 16-column block) of block row a (16 rows): row 16 a + li, columns 16 bb + 4 lg + (0 .. 3).
+    // The 16-B stores of item t are issued from inside the first k step of item t + 1 (before the MFMA that restarts the block
+    // from zero), in the shadow of running MFMAs.
+    constexpr int NBB = MS == 32 ? 4 * TN : 2 * TN, NA = FA;
     const int mloc0 = wm * 32 * TM + li, nloc0 = wn * 32 * TN + 4 * lg;
-    auto coloff = [](int bb) { return 32 * (bb >> 2) + 8 * (bb & 3); };
+    auto coloff = [](int bb) { return MS == 32 ? 32 * (bb >> 2) + 8 * (bb & 3) : 16 * bb; };
     auto get4 = [&](int a, int bb) {
-        const int b = bb >> 2, q = bb & 3;
-        return (f32x4){acc[a][b][4 * q], acc[a][b][4 * q + 1], acc[a][b][4 * q + 2], acc[a][b][4 * q + 3]};
+        const int A_ = MS == 32 ? a : a >> 1, b = MS == 32 ? bb >> 2 : bb >> 1, q = MS == 32 ? bb & 3 : 2 * (a & 1) + (bb & 1);
+        return (f32x4){acc[A_][b][4 * q], acc[A_][b][4 * q + 1], acc[A_][b][4 * q + 2], acc[A_][b][4 * q + 3]};
     };
     auto set4 = [&](int a, int bb, const f32x4 x) {
-        const int b = bb >> 2, q = bb & 3;
-        acc[a][b][4 * q] = x[0]; acc[a][b][4 * q + 1] = x[1]; acc[a][b][4 * q + 2] = x[2]; acc[a][b][4 * q + 3] = x[3];
+        const int A_ = MS == 32 ? a : a >> 1, b = MS == 32 ? bb >> 2 : bb >> 1, q = MS == 32 ? bb & 3 : 2 * (a & 1) + (bb & 1);
+        acc[A_][b][4 * q] = x[0]; acc[A_][b][4 * q + 1] = x[1]; acc[A_][b][4 * q + 2] = x[2]; acc[A_][b][4 * q + 3] = x[3];
     };
     __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc((void *)p.C, 0, 0, 0x00020000);   // nothing pending: all out of range
     unsigned st_off[NBB];                                          // byte offset of (row mloc0, sub-block bb), or out of range
@@ -421,13 +474,25 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_x3_kernel(const NtArgs
 #pragma unroll
     for (int b = 0; b < TN; ++b) stg_off[b] = NT_OOB;
     unsigned char *const stg = smem + 2 * STAGE + wave * 4096;
-    const unsigned stg_wr = (unsigned)(li * 128), stg_sw = (unsigned)(li & 7);      // writer: row li, 16-B column (2 q + lg) ^ (li & 7)
-    const unsigned stg_rd = (unsigned)((lane >> 3) * 128 + (((lane & 7) ^ (lane >> 3)) * 16));
+    // writer: MS = 32: row li, 16-B column (2 q + lg) ^ (li & 7); MS = 16: row 16 ar + li, 16-B column (4 bc + lg) ^ (li & 7);
+    // reader: lane l takes row 8 j + (l >> 3), 16-B column (l & 7) ^ (l >> 3)
     u32x4 pend[4];                                                 // a block on its way out: read back from the staging block
+    // (a, b): a 32 x 32 block of the wave tile, for both instruction shapes
     auto stage_block = [&](int a, int b) {                         // accumulators -> LDS -> pend (LDS operations are in order)
+        // (lane geometry from the hardware lane id, as in finish_item: nothing of it is carried through the chunk loop)
+        int lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+        asm volatile("" : "+v"(lane));
+        const int li = MS == 32 ? lane & 31 : lane & 15, lg = MS == 32 ? lane >> 5 : lane >> 4;
+        const unsigned stg_wr = (unsigned)(li * 128), stg_sw = (unsigned)(li & 7);
+        const unsigned stg_rd = (unsigned)((lane >> 3) * 128 + (((lane & 7) ^ (lane >> 3)) * 16));
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-            *reinterpret_cast<u32x4 *>(stg + stg_wr + (((unsigned)(2 * q + lg) ^ stg_sw) * 16)) = __builtin_bit_cast(u32x4, get4(a, 4 * b + q));
+        for (int q = 0; q < 4; ++q) {
+            if (MS == 32)
+                *reinterpret_cast<u32x4 *>(stg + stg_wr + (((unsigned)(2 * q + lg) ^ stg_sw) * 16)) = __builtin_bit_cast(u32x4, get4(a, 4 * b + q));
+            else
+                *reinterpret_cast<u32x4 *>(stg + stg_wr + (q >> 1) * 2048 + (((unsigned)(4 * (q & 1) + lg) ^ stg_sw) * 16)) =
+                    __builtin_bit_cast(u32x4, get4(2 * a + (q >> 1), 2 * b + (q & 1)));
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) pend[j] = *reinterpret_cast<const u32x4 *>(stg + stg_rd + j * 1024);
     };
@@ -445,11 +510,19 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_x3_kernel(const NtArgs
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const unsigned off = st_off[4 * b + q] + (unsigned)(a * 32 * p.ldc) * 4u;
-            if (!(X3_ABLATE & 4)) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, get4(a, 4 * b + q)), rsC, off, 0, 0);
+            const int ra = MS == 32 ? a : 2 * a + (q >> 1), bb = MS == 32 ? 4 * b + q : 2 * b + (q & 1);
+            const unsigned off = st_off[bb] + (unsigned)(ra * FR * p.ldc) * 4u;
+            if (!(X3_ABLATE & 4)) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, get4(ra, bb)), rsC, off, 0, 0);
         }
     };
     auto finish_item = [&]() {
+        // The lane geometry the epilogue needs is derived HERE from the hardware lane id (v_mbcnt_*: no live-in register, opaque
+        // to common-subexpression elimination): held from the prologue these values stayed in registers -- on the 256 x 128 tiles
+        // in scratch -- across the whole item (tools/spill_table.py).
+        int lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+        asm volatile("" : "+v"(lane));
+        const int li = MS == 32 ? lane & 31 : lane & 15, lg = MS == 32 ? lane >> 5 : lane >> 4;
+        const int mloc0 = wm * 32 * TM + li, nloc0 = wn * 32 * TN + 4 * lg;
         int tm, tn;
         decode(cp.tile, tm, tn);
         const long long m0 = (long long)tm * BM;
@@ -472,8 +545,8 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_x3_kernel(const NtArgs
 #pragma unroll
                 for (int bb = 0; bb < NBB; ++bb)
 #pragma unroll
-                    for (int a = 0; a < TM; ++a) {
-                        const int ml = mloc0 + 32 * a, nl = nloc0 + coloff(bb);
+                    for (int a = 0; a < NA; ++a) {
+                        const int ml = mloc0 + FR * a, nl = nloc0 + coloff(bb);
                         set4(a, bb, get4(a, bb) + __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
                                                       rsD, nl < ncols ? (unsigned)(ml * p.ldadd + nl) * 4u : NT_OOB, 0, 0)));
                     }
@@ -484,7 +557,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_x3_kernel(const NtArgs
                 for (int bb = 0; bb < NBB; ++bb) {
                     const f32x4 bz = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, (unsigned)(nloc0 + coloff(bb)) * 4u, 0, 0));
 #pragma unroll
-                    for (int a = 0; a < TM; ++a) set4(a, bb, get4(a, bb) + bz);
+                    for (int a = 0; a < NA; ++a) set4(a, bb, get4(a, bb) + bz);
                 }
             }
             if (EPI && p.row_bias) {                               // a bias per group of rows: the heads' per-sample term
@@ -492,8 +565,8 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_x3_kernel(const NtArgs
                 // masked lanes' NT_OOB offset is out of range: an unbounded descriptor made them read row_bias + 1 GiB)
                 __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc((void *)p.row_bias, 0, p.rb_bytes, 0x00020000);
 #pragma unroll
-                for (int a = 0; a < TM; ++a) {
-                    const unsigned row = (unsigned)(m0 + mloc0 + 32 * a);
+                for (int a = 0; a < NA; ++a) {
+                    const unsigned row = (unsigned)(m0 + mloc0 + FR * a);
                     const unsigned grp = row < (unsigned)p.M ? (p.rows_per_group == 1 ? row : __umulhi(row, p.rpg_magic)) : 0u;
 #pragma unroll
                     for (int bb = 0; bb < NBB; ++bb) {
@@ -517,8 +590,8 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_x3_kernel(const NtArgs
 #pragma unroll
                 for (int bb = 0; bb < NBB; ++bb)
 #pragma unroll
-                    for (int a = 0; a < TM; ++a) {
-                        const int ml = mloc0 + 32 * a, nl = nloc0 + coloff(bb);
+                    for (int a = 0; a < NA; ++a) {
+                        const int ml = mloc0 + FR * a, nl = nloc0 + coloff(bb);
                         const f32x4 g = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
                                                                      rsG, nl < ncols ? (unsigned)(ml * p.ldgate + nl) * 4u : NT_OOB, 0, 0));
                         f32x4 x = get4(a, bb);
@@ -537,14 +610,22 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_x3_kernel(const NtArgs
                     float cs[4] = {0.f, 0.f, 0.f, 0.f}, cq[4] = {0.f, 0.f, 0.f, 0.f}, pv[4];
                     const f32x4 x0 = get4(0, bb);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {                  // row li = 0 of block a = 0: lanes 0 / 32
-                        const float p0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x0[r]), 0));
-                        const float p1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x0[r]), 32));
-                        pv[r] = lg ? p1 : p0;
+                    for (int r = 0; r < 4; ++r) {                  // row li = 0 of block a = 0: the first lane of every lg
+                        if (MS == 32) {
+                            const float p0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x0[r]), 0));
+                            const float p1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x0[r]), 32));
+                            pv[r] = lg ? p1 : p0;
+                        } else {
+                            const float p0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x0[r]), 0));
+                            const float p1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x0[r]), 16));
+                            const float p2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x0[r]), 32));
+                            const float p3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x0[r]), 48));
+                            pv[r] = (lg & 2) ? ((lg & 1) ? p3 : p2) : ((lg & 1) ? p1 : p0);
+                        }
                     }
 #pragma unroll
-                    for (int a = 0; a < TM; ++a)
-                        if (mloc0 + 32 * a < mrows) {
+                    for (int a = 0; a < NA; ++a)
+                        if (mloc0 + FR * a < mrows) {
                             const f32x4 x = get4(a, bb);
 #pragma unroll
                             for (int r = 0; r < 4; ++r) {
@@ -554,12 +635,12 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_x3_kernel(const NtArgs
                             }
                         }
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {                  // DPP adds: the sums end up in lanes 31 / 63
-                        cs[r] = x3_half_wave_sum(cs[r]);
-                        cq[r] = x3_half_wave_sum(cq[r]);
+                    for (int r = 0; r < 4; ++r) {                  // DPP adds: the sums end up in the last lane of every lg
+                        cs[r] = MS == 32 ? x3_half_wave_sum(cs[r]) : x3_row_sum(cs[r]);
+                        cq[r] = MS == 32 ? x3_half_wave_sum(cq[r]) : x3_row_sum(cq[r]);
                     }
                     const int nl = nloc0 + coloff(bb);
-                    if (li == 31 && nl < ncols) {
+                    if (li == FR - 1 && nl < ncols) {
                         *reinterpret_cast<float4 *>(P + n0 + nl) = make_float4(cs[0], cs[1], cs[2], cs[3]);
                         *reinterpret_cast<float4 *>(P + p.N + n0 + nl) = make_float4(cq[0], cq[1], cq[2], cq[3]);
                         *reinterpret_cast<float4 *>(P + 2 * p.N + n0 + nl) = make_float4(pv[0], pv[1], pv[2], pv[3]);
@@ -567,22 +648,23 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_x3_kernel(const NtArgs
                 }
             }
         } else {
-            // partial tile (operands swapped): D row (8q + 4 lg + r) = activation row, D column li = weight row: 128-B
-            // atomic segments.  The holder of the tile's first chunk adds the bias / addend.
+            // partial tile (operands swapped): MS = 32: D row (8q + 4 lg + r) = activation row, D column li = weight row: 128-B
+            // atomic segments; MS = 16: D row (4 lg + r), D column li, per 16 x 16 block: 64-B segments.  The holder of the
+            // tile's first chunk adds the bias / addend.
             const bool head = cp.kb == 0;
             const int mla = wm * 32 * TM + 4 * lg, nla = wn * 32 * TN + li;
 #pragma unroll
-            for (int b = 0; b < TN; ++b) {
-                const int nl = nla + 32 * b;
+            for (int b = 0; b < FW; ++b) {
+                const int nl = nla + FR * b;
                 const bool nok = nl < ncols;
                 const float bz = (head && p.bias && nok) ? p.bias[n0 + nl] : 0.f;
 #pragma unroll
-                for (int a = 0; a < TM; ++a)
+                for (int a = 0; a < FA; ++a)
 #pragma unroll
-                    for (int j = 0; j < 16; ++j) {
-                        const int ml = mla + 32 * a + 8 * (j >> 2) + (j & 3);
+                    for (int j = 0; j < (MS == 32 ? 16 : 4); ++j) {
+                        const int ml = mla + FR * a + (MS == 32 ? 8 * (j >> 2) + (j & 3) : j);
                         if (nok && ml < mrows) {
-                            float o = acc[a][b][j] + bz;
+                            float o = (MS == 32 ? acc[a][b][j] : acc[a >> 1][b >> 1][4 * (2 * (a & 1) + (b & 1)) + j]) + bz;
                             if (head && p.addend) o += p.addend[(m0 + ml) * p.ldadd + n0 + nl];
                             atomicAdd(p.C + (m0 + ml) * p.ldc + n0 + nl, o);
                         }
@@ -603,7 +685,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_x3_kernel(const NtArgs
     constexpr int BAR = 2 * TM * TN > NFR + 2 ? 2 * TM * TN : NFR + 2;       // MFMAs after the barrier
     constexpr int CT_PER_Q = 4, NCT = NQ * CT_PER_Q;               // conversion tasks: per quad 2 pairs, the writes, the reload
     constexpr int C_LO = 1, C_HI = NM - BAR - 1;                   // MFMA gaps that take them
-    static_assert(BAR < SM && NFR + 2 <= SM, "k step too short for its fragment reads");
+    static_assert(MS == 16 || (BAR < SM && NFR + 2 <= SM), "k step too short for its fragment reads");
     auto conv_task = [&](int st, int k) {
         const int q = k / CT_PER_Q, sub = k % CT_PER_Q;
         if (X3_ABLATE & 1) return;
@@ -671,6 +753,80 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_x3_kernel(const NtArgs
                     }
     };
 
+    // ---- the same chunk on v_mfma_f32_16x16x32_bf16: ONE k step of 6 FA FW instructions; product t over all the wave's 16 x 16
+    // blocks, walked 32 x 32 block by 32 x 32 block (four instructions each: the unit of the result's staging).  Parts:
+    //   t:  0 ah wh | 1 ah wm | 2 ah wl | 3 am wh | 4 al wh | 5 am wm        last use: Ah, Wl: t2; Wh, Al: t4; Am, Wm: t5
+    // so the parts of THIS chunk that the previous one used to its end (Wm, Am) or that are needed late (Wl, Al) are read from the
+    // first product on, one every SP instructions, in the order of their first use (Wm t1, Wl t2, Am t3, Al t4); behind the barrier
+    // -- BAR16 instructions before the end, after Ah's last use -- Ah of the NEXT chunk, and from the first instruction of the last
+    // product on (Wh's last use is t4) its Wh.  One set of fragment registers.
+    constexpr int PM = FA * FW, NM16 = 6 * PM;
+    constexpr int SP = PM >= 32 ? 4 : (PM >= 16 ? 2 : 1);
+    constexpr int BAR16 = 2 * FA + 4 > NM16 / 5 ? 2 * FA + 4 : NM16 / 5;
+    constexpr int C_HI16 = NM16 - BAR16 - 1;
+    constexpr int L1 = 2 * FW + 2 * FA;
+    static_assert(MS == 32 || (1 + SP * (FW - 1) + 6 <= PM && 1 + SP * (2 * FW - 1) + 6 <= 2 * PM && 1 + SP * (2 * FW + FA - 1) + 6 <= 3 * PM &&
+                               1 + SP * (L1 - 1) + 6 <= 4 * PM && 1 + SP * (L1 - 1) < NM16 - BAR16),
+                  "16x16x32: a part would not be back before its first use");
+    static_assert(MS == 32 || (NM16 - BAR16 >= 3 * PM && NM16 - BAR16 + 1 + 2 * (FA - 1) < NM16 && 5 * PM + 2 * (FW - 1) < NM16),
+                  "16x16x32: the next chunk's first parts do not fit behind the barrier");
+    auto chunk16 = [&](auto first_c, int st) {
+        constexpr bool FIRST = decltype(first_c)::value;
+#pragma unroll
+        for (int t = 0; t < 6; ++t)
+#pragma unroll
+        for (int sb = 0; sb < PM / 4; ++sb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int idx = t * PM + 4 * sb + q;
+            const int a32 = sb / TN, b32 = sb % TN, a16 = 2 * a32 + (q >> 1), b16 = 2 * b32 + (q & 1);
+            if (idx == NM16 - BAR16) {
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (!(X3_ABLATE & 8)) __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            f32x4a c = {acc[a32][b32][4 * q], acc[a32][b32][4 * q + 1], acc[a32][b32][4 * q + 2], acc[a32][b32][4 * q + 3]};
+            if (FIRST && t == 0) {                                 // the pending stores of the 32 x 32 block, then its restart from zero
+                if (q == 0) {
+                    if (STG) {
+                        if (sb > 0) flush_block((sb - 1) / TN, (sb - 1) % TN);
+                        stage_block(a32, b32);
+                    } else if (!ATOMIC) {
+                        store_block(a32, b32);
+                    }
+                }
+                c = (f32x4a){0.f, 0.f, 0.f, 0.f};
+            }
+            if (FIRST && STG && idx == PM) flush_block(TM - 1, TN - 1);
+            const X3Parts &A = fa[0][a16], &W = fw[0][b16];
+            const u32x4 ap = t <= 2 ? A.h : (t == 4 ? A.l : A.m);
+            const u32x4 wp = (t == 0 || t == 3 || t == 4) ? W.h : (t == 2 ? W.l : W.m);
+            c = ATOMIC ? x3_mfma16(ap, wp, c) : x3_mfma16(wp, ap, c);
+            acc[a32][b32][4 * q] = c[0]; acc[a32][b32][4 * q + 1] = c[1]; acc[a32][b32][4 * q + 2] = c[2]; acc[a32][b32][4 * q + 3] = c[3];
+            if (idx % X3_FENCE16 == 0) __builtin_amdgcn_sched_barrier(0);
+            if (!(X3_ABLATE & 16)) {
+                if (idx >= 1 && idx < 1 + SP * L1 && (idx - 1) % SP == 0) {
+                    const int j = (idx - 1) / SP;
+                    if (j < FW) read_part(st, false, 1, j);                               // Wm
+                    else if (j < 2 * FW) read_part(st, false, 2, j - FW);                 // Wl
+                    else if (j < 2 * FW + FA) read_part(st, true, 1, j - 2 * FW);         // Am
+                    else read_part(st, true, 2, j - 2 * FW - FA);                         // Al
+                }
+                const int ja = idx - (NM16 - BAR16 + 1), jw = idx - 5 * PM;
+                if (ja >= 0 && ja < 2 * FA && ja % 2 == 0) read_part(st ^ 1, true, 0, ja / 2);      // Ah of the next chunk
+                if (jw >= 0 && jw < 2 * FW && jw % 2 == 0) read_part(st ^ 1, false, 0, jw / 2);     // Wh of the next chunk
+            }
+            if (idx >= C_LO && idx < C_HI16) {
+                const int i0 = idx - C_LO, span = C_HI16 - C_LO;
+                const int k0 = (i0 * NCT) / span, k1 = ((i0 + 1) * NCT) / span;
+#pragma unroll
+                for (int k = k0; k < k1; ++k) conv_task(st ^ 1, k);
+            }
+        }
+    };
+
     // ---- prologue: chunk 0 converted into stage 0, chunk 1 in the raw registers, the first fragments read
     issue_begin();
 #pragma unroll
@@ -689,15 +845,23 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_x3_kernel(const NtArgs
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    if (MS == 32) {
 #pragma unroll
-    for (int r = 0; r < NFR; ++r) read_frag(0, 0, 0, r);
+        for (int r = 0; r < NFR; ++r) read_frag(0, 0, 0, r);
+    } else {
+#pragma unroll
+        for (int f = 0; f < FA; ++f) read_part(0, true, 0, f);
+#pragma unroll
+        for (int f = 0; f < FW; ++f) read_part(0, false, 0, f);
+    }
     int stage = 0;
     while (cp.valid) {
         // the item's first chunk is peeled off the loop: one code path per loop body, so the loop-carried registers (raw
         // values in flight, accumulators) need no copies at a merge
         issue_begin();                                             // the chunk the conversion tasks reload the registers with
         __builtin_amdgcn_sched_barrier(0);
-        chunk(std::true_type(), stage);
+        if constexpr (MS == 32) chunk(std::true_type(), stage);
+        else chunk16(std::true_type(), stage);
         __builtin_amdgcn_sched_barrier(0);
         advance_load();
         stage ^= 1;
@@ -705,7 +869,8 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_x3_kernel(const NtArgs
         while (cp.kc != cp.ke) {
             issue_begin();
             __builtin_amdgcn_sched_barrier(0);
-            chunk(std::false_type(), stage);
+            if constexpr (MS == 32) chunk(std::false_type(), stage);
+            else chunk16(std::false_type(), stage);
             __builtin_amdgcn_sched_barrier(0);
             advance_load();
             stage ^= 1;
@@ -725,8 +890,11 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_x3_kernel(const NtArgs
     }
 }
 
+#ifndef X3_KERNEL_ONLY                // (tools/x3_inst.hip compiles single instances of the kernel for ISA inspection)
 // ------------------------------------------------------------------ host side
-template <int TM, int TN, int WM, int WN, int OCC, int RATE>      // RATE: fp32-equivalent kflop / us a CU sustains on this tile's loop
+static bool x3_shape16(int cfg_index, bool atomic, bool epi, bool pw);
+
+template <int TM, int TN, int WM, int WN, int OCC, int RATE, int CFG>      // RATE: fp32-equivalent kflop / us a CU sustains on this tile's loop
 struct X3Cfg {
     static constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     static constexpr int LDS = 2 * 3 * (BM + BN) * 64;              // two stages of three bf16 parts of [rows][32 k]
@@ -787,7 +955,11 @@ struct X3Cfg {
 
     template <bool ATOMIC, bool WT, bool AT, bool EPI, bool PW = false>
     static void go(int grid, hipStream_t s, const NtArgs &a) {
-        hipLaunchKernelGGL((gemm_x3_kernel<TM, TN, WM, WN, OCC, ATOMIC, WT, AT, EPI, PW>), dim3(grid), dim3(64 * WM * WN), 0, s, a);
+        // the matrix instruction is chosen per instance class (tile, atomic / extended epilogue / pre-split operand): nt_switches().shape16
+        if (x3_shape16(CFG, ATOMIC, EPI, PW))
+            hipLaunchKernelGGL((gemm_x3_kernel<TM, TN, WM, WN, OCC, ATOMIC, WT, AT, EPI, PW, 16>), dim3(grid), dim3(64 * WM * WN), 0, s, a);
+        else
+            hipLaunchKernelGGL((gemm_x3_kernel<TM, TN, WM, WN, OCC, ATOMIC, WT, AT, EPI, PW, 32>), dim3(grid), dim3(64 * WM * WN), 0, s, a);
     }
 
     template <bool WT, bool AT = false>
@@ -844,9 +1016,9 @@ struct X3Cfg {
     }
 };
 
-typedef X3Cfg<2, 2, 2, 2, 1, 660> X3Square;   // 128 x 128, 4 waves of 64 x 64 (96 KB of LDS): one per CU
-typedef X3Cfg<4, 2, 2, 2, 1, 760> X3Big;      // 256 x 128, 4 waves of 128 x 64 (144 KB of LDS): one per CU, one wave per SIMD
-typedef X3Cfg<2, 1, 2, 2, 2, 540> X3Narrow;   // 128 x 64, 4 waves of 64 x 32 (72 KB of LDS): two per CU
+typedef X3Cfg<2, 2, 2, 2, 1, 660, 1> X3Square;   // 128 x 128, 4 waves of 64 x 64 (96 KB of LDS): one per CU
+typedef X3Cfg<4, 2, 2, 2, 1, 760, 0> X3Big;      // 256 x 128, 4 waves of 128 x 64 (144 KB of LDS): one per CU, one wave per SIMD
+typedef X3Cfg<2, 1, 2, 2, 2, 540, 2> X3Narrow;   // 128 x 64, 4 waves of 64 x 32 (72 KB of LDS): two per CU
 
 NtSwitches &nt_switches() {
     static NtSwitches sw = [] {
@@ -857,6 +1029,15 @@ NtSwitches &nt_switches() {
         s.cfg = (e && *e) ? atoi(e) : -1;
         e = getenv("PDGN_X3_SPLITK");                 // 0: weight gradients on the flattened stream-K order (A/B arm)
         s.splitk = !(e && e[0] == '0');
+        // the bf16 matrix instruction per instance class: bit (4 tile + class) of shape16 set = v_mfma_f32_16x16x32_bf16; tile 0 256x128,
+        // 1 128x128, 2 128x64; class 0 plain, 1 pre-split second operand, 2 atomic (stream-K tails, weight gradients), 3 extended
+        // epilogue.  PDGN_X3_SHAPE = 32 / 16: every class; PDGN_X3_SHAPE16_MASK = the mask itself (hex); default X3_DEFAULT_MASK
+        s.shape16 = X3_DEFAULT_MASK;
+        e = getenv("PDGN_X3_SHAPE");
+        if (e && *e) s.shape16 = atoi(e) == 16 ? 0xfff : 0;
+        e = getenv("PDGN_X3_SHAPE16_MASK");
+        if (e && *e) s.shape16 = (int)strtol(e, nullptr, 16) & 0xfff;
+        s.shape16_default = s.shape16;
         return s;
     }();
     return sw;
@@ -878,7 +1059,24 @@ extern "C" int pdgn_gemm_set_config(int cfg) {
     return old;
 }
 
+// shape: 32 = v_mfma_f32_32x32x16_bf16, 16 = v_mfma_f32_16x16x32_bf16 for EVERY later launch, -1 = back to the process default (the
+// built-in per-class mask or what the environment said),
+// 0x1000 | mask = that per-class mask (nt_switches), anything else = leave.  Returns the mask in force before the call (tests /
+// tools: both shapes run through every direct GEMM test).
+extern "C" int pdgn_gemm_set_shape(int shape) {
+    const int old = nt_switches().shape16;
+    if (shape == 16) nt_switches().shape16 = 0xfff;
+    else if (shape == 32) nt_switches().shape16 = 0;
+    else if (shape == -1) nt_switches().shape16 = nt_switches().shape16_default;
+    else if (shape >= 0x1000 && shape <= 0x1fff) nt_switches().shape16 = shape & 0xfff;
+    return old;
+}
+
 static int x3_mode() { return nt_switches().mode; }
+static bool x3_shape16(int cfg_index, bool atomic, bool epi, bool pw) {
+    const int cls = epi ? 3 : atomic ? 2 : pw ? 1 : 0;
+    return (nt_switches().shape16 >> (4 * cfg_index + cls)) & 1;
+}
 
 static int x3_pick(long long m, int n, int k, bool stats) {
     const int forced = nt_switches().cfg;          // 0 .. 2 (3, the fp32 kernel's fourth, reads as 2)
@@ -902,7 +1100,8 @@ template <bool WT>
 static int x3_dispatch(long long m, int n, int k, const float *A, int lda, const float *W, int ldw, const float *bias,
                        const float *addend, int ldadd, float *C, int ldc, float *stat_part, hipStream_t s,
                        const NtEpi &epi = NtEpi(), const unsigned short *Wp = nullptr, long long wplane = 0) {
-    switch (x3_pick(m, n, k, stat_part != nullptr || epi.any())) {
+    const int cfg = x3_pick(m, n, k, stat_part != nullptr || epi.any());
+    switch (cfg) {
         case 0: return X3Big::launch<WT>(m, n, k, A, lda, W, ldw, bias, addend, ldadd, C, ldc, stat_part, s, epi, false, Wp, wplane);
         case 2: return X3Narrow::launch<WT>(m, n, k, A, lda, W, ldw, bias, addend, ldadd, C, ldc, stat_part, s, epi, false, Wp, wplane);
         default: return X3Square::launch<WT>(m, n, k, A, lda, W, ldw, bias, addend, ldadd, C, ldc, stat_part, s, epi, false, Wp, wplane);
@@ -989,7 +1188,8 @@ extern "C" int pdgn_gemm_tn_big(long long m, int n, int k, const float *dY, int 
         return PDGN_ERR_INVALID;
     hipStream_t s = (hipStream_t)stream;
     // kernel roles: output rows = n (columns of dY), output columns = k (columns of X), reduction = m
-    switch (x3_pick(n, k, (int)(m > 0x7fffffff ? 0x7fffffff : m), false)) {
+    const int cfg = x3_pick(n, k, (int)(m > 0x7fffffff ? 0x7fffffff : m), false);
+    switch (cfg) {
         case 0: return X3Big::launch<true, true>(n, k, (int)m, dY, ldy, X, ldx, nullptr, nullptr, 0, dW, k, nullptr, s, NtEpi(), dw_is_zero != 0);
         case 2: return X3Narrow::launch<true, true>(n, k, (int)m, dY, ldy, X, ldx, nullptr, nullptr, 0, dW, k, nullptr, s, NtEpi(), dw_is_zero != 0);
         default: return X3Square::launch<true, true>(n, k, (int)m, dY, ldy, X, ldx, nullptr, nullptr, 0, dW, k, nullptr, s, NtEpi(), dw_is_zero != 0);
@@ -1029,3 +1229,4 @@ extern "C" int pdgn_gemm_nt_config(long long m, int n, int k, int with_stats) {
                                                                       : X3Narrow::plan(m, n, k, sk).grid_sk;
     return c + (g ? 16 : 0);
 }
+#endif  // X3_KERNEL_ONLY

@@ -900,7 +900,7 @@ def bilateral_weighting(x2d, bn_x, u2d, bn_u, training, k, act="leaky_relu", pre
     act(bn_u(u2d)) * softmax_slots_permute(act(bn_x(x2d))), shape of u2d."""
     x2d, pre_bias_x = _fold_pre_bias(x2d, pre_bias_x, training)
     u2d, pre_bias_u = _fold_pre_bias(u2d, pre_bias_u, training)
-    if x2d.shape[1] % 4:
+    if x2d.shape[1] % 4 or k > 16:           # (the fused adjoint holds all k slots of a channel pair in registers: k <= 16)
         w = bn_softmax_slots_permute(x2d, bn_x, training, k, act=act, pre_bias=pre_bias_x)
         return bn_act(u2d, bn_u, training, act=act, mul=w.view(u2d.shape), pre_bias=pre_bias_u, partials=partials_u)
     if training:

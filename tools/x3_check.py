@@ -25,7 +25,9 @@ def timeit(fn, n=10):
     return s.elapsed_time(e) / n * 1e3
 
 
-print("mode", os.environ.get("PDGN_GEMM", "x3"), "cfg", os.environ.get("PDGN_NT_CFG", "auto"))
+if len(sys.argv) > 1:
+    _lib.set_gemm_shape(int(sys.argv[1]))
+print("mode", os.environ.get("PDGN_GEMM", "x3"), "cfg", os.environ.get("PDGN_NT_CFG", "auto"), "shape", _lib.set_gemm_shape(0))
 for (m, n, k) in [(1000, 64, 36), (4099, 132, 100), (35840, 512, 5120), (35840, 12832, 128), (71680, 1024, 256), (358400, 512, 64),
                   (17920, 256, 2560), (35840, 256, 128)]:
     a = torch.randn(m, k, device=dev) * torch.rand(m, 1, device=dev) * 3
