@@ -55,7 +55,7 @@ def parse():
     ap.add_argument("--issue", default="list", choices=("list", "eager"),
                     help="list (default, one process): the iteration is captured once and every step re-issues its launches "
                          "from C on the eager schedule's streams (trainer.capture_list, csrc/replay.hip); eager: every "
-                         "launch issued from Python (always under data parallelism: collectives cannot be captured)")
+                         "launch issued from Python")
     ap.add_argument("--no-roofline", action="store_true", help="skip the roofline kernels (for clean rocprof traces)")
     ap.add_argument("--eval", action="store_true", help="time config C5 (Chamfer + EMD, 512 pairs of 2048 points)")
     ap.add_argument("--eval-pairs", type=int, default=512)
@@ -328,11 +328,15 @@ def eval_c5(pairs=512, steps=5, warmup=1):
     peak_pairs = 4 * 256 * 2.4e9 / (cyc / P)
     ach = P / (ms_emd * 1e-3)
     dense = 19.0 * N * N * P
+    # the ALGORITHM's own floor, next to the issue-mix one: every executed element takes one v_exp_f32 or
+    # v_sqrt_f32 (quarter rate: 8 lanes per clock and SIMD); the rest of its 6.9 instructions is this kernel's way of feeding it
+    trans_floor_us = sum(elements.values()) / (4 * 256 * 8 * 2.4e9) * 1e6
     return {"pairs": P, "pairs_per_s": P / dt, "ms_per_step": dt * 1e3, "ms_per_512": dt * 1e3 * 512.0 / P,
             "finite": bool(torch.isfinite(cd).all() and torch.isfinite(emd).all()),
             "roofline": {"kernel": "emd_cost_kernel (fused approximate-EMD cost)", "bound": "valu-issue",
                          "achieved": ach, "peak": peak_pairs, "unit": "pairs/s", "frac": ach / peak_pairs,
                          "instr_per_element": instr_per_element, "exp_frac": exp_frac,
+                         "transcendental_floor_us": trans_floor_us, "frac_of_transcendental_rate": trans_floor_us / (ms_emd * 1e3),
                          "executed_elements_per_pair": sum(elements.values()) / P, "dense_elements_per_pair": 19.0 * N * N,
                          "executed_fraction_of_dense": sum(elements.values()) / dense,
                          "traffic": None, "us_per_launch": ms_emd * 1e3,
@@ -409,15 +413,23 @@ def measure_and_report(args, trainer, reals, zs, world, rank, device, res):
     for _ in range(2):
         step(reals, *zs[0])
     issue = "hipgraph" if graphed else "eager"
-    if not graphed and getattr(args, "issue", "eager") == "list" and not trainer.distributed and getattr(trainer, "overlap", False):
-        try:                                   # the SAME launches as the eager step, re-issued from a recorded list
+    if not graphed and getattr(args, "issue", "eager") == "list" and getattr(trainer, "overlap", False):
+        # the SAME launches as the eager step, re-issued from a recorded list; under data parallelism the gradient all-reduces are
+        # host points of the list (trainer.capture_list), issued between its ranges
+        ok = 1
+        try:
             trainer.capture_list(reals, *zs[0])
-            step, issue = (lambda reals, z1, z2: trainer.step_list(None, z1, z2)), "list"
-            step(reals, *zs[0])
         except Exception as e:                 # a capture problem must not lose the measurement
             print("launch-list capture failed (%r): issuing eagerly" % (e,), file=sys.stderr)
             torch.cuda.synchronize()
-            step = trainer.step
+            ok = 0
+        if world > 1:                          # every rank issues the same sequence of collectives: all on the list, or none
+            flag = torch.tensor([ok], device=device, dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            ok = int(flag.item())
+        if ok:
+            step, issue = (lambda reals, z1, z2: trainer.step_list(None, z1, z2)), "list"
+            step(reals, *zs[0])
     for i in range(args.warmup):
         step(reals, *zs[i])
     barrier()

@@ -527,6 +527,11 @@ int pdgn_replay_set_stream(void *plan, int chain, pdgn_stream_t stream);
 int pdgn_replay_launch(void *plan);
 int pdgn_replay_launch_range(void *plan, int lo, int hi); /* nodes [lo, hi) of the list */
 int pdgn_replay_position(void *plan, int chain, int nth); /* list position of a chain's n-th node, or -1 */
+/* Markers with id >= 64 are HOST POINTS, not stream tags: places of the list at which the caller does what a capture cannot
+ * record (the RCCL all-reduces of the data-parallel iteration).  Returns their number; ids / list positions / chains of the first
+ * max_out in list order.  The caller issues [lo, pos + 1), makes its own call on that chain's stream, and goes on. */
+int pdgn_replay_points(void *plan, int *ids, int *pos, int *chain, int max_out);
+int pdgn_replay_joined(void *plan); /* 1: the chain of marker 0 ends behind every other chain's last node */
 int pdgn_replay_launch_timed(void *plan, double *us32); /* measurement: host microseconds per call kind / chain */
 int pdgn_replay_probe_chain(void *plan, int chain, int stride, float *ms_out, int *pos_out, int max_out); /* measurement: device-time progress of one chain */
 int pdgn_replay_destroy(void *plan);

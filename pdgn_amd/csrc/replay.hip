@@ -14,6 +14,11 @@
 // depends only on earlier ones); a node continues the chain of its first dependency that is still the tail of a chain, a
 // marker node opens the chain of its id, anything else opens an anonymous chain (replayed on a spare stream).  Dependencies
 // inside a chain are stream order; dependencies across chains become hipEventRecord / hipStreamWaitEvent pairs.
+//
+// Marker ids >= PDGN_REPLAY_POINT_BASE (64) do not name a stream: they are POINTS of the list at which the host does something the
+// capture could not record -- under data parallelism the RCCL all-reduces of the gradient buffers (a collective cannot be
+// captured).  Such a marker stays in the chain of the stream it was launched on; pdgn_replay_points reports its id, its position
+// in the list and its chain, and the caller issues the list in ranges with its own calls in between (pdgn_amd/trainer.py).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -34,6 +39,7 @@ enum NodeKind { NK_KERNEL = 0, NK_MEMSET = 1, NK_MEMCPY = 2, NK_EMPTY = 3 };
 struct RNode {
     int kind = NK_EMPTY;
     int chain = -1;
+    int point = -1;                  // id of a host point (marker id >= 64), or -1
     int record = -1;                 // event to record after this node (another chain waits for it), or -1
     std::vector<int> waits;          // events this node's chain must wait for before the node
     // kernel
@@ -55,6 +61,7 @@ struct RPlan {
     std::vector<hipStream_t> chain_stream;
     std::vector<hipEvent_t> events;
     int counts[8] = {0};             // nodes, kernels, memsets, memcpys, empties, chains, events, labelled chains
+    int joined = 0;                  // the last node of chain 'marker 0' has the last node of every other chain among its ancestors
     hipStream_t origin = nullptr;    // the capture's origin stream: chain of marker 0
 };
 
@@ -133,6 +140,7 @@ extern "C" int pdgn_replay_build(void *graph_, void **plan_out) {
             if (hipGetFuncBySymbol(&f, p.func) == hipSuccess && f) r.func = f;      // a __global__ function's host stub
             else { (void)hipGetLastError(); r.func = (hipFunction_t)p.func; }       // launched through the module API
             if (is_marker(p) && p.kernelParams) marker = *(int *)p.kernelParams[0];
+            if (marker >= 64) { r.point = marker; marker = -1; }     // a host point: an ordinary node of its stream's chain
             ++plan->counts[1];
         } else if (t == hipGraphNodeTypeMemset) {
             hipMemsetParams p;
@@ -226,6 +234,22 @@ extern "C" int pdgn_replay_build(void *graph_, void **plan_out) {
             plan->nodes.swap(nn);
         }
     }
+    {
+        // is every chain's tail an ancestor of the issuing chain's tail?  (backward walk over the captured dependencies)
+        int main_chain = -1;
+        for (size_t c = 0; c < plan->chain_label.size(); ++c) if (plan->chain_label[c] == 0) main_chain = (int)c;
+        if (main_chain >= 0) {
+            std::vector<char> anc(n, 0);
+            std::vector<int> stack{tail[main_chain]};
+            anc[tail[main_chain]] = 1;
+            while (!stack.empty()) {
+                const int u = stack.back(); stack.pop_back();
+                for (int d : deps[u]) if (!anc[d]) { anc[d] = 1; stack.push_back(d); }
+            }
+            plan->joined = 1;
+            for (size_t c = 0; c < tail.size(); ++c) if (!anc[tail[c]]) plan->joined = 0;
+        }
+    }
     for (auto &ev : plan->events)
         if ((e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) != hipSuccess) { delete plan; return (int)e; }
     plan->chain_stream.assign(tail.size(), nullptr);
@@ -297,6 +321,30 @@ extern "C" int pdgn_replay_launch(void *plan_) {
     RPlan *plan = (RPlan *)plan_;
     if (!plan) return PDGN_ERR_INVALID;
     return pdgn_replay_launch_range(plan_, 0, (int)plan->nodes.size());
+}
+
+// Host points of the list (markers with id >= 64), in list order: ids[i], list position pos[i], chain[i]; returns their number
+// (at most max_out are written), or a negative error.
+extern "C" int pdgn_replay_points(void *plan_, int *ids, int *pos, int *chain, int max_out) {
+    RPlan *plan = (RPlan *)plan_;
+    if (!plan || max_out < 0) return PDGN_ERR_INVALID;
+    int n = 0;
+    for (size_t i = 0; i < plan->nodes.size(); ++i)
+        if (plan->nodes[i].point >= 0) {
+            if (n < max_out) {
+                if (ids) ids[n] = plan->nodes[i].point;
+                if (pos) pos[n] = (int)i;
+                if (chain) chain[n] = plan->nodes[i].chain;
+            }
+            ++n;
+        }
+    return n;
+}
+
+// 1 when the issuing chain's last node comes after every chain's last node in the captured dependencies, else 0.
+extern "C" int pdgn_replay_joined(void *plan_) {
+    RPlan *plan = (RPlan *)plan_;
+    return plan ? plan->joined : 0;
 }
 
 // Position in the list of the n-th node (0-based) of chain `chain`, or -1: lets a caller cut the list at a point of one

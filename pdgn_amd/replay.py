@@ -14,6 +14,36 @@ from . import _lib
 from ._lib import check
 
 MAIN, D0, LP, KNN = 0, 1, 5, 6            # marker ids of the overlapped schedule's streams (D1..D4 = 1..4)
+POINT_BASE = 64                           # marker ids from here on: host points (csrc/replay.hip)
+
+
+class Recorder:
+    """Host points of a capture: what the iteration does that a stream capture cannot record -- the RCCL all-reduces of the
+    data-parallel step.  While a Recorder is active (`with recorder:` around the capture), `point(fn)` launches a marker on
+    the current stream instead of calling `fn`; the launch list reports the marker's position and chain, and the replay calls
+    `fn` there, on that chain's stream, between two ranges of the list (PDGNTrainer.step_list)."""
+
+    active = None
+
+    def __init__(self):
+        self.fns = []
+
+    def __enter__(self):
+        Recorder.active = self
+        return self
+
+    def __exit__(self, *exc):
+        Recorder.active = None
+
+    def point(self, fn):
+        pid = POINT_BASE + len(self.fns)
+        self.fns.append(fn)
+        mark(pid, torch.cuda.current_stream())
+        return pid
+
+
+def recorder():
+    return Recorder.active
 
 
 def mark(stream_id, stream):
@@ -41,6 +71,16 @@ class LaunchList:
         check(L.pdgn_replay_chains(self._plan, labels, sizes), "pdgn_replay_chains")
         self.labels, self.sizes = list(labels), list(sizes)
         self._bound = None
+        L.pdgn_replay_points.restype = ctypes.c_int
+        n = L.pdgn_replay_points(self._plan, None, None, None, 0)
+        if n < 0:
+            raise _lib.PdgnHipError("pdgn_replay_points failed with %d" % n)
+        ids, pos, chain = (ctypes.c_int * max(n, 1))(), (ctypes.c_int * max(n, 1))(), (ctypes.c_int * max(n, 1))()
+        L.pdgn_replay_points(self._plan, ids, pos, chain, n)
+        self.points = [(pos[i], ids[i] - POINT_BASE, self.labels[chain[i]]) for i in range(n)]     # (list position, point index, chain's marker id)
+        # the last launch of the issuing stream's chain is behind the last launch of every other chain (a join that no later launch of
+        # the issuing stream follows would be dropped, and the next iteration could overtake a side stream's tail)
+        self.joined = bool(L.pdgn_replay_joined(self._plan))
 
     def bind(self, streams, spare):
         """streams: {marker id: torch stream}; spare: streams for chains without a marker (dealt out round-robin)."""

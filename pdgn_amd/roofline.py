@@ -252,7 +252,7 @@ def knn3_largest(B, base_points, device):
     e = _entry("knn3_wave4_kernel (n=%d, m=%d, k=20)" % (n, m), "hbm", float(B * (12 * n + 12 * m + 8 * m * k)), us)
     e["distance_evals_per_s"] = B * n * m / us * 1e6
     e["note"] = ("selection-bound, not bandwidth-bound (intensity ~80 flop/B): vector-ALU issue utilisation and wait "
-                 "fractions are in profiles/r03_pmc_mfma.csv; the HBM fraction is reported because the north star asks for it")
+                 "fractions are in the round's profiles/r*_pmc_summary.txt (knn3_largest row); the HBM fraction is reported because the north star asks for it")
     return e
 
 

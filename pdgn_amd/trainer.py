@@ -112,17 +112,40 @@ class FlatGrads:
         gradient of the bucket is still missing (its slice would be zero-filled under a running collective)."""
         if self._early_done or self.n_early == 0 or not (dist.is_available() and dist.is_initialized()):
             return
-        if _capturing(self.buf.device):
+        rec = _recorder(self.buf.device)
+        if _capturing(self.buf.device) and rec is None:
             return
         if any(p.grad is None for p in self.params[:self.n_early]):
             return
         self._pack(0, self.n_early)
         self._early_done = True
+        if rec is not None:                                      # launch-list capture: the collective becomes a host point of the list
+
+            def start(fg=self, group=group):
+                fg._early_work = dist.all_reduce(fg.buf[:fg.early_numel], op=dist.ReduceOp.SUM, group=group, async_op=True)
+            rec.point(start)
+            return
         self._early_work = dist.all_reduce(self.buf[:self.early_numel], op=dist.ReduceOp.SUM, group=group, async_op=True)
 
     def all_reduce_mean(self, group=None):
         """Average over ranks (RCCL all-reduce over xGMI when the backend is nccl)."""
         if dist.is_available() and dist.is_initialized():
+            rec = _recorder(self.buf.device)
+            if rec is not None:                                  # launch-list capture: host points; the division is captured
+                early = self._early_done
+
+                def reduce(fg=self, group=group, early=early):
+                    if early:
+                        if fg.early_numel < fg.buf.numel():
+                            dist.all_reduce(fg.buf[fg.early_numel:], op=dist.ReduceOp.SUM, group=group)
+                        fg._early_work.wait()
+                        fg._early_work = None
+                    else:
+                        dist.all_reduce(fg.buf, op=dist.ReduceOp.SUM, group=group)
+                rec.point(reduce)
+                if dist.get_world_size(group) > 1:
+                    self.buf.div_(dist.get_world_size(group))
+                return
             if self._early_done:
                 if self.early_numel < self.buf.numel():
                     dist.all_reduce(self.buf[self.early_numel:], op=dist.ReduceOp.SUM, group=group)
@@ -136,6 +159,15 @@ class FlatGrads:
 
 def _capturing(device):
     return device.type == "cuda" and torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
+
+
+def _recorder(device):
+    """The active host-point recorder of a launch-list capture (replay.Recorder), or None."""
+    if device.type != "cuda":
+        return None
+    from . import replay
+    rec = replay.recorder()
+    return rec if rec is not None and _capturing(device) else None
 
 
 def world_size():
@@ -654,11 +686,15 @@ class PDGNTrainer:
         """Record the stream-overlapped iteration ONCE (stream capture into a hipGraph that is kept but never instantiated)
         and turn it into a launch list: `step_list` then re-issues the same ~1300 launches with plain HIP calls on the
         streams the eager schedule uses -- ~4 us of host time per launch instead of ~20 (autograd nodes, allocations,
-        ctypes), and none of hipGraphLaunch's own scheduling (slower than eager here).  Single
-        process only: a collective cannot be captured (the data-parallel path stays eager)."""
+        ctypes), and none of hipGraphLaunch's own scheduling (slower than eager here).
+        Data parallel: a collective cannot be captured, so every gradient all-reduce -- D_k's on D_k's stream, the generator's
+        early bucket from inside the backward, the rest behind it -- is recorded as a HOST POINT (a marker node, replay.Recorder):
+        `step_list` issues the list in ranges and makes the RCCL calls between them, on the streams and at the places of the
+        eager schedule (packing, the division by the world size and the optimizer steps are ordinary captured launches).
+        The `warmup` iterations are real optimizer updates."""
         from . import replay
-        if self.distributed or not self.overlap:
-            raise RuntimeError("capture_list: single-process, stream-overlapped schedule only")
+        if not self.overlap:
+            raise RuntimeError("capture_list: stream-overlapped schedule only")
         self._static = self._state([r.clone() for r in reals], z1.clone(), z2.clone())
         side = torch.cuda.Stream(device=self.device)
         side.wait_stream(torch.cuda.current_stream(self.device))
@@ -667,17 +703,34 @@ class PDGNTrainer:
                 self._step_overlapped(None, None, None, st=self._state(self._static["reals"], self._static["z1"], self._static["z2"]))
         torch.cuda.current_stream(self.device).wait_stream(side)
         torch.cuda.synchronize(self.device)
+        if self.distributed and dist.is_available() and dist.is_initialized():
+            # The process group's watchdog thread polls the completion events of the collectives it still lists (every 100 ms).
+            # Such a poll while this thread captures ends the process (measured on ROCm 7.2: "operation not permitted on an
+            # event last recorded in a capturing stream", one capture in three): the warm-up's collectives are complete after
+            # the synchronise above -- give the watchdog its next rounds to drop them, so that it holds nothing during the capture.
+            import time
+            time.sleep(float(os.environ.get("PDGN_CAPTURE_QUIESCE_S", "0.5")))
         g = torch.cuda.CUDAGraph(keep_graph=True)            # the recorded graph is read back, never launched
         defer, self._defer_d = self._defer_d, False           # capture order = issue order of the replay: D_k's launches
         self._static["tag_streams"] = True                   # next to the level that feeds them
+        rec = replay.Recorder()
         try:
-            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+            with rec, torch.cuda.graph(g, capture_error_mode="thread_local"):
                 self._step_overlapped(None, None, None, st=self._static)
         finally:
             self._defer_d = defer
             self._static.pop("tag_streams", None)
         release_zero_arena()                                # the capture's arena lives in the graph's private pool
         self._list = replay.LaunchList(g)
+        if len(self._list.points) != len(rec.fns):
+            raise RuntimeError("capture_list: %d host points recorded, %d found in the list" % (len(rec.fns), len(self._list.points)))
+        self._list_points = [(pos, rec.fns[i], label) for pos, i, label in self._list.points]
+        # the iteration's last launch on the issuing stream must be behind everything else (the next iteration's input copies and
+        # the caller's reads of the losses are ordered against THAT stream only): every chain's last node must reach it
+        info = self._list.info
+        if info["chains"] != info["labelled"] or not self._list.joined:
+            raise RuntimeError("capture_list: %d chains, %d tagged, joined=%s: a launch on an untagged stream, or a side stream whose "
+                               "last launch the issuing stream never waits for" % (info["chains"], info["labelled"], self._list.joined))
         self._list_spare = [torch.cuda.Stream(device=self.device) for _ in range(2)]
         self._list_done = None
         self._list_pace = float(os.environ.get("PDGN_LIST_PACE", "1.0"))     # 1.0: the previous iteration's end
@@ -703,18 +756,27 @@ class PDGNTrainer:
         # One iteration in flight: the list is issued in ~5 ms, the device needs ~6x that.  A host that runs several
         # iterations ahead fills the runtime's queues, blocks inside a launch for ONE stream and starves the others
         # (measured: 30.5 ms/step unbounded, 30.7 with two iterations in flight, 29.2 with one; the eager host's 25 ms
-        # per iteration paced it by accident).  The wait is on the END of the previous iteration, recorded below.
-        # The wait is on a point INSIDE the previous iteration (after `_list_pace` of the issuing stream's launches, recorded
-        # below): the next list is then issued underneath the previous iteration's tail, and the device finds its first
-        # kernels queued when that tail ends.
+        # per iteration paced it by accident).  The wait is on an event recorded after `_list_pace` of the issuing stream's
+        # launches of the previous iteration: 1.0 (the default, the measured best) = its end.
         if self._list_done is not None:
             self._list_done.synchronize()
         cut = self._list.position(replay.MAIN, self._list_pace)
-        self._list.launch(0, cut)
-        if self._list_done is None:
-            self._list_done = torch.cuda.Event()
-        self._list_done.record(streams[replay.MAIN])
-        self._list.launch(cut)
+        # the list in ranges: [.. cut) | pacing event | .. and, under data parallelism, every host point's collective behind the
+        # range that ends with its marker, on the stream the marker was recorded on
+        stops = sorted([(cut, 0, None, None)] + [(pos + 1, 1, fn, label) for pos, fn, label in self._list_points], key=lambda t: t[:2])
+        lo = 0
+        for at, kind, fn, label in stops:
+            if at > lo:
+                self._list.launch(lo, at)
+                lo = at
+            if kind == 0:
+                if self._list_done is None:
+                    self._list_done = torch.cuda.Event()
+                self._list_done.record(streams[replay.MAIN])
+            else:
+                with torch.cuda.stream(streams[label]):
+                    fn()
+        self._list.launch(lo)
         return st["out"]
 
     def _sync(self):

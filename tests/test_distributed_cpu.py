@@ -344,3 +344,61 @@ def test_early_bucket_waits_for_gradients_that_arrive_late_gloo():
         np.testing.assert_array_equal(x["bucketed"], x["flat"])
     np.testing.assert_array_equal(r[0]["bucketed"], r[1]["bucketed"])
     assert not np.array_equal(r[0]["bucketed"], np.zeros_like(r[0]["bucketed"]))
+
+
+def test_launch_list_ranges_and_host_points_order():
+    """PDGNTrainer.step_list issues the list in ranges with the host points' calls between them (the data-parallel collectives)
+    and the pacing event where the cut falls: the order of launches, calls and the event record, on a fake list."""
+    sys.path.insert(0, ROOT)
+    from pdgn_amd import trainer as T
+
+    log = []
+
+    class FakeList:
+        info = {"nodes": 100}
+
+        def bind(self, streams, spare):
+            pass
+
+        def launch(self, lo=0, hi=None):
+            log.append(("launch", lo, 100 if hi is None else hi))
+
+        def position(self, label, fraction):
+            return 60
+
+    class FakeEvent:
+        def synchronize(self):
+            log.append(("sync",))
+
+        def record(self, stream):
+            log.append(("record", stream))
+
+    tr = T.PDGNTrainer.__new__(T.PDGNTrainer)
+    tr.device = torch.device("cpu")
+    tr._static = {"reals": [], "z1": torch.zeros(1), "z2": torch.zeros(1), "out": {"x": 1}}
+    tr._list, tr._list_spare, tr._list_done, tr._list_pace = FakeList(), [], FakeEvent(), 0.6
+    tr._list_points = [(10, lambda: log.append(("call", "d1")), 1), (59, lambda: log.append(("call", "early")), 0),
+                       (80, lambda: log.append(("call", "rest")), 0)]
+
+    class Ctx:
+        def __init__(self, s):
+            self.s = s
+
+        def __enter__(self):
+            log.append(("stream", self.s))
+
+        def __exit__(self, *a):
+            pass
+
+    import types
+    fake_streams = types.SimpleNamespace(lp="lp", knn="knn", d=["d1", "d2", "d3", "d4"])
+    orig = (T._streams.plan, torch.cuda.current_stream, torch.cuda.stream)
+    T._streams.plan, torch.cuda.current_stream, torch.cuda.stream = (lambda dev: fake_streams), (lambda dev=None: "main"), Ctx
+    try:
+        out = tr.step_list()
+    finally:
+        T._streams.plan, torch.cuda.current_stream, torch.cuda.stream = orig
+    assert out == {"x": 1}
+    assert log == [("sync",), ("launch", 0, 11), ("stream", "d1"), ("call", "d1"), ("launch", 11, 60), ("record", "main"),
+                   ("stream", "main"), ("call", "early"), ("launch", 60, 81), ("stream", "main"), ("call", "rest"),
+                   ("launch", 81, 100)], log

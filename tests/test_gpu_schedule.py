@@ -164,6 +164,37 @@ def test_rccl_path_at_world_size_one_equals_single_process():
         assert len(b._graphs) == 6
         b._graphs, b._static = [], None                          # the graphs go before the communicator does
         torch.cuda.synchronize()
+        # the LAUNCH LIST under data parallelism -- the same iteration re-issued from C in ranges, the five
+        # collectives (D1..D4's on their streams, the generator's early bucket from inside the backward, the rest behind it)
+        # as host points between the ranges.  From identical state it must equal the eager data-parallel iteration.
+        ts = []
+        for net in [b.G] + b.D:
+            ts += list(net.parameters()) + list(net.buffers())
+        for opt in [b.optG] + b.optD:
+            for st in opt.state.values():
+                ts += [v for v in st.values() if torch.is_tensor(v)]
+        snap = [t.detach().clone() for t in ts]
+        eager = {k: v.item() for k, v in b.step(reals, z1, z2).items()}
+        after = [p.detach().clone() for p in b.G.parameters()]
+        b.capture_list(reals, z1, z2)
+        assert len(b._list_points) == 6, b._list_points          # 4 discriminator buffers + early bucket + rest of the generator's
+        assert sorted({lab for _, _, lab in b._list_points}) == [0, 1, 2, 3, 4]      # on the issuing stream and on D1..D4's
+        assert b._list.joined and b._list.info["chains"] == b._list.info["labelled"]
+        with torch.no_grad():
+            for t, v in zip(ts, snap):
+                t.copy_(v)
+        listed = {k: v.item() for k, v in b.step_list(reals, z1, z2).items()}
+        torch.cuda.synchronize()
+        for k in eager:
+            assert abs(listed[k] - eager[k]) <= 2e-3 * max(1.0, abs(eager[k])), (k, listed[k], eager[k])
+        for p, q in zip(b.G.parameters(), after):
+            assert (p - q).abs().max().item() <= 3e-4
+        for _ in range(2):                                       # further replays: finite, no stale bucket state
+            out = b.step_list(reals, z1, z2)
+            torch.cuda.synchronize()
+            assert all(torch.isfinite(v).item() for v in out.values())
+        b._list, b._list_points, b._static = None, [], None
+        torch.cuda.synchronize()
     finally:
         dist.destroy_process_group()
 
