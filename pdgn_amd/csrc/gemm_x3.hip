@@ -295,9 +295,11 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_x3_kernel(const NtArgs
                                                          ok ? (int)(((long long)(ld_mrows - 1) * p.lda + (p.K - ld_k0)) * 4) : 0, 0x00020000);
         else rsA = __builtin_amdgcn_make_buffer_rsrc((void *)(p.A + (long long)ld_k0 * p.lda + ld_m0), 0,
                                                      ok ? (int)(((long long)(krows - 1) * p.lda + ld_mrows) * 4) : 0, 0x00020000);
-        // PW: ONE descriptor from the tile's start in plane h to the end of plane l (the plane offset of a load is part of the
-        // range check): rows past the tile read the following rows' / plane's parts -- finite values that only reach output
-        // columns which are never stored -- and everything past plane l reads zero; the K tail is masked by kokW as always
+        // PW: ONE descriptor from the tile's start in plane h to the end of plane l; the plane offset of a load travels in the
+        // instruction's SCALAR offset, which the hardware's range check does not see (raw buffers: voffset + immediate only):
+        // rows past the operand's last one are masked per lane instead (load_quad: rowokW), so that no plane is read past its
+        // N rows; rows inside the operand but past the TILE cannot occur (a tile's rows are min(BN, N - n0)); the K tail is masked
+        // by kokW as always
         if (PW) rsW = __builtin_amdgcn_make_buffer_rsrc((void *)(p.Wp + (long long)ld_n0 * p.ldw + ld_k0), 0,
                                                         ok ? (int)((2 * p.wplane + (long long)(p.N - 1 - ld_n0) * p.ldw + (p.K - ld_k0)) * 2) : 0, 0x00020000);
         else if (!WT) rsW = __builtin_amdgcn_make_buffer_rsrc((void *)(p.W + (long long)ld_n0 * p.ldw + ld_k0), 0,
@@ -316,9 +318,10 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_x3_kernel(const NtArgs
         if (PW && !isA) {
             // parts h, m, l of the quad: the same tile-relative offset in each plane, the plane offset in the scalar offset
             const unsigned off = g0 + (unsigned)(j * (NTH / 4) * ld_) * 2u;
+            const bool rowok = (int)(tid >> 2) + j * (NTH / 4) < ld_nrows;          // (the scalar plane offset escapes the range check)
 #pragma unroll
             for (int part = 0; part < 3; ++part) {
-                const u32x4 x = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, kokW ? off : NT_OOB, (int)(part * p.wplane * 2), 0));
+                const u32x4 x = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (kokW && rowok) ? off : NT_OOB, (int)(part * p.wplane * 2), 0));
 #pragma unroll
                 for (int e = 0; e < 4; ++e) rawp[j][4 * part + e] = x[e];
             }

@@ -74,7 +74,10 @@ def test_approxmatch_and_cost_vs_oracle(sl, b, n, m):
     # - sum)` has cancelled almost everything over nine levels, so their relative error is set by the summation order of the
     # 2048-term sums (tree on the GPU, serial in the oracle), not by the arithmetic (tools history: round 4, match_err).  The cost
     # the API returns holds 1e-4 relative (next lines).
-    np.testing.assert_allclose(match.cpu().numpy(), ref_match, rtol=1e-4, atol=2e-4 * float(ref_match.max()))
+    # (the scale-relative floor follows the measured one per size -- 3e-5 of the scale up to 512 points (measured 1.3e-5),
+    # 2e-4 only at 2048 x 2048 (measured 9.3e-5) -- so that the small entries of the small cases stay checked)
+    floor = (2e-4 if max(n, m) > 512 else 3e-5) * float(ref_match.max())
+    np.testing.assert_allclose(match.cpu().numpy(), ref_match, rtol=1e-4, atol=floor)
     cost = MatchCost(dev(a), dev(c), match)
     np.testing.assert_allclose(cost.cpu().numpy(), ref_cost, rtol=RTOL)
     np.testing.assert_allclose(MatchCost(dev(a), dev(c), dev(ref_match)).cpu().numpy(), ref_cost, rtol=1e-5)
