@@ -1,8 +1,8 @@
 #!/bin/bash
 # Everything under profiles/ for one round, on one MI355X box (run through gpurun from the repo root):
-#   bash tools/collect_profiles.sh gpurun_out/prof r04
+#   bash tools/collect_profiles.sh gpurun_out/prof r05
 set -u
-OUT=${1:-gpurun_out/prof}; TAG=${2:-r04}
+OUT=${1:-gpurun_out/prof}; TAG=${2:-r05}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 # the bench line as the driver runs it (launch-list issue, cpu_baseline at B = 35), and the same with every launch issued from Python
@@ -38,5 +38,12 @@ python3 tools/host_time.py > $OUT/${TAG}_host_time.txt 2>&1
 python3 tools/phase_events.py > $OUT/${TAG}_phases_overlapped.txt 2>&1
 python3 tools/finalize_bench.py 2>&1 | grep -v amdgpu.ids > $OUT/${TAG}_finalize_bench.txt
 python3 bench.py --base-points 256 --steps 10 --warmup 3 --no-cpu-baseline --no-eval-c5 > $OUT/${TAG}_bench_c4.json 2>> $OUT/bench.err
+# round 5: both bf16 matrix instructions (x3_check with the shape forced), the launch list under a one-rank RCCL group, the
+# torch-native / library launches with their owners, the block fixtures' backward error, the register table of the shipped library
+python3 tools/x3_check.py 16 2>&1 | grep -v amdgpu.ids > $OUT/${TAG}_x3_check_16x16x32.txt
+bash tools/dp_list_ab.sh $OUT/${TAG}_dp_list_ab.txt 3 > /dev/null 2>&1
+python3 tools/glue_owners.py 35 2>&1 | grep -v -E "amdgpu.ids|Warning|_warn" > $OUT/${TAG}_glue_owners.txt
+python3 tools/backward_error.py 2>&1 | grep -v amdgpu.ids > $OUT/${TAG}_backward_error.txt
+python3 tools/spill_table.py > $OUT/${TAG}_spill_table.txt 2>&1
 rm -rf $OUT/kt_bench $OUT/kt_roof $OUT/kt_eval $OUT/pmc $OUT/pmc.*.log $OUT/x3pmc
 ls -la $OUT
