@@ -55,7 +55,7 @@
 #define X3_FENCE16 2                  // the same for the 16x16x32 form
 #endif
 #ifndef X3_ABLATE
-#define X3_ABLATE 0                   // tools/x3_bench.hip (measurement only): 1 no conversion tasks, 2 no operand loads, 4 no stores, 8 no barrier, 16 no fragment reads, 32 no split arithmetic, 64 one LDS write per group, 128 direct (unstaged) result stores
+#define X3_ABLATE 0                   // tools/x3_bench.hip (measurement only): 1 no conversion tasks, 2 no operand loads, 4 no stores, 8 no barrier, 16 no fragment reads, 32 no split arithmetic, 64 one LDS write per group, 128 direct (unstaged) result stores, 256 first operand always from the same (cache-resident) block, 512 second operand likewise
 #endif
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -291,7 +291,8 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_x3_kernel(const NtArgs
         kokW = ld_k0 + 4 * kqW < p.K;
         const int krows = min(NT_BK, p.K - ld_k0);
         const bool ok = ld.valid;
-        if (!AT) rsA = __builtin_amdgcn_make_buffer_rsrc((void *)(p.A + ld_m0 * p.lda + ld_k0), 0,
+        if (!AT && (X3_ABLATE & 256)) rsA = __builtin_amdgcn_make_buffer_rsrc((void *)p.A, 0, ok ? 0x7fffffff : 0, 0x00020000);   // (measurement: every chunk of every tile reads the SAME 256 x 32 block: cache hits)
+        else if (!AT) rsA = __builtin_amdgcn_make_buffer_rsrc((void *)(p.A + ld_m0 * p.lda + ld_k0), 0,
                                                          ok ? (int)(((long long)(ld_mrows - 1) * p.lda + (p.K - ld_k0)) * 4) : 0, 0x00020000);
         else rsA = __builtin_amdgcn_make_buffer_rsrc((void *)(p.A + (long long)ld_k0 * p.lda + ld_m0), 0,
                                                      ok ? (int)(((long long)(krows - 1) * p.lda + ld_mrows) * 4) : 0, 0x00020000);
@@ -302,6 +303,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_x3_kernel(const NtArgs
         // by kokW as always
         if (PW) rsW = __builtin_amdgcn_make_buffer_rsrc((void *)(p.Wp + (long long)ld_n0 * p.ldw + ld_k0), 0,
                                                         ok ? (int)((2 * p.wplane + (long long)(p.N - 1 - ld_n0) * p.ldw + (p.K - ld_k0)) * 2) : 0, 0x00020000);
+        else if (!WT && (X3_ABLATE & 512)) rsW = __builtin_amdgcn_make_buffer_rsrc((void *)p.W, 0, ok ? 0x7fffffff : 0, 0x00020000);
         else if (!WT) rsW = __builtin_amdgcn_make_buffer_rsrc((void *)(p.W + (long long)ld_n0 * p.ldw + ld_k0), 0,
                                                          ok ? (int)(((long long)(ld_nrows - 1) * p.ldw + (p.K - ld_k0)) * 4) : 0, 0x00020000);
         else rsW = __builtin_amdgcn_make_buffer_rsrc((void *)(p.W + (long long)ld_k0 * p.ldw + ld_n0), 0,
