@@ -17,7 +17,9 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-ffp-contract=
          "-Wall", "-Wno-unused-function"]
 # gemm_x3.hip: a k chunk is ONE fully unrolled straight line of up to 192 matrix instructions with the conversion, load and LDS
 # work placed between them; the default budget of `#pragma unroll` (16 K IR instructions) refuses the 16x16x32 form's chunk
-EXTRA_FLAGS = {"gemm_x3.hip": ["-mllvm", "-pragma-unroll-threshold=200000"]}
+EXTRA_FLAGS = {"gemm_x3.hip": ["-mllvm", "-pragma-unroll-threshold=200000"],
+               "gemm_x3_16.hip": ["-mllvm", "-pragma-unroll-threshold=200000"]}
+EXTRA_DEPS = {"gemm_x3_16.hip": ["gemm_x3.hip"]}          # sources a translation unit #includes besides the headers
 
 
 def sources():
@@ -44,8 +46,8 @@ def build(force=False, verbose=False):
         obj = os.path.join(HERE, "build", os.path.basename(src)[:-4] + ".o")
         objs.append(obj)
         if (not force) and os.path.exists(obj) and os.path.getmtime(obj) > max(
-                os.path.getmtime(src), *(os.path.getmtime(os.path.join(CSRC, h))
-                                         for h in os.listdir(CSRC) if h.endswith(".h")),
+                os.path.getmtime(src), *(os.path.getmtime(os.path.join(CSRC, d)) for d in EXTRA_DEPS.get(os.path.basename(src), [])),
+                *(os.path.getmtime(os.path.join(CSRC, h)) for h in os.listdir(CSRC) if h.endswith(".h")),
                 os.path.getmtime(os.path.join(os.path.dirname(HERE), "include", "pdgn_hip.h"))):
             continue
         cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(os.path.basename(src), []) + ["-c", src, "-o", obj]

@@ -459,8 +459,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_x3_kernel(const NtArgs
     //   MS = 16: sub-block bb (= 16-column block) of block row a (16 rows): row 16 a + li, columns 16 bb + 4 lg + (0 .. 3).
     // The 16-B stores of item t are issued from inside the first k step of item t + 1 (before the MFMA that restarts the block
     // from zero), in the shadow of running MFMAs.
-    constexpr int NBB = MS == 32 ? 4 * TN : 2 * TN, NA = FA;
-    const int mloc0 = wm * 32 * TM + li, nloc0 = wn * 32 * TN + 4 * lg;
+    constexpr int NBB = MS == 32 ? 4 * TN : 2 * TN, NA = FA;      // (mloc0 / nloc0, the lane's first row / column: finish_item derives them)
     auto coloff = [](int bb) { return MS == 32 ? 32 * (bb >> 2) + 8 * (bb & 3) : 16 * bb; };
     auto get4 = [&](int a, int bb) {
         const int A_ = MS == 32 ? a : a >> 1, b = MS == 32 ? bb >> 2 : bb >> 1, q = MS == 32 ? bb & 3 : 2 * (a & 1) + (bb & 1);
@@ -898,6 +897,8 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_x3_kernel(const NtArgs
 #ifndef X3_KERNEL_ONLY                // (tools/x3_inst.hip compiles single instances of the kernel for ISA inspection)
 // ------------------------------------------------------------------ host side
 static bool x3_shape16(int cfg_index, bool atomic, bool epi, bool pw);
+// gemm_x3_16.hip: instance (tile cfg, flags = ATOMIC | WT << 1 | AT << 2 | EPI << 3 | PW << 4) of gemm_x3_kernel<..., 16>
+void x3_launch16(int cfg, int flags, int grid, hipStream_t s, const NtArgs &a);
 
 template <int TM, int TN, int WM, int WN, int OCC, int RATE, int CFG>      // RATE: fp32-equivalent kflop / us a CU sustains on this tile's loop
 struct X3Cfg {
@@ -961,8 +962,9 @@ struct X3Cfg {
     template <bool ATOMIC, bool WT, bool AT, bool EPI, bool PW = false>
     static void go(int grid, hipStream_t s, const NtArgs &a) {
         // the matrix instruction is chosen per instance class (tile, atomic / extended epilogue / pre-split operand): nt_switches().shape16
+        // (the 16x16x32 instances live in their own translation unit, gemm_x3_16.hip: the two compile side by side)
         if (x3_shape16(CFG, ATOMIC, EPI, PW))
-            hipLaunchKernelGGL((gemm_x3_kernel<TM, TN, WM, WN, OCC, ATOMIC, WT, AT, EPI, PW, 16>), dim3(grid), dim3(64 * WM * WN), 0, s, a);
+            x3_launch16(CFG, (ATOMIC ? 1 : 0) | (WT ? 2 : 0) | (AT ? 4 : 0) | (EPI ? 8 : 0) | (PW ? 16 : 0), grid, s, a);
         else
             hipLaunchKernelGGL((gemm_x3_kernel<TM, TN, WM, WN, OCC, ATOMIC, WT, AT, EPI, PW, 32>), dim3(grid), dim3(64 * WM * WN), 0, s, a);
     }

@@ -1,5 +1,6 @@
 // x3_bench.hip -- pdgn_gemm_nt (gemm_x3.hip) alone, with compile-time ablations (-DX3_ABLATE=n) to see where its time goes.
-//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -DX3_ABLATE=0 -Ipdgn_amd/csrc tools/x3_bench.hip -o /tmp/x3b
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -mllvm -pragma-unroll-threshold=200000 -DX3_ABLATE=0 [-DX3_DEFAULT_SHAPE=16] \
+//         -Ipdgn_amd/csrc tools/x3_bench.hip pdgn_amd/csrc/gemm_x3_16.hip -o /tmp/x3b
 #ifdef X3_DEFAULT_SHAPE                 // -DX3_DEFAULT_SHAPE=16: every instance class on v_mfma_f32_16x16x32_bf16
 #define X3_DEFAULT_MASK (X3_DEFAULT_SHAPE == 16 ? 0xfff : 0)
 #endif
