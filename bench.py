@@ -432,12 +432,31 @@ def measure_and_report(args, trainer, reals, zs, world, rank, device, res):
             step(reals, *zs[0])
     for i in range(args.warmup):
         step(reals, *zs[i])
+    # the dominant kernel (conv2's dense half, stage 4, forward: one launch per generator pass) timed INSIDE the timed steps: HIP
+    # events around each of its launches, on the stream the launch list issues it on (csrc/replay.hip)
+    in_step = None
+    if issue == "list" and not getattr(args, "no_roofline", False):
+        try:
+            from pdgn_amd import roofline as _rf
+            spans = _rf.conv2_in_step_spans(trainer._list, args.batch, args.base_points)
+            if spans:
+                trainer._list.time_spans(spans, args.steps)
+                in_step = True
+        except Exception as e:
+            print("in-step kernel timing unavailable (%r)" % (e,), file=sys.stderr)
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
         out = step(reals, *zs[args.warmup + i])
     barrier()
     dt_local = time.perf_counter() - t0
+    if in_step:
+        try:
+            in_step = trainer._list.timed_ms()
+            trainer._list.time_spans([], 0)
+        except Exception as e:
+            print("in-step kernel timing failed (%r)" % (e,), file=sys.stderr)
+            in_step = None
     dt, dts = dt_local, [dt_local]
     if world > 1:
         t = torch.tensor([dt_local], device=device, dtype=torch.float64)
@@ -500,6 +519,8 @@ def measure_and_report(args, trainer, reals, zs, world, rank, device, res):
             try:
                 from pdgn_amd import roofline
                 line["roofline"] = roofline.measure(args.batch, args.base_points, device)
+                if in_step:
+                    line["roofline"] = roofline.attach_in_step(line["roofline"], in_step)
                 line["gemm_accuracy"] = roofline.gemm_accuracy(device)        # both kernels against fp64, same operands
             except Exception as e:                               # never lose the headline number
                 line["roofline"] = {"error": repr(e)}

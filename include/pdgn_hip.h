@@ -317,6 +317,16 @@ int pdgn_gemm_nt_ps(long long m, int n, int k, const float *A, int lda, const un
                     const float *bias, const float *addend, int ldadd, float *C, int ldc, float *stat_part,
                     const float *row_bias, int ld_rb, int rows_per_group, int act, const float *gate, int ldgate,
                     pdgn_stream_t stream);
+/* Stream-K tails without atomics (matrix-core mode).  A launch whose tiles do not fill the last round of workgroups finishes with a
+ * tail that splits the leftover tiles' k range over the CUs.  With a workspace of pdgn_gemm_tail_workspace_floats(m, n, k, with_stats)
+ * floats handed over by pdgn_gemm_set_tail_workspace -- to the NEXT pdgn_gemm_nt / _nn / _nt_ps call of the calling thread, which
+ * consumes it -- the tail stores partial tiles there and a small kernel adds them into C (deterministic, no zero-fill); without one
+ * it adds them with fp32 atomics.  The buffer must stay valid until that call's launches have run.  No reference counterpart. */
+long long pdgn_gemm_tail_workspace_floats(long long m, int n, int k, int with_stats);
+int pdgn_gemm_set_tail_workspace(float *ws, long long floats);
+/* The kernel instance (host symbol; NULL for the 16x16x32 arm) and grid of the plain data-parallel launch of pdgn_gemm_nt_ps(m, n, k)
+ * under the switches in force: for measurements that look that launch up in a recorded iteration.  Host-side only. */
+int pdgn_gemm_nt_ps_launch_info(long long m, int n, int k, const void **sym, int *grid);
 /* Process-wide switches of the dense contractions (read from PDGN_GEMM / PDGN_NT_CFG once, at first use).
  * pdgn_gemm_set_mode: 1 = bf16 matrix cores (default), 0 = fp32 matrix instructions, < 0 = query; returns the previous mode.
  * pdgn_gemm_set_config: -1 = the launch model's pick (default), 0 .. 3 = force a tile configuration (measurement / tests),
@@ -532,6 +542,15 @@ int pdgn_replay_position(void *plan, int chain, int nth); /* list position of a 
  * max_out in list order.  The caller issues [lo, pos + 1), makes its own call on that chain's stream, and goes on. */
 int pdgn_replay_points(void *plan, int *ids, int *pos, int *chain, int max_out);
 int pdgn_replay_joined(void *plan); /* 1: the chain of marker 0 ends behind every other chain's last node */
+/* In-iteration timing: pdgn_replay_kernel_nodes finds the list positions of the nodes launched through a host symbol (a kernel
+ * instance, e.g. from pdgn_gemm_nt_ps_launch_info) with a given grid.x (< 0: any); pdgn_replay_chain_neighbor steps along a node's
+ * chain (the memset in front of a stream-K launch, the tail kernel behind it); pdgn_replay_time_spans brackets spans [first, last] of
+ * one chain with two timing events on that chain's stream for the next `slots` passes; pdgn_replay_time_read waits for them and
+ * returns ms_out[i * slots + j] for j < counts[i].  bench.py measures its roofline kernel this way, inside the timed steps. */
+int pdgn_replay_kernel_nodes(void *plan, const void *sym, int gx, int *pos, int max_out);
+int pdgn_replay_chain_neighbor(void *plan, int pos, int dir, int *kind_out, const void **sym_out);
+int pdgn_replay_time_spans(void *plan, const int *first, const int *last, int n, int slots);
+int pdgn_replay_time_read(void *plan, float *ms_out, int *counts);
 int pdgn_replay_launch_timed(void *plan, double *us32); /* measurement: host microseconds per call kind / chain */
 int pdgn_replay_probe_chain(void *plan, int chain, int stride, float *ms_out, int *pos_out, int max_out); /* measurement: device-time progress of one chain */
 int pdgn_replay_destroy(void *plan);

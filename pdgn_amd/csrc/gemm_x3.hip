@@ -186,7 +186,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_x3_kernel(const NtArgs
         bool valid;
     };
     auto next_item = [&](Cur &c) {
-        if (ATOMIC && p.sk_split) {                                // split-K: one item per workgroup
+        if (p.sk_split && (ATOMIC || p.sk_ws)) {                   // split-K: one item per workgroup (atomics into C, or a partial tile into the workspace)
             const int slice = v / p.sk_split;
             c.tile = p.tile_begin + v % p.sk_split;
             c.kc = c.kb = (int)(slice * p.sk_per_wg);
@@ -469,6 +469,9 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_x3_kernel(const NtArgs
         const int A_ = MS == 32 ? a : a >> 1, b = MS == 32 ? bb >> 2 : bb >> 1, q = MS == 32 ? bb & 3 : 2 * (a & 1) + (bb & 1);
         acc[A_][b][4 * q] = x[0]; acc[A_][b][4 * q + 1] = x[1]; acc[A_][b][4 * q + 2] = x[2]; acc[A_][b][4 * q + 3] = x[3];
     };
+    // p.sk_ws (stream-K tail without atomics, round 5): the workgroup's partial tile goes to slot v of a workspace of whole BM x BN
+    // tiles (pitch BN) through the ordinary store path; x3_sk_reduce_kernel adds the slices of a tile and writes C
+    const int ldc_eff = (!ATOMIC && p.sk_ws) ? BN : p.ldc;
     __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc((void *)p.C, 0, 0, 0x00020000);   // nothing pending: all out of range
     unsigned st_off[NBB];                                          // byte offset of (row mloc0, sub-block bb), or out of range
 #pragma unroll
@@ -504,7 +507,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_x3_kernel(const NtArgs
 #pragma unroll
         for (int j = 0; j < 4; ++j)
             if (!(X3_ABLATE & 4))
-                __builtin_amdgcn_raw_buffer_store_b128(pend[j], rsC, stg_off[b] + (unsigned)((a * 32 + 8 * j) * p.ldc) * 4u, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(pend[j], rsC, stg_off[b] + (unsigned)((a * 32 + 8 * j) * ldc_eff) * 4u, 0, 0);
     };
     auto store_block = [&](int a, int b) {
         if (STG) {
@@ -515,7 +518,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_x3_kernel(const NtArgs
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int ra = MS == 32 ? a : 2 * a + (q >> 1), bb = MS == 32 ? 4 * b + q : 2 * b + (q & 1);
-            const unsigned off = st_off[bb] + (unsigned)(ra * FR * p.ldc) * 4u;
+            const unsigned off = st_off[bb] + (unsigned)(ra * FR * ldc_eff) * 4u;
             if (!(X3_ABLATE & 4)) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, get4(ra, bb)), rsC, off, 0, 0);
         }
     };
@@ -531,17 +534,19 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_x3_kernel(const NtArgs
         decode(cp.tile, tm, tn);
         const long long m0 = (long long)tm * BM;
         const int n0 = tn * BN;
-        const long long mrows = min((long long)BM, p.M - m0);
-        const int ncols = min(BN, p.N - n0);
+        const bool to_ws = !ATOMIC && p.sk_ws != nullptr;
+        const long long mrows = to_ws ? BM : min((long long)BM, p.M - m0);      // (a partial tile is stored whole: rows / columns past
+        const int ncols = to_ws ? BN : min(BN, p.N - n0);                       //  the matrix hold zeros and are not read back)
         if (!ATOMIC) {
-            rsC = __builtin_amdgcn_make_buffer_rsrc((void *)(p.C + m0 * p.ldc + n0), 0, (int)(mrows * p.ldc * 4), 0x00020000);
+            if (to_ws) rsC = __builtin_amdgcn_make_buffer_rsrc((void *)(p.sk_ws + (size_t)v * BM * BN), 0, BM * BN * 4, 0x00020000);
+            else rsC = __builtin_amdgcn_make_buffer_rsrc((void *)(p.C + m0 * p.ldc + n0), 0, (int)(mrows * p.ldc * 4), 0x00020000);
 #pragma unroll
             for (int bb = 0; bb < NBB; ++bb)
-                st_off[bb] = (nloc0 + coloff(bb) < ncols && !(p.dbg & 1)) ? (unsigned)(mloc0 * p.ldc + nloc0 + coloff(bb)) * 4u : NT_OOB;
+                st_off[bb] = (nloc0 + coloff(bb) < ncols && !(p.dbg & 1)) ? (unsigned)(mloc0 * ldc_eff + nloc0 + coloff(bb)) * 4u : NT_OOB;
 #pragma unroll
             for (int b = 0; b < TN; ++b) {
                 const int nl = wn * 32 * TN + 32 * b + 4 * (lane & 7);
-                stg_off[b] = (nl < ncols && !(p.dbg & 1)) ? (unsigned)((wm * 32 * TM + (lane >> 3)) * p.ldc + nl) * 4u : NT_OOB;
+                stg_off[b] = (nl < ncols && !(p.dbg & 1)) ? (unsigned)((wm * 32 * TM + (lane >> 3)) * ldc_eff + nl) * 4u : NT_OOB;
             }
             if (p.addend) {                                        // out of range reads 0
                 __amdgpu_buffer_rsrc_t rsD = __builtin_amdgcn_make_buffer_rsrc((void *)(p.addend + m0 * p.ldadd + n0), 0,
@@ -897,6 +902,56 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_x3_kernel(const NtArgs
 #ifndef X3_KERNEL_ONLY                // (tools/x3_inst.hip compiles single instances of the kernel for ISA inspection)
 // ------------------------------------------------------------------ host side
 static bool x3_shape16(int cfg_index, bool atomic, bool epi, bool pw);
+
+// ---- stream-K tails without atomics (round 5).  A launch whose tiles do not fill the last round of workgroups used to finish with
+// a second launch that split the leftover tiles' k range over all CUs and ADDED its partial tiles into C with fp32 atomics (after
+// a zero-fill of those rows).  Inside the iteration those tails were the slowest launches per flop of the whole step -- conv2's
+// forward: 371 us for 0.19 rounds of work that take 77 us as whole tiles (tools/sk_tails.py: 1.6 ms of tails per iteration on the
+// issuing stream).  Now the tail's workgroups store their partial tiles -- whole BM x BN tiles, the ordinary store path -- into a
+// workspace and a small kernel adds a tile's slices (in order: deterministic) plus bias / addend into C: no atomics, no zero-fill.
+// The workspace is the CALLER's (kernels never allocate, and an allocation under a stream capture would end the capture):
+// pdgn_gemm_tail_workspace_floats says how much a problem's tail wants, pdgn_gemm_set_tail_workspace hands a buffer to the NEXT
+// contraction call of the calling thread (thread-local, consumed by that call); without one the atomic form runs.
+static thread_local float *x3_tail_ws = nullptr;
+static thread_local long long x3_tail_ws_floats = 0;
+static float *x3_take_workspace(size_t floats) {
+    static const bool off = [] { const char *e = getenv("PDGN_X3_SK_WS"); return e && e[0] == '0'; }();   // 0: the atomic tails (A/B)
+    float *p = (!off && x3_tail_ws && (size_t)x3_tail_ws_floats >= floats) ? x3_tail_ws : nullptr;
+    x3_tail_ws = nullptr;
+    x3_tail_ws_floats = 0;
+    return p;
+}
+
+// C tile t of the tail = sum over the S slices ws[(s T + t)] (+ bias + addend); gridDim.y workgroups per tile (BM % (8 * 1) == 0)
+__global__ __launch_bounds__(256) void x3_sk_reduce_kernel(const float *__restrict__ ws, int S, int T, int BM, int BN, int tile_begin,
+                                                           int tiles_m, int tiles_n, long long M, int N, float *__restrict__ C, int ldc,
+                                                           const float *__restrict__ bias, const float *__restrict__ addend, int ldadd) {
+    const int t = blockIdx.x, tile = tile_begin + t;
+    const int per_group = NT_GROUP_M * tiles_n;
+    const int grp = tile / per_group, r = tile - grp * per_group, first = grp * NT_GROUP_M;
+    const int gsz = min(NT_GROUP_M, tiles_m - first);
+    const int tn = r / gsz, tm = first + (r - tn * gsz);
+    const long long m0 = (long long)tm * BM;
+    const int n0 = tn * BN;
+    const int mrows = (int)min((long long)BM, M - m0), ncols = min(BN, N - n0);
+    const int q4 = BN / 4;
+    const int rows_per = BM / (int)gridDim.y;                     // gridDim.y workgroups share a tile by rows (48 tiles alone fill a fifth of the chip)
+    for (int e = threadIdx.x; e < rows_per * q4; e += 256) {
+        const int row = blockIdx.y * rows_per + e / q4, c4 = (e % q4) * 4;
+        if (row >= mrows || c4 >= ncols) continue;                  // (N % 4 == 0: a float4 is all in or all out)
+        float4 a = *reinterpret_cast<const float4 *>(ws + ((size_t)t * BM + row) * BN + c4);
+        for (int sl = 1; sl < S; ++sl) {
+            const float4 b = *reinterpret_cast<const float4 *>(ws + (((size_t)sl * T + t) * BM + row) * BN + c4);
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        }
+        if (bias) { const float4 b = *reinterpret_cast<const float4 *>(bias + n0 + c4); a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
+        if (addend) {
+            const float4 b = *reinterpret_cast<const float4 *>(addend + (m0 + row) * ldadd + n0 + c4);
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        }
+        *reinterpret_cast<float4 *>(C + (m0 + row) * ldc + n0 + c4) = a;
+    }
+}
 // gemm_x3_16.hip: instance (tile cfg, flags = ATOMIC | WT << 1 | AT << 2 | EPI << 3 | PW << 4) of gemm_x3_kernel<..., 16>
 void x3_launch16(int cfg, int flags, int grid, hipStream_t s, const NtArgs &a);
 
@@ -969,6 +1024,19 @@ struct X3Cfg {
             hipLaunchKernelGGL((gemm_x3_kernel<TM, TN, WM, WN, OCC, ATOMIC, WT, AT, EPI, PW, 32>), dim3(grid), dim3(64 * WM * WN), 0, s, a);
     }
 
+    // floats of workspace the stream-K tail of (m, n, k) wants (0: no tail)
+    static long long tail_floats(long long m, int n, int k, bool allow_sk) {
+        const Plan pl = plan(m, n, k, allow_sk);
+        if (!pl.grid_sk) return 0;
+        const long long T = (long long)pl.tiles_m * pl.tiles_n;
+        const int t_tail = (int)(T - pl.dp_tiles), slots_ = nt_cus() * WG_PER_CU;
+        int s_tail = slots_ / t_tail < 1 ? 1 : slots_ / t_tail;
+        s_tail = s_tail > pl.kchunks ? pl.kchunks : s_tail;
+        const int per_tail = (pl.kchunks + s_tail - 1) / s_tail;
+        s_tail = (pl.kchunks + per_tail - 1) / per_tail;
+        return (long long)s_tail * t_tail * BM * BN;
+    }
+
     template <bool WT, bool AT = false>
     static int launch(long long m, int n, int k, const float *A, int lda, const float *W, int ldw, const float *bias,
                       const float *addend, int ldadd, float *C, int ldc, float *stat_part, hipStream_t s,
@@ -983,6 +1051,7 @@ struct X3Cfg {
         a.rb_bytes = epi.row_bias ? (int)((((m + a.rows_per_group - 1) / a.rows_per_group - 1) * (long long)epi.ld_rb + n) * 4) : 0;
         a.act = epi.act; a.gate = epi.gate; a.ldgate = epi.ldgate; a.sk_split = 0;
         a.Wp = Wp; a.wplane = wplane;
+        a.sk_ws = nullptr;
         a.tiles_m = pl.tiles_m; a.tiles_n = pl.tiles_n; a.kchunks = pl.kchunks;
         a.dbg = 0;
 #ifdef PDGN_NT_DEBUG
@@ -1001,7 +1070,20 @@ struct X3Cfg {
             go<true, WT, AT, false>((int)T * S, s, a);
             return pdgn_launch_status();
         }
-        if (pl.grid_sk) {
+        // stream-K tail: the leftover tiles' k range in S slices, partial tiles to the workspace + a reduce (no atomics); the atomic
+        // form (zero-fill + fp32 atomics into C) when there is no workspace
+        const int t_tail = pl.grid_sk ? (int)(T - pl.dp_tiles) : 0;
+        int s_tail = 0, per_tail = 0;
+        float *ws = nullptr;
+        if (t_tail > 0 && !AT) {
+            const int slots_ = nt_cus() * WG_PER_CU;
+            s_tail = slots_ / t_tail < 1 ? 1 : slots_ / t_tail;
+            s_tail = s_tail > pl.kchunks ? pl.kchunks : s_tail;
+            per_tail = (pl.kchunks + s_tail - 1) / s_tail;
+            s_tail = (pl.kchunks + per_tail - 1) / per_tail;
+            ws = x3_take_workspace((size_t)s_tail * t_tail * BM * BN);
+        }
+        if (pl.grid_sk && !ws) {
             const long long r0 = (long long)(pl.dp_tiles / (NT_GROUP_M * pl.tiles_n)) * NT_GROUP_M * BM;
             if (!prezeroed && hipMemsetAsync(C + r0 * ldc, 0, (size_t)(m - r0) * ldc * sizeof(float), s) != hipSuccess) return pdgn_launch_status();
         }
@@ -1014,7 +1096,14 @@ struct X3Cfg {
             } else if (!AT && epi.any()) go<false, WT, false, true>(pl.grid_dp, s, a);
             else go<false, WT, AT, false>(pl.grid_dp, s, a);
         }
-        if (pl.grid_sk) {
+        if (pl.grid_sk && ws) {
+            a.tile_begin = pl.dp_tiles; a.tile_end = (int)T; a.sk_split = t_tail; a.sk_per_wg = per_tail; a.sk_ws = ws;
+            a.bias = nullptr; a.addend = nullptr;                  // (the reduce adds them)
+            if (CAN_PW && Wp) go<false, false, false, false, CAN_PW>(s_tail * t_tail, s, a);
+            else go<false, WT, AT, false>(s_tail * t_tail, s, a);
+            hipLaunchKernelGGL(x3_sk_reduce_kernel, dim3(t_tail, 8), dim3(256), 0, s, ws, s_tail, t_tail, BM, BN, pl.dp_tiles, pl.tiles_m,
+                               pl.tiles_n, m, n, C, ldc, bias, addend, ldadd);
+        } else if (pl.grid_sk) {
             a.tile_begin = pl.dp_tiles; a.tile_end = (int)T; a.sk_per_wg = pl.sk_per_wg;
             if (CAN_PW && Wp) go<true, false, false, false, CAN_PW>(pl.grid_sk, s, a);
             else go<true, WT, AT, false>(pl.grid_sk, s, a);
@@ -1181,6 +1270,45 @@ extern "C" int pdgn_gemm_nt_ps(long long m, int n, int k, const float *A, int ld
     e.ldgate = ldgate;
     return x3_dispatch<false>(m, n, k, A, lda, nullptr, ldw, bias, addend, ldadd, C, ldc, stat_part, (hipStream_t)stream, e, Wplanes,
                               wplane);
+}
+
+// Stream-K tails without atomics: floats of workspace the tail of pdgn_gemm_nt / _nn / _nt_ps (m, n, k) wants (0: that launch has no
+// tail, or runs on the fp32 instructions), and the hand-over of a buffer to the NEXT such call of the calling thread.
+extern "C" long long pdgn_gemm_tail_workspace_floats(long long m, int n, int k, int with_stats) {
+    if (!x3_mode() || m < 1 || n < 4 || k < 4) return 0;
+    const bool sk = !with_stats;
+    switch (x3_pick(m, n, k, with_stats != 0)) {
+        case 0: return X3Big::tail_floats(m, n, k, sk);
+        case 2: return X3Narrow::tail_floats(m, n, k, sk);
+        default: return X3Square::tail_floats(m, n, k, sk);
+    }
+}
+extern "C" int pdgn_gemm_set_tail_workspace(float *ws, long long floats) {
+    if (floats < 0 || ((uintptr_t)ws & 15)) return PDGN_ERR_INVALID;
+    x3_tail_ws = ws;
+    x3_tail_ws_floats = ws ? floats : 0;
+    return 0;
+}
+
+// Which kernel instance and grid the plain (no bias / addend / epilogue) data-parallel launch of pdgn_gemm_nt_ps(m, n, k, ...) uses under
+// the switches in force: *sym = the instance's host symbol (NULL for an instance that lives in another translation unit: the
+// 16x16x32 arm), *grid = its grid.  Lets a measurement find that launch inside a recorded iteration (pdgn_replay_kernel_nodes).
+extern "C" int pdgn_gemm_nt_ps_launch_info(long long m, int n, int k, const void **sym, int *grid) {
+    if (!x3_mode() || m < 1 || n < 4 || k < 4 || !sym || !grid) return PDGN_ERR_INVALID;
+    const int cfg = x3_pick(m, n, k, false);
+    const bool s16 = x3_shape16(cfg, false, false, true);
+    *sym = nullptr;
+    if (cfg == 0) {
+        *grid = X3Big::plan(m, n, k, true).grid_dp;
+        if (!s16) *sym = (const void *)gemm_x3_kernel<4, 2, 2, 2, 1, false, false, false, false, true, 32>;
+    } else if (cfg == 2) {
+        *grid = X3Narrow::plan(m, n, k, true).grid_dp;
+        if (!s16) *sym = (const void *)gemm_x3_kernel<2, 1, 2, 2, 2, false, false, false, false, true, 32>;
+    } else {
+        *grid = X3Square::plan(m, n, k, true).grid_dp;
+        if (!s16) *sym = (const void *)gemm_x3_kernel<2, 2, 2, 2, 1, false, false, false, false, true, 32>;
+    }
+    return 0;
 }
 
 // Weight gradient of a point-major dense layer, dW (n x k) = dY (m x n)^T X (m x k): the same kernel with BOTH operands

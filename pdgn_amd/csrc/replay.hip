@@ -40,6 +40,8 @@ struct RNode {
     int kind = NK_EMPTY;
     int chain = -1;
     int point = -1;                  // id of a host point (marker id >= 64), or -1
+    void *sym = nullptr;             // kernel: the host symbol it was launched through (identifies a kernel instance)
+    int tstart = -1, tstop = -1;     // timed span that begins in front of / ends behind this node, or -1
     int record = -1;                 // event to record after this node (another chain waits for it), or -1
     std::vector<int> waits;          // events this node's chain must wait for before the node
     // kernel
@@ -62,6 +64,10 @@ struct RPlan {
     std::vector<hipEvent_t> events;
     int counts[8] = {0};             // nodes, kernels, memsets, memcpys, empties, chains, events, labelled chains
     int joined = 0;                  // the last node of chain 'marker 0' has the last node of every other chain among its ancestors
+    // in-iteration timing of chosen kernel nodes (bench.py's roofline: the dominant kernel's duration INSIDE the timed region)
+    int time_slots = 0;
+    std::vector<int> time_count;     // per timed span: passes recorded so far
+    std::vector<hipEvent_t> time_ev; // [span][slot][start, stop]
     hipStream_t origin = nullptr;    // the capture's origin stream: chain of marker 0
 };
 
@@ -136,6 +142,7 @@ extern "C" int pdgn_replay_build(void *graph_, void **plan_out) {
             r.shmem = p.sharedMemBytes;
             r.params = p.kernelParams;
             r.extra = p.extra;
+            r.sym = (void *)p.func;
             hipFunction_t f = nullptr;
             if (hipGetFuncBySymbol(&f, p.func) == hipSuccess && f) r.func = f;      // a __global__ function's host stub
             else { (void)hipGetLastError(); r.func = (hipFunction_t)p.func; }       // launched through the module API
@@ -296,6 +303,9 @@ extern "C" int pdgn_replay_launch_range(void *plan_, int lo, int hi) {
         hipStream_t s = plan->chain_stream[r.chain];
         for (int w : r.waits)
             if ((e = hipStreamWaitEvent(s, plan->events[w], 0)) != hipSuccess) return (int)e;
+        if (r.tstart >= 0 && plan->time_count[r.tstart] < plan->time_slots &&
+            (e = hipEventRecord(plan->time_ev[(r.tstart * plan->time_slots + plan->time_count[r.tstart]) * 2], s)) != hipSuccess)
+            return (int)e;
         switch (r.kind) {
         case NK_KERNEL:
             e = hipModuleLaunchKernel(r.func, r.gx, r.gy, r.gz, r.bx, r.by, r.bz, r.shmem, s, r.params, r.extra);
@@ -312,7 +322,85 @@ extern "C" int pdgn_replay_launch_range(void *plan_, int lo, int hi) {
             break;
         }
         if (e != hipSuccess) return (int)e;
+        if (r.tstop >= 0 && plan->time_count[r.tstop] < plan->time_slots) {
+            if ((e = hipEventRecord(plan->time_ev[(r.tstop * plan->time_slots + plan->time_count[r.tstop]) * 2 + 1], s)) != hipSuccess)
+                return (int)e;
+            ++plan->time_count[r.tstop];
+        }
         if (r.record >= 0 && (e = hipEventRecord(plan->events[r.record], s)) != hipSuccess) return (int)e;
+    }
+    return 0;
+}
+
+// Kernel nodes launched through host symbol `sym` with grid.x == gx (gx < 0: any grid): their list positions (at most max_out
+// written); returns their number.  `sym` identifies a kernel INSTANCE (e.g. pdgn_gemm_nt_ps_launch_info).
+extern "C" int pdgn_replay_kernel_nodes(void *plan_, const void *sym, int gx, int *pos, int max_out) {
+    RPlan *plan = (RPlan *)plan_;
+    if (!plan || !sym || max_out < 0) return PDGN_ERR_INVALID;
+    int n = 0;
+    for (size_t i = 0; i < plan->nodes.size(); ++i) {
+        const RNode &r = plan->nodes[i];
+        if (r.kind == NK_KERNEL && r.sym == sym && (gx < 0 || (int)r.gx == gx)) {
+            if (n < max_out && pos) pos[n] = (int)i;
+            ++n;
+        }
+    }
+    return n;
+}
+
+// List position of the next (dir > 0) / previous (dir < 0) node of the same chain as the node at `pos`, or -1; kind_out (may be
+// NULL) receives that node's kind (0 kernel, 1 memset, 2 memcpy, 3 empty) and sym_out its kernel symbol.
+extern "C" int pdgn_replay_chain_neighbor(void *plan_, int pos, int dir, int *kind_out, const void **sym_out) {
+    RPlan *plan = (RPlan *)plan_;
+    if (!plan || pos < 0 || pos >= (int)plan->nodes.size() || dir == 0) return -1;
+    const int c = plan->nodes[pos].chain, n = (int)plan->nodes.size();
+    for (int i = pos + (dir > 0 ? 1 : -1); i >= 0 && i < n; i += (dir > 0 ? 1 : -1))
+        if (plan->nodes[i].chain == c) {
+            if (kind_out) *kind_out = plan->nodes[i].kind;
+            if (sym_out) *sym_out = plan->nodes[i].sym;
+            return i;
+        }
+    return -1;
+}
+
+// Time SPANS of the list INSIDE the iterations that follow: span i runs from in front of the node at first[i] to behind the node at
+// last[i] (both of one chain, i.e. one stream): two timing events on that stream per pass (bench.py: "measured live ... with HIP
+// events over the timed region, on the stream the kernel is launched on"), for the next `slots` passes.  pdgn_replay_time_read
+// returns the durations (ms_out[i * slots + j], j < counts[i]) once they have completed; n = 0 switches the timing off.
+extern "C" int pdgn_replay_time_spans(void *plan_, const int *first, const int *last, int n, int slots) {
+    RPlan *plan = (RPlan *)plan_;
+    if (!plan || n < 0 || slots < 0 || (n > 0 && (!first || !last))) return PDGN_ERR_INVALID;
+    for (auto &r : plan->nodes) r.tstart = r.tstop = -1;
+    for (auto ev : plan->time_ev) if (ev) (void)hipEventDestroy(ev);
+    plan->time_ev.clear();
+    plan->time_count.assign((size_t)n, 0);
+    plan->time_slots = n ? slots : 0;
+    const int N = (int)plan->nodes.size();
+    for (int i = 0; i < n; ++i) {
+        if (first[i] < 0 || last[i] >= N || first[i] > last[i] || plan->nodes[first[i]].chain != plan->nodes[last[i]].chain)
+            return PDGN_ERR_INVALID;
+        plan->nodes[first[i]].tstart = i;
+        plan->nodes[last[i]].tstop = i;
+    }
+    plan->time_ev.assign((size_t)n * slots * 2, nullptr);
+    for (auto &ev : plan->time_ev) {
+        hipError_t e = hipEventCreate(&ev);
+        if (e != hipSuccess) return (int)e;
+    }
+    return 0;
+}
+
+extern "C" int pdgn_replay_time_read(void *plan_, float *ms_out, int *counts) {
+    RPlan *plan = (RPlan *)plan_;
+    if (!plan || !ms_out || !counts) return PDGN_ERR_INVALID;
+    for (size_t i = 0; i < plan->time_count.size(); ++i) {
+        counts[i] = plan->time_count[i];
+        for (int j = 0; j < plan->time_count[i]; ++j) {
+            const size_t k = (i * plan->time_slots + j) * 2;
+            hipError_t e = hipEventSynchronize(plan->time_ev[k + 1]);
+            if (e == hipSuccess) e = hipEventElapsedTime(&ms_out[i * plan->time_slots + j], plan->time_ev[k], plan->time_ev[k + 1]);
+            if (e != hipSuccess) return (int)e;
+        }
     }
     return 0;
 }
@@ -463,6 +551,7 @@ extern "C" int pdgn_replay_destroy(void *plan_) {
     RPlan *plan = (RPlan *)plan_;
     if (!plan) return 0;
     for (auto ev : plan->events) if (ev) (void)hipEventDestroy(ev);
+    for (auto ev : plan->time_ev) if (ev) (void)hipEventDestroy(ev);
     delete plan;
     return 0;
 }

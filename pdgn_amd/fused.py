@@ -341,6 +341,19 @@ def split_planes(w, want_t):
     return Planes(P, PT, (n, k))
 
 
+def _tail_workspace(L, m, n, k, with_stats, device):
+    """The stream-K tail of the next contraction call without atomics (csrc/gemm_x3.hip): a buffer for its partial tiles, handed to
+    the library for that ONE call.  Returned so that the caller keeps it alive until its launch is issued (stream-ordered reuse
+    by the caching allocator is safe: the next user runs behind this call on the same stream)."""
+    L.pdgn_gemm_tail_workspace_floats.restype = ctypes.c_longlong
+    need = L.pdgn_gemm_tail_workspace_floats(ctypes.c_longlong(m), n, k, 1 if with_stats else 0)
+    if need <= 0:
+        return None
+    ws = torch.empty(need, dtype=F32, device=device)
+    check(L.pdgn_gemm_set_tail_workspace(ptr(ws), ctypes.c_longlong(need)), "pdgn_gemm_set_tail_workspace")
+    return ws
+
+
 def gemm_nt_planes(a, P, n, k, bias=None, addend=None, want_stats=False):
     """a (m, k) @ W^T for a weight given as its planes P [3][n][ld] (Planes.p of W, or Planes.t for the product with W itself:
     then n, k are W^T's); everything else as gemm_nt."""
@@ -357,6 +370,7 @@ def gemm_nt_planes(a, P, n, k, bias=None, addend=None, want_stats=False):
     b = bias.detach().contiguous() if bias is not None else None
     if addend is not None:
         addend = _pad_cols(addend)
+    ws = _tail_workspace(L, m, n, k, want_stats, a.device)
     check(L.pdgn_gemm_nt_ps(ctypes.c_longlong(m), n, k, ptr(ap), ap.stride(0), ptr(P), P.shape[2], ctypes.c_longlong(P.shape[1] * P.shape[2]),
                             ptr(b), ptr(addend), addend.stride(0) if addend is not None else 0, ptr(out), n, ptr(part), None, 0, 1, 0,
                             None, 0, stream_of(a)), "pdgn_gemm_nt_ps")
@@ -397,6 +411,7 @@ def gemm_nt(a, w, bias=None, addend=None, want_stats=False, w_transposed=False):
         part = torch.empty((L.pdgn_gemm_nt_stat_rows(ctypes.c_longlong(m), np_, kp), 3 * np_), dtype=F32, device=a.device)
     b = bias.detach().contiguous() if bias is not None else None
     fn = L.pdgn_gemm_nn if w_transposed else L.pdgn_gemm_nt
+    ws = _tail_workspace(L, m, np_, kp, want_stats, a.device)       # (kept alive to the end of this function: the launch is issued by then)
     check(fn(ctypes.c_longlong(m), np_, kp, ptr(ap), ap.stride(0), ptr(wp), wp.stride(0), ptr(b), ptr(addend),
              addend.stride(0) if addend is not None else 0, ptr(out), np_, ptr(part), stream_of(a)),
           "pdgn_gemm_nn" if w_transposed else "pdgn_gemm_nt")

@@ -104,6 +104,42 @@ class LaunchList:
         check(_lib.lib().pdgn_replay_launch_range(self._plan, int(lo), self.info["nodes"] if hi is None else int(hi)),
               "pdgn_replay_launch_range")
 
+    def kernel_nodes(self, sym, grid_x=-1):
+        """List positions of the kernel nodes launched through host symbol `sym` (an int address) with grid.x == grid_x."""
+        L = _lib.lib()
+        n = L.pdgn_replay_kernel_nodes(self._plan, ctypes.c_void_p(sym), int(grid_x), None, 0)
+        if n <= 0:
+            return []
+        pos = (ctypes.c_int * n)()
+        L.pdgn_replay_kernel_nodes(self._plan, ctypes.c_void_p(sym), int(grid_x), pos, n)
+        return list(pos)
+
+    def neighbor(self, pos, direction):
+        """(list position, kind, kernel symbol) of the next / previous node of `pos`'s chain; position -1 when there is none."""
+        kind, sym = ctypes.c_int(-1), ctypes.c_void_p()
+        L = _lib.lib()
+        L.pdgn_replay_chain_neighbor.restype = ctypes.c_int
+        p = L.pdgn_replay_chain_neighbor(self._plan, int(pos), int(direction), ctypes.byref(kind), ctypes.byref(sym))
+        return p, kind.value, sym.value
+
+    def time_spans(self, spans, slots):
+        """Bracket spans [(first, last), ...] of the list (each inside one chain) with timing events on that chain's stream for the
+        next `slots` passes (csrc/replay.hip); [] switches the timing off."""
+        n = len(spans)
+        first = (ctypes.c_int * max(n, 1))(*[a for a, _ in spans])
+        last = (ctypes.c_int * max(n, 1))(*[b for _, b in spans])
+        check(_lib.lib().pdgn_replay_time_spans(self._plan, first, last, n, int(slots)), "pdgn_replay_time_spans")
+        self._timed = (n, int(slots))
+
+    def timed_ms(self):
+        """[[ms, ...] per timed span]: durations of the passes recorded since time_spans (waits for them)."""
+        n, slots = getattr(self, "_timed", (0, 0))
+        if n == 0:
+            return []
+        ms, cnt = (ctypes.c_float * (n * slots))(), (ctypes.c_int * n)()
+        check(_lib.lib().pdgn_replay_time_read(self._plan, ms, cnt), "pdgn_replay_time_read")
+        return [[ms[i * slots + j] for j in range(cnt[i])] for i in range(n)]
+
     def position(self, label, fraction):
         """List position right after `fraction` of the launches of the chain with marker id `label`."""
         c = self.labels.index(label)

@@ -97,7 +97,10 @@ def _nt_entry(label, M, N, K, device):
     from .fused import split_planes
     planes = split_planes(w, False) if x3 else None
 
+    from .fused import _tail_workspace
+
     def run():
+        ws = _tail_workspace(L, M, N, K, False, device)            # the stream-K tail without atomics, as the step's calls run it
         if planes is not None:
             P = planes.p
             check(L.pdgn_gemm_nt_ps(ctypes.c_longlong(M), N, K, ptr(a), K, ptr(P), P.shape[2], ctypes.c_longlong(P.shape[1] * P.shape[2]),
@@ -266,6 +269,56 @@ def emd_cost_c5(B, base_points, device, pairs=512):
     us = _time_us(lambda: emd_cost(a, b))
     return {"kernel": "emd_cost_kernel (%d pairs of 2048 x 2048)" % pairs, "bound": "valu-issue", "us_per_launch": us,
             "pairs_per_s": pairs / us * 1e6}
+
+
+def conv2_in_step_spans(launch_list, B, base_points):
+    """Spans of a recorded iteration (PDGNTrainer.capture_list) that ARE the dominant contraction: conv2's dense half at stage 4,
+    forward, one per generator pass.  The data-parallel launch is found by the kernel INSTANCE and grid pdgn_gemm_nt_ps uses for
+    that problem (pdgn_gemm_nt_ps_launch_info); the span takes in what belongs to the same call on the same stream: the memset in
+    front of it and the stream-K tail launch behind it (560 tiles on 256 CUs: two whole rounds + a tail of 48 tiles).  [] when
+    the instance cannot be named (fp32 mode, the 16x16x32 arm)."""
+    if gemm_mode() != "x3":
+        return []
+    L = _lib.lib()
+    sym, grid = ctypes.c_void_p(), ctypes.c_int()
+    if L.pdgn_gemm_nt_ps_launch_info(ctypes.c_longlong(B * 8 * base_points), 512, 5120, ctypes.byref(sym), ctypes.byref(grid)) != 0 or not sym.value:
+        return []
+    cfg = L.pdgn_gemm_nt_config(ctypes.c_longlong(B * 8 * base_points), 512, 5120, 0)
+    spans = []
+    for pos in launch_list.kernel_nodes(sym.value, grid.value):
+        first = last = pos
+        if cfg >= 16:                                            # a stream-K tail follows: memset | data-parallel | tail
+            p, kind, _ = launch_list.neighbor(pos, -1)
+            if p >= 0 and kind == 1:
+                first = p
+            p, kind, _ = launch_list.neighbor(pos, +1)
+            if p >= 0 and kind == 0:
+                last = p
+        spans.append((first, last))
+    return spans
+
+
+def attach_in_step(top, launches_ms):
+    """The dominant kernel's roofline entry from its launches INSIDE the timed steps (HIP events on the stream it is launched on,
+    around every launch: csrc/replay.hip); the stand-alone figure of `measure` (20 launches back to back) moves to `back_to_back`."""
+    ms = [v for node in launches_ms for v in node]
+    if not ms:
+        return top
+    us = sum(ms) / len(ms) * 1e3
+    work = top["algorithmic_flops_per_launch"]
+    out = dict(top)
+    out["back_to_back"] = {"us_per_launch": top["us_per_launch"], "achieved": top["achieved"], "frac": top["frac"],
+                           "what": "the same launch alone, 20 back to back after 3 (the chip's power limit holds ~1.7 GHz there; "
+                                   "between the iteration's bandwidth-bound kernels it clocks higher)"}
+    out["us_per_launch"] = us
+    out["achieved"] = work / us / 1e6
+    out["frac"] = out["achieved"] / out["peak"]
+    out["timing"] = ("HIP events around each of the contraction's %d calls inside the timed steps (one per generator pass and step: memset + "
+                     "data-parallel launch + stream-K tail launch, as pdgn_gemm_nt_ps issues them), on the stream the launch list issues "
+                     "them on; min %.1f / max %.1f us" % (len(ms), min(ms) * 1e3, max(ms) * 1e3))
+    if "mfma" in out and "executed_tflops" in out["mfma"]:
+        out["mfma"] = dict(out["mfma"], executed_tflops=out["achieved"] * X3_PRODUCTS)
+    return out
 
 
 ENTRIES = (conv2_dense_stage4, per_point_stage4, conv2_dense_dx_stage4, weight_grad_stage4, bn_act_backward_stage4,

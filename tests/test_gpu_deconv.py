@@ -1524,3 +1524,57 @@ def test_head_mlp_vs_torch(B, M, Fo, nc):
     for n, a, b in zip(names, got, want):
         tol = 1e-4 * max(1.0, float(b.abs().max()))
         assert (a.double() - b).abs().max().item() < tol * (20 if n.startswith("d") and n != "dx" else 1), n
+
+
+@pytest.mark.parametrize("M,N,K", [(35840, 512, 5120), (17920, 256, 2560), (9000, 132, 1284), (4100, 64, 6432), (8960, 128, 1280)])
+def test_stream_k_tail_without_atomics(M, N, K):
+    """Round 5: a launch whose tiles do not fill the last round of workgroups finishes its leftover tiles as split-K partial tiles
+    in a caller-provided workspace + a reduce kernel (csrc/gemm_x3.hip: pdgn_gemm_tail_workspace_floats / pdgn_gemm_set_tail_workspace)
+    instead of fp32 atomics into zero-filled rows: against fp64, against the atomic form, bit-identical from run to run, with bias
+    and addend, on partial edge tiles; and the hand-over is consumed by exactly one call."""
+    import ctypes
+    from pdgn_amd import _lib, fused
+    from pdgn_amd._lib import ptr, stream_of
+    L = _lib.lib()
+    L.pdgn_gemm_tail_workspace_floats.restype = ctypes.c_longlong
+    need = L.pdgn_gemm_tail_workspace_floats(ctypes.c_longlong(M), N, K, 0)
+    cfg = L.pdgn_gemm_nt_config(ctypes.c_longlong(M), N, K, 0)
+    assert (need > 0) == (cfg >= 16), (need, cfg)                       # a tail exactly where the launch model plans one
+    assert L.pdgn_gemm_tail_workspace_floats(ctypes.c_longlong(M), N, K, 1) == 0      # launches with statistics have no tail
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    a = torch.randn(M, K, device="cuda", generator=g)
+    w = torch.randn(N, K, device="cuda", generator=g)
+    bias = torch.randn(N, device="cuda", generator=g)
+    add = torch.randn(M, N, device="cuda", generator=g)
+    ref = a.double() @ w.double().t() + bias.double() + add.double()
+    mag = a.double().abs() @ w.double().abs().t() + 1.0
+
+    def run(with_ws):
+        c = torch.full((M, N), float("nan"), device="cuda")
+        ws = torch.empty(max(need, 1), device="cuda")
+        if with_ws and need:
+            assert L.pdgn_gemm_set_tail_workspace(ptr(ws), ctypes.c_longlong(need)) == 0
+        assert L.pdgn_gemm_nt(ctypes.c_longlong(M), N, K, ptr(a), K, ptr(w), K, ptr(bias), ptr(add), N, ptr(c), N, None, stream_of(a)) == 0
+        torch.cuda.synchronize()
+        return c
+    c1, c2, c_atomic = run(True), run(True), run(False)
+    assert ((c1.double() - ref).abs() / mag).max().item() < 1e-6
+    assert ((c_atomic.double() - ref).abs() / mag).max().item() < 1e-6
+    assert torch.equal(c1, c2), "the workspace form sums a tile's slices in a fixed order"
+    # consumed by ONE call: the second call after one hand-over runs the atomic form (and is still right)
+    ws = torch.empty(max(need, 1), device="cuda")
+    if need:
+        assert L.pdgn_gemm_set_tail_workspace(ptr(ws), ctypes.c_longlong(need)) == 0
+    for _ in range(2):
+        c = torch.full((M, N), float("nan"), device="cuda")
+        assert L.pdgn_gemm_nt(ctypes.c_longlong(M), N, K, ptr(a), K, ptr(w), K, None, None, 0, ptr(c), N, None, stream_of(a)) == 0
+        assert ((c.double() - (a.double() @ w.double().t())).abs() / mag).max().item() < 1e-6
+    # too small a buffer is ignored (atomic form), never overrun
+    if need:
+        small = torch.empty(need // 2, device="cuda")
+        assert L.pdgn_gemm_set_tail_workspace(ptr(small), ctypes.c_longlong(need // 2)) == 0
+        c = torch.full((M, N), float("nan"), device="cuda")
+        assert L.pdgn_gemm_nt(ctypes.c_longlong(M), N, K, ptr(a), K, ptr(w), K, None, None, 0, ptr(c), N, None, stream_of(a)) == 0
+        assert torch.isfinite(c).all()
+    # the Python wrappers hand it over themselves: linear layers through fused.gemm_nt are deterministic now
+    assert torch.equal(fused.gemm_nt(a, w, bias), fused.gemm_nt(a, w, bias))

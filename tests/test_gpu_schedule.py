@@ -267,3 +267,35 @@ def test_lean_adam_step_is_the_optimizers_own_step():
     first.grad = None
     lean.step()
     assert torch.equal(first, before)
+
+
+def test_in_step_timing_of_the_dominant_contraction():
+    """bench.py's roofline kernel is timed INSIDE the timed steps: csrc/replay.hip brackets the spans of the recorded iteration that
+    are conv2's dense half at stage 4 (memset | data-parallel launch | tail | reduce, one span per generator pass) with timing
+    events on their own stream (pdgn_replay_kernel_nodes / _chain_neighbor / _time_spans / _time_read)."""
+    from pdgn_amd import roofline
+    from pdgn_amd.trainer import PDGNTrainer, noise, synthetic_batch
+    dev = torch.device("cuda:0")
+    torch.manual_seed(5)
+    tr = PDGNTrainer(device=dev, distributed=False)
+    tr.train()
+    B = 35
+    reals, z1, z2 = synthetic_batch(B, dev), noise(B, dev), noise(B, dev)
+    tr.step(reals, z1, z2)
+    tr.capture_list(reals, z1, z2)
+    spans = roofline.conv2_in_step_spans(tr._list, B, 128)
+    assert len(spans) == 2 and all(a <= b for a, b in spans), spans          # one call per generator pass
+    tr._list.time_spans(spans, 3)
+    for _ in range(4):                                                        # one pass more than slots: the surplus is not recorded
+        tr.step_list(None, z1, z2)
+    ms = tr._list.timed_ms()
+    assert [len(v) for v in ms] == [3, 3]
+    flops = 2.0 * B * 1024 * 512 * 5120
+    for v in ms:
+        for t in v:
+            assert 0.3 < t < 5.0, ms                                          # ~1 ms per call on an MI355X
+            assert flops / (t * 1e-3) / 1e12 < 416.7                          # never above the roof it is priced against
+    tr._list.time_spans([], 0)
+    out = tr.step_list(None, z1, z2)
+    torch.cuda.synchronize()
+    assert all(torch.isfinite(v).item() for v in out.values())

@@ -16,6 +16,7 @@ python3 tools/step_kernels.py $OUT/kt_bench 8 > $OUT/${TAG}_step_kernels.txt
 python3 tools/main_chain.py $OUT/kt_bench 6 > $OUT/${TAG}_main_chain.txt
 python3 tools/side_queues.py $OUT/kt_bench 6 22 > $OUT/${TAG}_side_queues.txt 2>&1
 python3 tools/wait_gap.py $OUT/kt_bench 2 > $OUT/${TAG}_wait_gap.txt 2>&1
+python3 tools/conv2_in_step.py $OUT/kt_bench > $OUT/${TAG}_conv2_in_step.txt 2>&1
 MS=$(python3 -c "import json,sys; print(json.load(open(sys.argv[1]))[\"ms_per_step\"])" $OUT/${TAG}_bench_full.json)
 python3 tools/queue_timeline.py $OUT/kt_bench $MS > $OUT/${TAG}_queue_timeline.txt 2>&1
 # the roofline kernels alone
