@@ -28,7 +28,12 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 matrix peak (v_mfma_f32_32x32x2_f32 / 16x16x4_f32)
-GEMM_ARITHMETIC = ("fp32 matrix instructions (PDGN_GEMM=fp32)" if os.environ.get("PDGN_GEMM", "x3").startswith("f") else   # (the library reads the same variable at first use)
+_GEMM_ENV = os.environ.get("PDGN_GEMM", "")                      # (the library reads the same variable at first use)
+GEMM_ARITHMETIC = ("fp32 matrix instructions (PDGN_GEMM=fp32)" if _GEMM_ENV.startswith("f") else
+                   "fp32 operands, results and accumulation; each product = three fp16 MFMA partial products of the operands' two-way "
+                   "fp16 splits after an exact power-of-two scaling by the operand's largest magnitude (csrc/gemm_x3.hip, NP = 2): "
+                   "against fp64 below the fp32 matrix instructions' error (gemm_accuracy; tests/test_gpu_deconv.py); "
+                   "PDGN_GEMM=x3 / fp32 select the three-part bf16 form / the fp32 instructions" if not _GEMM_ENV.startswith("x3") else
                    "fp32 operands, results and accumulation; each product = six bf16 MFMA partial products of the operands' "
                    "three-way bf16 splits (csrc/gemm_x3.hip): error per product <= 2^-23, against fp64 below the fp32 matrix "
                    "instructions' (tests/test_gpu_deconv.py); PDGN_GEMM=fp32 selects those instructions")
@@ -508,8 +513,8 @@ def measure_and_report(args, trainer, reals, zs, world, rank, device, res):
             # run on -- the same roof `roofline` prices the dominant kernel against (bf16 matrix peak / 6 products per fp32
             # product for the x3 kernels, the fp32 matrix peak for PDGN_GEMM=fp32) -- and, named, against the fp32 peak
             from pdgn_amd import roofline as _rf
-            x3 = _rf.gemm_mode() == "x3"
-            peak = (_rf.MFMA_BF16_PEAK_TFLOPS / 6.0 if x3 else MFMA_F32_PEAK_TFLOPS) * 1e12
+            nprod = _rf.products()
+            peak = (_rf.MFMA_BF16_PEAK_TFLOPS / nprod if nprod else MFMA_F32_PEAK_TFLOPS) * 1e12
             line["step_mfma_frac"] = total / (ms * 1e-3) / peak
             line["step_mfma_frac_peak_tflops"] = peak / 1e12
             line["step_frac_of_fp32_instruction_peak"] = total / (ms * 1e-3) / (MFMA_F32_PEAK_TFLOPS * 1e12)

@@ -252,7 +252,9 @@ int pdgn_bn_softmax_slots_permute(long long m, int k, int c, int act, const floa
  * row); w may be NULL (not needed when no backward pass follows). */
 int pdgn_bn_softmax_slots_permute_mul(long long m, int k, int c, int act, const float *x, const float *stats,
                                       int act_u, const float *u, const float *stats_u, float *w, float *y,
-                                      pdgn_stream_t stream);
+                                      unsigned *max_out, pdgn_stream_t stream);
+/* (max_out, may be NULL: a 1-KB device slot that receives 256 partial maxima of |y| -- what pdgn_absmax_partials would compute by a
+ * pass over y -- for the two-part contraction that consumes y, pdgn_gemm_set_operand_scales; the call zero-fills it.) */
 /* Adjoint of pdgn_bn_softmax_slots_permute_mul in two passes over (x, u, w, dy): BatchNorm_u backward, slot-softmax
  * backward and BatchNorm_x backward with dW / dh kept in registers.  scratch: pdgn_bilateral_scratch_floats(m,k,c)
  * floats; bsums_x (2c) = [sum dz_x | sum dz_x*xhat] (= dbeta, dgamma of BN_x), bsums_u (4c) likewise for BN_u;
@@ -314,7 +316,7 @@ int pdgn_split_bf16x3(int rows, int cols, const float *src, int ld_src, unsigned
                       long long plane_stride, unsigned short *planes_t, int ld_planes_t, long long plane_stride_t,
                       pdgn_stream_t stream);
 int pdgn_gemm_nt_ps(long long m, int n, int k, const float *A, int lda, const unsigned short *Wplanes, int ldw, long long wplane,
-                    const float *bias, const float *addend, int ldadd, float *C, int ldc, float *stat_part,
+                    int parts, const float *bias, const float *addend, int ldadd, float *C, int ldc, float *stat_part,
                     const float *row_bias, int ld_rb, int rows_per_group, int act, const float *gate, int ldgate,
                     pdgn_stream_t stream);
 /* Stream-K tails without atomics (matrix-core mode).  A launch whose tiles do not fill the last round of workgroups finishes with a
@@ -326,9 +328,13 @@ long long pdgn_gemm_tail_workspace_floats(long long m, int n, int k, int with_st
 int pdgn_gemm_set_tail_workspace(float *ws, long long floats);
 /* The kernel instance (host symbol; NULL for the 16x16x32 arm) and grid of the plain data-parallel launch of pdgn_gemm_nt_ps(m, n, k)
  * under the switches in force: for measurements that look that launch up in a recorded iteration.  Host-side only. */
-int pdgn_gemm_nt_ps_launch_info(long long m, int n, int k, const void **sym, int *grid);
+int pdgn_gemm_nt_ps_launch_info(long long m, int n, int k, int parts, const void **sym, int *grid);
+/* Host symbols of the small kernels a contraction call may launch around its matrix-core kernels: the reduce of a stream-K tail's
+ * partial tiles, the scan of an operand's maxima (mode 2). */
+int pdgn_gemm_aux_symbols(const void **reduce, const void **scan);
 /* Process-wide switches of the dense contractions (read from PDGN_GEMM / PDGN_NT_CFG once, at first use).
- * pdgn_gemm_set_mode: 1 = bf16 matrix cores (default), 0 = fp32 matrix instructions, < 0 = query; returns the previous mode.
+ * pdgn_gemm_set_mode: 1 = bf16 matrix cores, three parts, 2 = fp16 matrix cores, two scaled parts (below), 0 = fp32 matrix
+ * instructions, < 0 = query; returns the previous mode.
  * pdgn_gemm_set_config: -1 = the launch model's pick (default), 0 .. 3 = force a tile configuration (measurement / tests),
  * < -1 = query; returns the previous value.
  * pdgn_gemm_set_shape: the bf16 matrix instruction of the matrix-core mode: 32 = v_mfma_f32_32x32x16_bf16 for every launch, 16 =
@@ -336,6 +342,30 @@ int pdgn_gemm_nt_ps_launch_info(long long m, int n, int k, const void **sym, int
  * per instance class, 0x1000 | mask = a per-class mask (bit 4 * tile + class; gemm_x3.hip), anything else = query; returns the
  * previous mask.  PDGN_X3_SHAPE / PDGN_X3_SHAPE16_MASK set the process default. */
 int pdgn_gemm_set_mode(int mode);
+/* Mode 2 (round 5; PDGN_GEMM=x2): the same contractions on the fp16 matrix cores with TWO parts per value.  An operand is multiplied
+ * by a power of two 2^e, e = 14 - floor(log2 max |x|) over the whole operand (so that nothing leaves fp16's range: max |x| 2^e in
+ * [2^14, 2^15)), split as x 2^e = h + l (round-to-nearest fp16 of the value and of the exact remainder: |err| <= 2^-23 |x| for
+ * values within 2^-18 of the operand's largest, an absolute 2^-40 max |x| below), a product is the three fp16 MFMA products
+ * al wh + ah wl + ah wh accumulated in fp32, and the result is multiplied by 2^-(e_A + e_W) (exact).  Per product |err| <=
+ * ~2^-21 |a w| in the worst case, in sums dominated by the fp32 accumulation all modes share (measured against fp64 next to the
+ * other two modes: bench.py gemm_accuracy, tests/test_gpu_deconv.py).  Half the matrix-core work of mode 1.
+ * The maxima come from a scan of each operand in front of the launch (x2_absmax_kernel: 256 partial maxima into a 1-KB slot, which
+ * every consumer reduces itself: no atomics, nothing to re-arm), the slot taken from a ring the caller provides once:
+ * pdgn_gemm_set_scale_slots(device memory, bytes; 1 KB per slot; more slots than launches can be in flight -- the library never
+ * allocates); without one the contractions of mode 2 return PDGN_ERR_INVALID.  An operand's maxima can also be computed by the caller
+ * (pdgn_absmax_partials into a 1-KB device slot of its own) and handed over for the operands of the calling thread's next
+ * contraction call (pdgn_gemm_set_operand_scales: first / second operand as that entry point takes them -- pdgn_gemm_tn_big: dY, X --
+ * NULL = scanned by the call; consumed by that call): an activation that feeds several products is scanned once.
+ * pdgn_split_f16x2 = pdgn_split_bf16x3 for this mode: two fp16 planes (h | l, already scaled) and the exponent as one int32 right
+ * behind them (element offset 2 * plane_stride: the buffer holds 2 * plane_stride + 2 elements); pdgn_gemm_nt_ps takes such planes
+ * while mode 2 is in force (the caller keeps planes and mode consistent).  No reference counterpart. */
+int pdgn_gemm_set_scale_slots(void *slots, long long bytes);
+int pdgn_absmax_partials(long long rows, int cols, const float *src, int ld, unsigned *slot, pdgn_stream_t stream);
+int pdgn_gemm_set_operand_scales(const unsigned *max_a, const unsigned *max_w);
+int pdgn_gemm_two_part(long long m, int n, int k, long long scan_bytes);
+int pdgn_split_f16x2(int rows, int cols, const float *src, int ld_src, unsigned short *planes, int ld_planes,
+                     long long plane_stride, unsigned short *planes_t, int ld_planes_t, long long plane_stride_t,
+                     pdgn_stream_t stream);
 int pdgn_gemm_set_config(int cfg);
 int pdgn_gemm_set_shape(int shape);
 int pdgn_gemm_nt(long long m, int n, int k, const float *A, int lda, const float *W, int ldw,

@@ -10,7 +10,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "libpdgn_hip.so")
-ABI_VERSION = 22
+ABI_VERSION = 23
 _lib = None
 
 
@@ -32,7 +32,22 @@ def lib():
         if got != ABI_VERSION:
             raise PdgnHipError("libpdgn_hip.so ABI %d != expected %d: rebuild" % (got, ABI_VERSION))
         _lib = handle
+        if handle.pdgn_gemm_set_mode(-1) == 2:                     # the default mode (PDGN_GEMM unset or x2)
+            _attach_scale_slots(handle)
     return _lib
+
+
+_SCALE_SLOTS = None
+
+
+def _attach_scale_slots(handle):
+    """Two-part mode (csrc/gemm_x3.hip): the ring of operand-scale slots is the caller's memory -- the library never allocates.
+    4 Ki slots of 1 KB: an iteration is < 10^3 scans inside the library and at most two iterations are in flight."""
+    global _SCALE_SLOTS
+    if _SCALE_SLOTS is None and torch.cuda.is_available():
+        _SCALE_SLOTS = torch.zeros(1 << 20, dtype=torch.int32, device="cuda")
+        check(handle.pdgn_gemm_set_scale_slots(ctypes.c_void_p(_SCALE_SLOTS.data_ptr()), ctypes.c_longlong(_SCALE_SLOTS.numel() * 4)),
+              "pdgn_gemm_set_scale_slots")
 
 
 def stream_of(t):
@@ -68,18 +83,30 @@ def require(t, name, dtype, dim=None):
 def gemm_mode():
     """'x3' (fp32 products as six bf16 MFMA products, csrc/gemm_x3.hip -- the default) or 'fp32' (the fp32 matrix instructions,
     csrc/gemm_nt.hip): what pdgn_gemm_nt / _nn / _nt_ex / _tn_big launch.  PDGN_GEMM in the environment sets the initial value."""
-    return "x3" if lib().pdgn_gemm_set_mode(-1) else "fp32"
+    return _MODE_NAMES[lib().pdgn_gemm_set_mode(-1)]
+
+
+_MODE_NAMES = {0: "fp32", 1: "x3", 2: "x2"}
+DEFAULT_GEMM_MODE = os.environ.get("PDGN_GEMM") or "x2"          # what the library starts in (it reads the same variable at first use)
+
+
+def matrix_core_mode():
+    """True in the two modes that multiply split operands on the bf16 / fp16 matrix cores (csrc/gemm_x3.hip)."""
+    return gemm_mode() != "fp32"
 
 
 def set_gemm_mode(mode):
-    """Select the arithmetic of the dense contractions for this process: "x3" (bf16 matrix cores, the process default's matrix
-    instruction per instance class), "x3_16" / "x3_32" (every class on v_mfma_f32_16x16x32_bf16 / _32x32x16_bf16), "fp32" (fp32
-    matrix instructions); returns the previous mode's name ("x3" | "fp32")."""
+    """Select the arithmetic of the dense contractions for this process: "x3" (bf16 matrix cores, three parts per value; the
+    process default's matrix instruction per instance class), "x3_16" / "x3_32" (every class on v_mfma_f32_16x16x32_bf16 /
+    _32x32x16_bf16), "x2" (fp16 matrix cores, two scaled parts per value), "fp32" (fp32 matrix instructions); returns the previous
+    mode's name ("x3" | "x2" | "fp32").  Pre-split weights (fused.split_planes) belong to the mode they were made in."""
     m = str(mode)
-    old = lib().pdgn_gemm_set_mode(0 if m.startswith("f") else 1)
-    if not m.startswith("f"):
+    if m == "x2":
+        _attach_scale_slots(lib())
+    old = lib().pdgn_gemm_set_mode(0 if m.startswith("f") else 2 if m == "x2" else 1)
+    if not m.startswith("f"):                                      # (any matrix-core mode without a suffix: the process default's instruction per class)
         lib().pdgn_gemm_set_shape(16 if m.endswith("_16") else 32 if m.endswith("_32") else -1)
-    return "x3" if old else "fp32"
+    return _MODE_NAMES[old]
 
 
 def set_gemm_shape(shape):

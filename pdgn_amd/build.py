@@ -18,8 +18,9 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-ffp-contract=
 # gemm_x3.hip: a k chunk is ONE fully unrolled straight line of up to 192 matrix instructions with the conversion, load and LDS
 # work placed between them; the default budget of `#pragma unroll` (16 K IR instructions) refuses the 16x16x32 form's chunk
 EXTRA_FLAGS = {"gemm_x3.hip": ["-mllvm", "-pragma-unroll-threshold=200000"],
-               "gemm_x3_16.hip": ["-mllvm", "-pragma-unroll-threshold=200000"]}
-EXTRA_DEPS = {"gemm_x3_16.hip": ["gemm_x3.hip"]}          # sources a translation unit #includes besides the headers
+               "gemm_x3_16.hip": ["-mllvm", "-pragma-unroll-threshold=200000"],
+               "gemm_x3_h2.hip": ["-mllvm", "-pragma-unroll-threshold=200000"]}
+EXTRA_DEPS = {"gemm_x3_16.hip": ["gemm_x3.hip"], "gemm_x3_h2.hip": ["gemm_x3.hip"]}          # sources a translation unit #includes besides the headers
 
 
 def sources():

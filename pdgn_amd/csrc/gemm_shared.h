@@ -58,7 +58,35 @@ struct NtArgs {
     int ldgate;
     const unsigned short *Wp;         // gemm_x3, PW instances: the second operand pre-split into three bf16 planes [N][ldw]
     long long wplane;                 // elements between the planes
+    const unsigned *max_a, *max_w;    // gemm_x3, two-part (fp16) instances: X2_PARTS partial maxima (bit patterns of |x|) of each operand,
+                                      // which is multiplied by 2^e, e = x2_exponent(their maximum), before the split (pre-split
+                                      // second operand: its exponent sits behind its two planes instead)
 };
+
+// Two-part mode: an operand's scale.  A scan (x2_absmax_kernel, gemm_x3.hip) leaves X2_PARTS partial maxima of |x| (as bit patterns:
+// unsigned order = magnitude order; unused entries zero) in a 1-KB slot; every consumer reduces them itself (one load per thread of
+// a 256-thread workgroup) -- no atomics, no fences, nothing to re-arm.  e = 14 - floor(log2 max): max |x| 2^e in [2^14, 2^15).
+#define X2_PARTS 256
+__device__ __forceinline__ int x2_exponent(unsigned maxbits) {     // (NaN / Inf: the largest exponent field; the products carry them)
+    const int e = 14 - ((int)(maxbits >> 23) - 127);
+    return e > 126 ? 126 : (e < -126 ? -126 : e);
+}
+// max over the workgroup's 256 threads of two values each; scratch: 8 words of LDS; every thread must call (two barriers)
+__device__ __forceinline__ void x2_block_max2(unsigned &a, unsigned &b, unsigned *scratch) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        a = max(a, (unsigned)__shfl_xor((int)a, o));
+        b = max(b, (unsigned)__shfl_xor((int)b, o));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        scratch[threadIdx.x >> 6] = a;
+        scratch[4 + (threadIdx.x >> 6)] = b;
+    }
+    __syncthreads();
+    a = max(max(scratch[0], scratch[1]), max(scratch[2], scratch[3]));
+    b = max(max(scratch[4], scratch[5]), max(scratch[6], scratch[7]));
+    __syncthreads();
+}
 
 // ------------------------------------------------------------------ host side
 struct NtDev {
@@ -78,7 +106,8 @@ static inline int nt_cus() {
 
 // Process-wide switches of the dense contractions.  Read from the environment ONCE (first use); tests and tools change them
 // through pdgn_gemm_set_mode / pdgn_gemm_set_config (no getenv per launch, no environment mutation at run time).
-//   mode: 1 = products on the bf16 matrix cores (gemm_x3.hip, default), 0 = fp32 matrix instructions (gemm_nt.hip; PDGN_GEMM=fp32)
+//   mode: 2 = products on the matrix cores, two scaled fp16 parts per value where that pays and three bf16 parts elsewhere (gemm_x3.hip,
+//   default), 1 = three bf16 parts everywhere (PDGN_GEMM=x3), 0 = fp32 matrix instructions (gemm_nt.hip; PDGN_GEMM=fp32)
 //   cfg:  -1 = the launch model's pick (default), 0 .. 3 = a forced tile configuration (PDGN_NT_CFG; measurement / tests)
 //   shape16: per instance class of gemm_x3.hip, which bf16 matrix instruction it runs on (PDGN_X3_SHAPE / PDGN_X3_SHAPE16_MASK;
 //   pdgn_gemm_set_shape)

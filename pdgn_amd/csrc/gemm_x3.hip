@@ -41,6 +41,7 @@
 // Measured (MI355X, tools/x3_check.py, tools/x3_pmc.sh): 190-200 TFLOP/s on 35840 x 512 x 5120 (gemm_nt.hip: 135) with the
 // matrix pipe busy 68 % of the cycles at the 1.77 GHz the chip holds under this load (2.4 GHz nominal: the bf16 peak at
 // that clock is 1.84 PFLOP/s = 307 TFLOP/s of fp32 products).
+#include <atomic>
 #include <type_traits>
 
 #include "gemm_shared.h"
@@ -86,6 +87,21 @@ __device__ __forceinline__ void x3_split_pair(float a, float b, X3Parts &P, int 
 __device__ __forceinline__ f32x16 x3_mfma(const u32x4 a, const u32x4 b, const f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
+
+// NP = 2 (round 5): TWO fp16 parts of the operand scaled by a power of two, x 2^e = h + l (+ err), three partial products
+// al wh + ah wl + ah wh on v_mfma_f32_32x32x16_f16 (the kernel's comment at the template parameter NP)
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned x2_cvt_pk(float a, float b) {          // v_cvt_pk_f16_f32: round to nearest even
+    const f32x2 v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2));
+}
+__device__ __forceinline__ f32x16 x2_mfma(const u32x4 a, const u32x4 b, const f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+#ifndef X2_PRODUCTS
+#define X2_PRODUCTS 3                 // 4: al wl as well
+#endif
 
 typedef float f32x4a __attribute__((ext_vector_type(4)));
 // the other bf16 shape, K = 32 in one instruction of 16 cycles: lane (i = l & 15, g = l >> 4) holds k = 8 g .. 8 g + 7 of row i of
@@ -144,16 +160,17 @@ __device__ __forceinline__ float x3_row_sum(float v) {
 // weight by pdgn_split_bf16x3 with the same round-to-nearest remainders the loader computes: its quads are loaded part by part
 // (8 B per part and lane) and go to LDS as they are -- none of the 22 vector instructions per quad, a third of the split work
 // of a 256 x 128 tile.  Same parts, same products, same order: results are bit-identical to the unsplit operand's.
-template <int TM, int TN, int WM, int WN, int OCC, bool ATOMIC, bool WT, bool AT, bool EPI = false, bool PW = false, int MS = 32>
+template <int TM, int TN, int WM, int WN, int OCC, bool ATOMIC, bool WT, bool AT, bool EPI = false, bool PW = false, int MS = 32, int NP = 3>
 __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_x3_kernel(const NtArgs p) {
     static_assert(!PW || (!WT && !AT), "pre-split second operand: row-major (N x K) planes only");
     static_assert(MS == 32 || MS == 16, "matrix instruction: 32x32x16 or 16x16x32");
+    static_assert(NP == 3 || (NP == 2 && MS == 32), "parts: three bf16, or two fp16 on the 32x32x16 instruction");
     constexpr int NW = WM * WN, NTH = 64 * NW, BM = 32 * TM * WM, BN = 32 * TN * WN;
     // A chunk in LDS: per operand three bf16 parts of [rows][32 k] (64 B per row); the 16-B column c (k = 8c .. 8c + 7) of
     // row r is stored at position c ^ ((r >> 2) & 3): the b128 fragment reads -- serviced in the lane groups {0-3, 12-15, 20-27},
     // {4-11, 16-19, 28-31} (+32) of MI355X_MICROARCH.md's LDS table: the four rows with equal r & 3 of a group differ in
     // (r >> 2) & 3 -- and the b64 writes of the row-major loaders (16 lanes = 2 rows x 64 B) are bank-conflict-free.
-    constexpr int PART_A = BM * 64, PART_W = BN * 64, STAGE = 3 * (PART_A + PART_W);
+    constexpr int PART_A = BM * 64, PART_W = BN * 64, STAGE = NP * (PART_A + PART_W);
     // STG: the result leaves through a per-wave LDS staging block (32 rows x 128 B) so that a store instruction covers whole
     // 128-B lines (8 rows) instead of 32 B of each of 32 rows -- for the one-workgroup-per-CU tiles, whose LDS has the room
     constexpr bool STG = OCC == 1 && !ATOMIC && !(X3_ABLATE & 128);
@@ -170,6 +187,20 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_x3_kernel(const NtArgs
     const int v = xcd * gq + min(xcd, gr) + (pid >> 3);
 
     const int KC = p.kchunks;
+    // NP = 2: the operands' power-of-two scales (p.exps: exponent of A, of W; fp16 holds 2^-14 .. 2^16) and the result's
+    float scA = 1.f, scW = 1.f, unA = 1.f, unW = 1.f;
+    if (NP == 2) {
+        static_assert(NP != 2 || NTH == X2_PARTS, "one partial maximum per thread");
+        unsigned ma = p.max_a ? p.max_a[tid] : 0x47000000u, mw = (!PW && p.max_w) ? p.max_w[tid] : 0x47000000u;      // (none: 2^15, e = 0)
+        x2_block_max2(ma, mw, reinterpret_cast<unsigned *>(smem));
+        const int ea = __builtin_amdgcn_readfirstlane(x2_exponent(ma));
+        const int ew = PW ? __builtin_amdgcn_readfirstlane(*reinterpret_cast<const int *>(p.Wp + 2 * p.wplane))
+                          : __builtin_amdgcn_readfirstlane(x2_exponent(mw));
+        scA = __int_as_float((127 + ea) << 23);
+        scW = __int_as_float((127 + ew) << 23);
+        unA = __int_as_float((127 - ea) << 23);                    // (|e| <= 126: x2_exponent; applied one after the other: the
+        unW = __int_as_float((127 - ew) << 23);                    //  product of the two may be outside fp32's range, the result is not)
+    }
     // tile index -> (tile row, tile column), grouped: NT_GROUP_M tile rows are walked column by column (gemm_nt.hip)
     auto decode = [&](int tile, int &tm, int &tn) {
         const int per_group = NT_GROUP_M * p.tiles_n;
@@ -255,11 +286,11 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_x3_kernel(const NtArgs
             const int row = tid >> 2, col = tid & 3;               // octet j: row + j NTH / 4 (a multiple of 16: swizzle unchanged)
             kqW = 2 * col;
             goffW0 = (unsigned)(row * p.ldw + 8 * col) * 2u;
-            woffW0 = (unsigned)(3 * PART_A + row * 64 + ((col ^ x3_sw<MS>(row)) * 16));
+            woffW0 = (unsigned)(NP * PART_A + row * 64 + ((col ^ x3_sw<MS>(row)) * 16));
         } else if (!WT) {
             const int row = wave * 8 + r8;
             goffW0 = (unsigned)(row * p.ldw + 4 * c16) * 4u;
-            woffW0 = (unsigned)(3 * PART_A + row * 64 + (((c16 >> 1) ^ x3_sw<MS>(row)) * 16) + (c16 & 1) * 8);
+            woffW0 = (unsigned)(NP * PART_A + row * 64 + (((c16 >> 1) ^ x3_sw<MS>(row)) * 16) + (c16 & 1) * 8);
         } else {
             const int cq = tid % (BN / CUW), kq = tid / (BN / CUW);
             goffW0 = (unsigned)((4 * kq) * p.ldw + CUW * cq) * 4u;
@@ -302,7 +333,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_x3_kernel(const NtArgs
         // N rows; rows inside the operand but past the TILE cannot occur (a tile's rows are min(BN, N - n0)); the K tail is masked
         // by kokW as always
         if (PW) rsW = __builtin_amdgcn_make_buffer_rsrc((void *)(p.Wp + (long long)ld_n0 * p.ldw + ld_k0), 0,
-                                                        ok ? (int)((2 * p.wplane + (long long)(p.N - 1 - ld_n0) * p.ldw + (p.K - ld_k0)) * 2) : 0, 0x00020000);
+                                                        ok ? (int)(((NP - 1) * p.wplane + (long long)(p.N - 1 - ld_n0) * p.ldw + (p.K - ld_k0)) * 2) : 0, 0x00020000);
         else if (!WT && (X3_ABLATE & 512)) rsW = __builtin_amdgcn_make_buffer_rsrc((void *)p.W, 0, ok ? 0x7fffffff : 0, 0x00020000);
         else if (!WT) rsW = __builtin_amdgcn_make_buffer_rsrc((void *)(p.W + (long long)ld_n0 * p.ldw + ld_k0), 0,
                                                          ok ? (int)(((long long)(ld_nrows - 1) * p.ldw + (p.K - ld_k0)) * 4) : 0, 0x00020000);
@@ -322,7 +353,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_x3_kernel(const NtArgs
             const unsigned off = g0 + (unsigned)(j * (NTH / 4) * ld_) * 2u;
             const bool rowok = (int)(tid >> 2) + j * (NTH / 4) < ld_nrows;          // (the scalar plane offset escapes the range check)
 #pragma unroll
-            for (int part = 0; part < 3; ++part) {
+            for (int part = 0; part < NP; ++part) {
                 const u32x4 x = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (kokW && rowok) ? off : NT_OOB, (int)(part * p.wplane * 2), 0));
 #pragma unroll
                 for (int e = 0; e < 4; ++e) rawp[j][4 * part + e] = x[e];
@@ -372,6 +403,16 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_x3_kernel(const NtArgs
             cvl[e] = cvh[e] ^ cvm[e];
             return;
         }
+        if (NP == 2) {
+            // scaled into fp16's range (exact: a power of two), h = rn16, l = rn16 of the exact remainder
+            const float sc = q < QA ? scA : scW;
+            const float a2 = a * sc, b2 = b * sc;
+            const unsigned h = x2_cvt_pk(a2, b2);
+            const f16x2 hh = __builtin_bit_cast(f16x2, h);
+            cvh[e] = h;
+            cvl[e] = x2_cvt_pk(a2 - (float)hh[0], b2 - (float)hh[1]);
+            return;
+        }
         const unsigned h = x3_cvt_pk(a, b);
         const float ra = a - __uint_as_float(h << 16), rb = b - __uint_as_float(h & 0xffff0000u);      // exact
         const unsigned m = x3_cvt_pk(ra, rb);
@@ -397,13 +438,13 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_x3_kernel(const NtArgs
             const int kq0 = isA ? (int)(tid / (BM / CUA)) : (int)(tid / (BN / CUW));
             const int cq = isA ? (int)(tid % (BM / CUA)) : (int)(tid % (BN / CUW));
             const int row = CU * cq + (j % CU), kq = kq0 + d;
-            off = (unsigned)((isA ? 0 : 3 * PART_A) + row * 64 + (((kq >> 1) ^ x3_sw<MS>(row)) * 16) + (kq & 1) * 8);
+            off = (unsigned)((isA ? 0 : NP * PART_A) + row * 64 + (((kq >> 1) ^ x3_sw<MS>(row)) * 16) + (kq & 1) * 8);
         }
         unsigned char *dst = smem + st * STAGE + off;
         typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
         if (PW && !isA) {
 #pragma unroll
-            for (int part = 0; part < 3; ++part)
+            for (int part = 0; part < NP; ++part)
                 *reinterpret_cast<u32x4 *>(dst + part * ps) = (u32x4){rawp[j][4 * part], rawp[j][4 * part + 1], rawp[j][4 * part + 2], rawp[j][4 * part + 3]};
             return;
         }
@@ -412,6 +453,10 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_x3_kernel(const NtArgs
             return;
         }
         *reinterpret_cast<u32x2 *>(dst) = (u32x2){cvh[0], cvh[1]};
+        if (NP == 2) {
+            *reinterpret_cast<u32x2 *>(dst + ps) = (u32x2){cvl[0], cvl[1]};
+            return;
+        }
         *reinterpret_cast<u32x2 *>(dst + ps) = (u32x2){cvm[0], cvm[1]};
         *reinterpret_cast<u32x2 *>(dst + 2 * ps) = (u32x2){cvl[0], cvl[1]};
     };
@@ -421,19 +466,19 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_x3_kernel(const NtArgs
     constexpr int FR = MS == 32 ? 32 : 16;                         // rows of a fragment / of an output block
     constexpr int FA = 32 * TM / FR, FW = 32 * TN / FR, NPAR = MS == 32 ? 2 : 1;
     const unsigned a_rd = (unsigned)((wm * 32 * TM + li) * 64 + ((lg ^ x3_sw<MS>(li)) * 16));
-    const unsigned w_rd = (unsigned)(3 * PART_A + (wn * 32 * TN + li) * 64 + ((lg ^ x3_sw<MS>(li)) * 16));
+    const unsigned w_rd = (unsigned)(NP * PART_A + (wn * 32 * TN + li) * 64 + ((lg ^ x3_sw<MS>(li)) * 16));
     X3Parts fa[NPAR][FA], fw[NPAR][FW];                            // MS = 32: [parity of the k step]
     // fragment read r of k step s (A blocks first, 3 parts each) from stage st into parity `par`
     auto read_frag = [&](int st, int s, int par, int r) {
-        const int f = r / 3, part = r % 3;
+        const int f = r / NP, part = NP == 2 ? 2 * (r % NP) : r % NP;      // (NP = 2: parts h and l)
         if (f < FA) {
-            const u32x4 x = *reinterpret_cast<const u32x4 *>(smem + st * STAGE + ((a_rd ^ (unsigned)(32 * s)) + f * FR * 64 + part * PART_A));
+            const u32x4 x = *reinterpret_cast<const u32x4 *>(smem + st * STAGE + ((a_rd ^ (unsigned)(32 * s)) + f * FR * 64 + (NP == 2 ? part / 2 : part) * PART_A));
             if (part == 0) fa[par][f].h = x;
             else if (part == 1) fa[par][f].m = x;
             else fa[par][f].l = x;
         } else {
             const int b = f - FA;
-            const u32x4 x = *reinterpret_cast<const u32x4 *>(smem + st * STAGE + ((w_rd ^ (unsigned)(32 * s)) + b * FR * 64 + part * PART_W));
+            const u32x4 x = *reinterpret_cast<const u32x4 *>(smem + st * STAGE + ((w_rd ^ (unsigned)(32 * s)) + b * FR * 64 + (NP == 2 ? part / 2 : part) * PART_W));
             if (part == 0) fw[par][b].h = x;
             else if (part == 1) fw[par][b].m = x;
             else fw[par][b].l = x;
@@ -535,6 +580,14 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_x3_kernel(const NtArgs
         const long long m0 = (long long)tm * BM;
         const int n0 = tn * BN;
         const bool to_ws = !ATOMIC && p.sk_ws != nullptr;
+        if (NP == 2) {
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[a][b][r] = acc[a][b][r] * unA * unW;
+        }
         const long long mrows = to_ws ? BM : min((long long)BM, p.M - m0);      // (a partial tile is stored whole: rows / columns past
         const int ncols = to_ws ? BN : min(BN, p.N - n0);                       //  the matrix hold zeros and are not read back)
         if (!ATOMIC) {
@@ -690,7 +743,8 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_x3_kernel(const NtArgs
     //   * the fragment reads of the next k step;
     //   * BAR MFMAs before the end: the barrier (the next chunk's parts complete and visible, this stage read to the end), after
     //     which the remaining MFMAs cover the first fragment reads of the next chunk.
-    constexpr int SM = 6 * TM * TN, NM = 2 * SM, NFR = 3 * (TM + TN);        // MFMAs per k step / chunk, fragment reads per step
+    constexpr int NPROD = NP == 3 ? 6 : X2_PRODUCTS;               // partial products per fp32 product
+    constexpr int SM = NPROD * TM * TN, NM = 2 * SM, NFR = NP * (TM + TN);   // MFMAs per k step / chunk, fragment reads per step
     constexpr int BAR = 2 * TM * TN > NFR + 2 ? 2 * TM * TN : NFR + 2;       // MFMAs after the barrier
     constexpr int CT_PER_Q = 4, NCT = NQ * CT_PER_Q;               // conversion tasks: per quad 2 pairs, the writes, the reload
     constexpr int C_LO = 1, C_HI = NM - BAR - 1;                   // MFMA gaps that take them
@@ -713,7 +767,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_x3_kernel(const NtArgs
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
-            for (int t = 0; t < 6; ++t)
+            for (int t = 0; t < NPROD; ++t)
 #pragma unroll
                 for (int a = 0; a < TM; ++a)
 #pragma unroll
@@ -742,9 +796,15 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_x3_kernel(const NtArgs
                         }
                         if (FIRST && STG && s == 0 && t == 1 && a == 0 && b == 0) flush_block(TM - 1, TN - 1);
                         const X3Parts &A = fa[s][a], &W = fw[s][b];
+                        if (NP == 2) {                             // (al wl,) al wh, ah wl, ah wh
+                            const int u = t + 4 - NPROD;
+                            const u32x4 ap = u <= 1 ? A.l : A.h, wp = (u == 0 || u == 2) ? W.l : W.h;
+                            acc[a][b] = ATOMIC ? x2_mfma(ap, wp, c) : x2_mfma(wp, ap, c);
+                        } else {
                         const u32x4 ap = t == 0 ? A.l : (t == 1 || t == 3) ? A.m : A.h;      // al wh, am wm, ah wl, am wh, ah wm, ah wh
                         const u32x4 wp = t == 2 ? W.l : (t == 1 || t == 4) ? W.m : W.h;
                         acc[a][b] = ATOMIC ? x3_mfma(ap, wp, c) : x3_mfma(wp, ap, c);
+                        }
                         // fillers after MFMA idx; the scheduler's regions are X3_FENCE MFMAs long
                         if (idx % X3_FENCE == 0) __builtin_amdgcn_sched_barrier(0);
                         if (!(X3_ABLATE & 16)) {
@@ -952,8 +1012,110 @@ __global__ __launch_bounds__(256) void x3_sk_reduce_kernel(const float *__restri
         *reinterpret_cast<float4 *>(C + (m0 + row) * ldc + n0 + c4) = a;
     }
 }
+// ---- two-part mode (NP = 2): the operands' power-of-two scales.  fp16 holds 2^-14 .. 65504 (2^-24 with subnormals): an operand is
+// multiplied by 2^e, e = 14 - floor(log2(max |x|)), before its split -- max |x| 2^e in [2^14, 2^15): nothing overflows, and a
+// value keeps its full 22 bits while it is within 2^-18 of the operand's largest (smaller ones lose bits to fp16's subnormal
+// spacing: an ABSOLUTE error of at most 2^-40 max |x|).  The maximum is taken by a scan of the operand in front of the launch
+// (x2_absmax_kernel: one pass at memory speed, the last workgroup to finish turns the maximum into the exponent and re-arms the
+// slot) unless the caller hands one in (pdgn_gemm_set_operand_exponent; a pre-split operand carries its own behind its planes).
+// Slots (1 KB: X2_PARTS partial maxima, gemm_shared.h) come from a ring in a buffer the CALLER provides once
+// (pdgn_gemm_set_scale_slots: the library never allocates; a launch takes the next slot, so the buffer must hold more slots than
+// launches can be in flight).
+__global__ __launch_bounds__(1024) void x2_absmax_kernel(const float *__restrict__ X, long long rows, int cols, int ld, int vec,
+                                                         unsigned *__restrict__ slot) {
+    // a workgroup takes one contiguous range of 16-B units (4-B units when the operand is not 16-B addressable); a row-major
+    // operand without gaps is one flat array, otherwise the (row, column) of a thread's unit is tracked by increments
+    unsigned mx = 0;
+    const int cu = vec ? cols >> 2 : cols;                         // units per row
+    const long long total = rows * cu;
+    long long per = (total + gridDim.x - 1) / gridDim.x;
+    per = (per + 1023) / 1024 * 1024;
+    long long i = (long long)blockIdx.x * per + threadIdx.x;
+    const long long end = min(total, (long long)(blockIdx.x + 1) * per);
+    if (vec && ld == cols) {
+        const uint4 *__restrict__ P = reinterpret_cast<const uint4 *>(X);
+        for (; i + 3072 < end; i += 4096) {                        // four loads in flight per thread, 64 KB per workgroup
+            const uint4 a = P[i], b = P[i + 1024], c = P[i + 2048], d = P[i + 3072];
+            mx = max(mx, max(max(a.x & 0x7fffffffu, a.y & 0x7fffffffu), max(a.z & 0x7fffffffu, a.w & 0x7fffffffu)));
+            mx = max(mx, max(max(b.x & 0x7fffffffu, b.y & 0x7fffffffu), max(b.z & 0x7fffffffu, b.w & 0x7fffffffu)));
+            mx = max(mx, max(max(c.x & 0x7fffffffu, c.y & 0x7fffffffu), max(c.z & 0x7fffffffu, c.w & 0x7fffffffu)));
+            mx = max(mx, max(max(d.x & 0x7fffffffu, d.y & 0x7fffffffu), max(d.z & 0x7fffffffu, d.w & 0x7fffffffu)));
+        }
+        for (; i < end; i += 1024) {
+            const uint4 a = P[i];
+            mx = max(mx, max(max(a.x & 0x7fffffffu, a.y & 0x7fffffffu), max(a.z & 0x7fffffffu, a.w & 0x7fffffffu)));
+        }
+    } else if (i < end) {
+        long long r = i / cu;
+        int c = (int)(i - r * cu);
+        for (; i < end; i += 1024) {
+            if (vec) {
+                const uint4 a = *reinterpret_cast<const uint4 *>(X + r * ld + 4 * c);
+                mx = max(mx, max(max(a.x & 0x7fffffffu, a.y & 0x7fffffffu), max(a.z & 0x7fffffffu, a.w & 0x7fffffffu)));
+            } else {
+                mx = max(mx, __float_as_uint(X[r * ld + c]) & 0x7fffffffu);
+            }
+            c += 1024;
+            if (c >= cu) {
+                const int q = c / cu;
+                r += q;
+                c -= q * cu;
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, o));
+    __shared__ unsigned wmx[16];
+    if ((threadIdx.x & 63) == 0) wmx[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x < 16) {
+        mx = wmx[threadIdx.x];
+#pragma unroll
+        for (int o = 8; o >= 1; o >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, o));
+        if (threadIdx.x == 0) slot[blockIdx.x] = mx;
+    }
+    if (blockIdx.x == 0 && threadIdx.x >= gridDim.x && threadIdx.x < X2_PARTS) slot[threadIdx.x] = 0u;      // the entries no workgroup writes
+}
+static int x2_scan_launch(const float *X, long long rows, int cols, int ld, unsigned *slot, hipStream_t s) {
+    const int vec = (cols % 4 == 0 && ld % 4 == 0 && ((uintptr_t)X & 15) == 0) ? 1 : 0;
+    const long long units = rows * (vec ? cols / 4 : cols);
+    long long g = (units + 4095) / 4096;                           // 64 KB per workgroup and pass; at most one workgroup per CU and X2_PARTS in all
+    const int cap = nt_cus() < X2_PARTS ? nt_cus() : X2_PARTS;
+    g = g < 1 ? 1 : (g > cap ? cap : g);
+    hipLaunchKernelGGL(x2_absmax_kernel, dim3((int)g), dim3(1024), 0, s, X, rows, cols, ld, vec, slot);
+    return pdgn_launch_status();
+}
+static std::atomic<unsigned *> x2_ring{nullptr};
+static std::atomic<unsigned> x2_ring_slots{0};
+// the partial maxima of (rows x cols, pitch ld) on stream s: a device pointer valid for the launches that follow on s (NULL: no ring)
+const unsigned *x2_scan(const float *X, long long rows, int cols, int ld, hipStream_t s) {
+    static std::atomic<unsigned> next{0};
+    unsigned *ring = x2_ring.load();
+    const unsigned slots = x2_ring_slots.load();
+    if (!ring || !slots) return nullptr;
+    unsigned *sl = ring + (size_t)(next.fetch_add(1) % slots) * X2_PARTS;
+    if (x2_scan_launch(X, rows, cols, ld, sl, s) != 0) return nullptr;
+    return sl;
+}
+static thread_local const unsigned *x2_next_max_a = nullptr, *x2_next_max_w = nullptr;     // handed in for the NEXT contraction call's operands
+
 // gemm_x3_16.hip: instance (tile cfg, flags = ATOMIC | WT << 1 | AT << 2 | EPI << 3 | PW << 4) of gemm_x3_kernel<..., 16>
 void x3_launch16(int cfg, int flags, int grid, hipStream_t s, const NtArgs &a);
+// gemm_x3_h2.hip: the same of gemm_x3_kernel<..., 32, 2> (two fp16 parts), and an instance's host symbol
+void x3_launch_h2(int flags, int grid, hipStream_t s, const NtArgs &a);
+const void *x3_symbol_h2(int flags);
+// Where the two-part form pays (measured, tools/x2_shapes.py: every contraction of an iteration alone in both forms): it halves
+// the matrix-core work of a launch and needs the operands' maxima first -- a pass over every operand that does not bring them
+// along.  On the 256 x 128 tile, with a reduction of at least 128 and >= 20 GFLOP, the products are the larger part of the
+// launch (conv2's dense half 927 -> 782 us with both scans, its input gradient 952 -> 693, the per-point product 761 -> 610);
+// the smaller tiles' launches are bound by their operand path and only pay the scans (+5 .. 100 us each).  A launch that
+// would have to read more than 4.5 bytes per kflop for the maxima keeps three parts (the per-point product's input gradient:
+// 1.8 GB of dY for 118 GFLOP).
+static bool x2_pays(int cfg, long long m, int n, int k, long long scan_bytes) {
+    if (nt_switches().mode != 2 || cfg != 0 || k < 128) return false;
+    const double flops = 2.0 * (double)m * n * k;
+    return flops >= 2e10 && (double)scan_bytes <= 4.5e-3 * flops;
+}
 
 template <int TM, int TN, int WM, int WN, int OCC, int RATE, int CFG>      // RATE: fp32-equivalent kflop / us a CU sustains on this tile's loop
 struct X3Cfg {
@@ -1015,13 +1177,13 @@ struct X3Cfg {
     }
 
     template <bool ATOMIC, bool WT, bool AT, bool EPI, bool PW = false>
-    static void go(int grid, hipStream_t s, const NtArgs &a) {
+    static void go(int grid, hipStream_t s, const NtArgs &a, bool two_part = false) {
         // the matrix instruction is chosen per instance class (tile, atomic / extended epilogue / pre-split operand): nt_switches().shape16
         // (the 16x16x32 instances live in their own translation unit, gemm_x3_16.hip: the two compile side by side)
-        if (x3_shape16(CFG, ATOMIC, EPI, PW))
-            x3_launch16(CFG, (ATOMIC ? 1 : 0) | (WT ? 2 : 0) | (AT ? 4 : 0) | (EPI ? 8 : 0) | (PW ? 16 : 0), grid, s, a);
-        else
-            hipLaunchKernelGGL((gemm_x3_kernel<TM, TN, WM, WN, OCC, ATOMIC, WT, AT, EPI, PW, 32>), dim3(grid), dim3(64 * WM * WN), 0, s, a);
+        const int flags = (ATOMIC ? 1 : 0) | (WT ? 2 : 0) | (AT ? 4 : 0) | (EPI ? 8 : 0) | (PW ? 16 : 0);
+        if (two_part) x3_launch_h2(flags, grid, s, a);             // (256 x 128 tiles only: x2_pays)
+        else if (x3_shape16(CFG, ATOMIC, EPI, PW)) x3_launch16(CFG, flags, grid, s, a);
+        else hipLaunchKernelGGL((gemm_x3_kernel<TM, TN, WM, WN, OCC, ATOMIC, WT, AT, EPI, PW, 32>), dim3(grid), dim3(64 * WM * WN), 0, s, a);
     }
 
     // floats of workspace the stream-K tail of (m, n, k) wants (0: no tail)
@@ -1040,7 +1202,8 @@ struct X3Cfg {
     template <bool WT, bool AT = false>
     static int launch(long long m, int n, int k, const float *A, int lda, const float *W, int ldw, const float *bias,
                       const float *addend, int ldadd, float *C, int ldc, float *stat_part, hipStream_t s,
-                      const NtEpi &epi = NtEpi(), bool prezeroed = false, const unsigned short *Wp = nullptr, long long wplane = 0) {
+                      const NtEpi &epi = NtEpi(), bool prezeroed = false, const unsigned short *Wp = nullptr, long long wplane = 0,
+                      int parts = 3) {
         const bool allow_sk = stat_part == nullptr && ldc == n && !epi.any();
         const Plan pl = plan(m, n, k, allow_sk);
         NtArgs a;
@@ -1052,6 +1215,19 @@ struct X3Cfg {
         a.act = epi.act; a.gate = epi.gate; a.ldgate = epi.ldgate; a.sk_split = 0;
         a.Wp = Wp; a.wplane = wplane;
         a.sk_ws = nullptr;
+        a.max_a = a.max_w = nullptr;
+        // two parts or three: pre-split planes say it themselves; otherwise where it pays (x2_pays: mode 2, this tile, enough
+        // matrix-core work per byte that still has to be scanned for its maximum)
+        const unsigned *hand_a = x2_next_max_a, *hand_w = x2_next_max_w;
+        x2_next_max_a = x2_next_max_w = nullptr;
+        const bool two = Wp ? parts == 2
+                            : x2_pays(CFG, m, n, k, (hand_a ? 0 : (long long)m * k * 4) + (hand_w ? 0 : (long long)n * k * 4));
+        if (two && CFG != 0) return PDGN_ERR_INVALID;              // (two-part planes for a problem the other tiles take: x2_pays said no)
+        if (two) {
+            a.max_a = hand_a ? hand_a : x2_scan(A, AT ? (long long)k : m, AT ? (int)m : k, lda, s);
+            if (!Wp) a.max_w = hand_w ? hand_w : x2_scan(W, WT ? k : n, WT ? n : k, ldw, s);
+            if (!a.max_a || (!Wp && !a.max_w)) return PDGN_ERR_INVALID;     // (no slots: pdgn_gemm_set_scale_slots)
+        }
         a.tiles_m = pl.tiles_m; a.tiles_n = pl.tiles_n; a.kchunks = pl.kchunks;
         a.dbg = 0;
 #ifdef PDGN_NT_DEBUG
@@ -1067,7 +1243,7 @@ struct X3Cfg {
             const int S = (int)(slots / T) < pl.kchunks ? (int)(slots / T) : pl.kchunks;
             if (!prezeroed && hipMemsetAsync(C, 0, (size_t)m * ldc * sizeof(float), s) != hipSuccess) return pdgn_launch_status();
             a.tile_begin = 0; a.tile_end = (int)T; a.sk_split = (int)T; a.sk_per_wg = (pl.kchunks + S - 1) / S;
-            go<true, WT, AT, false>((int)T * S, s, a);
+            go<true, WT, AT, false>((int)T * S, s, a, two);
             return pdgn_launch_status();
         }
         // stream-K tail: the leftover tiles' k range in S slices, partial tiles to the workspace + a reduce (no atomics); the atomic
@@ -1091,22 +1267,22 @@ struct X3Cfg {
         if (pl.grid_dp) {
             a.tile_begin = 0; a.tile_end = pl.dp_tiles; a.sk_per_wg = 0;
             if (CAN_PW && Wp) {
-                if (epi.any()) go<false, false, false, true, CAN_PW>(pl.grid_dp, s, a);
-                else go<false, false, false, false, CAN_PW>(pl.grid_dp, s, a);
-            } else if (!AT && epi.any()) go<false, WT, false, true>(pl.grid_dp, s, a);
-            else go<false, WT, AT, false>(pl.grid_dp, s, a);
+                if (epi.any()) go<false, false, false, true, CAN_PW>(pl.grid_dp, s, a, two);
+                else go<false, false, false, false, CAN_PW>(pl.grid_dp, s, a, two);
+            } else if (!AT && epi.any()) go<false, WT, false, true>(pl.grid_dp, s, a, two);
+            else go<false, WT, AT, false>(pl.grid_dp, s, a, two);
         }
         if (pl.grid_sk && ws) {
             a.tile_begin = pl.dp_tiles; a.tile_end = (int)T; a.sk_split = t_tail; a.sk_per_wg = per_tail; a.sk_ws = ws;
             a.bias = nullptr; a.addend = nullptr;                  // (the reduce adds them)
-            if (CAN_PW && Wp) go<false, false, false, false, CAN_PW>(s_tail * t_tail, s, a);
-            else go<false, WT, AT, false>(s_tail * t_tail, s, a);
+            if (CAN_PW && Wp) go<false, false, false, false, CAN_PW>(s_tail * t_tail, s, a, two);
+            else go<false, WT, AT, false>(s_tail * t_tail, s, a, two);
             hipLaunchKernelGGL(x3_sk_reduce_kernel, dim3(t_tail, 8), dim3(256), 0, s, ws, s_tail, t_tail, BM, BN, pl.dp_tiles, pl.tiles_m,
                                pl.tiles_n, m, n, C, ldc, bias, addend, ldadd);
         } else if (pl.grid_sk) {
             a.tile_begin = pl.dp_tiles; a.tile_end = (int)T; a.sk_per_wg = pl.sk_per_wg;
-            if (CAN_PW && Wp) go<true, false, false, false, CAN_PW>(pl.grid_sk, s, a);
-            else go<true, WT, AT, false>(pl.grid_sk, s, a);
+            if (CAN_PW && Wp) go<true, false, false, false, CAN_PW>(pl.grid_sk, s, a, two);
+            else go<true, WT, AT, false>(pl.grid_sk, s, a, two);
         }
         return pdgn_launch_status();
     }
@@ -1120,7 +1296,7 @@ NtSwitches &nt_switches() {
     static NtSwitches sw = [] {
         NtSwitches s;
         const char *e = getenv("PDGN_GEMM");
-        s.mode = (e && e[0] == 'f') ? 0 : 1;
+        s.mode = (e && e[0] == 'f') ? 0 : (e && e[0] == 'x' && e[1] == '3') ? 1 : 2;      // fp32 | x3 | x2 (default: two parts where they pay)
         e = getenv("PDGN_NT_CFG");
         s.cfg = (e && *e) ? atoi(e) : -1;
         e = getenv("PDGN_X3_SPLITK");                 // 0: weight gradients on the flattened stream-K order (A/B arm)
@@ -1139,12 +1315,37 @@ NtSwitches &nt_switches() {
     return sw;
 }
 
-// mode: 1 = bf16 matrix cores (six partial products per fp32 product), 0 = fp32 matrix instructions, < 0 = leave.  Returns
-// the mode in force before the call.
+// mode: 1 = bf16 matrix cores (three bf16 parts, six partial products per fp32 product), 2 = fp16 matrix cores (two scaled fp16
+// parts, three partial products), 0 = fp32 matrix instructions, < 0 = leave.  Returns the mode in force before the call.
 extern "C" int pdgn_gemm_set_mode(int mode) {
     const int old = nt_switches().mode;
-    if (mode >= 0) nt_switches().mode = mode ? 1 : 0;
+    if (mode >= 0) nt_switches().mode = mode > 2 ? 1 : mode;
     return old;
+}
+
+// Two-part mode: the ring of scale slots (1 KB each; device memory that stays the library's to use until replaced; NULL / 0
+// detaches).  Without one the contractions of mode 2 are refused (-1) unless both operands' maxima are handed in.
+extern "C" int pdgn_gemm_set_scale_slots(void *slots, long long bytes) {
+    if (bytes < 0 || ((uintptr_t)slots & 15)) return PDGN_ERR_INVALID;
+    const long long n = bytes / (X2_PARTS * 4);
+    x2_ring_slots.store(0);
+    x2_ring.store((unsigned *)slots);
+    x2_ring_slots.store(slots ? (unsigned)(n > 0x7fffffff ? 0x7fffffff : n) : 0u);
+    return 0;
+}
+
+// Two-part mode: the partial maxima of an fp32 matrix (rows x cols, pitch ld) into a caller's 1-KB slot (256 words, device) on
+// `stream`, and the hand-over of such slots for the operands of the calling thread's next contraction call (first / second as that
+// entry point takes them; NULL: scanned by the call), which then does not scan them: an activation that feeds several products --
+// forward, weight gradient -- is scanned once.
+extern "C" int pdgn_absmax_partials(long long rows, int cols, const float *src, int ld, unsigned *slot, pdgn_stream_t stream) {
+    if (rows < 1 || cols < 1 || ld < cols || !src || !slot) return PDGN_ERR_INVALID;
+    return x2_scan_launch(src, rows, cols, ld, slot, (hipStream_t)stream);
+}
+extern "C" int pdgn_gemm_set_operand_scales(const unsigned *max_a, const unsigned *max_w) {
+    x2_next_max_a = max_a;
+    x2_next_max_w = max_w;
+    return 0;
 }
 
 // cfg: -1 = the launch model's pick, 0 .. 3 = force a tile configuration (measurement / tests), < -1 = leave.  Returns the
@@ -1185,6 +1386,12 @@ static int x3_pick(long long m, int n, int k, bool stats) {
     return best;
 }
 
+// Whether the contraction (m, n, k) runs on two parts under the switches in force when scan_bytes of its operands still have to be
+// scanned for their maxima (x2_pays): what a caller that pre-splits a weight (pdgn_split_f16x2 or _bf16x3) or hands maxima over asks first.
+extern "C" int pdgn_gemm_two_part(long long m, int n, int k, long long scan_bytes) {
+    if (!x3_mode() || m < 1 || n < 4 || k < 4) return 0;
+    return x2_pays(x3_pick(m, n, k, false), m, n, k, scan_bytes) ? 1 : 0;
+}
 static bool x3_args_ok(long long m, int n, int k, int lda, int ldw, int ldadd, int ldc, const float *addend, bool wt) {
     return m >= 1 && n >= 4 && k >= 4 && n % 4 == 0 && k % 4 == 0 && lda % 4 == 0 && ldw % 4 == 0 && ldc % 4 == 0 &&
            lda >= k && ldw >= (wt ? n : k) && ldc >= n && (!addend || (ldadd % 4 == 0 && ldadd >= n)) && lda < (1 << 19) &&
@@ -1195,12 +1402,13 @@ static bool x3_args_ok(long long m, int n, int k, int lda, int ldw, int ldadd, i
 template <bool WT>
 static int x3_dispatch(long long m, int n, int k, const float *A, int lda, const float *W, int ldw, const float *bias,
                        const float *addend, int ldadd, float *C, int ldc, float *stat_part, hipStream_t s,
-                       const NtEpi &epi = NtEpi(), const unsigned short *Wp = nullptr, long long wplane = 0) {
+                       const NtEpi &epi = NtEpi(), const unsigned short *Wp = nullptr, long long wplane = 0, int parts = 3) {
     const int cfg = x3_pick(m, n, k, stat_part != nullptr || epi.any());
+    if (Wp && parts == 2 && cfg != 0) return PDGN_ERR_INVALID;    // two-part planes: only where the launch model picks the 256 x 128 tile (pdgn_gemm_nt_config)
     switch (cfg) {
-        case 0: return X3Big::launch<WT>(m, n, k, A, lda, W, ldw, bias, addend, ldadd, C, ldc, stat_part, s, epi, false, Wp, wplane);
-        case 2: return X3Narrow::launch<WT>(m, n, k, A, lda, W, ldw, bias, addend, ldadd, C, ldc, stat_part, s, epi, false, Wp, wplane);
-        default: return X3Square::launch<WT>(m, n, k, A, lda, W, ldw, bias, addend, ldadd, C, ldc, stat_part, s, epi, false, Wp, wplane);
+        case 0: return X3Big::launch<WT>(m, n, k, A, lda, W, ldw, bias, addend, ldadd, C, ldc, stat_part, s, epi, false, Wp, wplane, parts);
+        case 2: return X3Narrow::launch<WT>(m, n, k, A, lda, W, ldw, bias, addend, ldadd, C, ldc, stat_part, s, epi, false, Wp, wplane, parts);
+        default: return X3Square::launch<WT>(m, n, k, A, lda, W, ldw, bias, addend, ldadd, C, ldc, stat_part, s, epi, false, Wp, wplane, parts);
     }
 }
 
@@ -1254,10 +1462,10 @@ extern "C" int pdgn_gemm_nt_ex(long long m, int n, int k, const float *A, int ld
 // product dX = dY W as well.  Bit-identical to the unsplit entry points on the bf16 matrix cores (the planes hold exactly the
 // parts the loader would compute); only there: with pdgn_gemm_set_mode(0) in force the call is refused (-1).
 extern "C" int pdgn_gemm_nt_ps(long long m, int n, int k, const float *A, int lda, const unsigned short *Wplanes, int ldw,
-                               long long wplane, const float *bias, const float *addend, int ldadd, float *C, int ldc,
+                               long long wplane, int parts, const float *bias, const float *addend, int ldadd, float *C, int ldc,
                                float *stat_part, const float *row_bias, int ld_rb, int rows_per_group, int act, const float *gate,
                                int ldgate, pdgn_stream_t stream) {
-    if (!x3_mode() || !Wplanes) return PDGN_ERR_INVALID;
+    if (!x3_mode() || !Wplanes || (parts != 3 && parts != 2)) return PDGN_ERR_INVALID;
     if (!x3_args_ok(m, n, k, lda, ldw, ldadd, ldc, addend, false)) return PDGN_ERR_INVALID;
     if (wplane < (long long)(n - 1) * ldw + k || wplane >= (1LL << 28) || ldw % 8 || wplane % 8 || ((uintptr_t)Wplanes & 15))
         return PDGN_ERR_INVALID;                                  // 16-B loads of 8 bf16: rows and planes start on 16-B boundaries
@@ -1269,7 +1477,7 @@ extern "C" int pdgn_gemm_nt_ps(long long m, int n, int k, const float *A, int ld
     e.row_bias = row_bias; e.ld_rb = ld_rb; e.rows_per_group = rows_per_group > 0 ? rows_per_group : 1; e.act = act; e.gate = gate;
     e.ldgate = ldgate;
     return x3_dispatch<false>(m, n, k, A, lda, nullptr, ldw, bias, addend, ldadd, C, ldc, stat_part, (hipStream_t)stream, e, Wplanes,
-                              wplane);
+                              wplane, parts);
 }
 
 // Stream-K tails without atomics: floats of workspace the tail of pdgn_gemm_nt / _nn / _nt_ps (m, n, k) wants (0: that launch has no
@@ -1293,12 +1501,16 @@ extern "C" int pdgn_gemm_set_tail_workspace(float *ws, long long floats) {
 // Which kernel instance and grid the plain (no bias / addend / epilogue) data-parallel launch of pdgn_gemm_nt_ps(m, n, k, ...) uses under
 // the switches in force: *sym = the instance's host symbol (NULL for an instance that lives in another translation unit: the
 // 16x16x32 arm), *grid = its grid.  Lets a measurement find that launch inside a recorded iteration (pdgn_replay_kernel_nodes).
-extern "C" int pdgn_gemm_nt_ps_launch_info(long long m, int n, int k, const void **sym, int *grid) {
+extern "C" int pdgn_gemm_nt_ps_launch_info(long long m, int n, int k, int parts, const void **sym, int *grid) {
     if (!x3_mode() || m < 1 || n < 4 || k < 4 || !sym || !grid) return PDGN_ERR_INVALID;
     const int cfg = x3_pick(m, n, k, false);
     const bool s16 = x3_shape16(cfg, false, false, true);
     *sym = nullptr;
-    if (cfg == 0) {
+    if (parts == 2) {
+        if (cfg != 0) return PDGN_ERR_INVALID;
+        *grid = X3Big::plan(m, n, k, true).grid_dp;
+        *sym = x3_symbol_h2(16);
+    } else if (cfg == 0) {
         *grid = X3Big::plan(m, n, k, true).grid_dp;
         if (!s16) *sym = (const void *)gemm_x3_kernel<4, 2, 2, 2, 1, false, false, false, false, true, 32>;
     } else if (cfg == 2) {
@@ -1308,6 +1520,14 @@ extern "C" int pdgn_gemm_nt_ps_launch_info(long long m, int n, int k, const void
         *grid = X3Square::plan(m, n, k, true).grid_dp;
         if (!s16) *sym = (const void *)gemm_x3_kernel<2, 2, 2, 2, 1, false, false, false, false, true, 32>;
     }
+    return 0;
+}
+
+// Host symbols of the two small kernels a contraction call may launch around its matrix-core kernels (the reduce of a stream-K
+// tail's partial tiles; the scan of an operand's maxima): for measurements that take a whole call out of a recorded iteration.
+extern "C" int pdgn_gemm_aux_symbols(const void **reduce, const void **scan) {
+    if (reduce) *reduce = (const void *)x3_sk_reduce_kernel;
+    if (scan) *scan = (const void *)x2_absmax_kernel;
     return 0;
 }
 

@@ -93,13 +93,16 @@ __global__ __launch_bounds__(SP_THREADS) void bn_softmax_perm_fwd_kernel(long lo
 // x (M, k, C) raw conv_all.3 output, u (M, k/2, 2C) raw inte_conv_hk output -- already in w's layout, so the thread
 // that owns channel pair c of point m holds exactly the float4s of u it has to scale.  w is written only when the
 // backward pass will need it (w_out != NULL); y always.  Neither activated tensor makes an extra HBM round trip.
+// max_out (may be NULL): 256 partial maxima of |y| as bit patterns (entry = workgroup % 256, combined with atomic max; zero-filled
+// by the launcher) -- what the two-part contraction that consumes y (conv2's dense half, gemm_x3.hip) would otherwise scan y for.
 template <int KT>
 __global__ __launch_bounds__(SP_THREADS) void bn_softmax_perm_mul_fwd_kernel(
     long long total2, int k_rt, int C, int act, const float *__restrict__ x, const float *__restrict__ stats,
     int act_u, const float *__restrict__ u, const float *__restrict__ stats_u, float *__restrict__ w_out,
-    float *__restrict__ y) {
+    float *__restrict__ y, unsigned *__restrict__ max_out) {
     const long long e = (long long)blockIdx.x * SP_THREADS + threadIdx.x;
-    if (e >= total2) return;
+    unsigned ymax = 0u;
+    if (e < total2) {
     constexpr int KM = KT ? KT : SP_MAXK;
     const int k = KT ? KT : k_rt;
     const int C2 = C / 2, c = (int)(e % C2) * 2;
@@ -149,7 +152,23 @@ __global__ __launch_bounds__(SP_THREADS) void bn_softmax_perm_mul_fwd_kernel(
             r.z = sp_act(__fmaf_rn(uu[p].z, su.z, hu.z), act_u) * wv.z;
             r.w = sp_act(__fmaf_rn(uu[p].w, su.w, hu.w), act_u) * wv.w;
             *reinterpret_cast<float4 *>(y + o + (size_t)p * 2 * C) = r;
+            ymax = max(max(ymax, max(__float_as_uint(r.x) & 0x7fffffffu, __float_as_uint(r.y) & 0x7fffffffu)),
+                       max(__float_as_uint(r.z) & 0x7fffffffu, __float_as_uint(r.w) & 0x7fffffffu));
         }
+    }
+    if (max_out) {                                                 // (uniform: every thread of the workgroup gets here)
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) ymax = max(ymax, (unsigned)__shfl_xor((int)ymax, o));
+        __shared__ unsigned wmax[SP_THREADS / 64];
+        if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = ymax;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned m = wmax[0];
+#pragma unroll
+            for (int i = 1; i < SP_THREADS / 64; ++i) m = max(m, wmax[i]);
+            atomicMax(max_out + (blockIdx.x & 255), m);
+        }
+    }
 }
 
 __global__ __launch_bounds__(SP_THREADS) void softmax_perm_bwd_kernel(long long total, int k, int C,
@@ -201,20 +220,21 @@ extern "C" int pdgn_bn_softmax_slots_permute(long long m, int k, int c, int act,
 
 extern "C" int pdgn_bn_softmax_slots_permute_mul(long long m, int k, int c, int act, const float *x, const float *stats,
                                                  int act_u, const float *u, const float *stats_u, float *w, float *y,
-                                                 pdgn_stream_t stream) {
+                                                 unsigned *max_out, pdgn_stream_t stream) {
     if (m < 1 || k < 2 || k > SP_MAXK || (k & 1) || c < 2 || (c & 1) || act < 0 || act > 2 || act_u < 0 || act_u > 2)
         return PDGN_ERR_INVALID;
     const long long total2 = m * (c / 2);
     const dim3 grid(cdiv(total2, SP_THREADS)), block(SP_THREADS);
     hipStream_t s = (hipStream_t)stream;
+    if (max_out && hipMemsetAsync(max_out, 0, 256 * sizeof(unsigned), s) != hipSuccess) return pdgn_launch_status();
     if (k == 10)
-        hipLaunchKernelGGL(bn_softmax_perm_mul_fwd_kernel<10>, grid, block, 0, s, total2, k, c, act, x, stats, act_u, u, stats_u, w, y);
+        hipLaunchKernelGGL(bn_softmax_perm_mul_fwd_kernel<10>, grid, block, 0, s, total2, k, c, act, x, stats, act_u, u, stats_u, w, y, max_out);
     else if (k == 20)
-        hipLaunchKernelGGL(bn_softmax_perm_mul_fwd_kernel<20>, grid, block, 0, s, total2, k, c, act, x, stats, act_u, u, stats_u, w, y);
+        hipLaunchKernelGGL(bn_softmax_perm_mul_fwd_kernel<20>, grid, block, 0, s, total2, k, c, act, x, stats, act_u, u, stats_u, w, y, max_out);
     else if (k == 4)
-        hipLaunchKernelGGL(bn_softmax_perm_mul_fwd_kernel<4>, grid, block, 0, s, total2, k, c, act, x, stats, act_u, u, stats_u, w, y);
+        hipLaunchKernelGGL(bn_softmax_perm_mul_fwd_kernel<4>, grid, block, 0, s, total2, k, c, act, x, stats, act_u, u, stats_u, w, y, max_out);
     else
-        hipLaunchKernelGGL(bn_softmax_perm_mul_fwd_kernel<0>, grid, block, 0, s, total2, k, c, act, x, stats, act_u, u, stats_u, w, y);
+        hipLaunchKernelGGL(bn_softmax_perm_mul_fwd_kernel<0>, grid, block, 0, s, total2, k, c, act, x, stats, act_u, u, stats_u, w, y, max_out);
     return pdgn_launch_status();
 }
 

@@ -357,7 +357,7 @@ class PointDeconv(nn.Module):
     # stream); forward_cl takes them from there while the parameters' versions still match, else builds them on the spot.
     def _weights_key(self, Fc):
         ws = [self.inte_conv_hk[0].weight, self.conv2.conv.weight] + ([self.conv_fea[0].weight] if self.bilateral else [])
-        return (Fc,) + tuple((w.data_ptr(), w._version) for w in ws)
+        return (Fc, getattr(self, "_rows_hint", None)) + tuple((w.data_ptr(), w._version) for w in ws)
 
     def _assemble_now(self, Fc):
         Fi, Fo, k = self.Fin, self.Fout, self.k
@@ -366,8 +366,9 @@ class PointDeconv(nn.Module):
                                                  self.conv_fea[0].weight if self.bilateral else None, Fi, Fo, k, T, Fc)
         want_t = torch.is_grad_enabled() and WcatV.requires_grad
         with torch.no_grad():
-            pv = split_planes(WcatV.detach(), want_t)
-            pb = split_planes(Wb.detach(), want_t)
+            rows = getattr(self, "_rows_hint", None)               # B * N of the last forward: decides three bf16 / two fp16 parts
+            pv = split_planes(WcatV.detach(), want_t, rows)
+            pb = split_planes(Wb.detach(), want_t, rows)
         return WcatC, WcatV, Wb, pv, pb
 
     def preassemble(self, Fc):
@@ -402,6 +403,7 @@ class PointDeconv(nn.Module):
         Fi, Fo, k = self.Fin, self.Fout, self.k
         Fc = Fi - Fv
         training = self.training
+        self._rows_hint = B * N                                        # (for the next pre-assembly: _assemble_now)
         knn_side = idx_ready
         if idx is None:
             idx, knn_side = start_feature_knn(xt, const, k, x_cf=x_cf)
@@ -444,6 +446,7 @@ class PointDeconv(nn.Module):
         inte_pre, a_pre = outs[0], outs[1]                             # (B,N,P,4F), (B,N,1,2Fo)
         part_i = outs[-1] if fuse_stats else None                      # BatchNorm partials of inte_pre
         w = None
+        inte_max = None                                                # inte's partial maxima when its producer emits them (two-part conv2)
         if self.bilateral:
             Wx = _w2d(self.conv_xyz[0])                   # (16, 6)
             Yx = linear_cl(pct.reshape(B * N, 3), _XyzTaps.apply(Wx)).view(B, N, -1)
@@ -459,8 +462,12 @@ class PointDeconv(nn.Module):
             if self.softmax:
                 # conv_all.4 + LeakyReLU + softmax over the k slots + interleave w[b,n,s=P*j+p,c'] -> [b,n,p,o=2c'+j]
                 # (:623-625, :634-641) AND inte = LeakyReLU(BN(inte_pre)) * w (:637, :642): one pass over both raw tensors
-                inte = bilateral_weighting(h, self.conv_all[4], inte_pre.view(-1, 4 * Fi), self.inte_conv_hk[1], training, k,
-                                           pre_bias_x=self.conv_all[3].bias, partials_u=part_i, partials_x=ph)
+                if planes_b is not None and planes_b.parts_p == 2:
+                    inte, inte_max = bilateral_weighting(h, self.conv_all[4], inte_pre.view(-1, 4 * Fi), self.inte_conv_hk[1], training, k,
+                                                         pre_bias_x=self.conv_all[3].bias, partials_u=part_i, partials_x=ph, want_max=True)
+                else:
+                    inte = bilateral_weighting(h, self.conv_all[4], inte_pre.view(-1, 4 * Fi), self.inte_conv_hk[1], training, k,
+                                               pre_bias_x=self.conv_all[3].bias, partials_u=part_i, partials_x=ph)
             else:
                 h = bn_act(h, self.conv_all[4], training, pre_bias=self.conv_all[3].bias, partials=ph)
                 w = h.view(B, N, 2, P, 2 * Fi).permute(0, 1, 3, 4, 2).reshape(B * N * P, 4 * Fi)
@@ -468,7 +475,7 @@ class PointDeconv(nn.Module):
         else:
             # inte = LeakyReLU(BN(inte_pre))  (:637)
             inte = bn_act(inte_pre.view(-1, 4 * Fi), self.inte_conv_hk[1], training, partials=part_i)
-        out_pre = linear_cl(inte.view(B * N, P * 4 * Fi), Wb, None, a_pre.view(B * N, 2 * Fo), planes=planes_b)    # sum in the GEMM's epilogue
+        out_pre = linear_cl(inte.view(B * N, P * 4 * Fi), Wb, None, a_pre.view(B * N, 2 * Fo), planes=planes_b, x_max=inte_max)    # sum in the GEMM's epilogue
         # (B,2Fout,N,1) -> view(B,Fout,2,N) -> (B,Fout,2N) (:645-647): point j*N+n of channel c is conv channel 2c+j at
         # point n; in point-major form that is (B, 2, N, Fout) -> (B, 2N, Fout), which the BatchNorm + ReLU pass stores
         # directly (interleave_n) instead of a permute copy behind it

@@ -298,7 +298,7 @@ _TN_BIG = os.environ.get("PDGN_TN_BIG", "1") == "1"            # A/B switch: wei
 
 def _tn_big_max():
     # x3: also the two largest outputs (measured 0.88x / 0.90x pdgn_gemm_tn's time); fp32 instructions: up to 1 M elements
-    return (1 << 22) if _lib.gemm_mode() == "x3" else (1 << 20)
+    return (1 << 22) if _lib.matrix_core_mode() else (1 << 20)
 
 
 def _pad_cols(t, mult=4):
@@ -318,27 +318,86 @@ _PLANES = os.environ.get("PDGN_PLANES", "1") == "1"            # A/B switch: 0 =
 
 
 class Planes:
-    """A weight's three bf16 parts (x = h + m + l, csrc/split.hip) as planes [3][rows][ld] (int16 storage), written ONCE per
-    weight instead of by every workgroup's loader of the contraction kernel; `t` = the same for the transpose (the input-gradient
-    product dX = dY W is the NT product against W^T) or None."""
-    __slots__ = ("p", "t", "shape")
+    """A weight's parts as planes, written ONCE per weight instead of by every workgroup's loader of the contraction kernel:
+    three bf16 parts (x = h + m + l, csrc/split.hip) as [3][rows][ld], or -- for a contraction that runs on two parts
+    (pdgn_gemm_two_part) -- two scaled fp16 parts [2][rows][ld] with the exponent behind them (int16 storage either way);
+    `t` = the same for the transpose (the input-gradient product dX = dY W is the NT product against W^T) or None.
+    parts_p / parts_t: 3 or 2."""
+    __slots__ = ("p", "t", "shape", "parts_p", "parts_t")
 
-    def __init__(self, p, t, shape):
-        self.p, self.t, self.shape = p, t, shape
+    def __init__(self, p, t, shape, parts_p=3, parts_t=3):
+        self.p, self.t, self.shape, self.parts_p, self.parts_t = p, t, shape, parts_p, parts_t
 
 
-def split_planes(w, want_t):
-    """pdgn_split_bf16x3 of a (rows, cols) fp32 matrix; None where the pre-split path does not apply (fp32-instruction mode,
-    sizes that would need padding)."""
-    if not (_PLANES and w.is_cuda and w.dim() == 2 and _lib.gemm_mode() == "x3") or w.shape[0] % 4 or w.shape[1] % 4 or w.stride(1) != 1:
+def two_part(m, n, k, scan_bytes):
+    """Whether the contraction (m, n, k) runs on two scaled fp16 parts when scan_bytes of its operands still have to be scanned
+    for their maxima (mode "x2" and a launch whose time is its matrix-core work: csrc/gemm_x3.hip x2_pays)."""
+    return _lib.gemm_mode() == "x2" and bool(_lib.lib().pdgn_gemm_two_part(ctypes.c_longlong(m), n, k, ctypes.c_longlong(scan_bytes)))
+
+
+def split_planes(w, want_t, rows=None):
+    """The pre-split planes of a (n, k) fp32 weight (Planes); None where the pre-split path does not apply (fp32-instruction mode,
+    sizes that would need padding).  rows: the row count of the activations it will multiply, when known -- it decides between
+    three bf16 and two fp16 parts per product (forward: (rows, n, k); input gradient through the transpose: (rows, k, n))."""
+    mode = _lib.gemm_mode()
+    if not (_PLANES and w.is_cuda and w.dim() == 2 and mode != "fp32") or w.shape[0] % 4 or w.shape[1] % 4 or w.stride(1) != 1:
         return None
     n, k = w.shape
     ldp, ldt = (k + 7) // 8 * 8, (n + 7) // 8 * 8
-    P = torch.empty((3, n, ldp), dtype=torch.int16, device=w.device)
-    PT = torch.empty((3, k, ldt), dtype=torch.int16, device=w.device) if want_t else None
-    check(_lib.lib().pdgn_split_bf16x3(n, k, ptr(w), w.stride(0), ptr(P), ldp, ctypes.c_longlong(n * ldp), ptr(PT), ldt,
-                                       ctypes.c_longlong(k * ldt if want_t else 0), stream_of(w)), "pdgn_split_bf16x3")
-    return Planes(P, PT, (n, k))
+    parts_p = 2 if rows and two_part(rows, n, k, rows * k * 4) else 3           # (the activations are scanned, the weight brings its exponent)
+    parts_t = 2 if rows and want_t and two_part(rows, k, n, rows * n * 4) else 3
+
+    def planes(parts, rows_, ld):                                  # [parts][rows][ld] (+ 16 B: two-part planes keep the exponent there)
+        buf = torch.empty(parts * rows_ * ld + 8, dtype=torch.int16, device=w.device)
+        return buf[:parts * rows_ * ld].view(parts, rows_, ld)
+    P = planes(parts_p, n, ldp)
+    PT = planes(parts_t, k, ldt) if want_t else None
+    L = _lib.lib()
+    st = stream_of(w)
+    if parts_p == parts_t or not want_t:
+        fn = L.pdgn_split_bf16x3 if parts_p == 3 else L.pdgn_split_f16x2
+        check(fn(n, k, ptr(w), w.stride(0), ptr(P), ldp, ctypes.c_longlong(n * ldp), ptr(PT), ldt,
+                 ctypes.c_longlong(k * ldt if want_t else 0), st), "pdgn_split")
+    else:                                                          # one form each: two launches
+        for parts, args in ((parts_p, (ptr(P), ldp, ctypes.c_longlong(n * ldp), None, 0, ctypes.c_longlong(0))),
+                            (parts_t, (None, 0, ctypes.c_longlong(0), ptr(PT), ldt, ctypes.c_longlong(k * ldt)))):
+            fn = L.pdgn_split_bf16x3 if parts == 3 else L.pdgn_split_f16x2
+            check(fn(n, k, ptr(w), w.stride(0), *args, st), "pdgn_split")
+    return Planes(P, PT, (n, k), parts_p, parts_t)
+
+
+_EXP_POOL, _EXP_NEXT = None, 0
+
+
+def operand_exponent(t):
+    """Two-part mode (csrc/gemm_x3.hip, "x2"): the scale of a 2-D fp32 operand -- 256 partial maxima of |t| from ONE scan
+    (pdgn_absmax_partials) in a 1-KB slot of a pool -- to hand to every contraction the operand feeds (forward and weight gradient
+    of a layer; input and weight gradient for dy) instead of a scan per call.  None in the other modes."""
+    global _EXP_POOL, _EXP_NEXT
+    if _lib.gemm_mode() != "x2" or not t.is_cuda or t.dim() != 2 or t.stride(1) != 1 or t.dtype != F32 or t.shape[1] % 4:
+        return None
+    if _EXP_POOL is None:
+        _EXP_POOL = torch.zeros((1 << 12, 256), dtype=torch.int32, device=t.device)   # round-robin: an iteration makes ~200 of them
+    slot = _EXP_POOL[_EXP_NEXT]
+    _EXP_NEXT = (_EXP_NEXT + 1) % _EXP_POOL.shape[0]
+    check(_lib.lib().pdgn_absmax_partials(ctypes.c_longlong(t.shape[0]), t.shape[1], ptr(t), t.stride(0), ptr(slot), stream_of(t)),
+          "pdgn_absmax_partials")
+    return slot
+
+
+def _max_slot(device):
+    """A 1-KB slot of the pool for a producer kernel that writes its output's partial maxima itself."""
+    global _EXP_POOL, _EXP_NEXT
+    if _EXP_POOL is None:
+        _EXP_POOL = torch.zeros((1 << 12, 256), dtype=torch.int32, device=device)
+    slot = _EXP_POOL[_EXP_NEXT]
+    _EXP_NEXT = (_EXP_NEXT + 1) % _EXP_POOL.shape[0]
+    return slot
+
+
+def _hand_exponents(L, ea, ew=None):
+    if ea is not None or ew is not None:
+        L.pdgn_gemm_set_operand_scales(ptr(ea), ptr(ew))
 
 
 def _tail_workspace(L, m, n, k, with_stats, device):
@@ -354,9 +413,15 @@ def _tail_workspace(L, m, n, k, with_stats, device):
     return ws
 
 
-def gemm_nt_planes(a, P, n, k, bias=None, addend=None, want_stats=False):
-    """a (m, k) @ W^T for a weight given as its planes P [3][n][ld] (Planes.p of W, or Planes.t for the product with W itself:
-    then n, k are W^T's); everything else as gemm_nt."""
+def planes_fit(P, m, n, k, with_stats=False):
+    """Whether planes P can serve the product (m, n, k): three-part planes always; two-part ones only where the launch model
+    picks the tile their instances exist for (the shape they were made for: split_planes' rows)."""
+    return P.shape[0] == 3 or (_lib.lib().pdgn_gemm_nt_config(ctypes.c_longlong(m), n, k, 1 if with_stats else 0) & 15) == 0
+
+
+def gemm_nt_planes(a, P, n, k, bias=None, addend=None, want_stats=False, exp_a=None):
+    """a (m, k) @ W^T for a weight given as its planes P [parts][n][ld] (Planes.p of W, or Planes.t for the product with W itself:
+    then n, k are W^T's; two-part planes: exp_a = a's maxima when the caller has them, operand_exponent); everything else as gemm_nt."""
     m = a.shape[0]
     if GEMM_LOG is not None:
         GEMM_LOG.append(("nt", m, n, k))
@@ -371,13 +436,14 @@ def gemm_nt_planes(a, P, n, k, bias=None, addend=None, want_stats=False):
     if addend is not None:
         addend = _pad_cols(addend)
     ws = _tail_workspace(L, m, n, k, want_stats, a.device)
-    check(L.pdgn_gemm_nt_ps(ctypes.c_longlong(m), n, k, ptr(ap), ap.stride(0), ptr(P), P.shape[2], ctypes.c_longlong(P.shape[1] * P.shape[2]),
+    _hand_exponents(L, exp_a)
+    check(L.pdgn_gemm_nt_ps(ctypes.c_longlong(m), n, k, ptr(ap), ap.stride(0), ptr(P), P.shape[2], ctypes.c_longlong(P.shape[1] * P.shape[2]), P.shape[0],
                             ptr(b), ptr(addend), addend.stride(0) if addend is not None else 0, ptr(out), n, ptr(part), None, 0, 1, 0,
                             None, 0, stream_of(a)), "pdgn_gemm_nt_ps")
     return (out, part) if want_stats else out
 
 
-def gemm_nt(a, w, bias=None, addend=None, want_stats=False, w_transposed=False):
+def gemm_nt(a, w, bias=None, addend=None, want_stats=False, w_transposed=False, exp_a=None):
     """a (m, k) @ w (n, k)^T (+ bias) (+ addend) on pdgn_gemm_nt -- or, with w_transposed, a (m, k) @ w (k, n) on
     pdgn_gemm_nn (the input gradient dy @ W straight from the layer's weight).  Channel counts that are not multiples
     of 4 (the xyz layers: k = 3, the heads' last conv: n = 3) are zero-padded for the launch.  want_stats: also returns
@@ -412,6 +478,7 @@ def gemm_nt(a, w, bias=None, addend=None, want_stats=False, w_transposed=False):
     b = bias.detach().contiguous() if bias is not None else None
     fn = L.pdgn_gemm_nn if w_transposed else L.pdgn_gemm_nt
     ws = _tail_workspace(L, m, np_, kp, want_stats, a.device)       # (kept alive to the end of this function: the launch is issued by then)
+    _hand_exponents(L, exp_a)
     check(fn(ctypes.c_longlong(m), np_, kp, ptr(ap), ap.stride(0), ptr(wp), wp.stride(0), ptr(b), ptr(addend),
              addend.stride(0) if addend is not None else 0, ptr(out), np_, ptr(part), stream_of(a)),
           "pdgn_gemm_nn" if w_transposed else "pdgn_gemm_nt")
@@ -420,7 +487,7 @@ def gemm_nt(a, w, bias=None, addend=None, want_stats=False, w_transposed=False):
     return (out, part) if want_stats else out
 
 
-def gemm_tn(dy, x):
+def gemm_tn(dy, x, exp_dy=None, exp_x=None):
     """dy (m, n)^T @ x (m, k) -> (n, k) on pdgn_gemm_tn (reduction over the rows split over workgroups)."""
     m, n = dy.shape
     k = x.shape[1]
@@ -429,12 +496,13 @@ def gemm_tn(dy, x):
     dyp, xp = _pad_cols(dy), _pad_cols(x)
     nk = dyp.shape[1] * xp.shape[1]
     # (long reductions -- >= 150 k rows -- also with 16 K .. 64 K outputs: 0.85-0.88x pdgn_gemm_tn's time, r03_gemm_shapes.txt)
-    if _TN_BIG and dyp.shape[1] >= 64 and xp.shape[1] >= 64 and (65536 if (m < 150000 or _lib.gemm_mode() != "x3") else 16384) <= nk <= _tn_big_max():
+    if _TN_BIG and dyp.shape[1] >= 64 and xp.shape[1] >= 64 and (65536 if (m < 150000 or not _lib.matrix_core_mode()) else 16384) <= nk <= _tn_big_max():
         # mid-sized outputs (4 .. 64 tiles of 128 x 128): the stream-K launch of the pdgn_gemm_nt kernel with both operands
         # transposed balances them better than pdgn_gemm_tn's split (measured, tools/gemm_shapes.py: 0.70-0.94x its time);
         # smaller outputs (and, on the fp32 kernels, the two largest ones: conv2's dense half, the per-point GEMM) stay on
         # pdgn_gemm_tn
         dwp = _zeros((dyp.shape[1], xp.shape[1]), dy.device)       # a slice of the backward pass's zero arena: no fill launch here
+        _hand_exponents(_lib.lib(), exp_dy, exp_x)
         check(_lib.lib().pdgn_gemm_tn_big(ctypes.c_longlong(m), dyp.shape[1], xp.shape[1], ptr(dyp), dyp.stride(0), ptr(xp),
                                           xp.stride(0), ptr(dwp), 1, stream_of(dy)), "pdgn_gemm_tn_big")
         return dwp if (dyp.shape[1] == n and xp.shape[1] == k) else dwp[:n, :k]
@@ -494,23 +562,27 @@ class LinearCL(Function):
     (models/PDGNet_v2.py:559-625, 835-862, 886-1014) as row-matrix products on the hand-written MFMA kernels (see above)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, addend, want_stats=False, planes=None):
+    def forward(ctx, x, weight, bias, addend, want_stats=False, planes=None, x_max=None):
         ctx.save_for_backward(x, weight)
         ctx.set_materialize_grads(False)          # no zero-filled "gradient" of the statistics partials (a launch per call)
         ctx.has_bias = bias is not None
         ctx.has_addend = addend is not None
         ctx.planes_t = None
+        ctx.exp_x = None
         if (planes is not None and x.is_cuda and x.shape[0] >= _PLANES_MIN_ROWS and planes.shape == tuple(weight.shape)
-                and x.shape[1] == weight.shape[1] and x.shape[1] % 4 == 0):
+                and x.shape[1] == weight.shape[1] and x.shape[1] % 4 == 0
+                and planes_fit(planes.p, x.shape[0], weight.shape[0], weight.shape[1], want_stats)):
             # the weight arrives pre-split (Planes): no split work for it in the kernel, forward and input gradient
             n, k = weight.shape
             ctx.thin = False
             ctx.planes_t = planes.t
+            # (a two-part product: x is scanned once, for this product and for its weight gradient)
+            ctx.exp_x = ex = (x_max if x_max is not None else operand_exponent(x)) if planes.parts_p == 2 else None
             if want_stats:
-                y, part = gemm_nt_planes(x, planes.p, n, k, bias, addend, want_stats=True)
+                y, part = gemm_nt_planes(x, planes.p, n, k, bias, addend, want_stats=True, exp_a=ex)
                 ctx.mark_non_differentiable(part)
                 return y, part
-            return gemm_nt_planes(x, planes.p, n, k, bias, addend)
+            return gemm_nt_planes(x, planes.p, n, k, bias, addend, exp_a=ex)
         ctx.thin = bool(x.is_cuda and x.shape[0] >= _OWN_MIN_ROWS and addend is None and weight.is_contiguous()
                         and _thin_ok(x, weight.shape[0], weight.shape[1]))
         if ctx.thin:
@@ -522,11 +594,12 @@ class LinearCL(Function):
             y = thin_nt(x, weight, k, 1, n, bias)
             return (y, None) if want_stats else y
         if x.is_cuda and x.shape[0] >= _OWN_MIN_ROWS:
+            ex = None                                              # (the library scans both operands itself where two parts pay)
             if want_stats and weight.shape[0] % 4 == 0:
-                y, part = gemm_nt(x, weight, bias, addend, want_stats=True)
+                y, part = gemm_nt(x, weight, bias, addend, want_stats=True, exp_a=ex)
                 ctx.mark_non_differentiable(part)
                 return y, part
-            y = gemm_nt(x, weight, bias, addend)
+            y = gemm_nt(x, weight, bias, addend, exp_a=ex)
             return (y, None) if want_stats else y
         y = torch.nn.functional.linear(x, weight, bias)
         y = y + addend if addend is not None else y
@@ -536,10 +609,10 @@ class LinearCL(Function):
     def backward(ctx, dy, *unused):
         x, weight = ctx.saved_tensors
         if dy is None:
-            return None, None, None, None, None, None
+            return None, None, None, None, None, None, None
         carried = take_input_grad(dy)
         if carried is not None:              # BNActMaxPool's backward already carried the gradient through this layer
-            return carried[0], carried[1], None, None, None, None
+            return carried[0], carried[1], None, None, None, None, None
         if is_placeholder(dy):
             raise RuntimeError("LinearCL.backward: received BNActMaxPool's gradient placeholder without the gradient it stands for "
                                "(another consumer of the layer's output, a hook or a copy sits between the two nodes)")
@@ -559,17 +632,26 @@ class LinearCL(Function):
                     db = _zeros((n,), dy.device)
             elif want_db:
                 db = _zeros((n,), dy.device) if zero_db else group_colsum(dy)[0]
-            return dx, dw, db, None, None, None
+            return dx, dw, db, None, None, None, None
+        # two-part products (mode "x2", where they pay): dy is scanned ONCE for the input and the weight gradient
+        ey = None
+        if own and _lib.gemm_mode() == "x2" and dy.shape[1] % 4 == 0:
+            m_, n_, k_ = dy.shape[0], weight.shape[0], weight.shape[1]
+            dx_two = (ctx.needs_input_grad[0] and ctx.planes_t is not None and ctx.planes_t.shape[0] == 2
+                      and planes_fit(ctx.planes_t, m_, k_, n_))
+            dw_two = ctx.needs_input_grad[1] and two_part(n_, k_, m_, (0 if dx_two else m_ * n_ * 4) + (0 if ctx.exp_x is not None else m_ * k_ * 4))
+            if dx_two or dw_two:
+                ey = operand_exponent(dy)
         if ctx.needs_input_grad[0]:
-            if ctx.planes_t is not None and own and dy.shape[1] % 4 == 0:
-                dx = gemm_nt_planes(dy, ctx.planes_t, weight.shape[1], weight.shape[0])      # dX = dY W = dY (W^T)^T
+            if ctx.planes_t is not None and own and dy.shape[1] % 4 == 0 and planes_fit(ctx.planes_t, dy.shape[0], weight.shape[1], weight.shape[0]):
+                dx = gemm_nt_planes(dy, ctx.planes_t, weight.shape[1], weight.shape[0], exp_a=ey)      # dX = dY W = dY (W^T)^T
             else:
-                dx = gemm_nt(dy, weight, w_transposed=True) if own else dy.matmul(weight)
+                dx = gemm_nt(dy, weight, w_transposed=True, exp_a=ey) if own else dy.matmul(weight)
         if ctx.needs_input_grad[1]:
-            dw = gemm_tn(dy, x) if own else dy.t().matmul(x)
+            dw = gemm_tn(dy, x, ey, ctx.exp_x) if own else dy.t().matmul(x)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = _zeros((dy.shape[1],), dy.device) if zero_db else group_colsum(dy)[0]
-        return dx, dw, db, (dy if ctx.has_addend and ctx.needs_input_grad[3] else None), None, None
+        return dx, dw, db, (dy if ctx.has_addend and ctx.needs_input_grad[3] else None), None, None, None
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -733,17 +815,18 @@ class HeadMLP(Function):
 _PLANES_MIN_ROWS = 4096        # below this a contraction is a few tiles: the split kernel's launches would cost more than they save
 
 
-def linear_cl(x2d, weight, bias=None, addend=None, want_stats=None, planes=None):
+def linear_cl(x2d, weight, bias=None, addend=None, want_stats=None, planes=None, x_max=None):
     """Dense layer on point-major rows (see LinearCL); `addend` (M, C_out) is added in the GEMM's epilogue.
+    x_max: x2d's partial maxima when its producer computed them (bilateral_weighting's want_max), for a two-part product.
     want_stats (True / False, not None): returns the PAIR (y, partials) -- with True the BatchNorm partial sums of y from
     the GEMM's epilogue, for bn_act / bilateral_weighting's `partials` argument (no statistics pass over y); None when
     this call did not produce them."""
     if want_stats is None:
-        return LinearCL.apply(x2d, weight, bias, addend, False, planes)
+        return LinearCL.apply(x2d, weight, bias, addend, False, planes, x_max)
     if want_stats:
-        y, part = LinearCL.apply(x2d, weight, bias, addend, True, planes)
+        y, part = LinearCL.apply(x2d, weight, bias, addend, True, planes, x_max)
         return y, ((part, stat_block_rows(x2d, weight, addend)) if part is not None else None)
-    return LinearCL.apply(x2d, weight, bias, addend, False, planes), None
+    return LinearCL.apply(x2d, weight, bias, addend, False, planes, x_max), None
 
 
 def stat_block_rows(x2d, weight, addend=None):
@@ -846,7 +929,7 @@ class BilateralWeighting(Function):
 
     @staticmethod
     def forward(ctx, x, u, gx, bx, rmx, rvx, pbx, gu, bu, rmu, rvu, pbu, training, momentum_x, eps_x, momentum_u, eps_u,
-                act, k, partials_u=None, partials_x=None):
+                act, k, partials_u=None, partials_x=None, want_max=False):
         rows, C = x.shape
         m = rows // k
         x, u = x.contiguous(), u.contiguous()
@@ -859,15 +942,20 @@ class BilateralWeighting(Function):
         need_w = any(ctx.needs_input_grad) and k not in (4, 10)
         w = torch.empty((m, k // 2, 2 * C), dtype=F32, device=x.device) if need_w else None
         y = torch.empty_like(u)
+        # want_max: y's partial maxima come out of the same pass (the two-part contraction that takes y would scan it otherwise)
+        ymax = _max_slot(x.device) if want_max else None
         check(L.pdgn_bn_softmax_slots_permute_mul(ctypes.c_longlong(m), k, C, act, ptr(x), ptr(stats_x), act, ptr(u),
-                                                  ptr(stats_u), ptr(w), ptr(y), stream_of(x)),
+                                                  ptr(stats_u), ptr(w), ptr(y), ptr(ymax), stream_of(x)),
               "pdgn_bn_softmax_slots_permute_mul")
         ctx.save_for_backward(x, u, w, stats_x, stats_u)
         ctx.cfg = (rows, C, act, bool(training), k, pbx is not None, pbu is not None)
+        if want_max:
+            ctx.mark_non_differentiable(ymax)
+            return y, ymax
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, *unused):
         x, u, w, stats_x, stats_u = ctx.saved_tensors
         rows, C, act, training, k, has_pbx, has_pbu = ctx.cfg
         L = _lib.lib()
@@ -906,25 +994,28 @@ class BilateralWeighting(Function):
             mark_zero_colsum(du)
             mark_zero_colsum(dx)
         return (dx, du, bsx[C:], bsx[:C], None, None, _pre_bias_grad(has_pbx, C, x.device), bsu[Cu:], bsu[:Cu], None, None,
-                _pre_bias_grad(has_pbu, Cu, x.device), None, None, None, None, None, None, None, None, None)
+                _pre_bias_grad(has_pbu, Cu, x.device), None, None, None, None, None, None, None, None, None, None)
 
 
 def bilateral_weighting(x2d, bn_x, u2d, bn_u, training, k, act="leaky_relu", pre_bias_x=None, pre_bias_u=None,
-                        partials_u=None, partials_x=None):
+                        partials_u=None, partials_x=None, want_max=False):
     """x2d (M*k, C) raw conv_all.3 output, u2d (M*k/2, 2C) raw inte_conv_hk output ->
-    act(bn_u(u2d)) * softmax_slots_permute(act(bn_x(x2d))), shape of u2d."""
+    act(bn_u(u2d)) * softmax_slots_permute(act(bn_x(x2d))), shape of u2d.  want_max: returns the PAIR (y, maxima) -- y's partial
+    maxima (a 1-KB slot for linear_cl's x_max: the two-part contraction that consumes y needs them) or None when this path did
+    not produce them."""
     x2d, pre_bias_x = _fold_pre_bias(x2d, pre_bias_x, training)
     u2d, pre_bias_u = _fold_pre_bias(u2d, pre_bias_u, training)
     if x2d.shape[1] % 4 or k > 16:           # (the fused adjoint holds all k slots of a channel pair in registers: k <= 16)
         w = bn_softmax_slots_permute(x2d, bn_x, training, k, act=act, pre_bias=pre_bias_x)
-        return bn_act(u2d, bn_u, training, act=act, mul=w.view(u2d.shape), pre_bias=pre_bias_u, partials=partials_u)
+        y = bn_act(u2d, bn_u, training, act=act, mul=w.view(u2d.shape), pre_bias=pre_bias_u, partials=partials_u)
+        return (y, None) if want_max else y
     if training:
         for bn in (bn_x, bn_u):
             if bn.track_running_stats:
                 _PENDING_COUNTS[bn.num_batches_tracked] = _PENDING_COUNTS.get(bn.num_batches_tracked, 0) + 1
     return BilateralWeighting.apply(x2d, u2d, bn_x.weight, bn_x.bias, bn_x.running_mean, bn_x.running_var, pre_bias_x,
                                     bn_u.weight, bn_u.bias, bn_u.running_mean, bn_u.running_var, pre_bias_u, training,
-                                    bn_x.momentum, bn_x.eps, bn_u.momentum, bn_u.eps, ACT[act], k, partials_u, partials_x)
+                                    bn_x.momentum, bn_x.eps, bn_u.momentum, bn_u.eps, ACT[act], k, partials_u, partials_x, want_max)
 
 
 class SmallLinearBNAct(Function):

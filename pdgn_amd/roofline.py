@@ -20,7 +20,13 @@ from ._lib import check, ptr, stream_of
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s achievable)
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32-input MFMA peak
 MFMA_BF16_PEAK_TFLOPS = 2500.0 # MI355X_MICROARCH.md: bf16 MFMA, dense
-X3_PRODUCTS = 6                # bf16 MFMA products per fp32 product in gemm_x3.hip (csrc/gemm_x3.hip header)
+X3_PRODUCTS = 6                # bf16 MFMA products per fp32 product in gemm_x3.hip (csrc/gemm_x3.hip header), mode "x3"
+X2_PRODUCTS = 3                # fp16 MFMA products per fp32 product, mode "x2" (two scaled fp16 parts; fp16 and bf16 share the matrix peak)
+
+
+def products(mode=None):
+    """Matrix-core products the contraction kernel issues per fp32 product in `mode` (default: the mode in force); 0: fp32 instructions."""
+    return {"x3": X3_PRODUCTS, "x2": X2_PRODUCTS}.get(mode or _lib.gemm_mode(), 0)
 _TRAFFIC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "traffic.json")
 
 
@@ -43,7 +49,13 @@ def gemm_mode():
     return _lib.gemm_mode()
 
 
-def _entry(name, bound, work, us, x3=False, **extra):
+def _two_part(m, n, k, scan_bytes):
+    from .fused import two_part
+    return two_part(m, n, k, scan_bytes)
+
+
+def _entry(name, bound, work, us, x3=False, two=False, **extra):
+    nprod = (X2_PRODUCTS if two else X3_PRODUCTS) if x3 else 0
     if bound == "hbm":
         ach, peak, unit = work / us / 1e3, HBM_PEAK_GBS, "GB/s"
         key = "algorithmic_bytes_per_launch"
@@ -51,13 +63,14 @@ def _entry(name, bound, work, us, x3=False, **extra):
         # algorithmic (fp32) flops per second.  The x3 kernel issues X3_PRODUCTS bf16 MFMA flops per algorithmic flop, so its
         # matrix-core ceiling in algorithmic flops is the bf16 peak / X3_PRODUCTS: frac = executed bf16 MFMA rate / bf16 peak.
         ach, unit = work / us / 1e6, "TFLOP/s"
-        peak = MFMA_BF16_PEAK_TFLOPS / X3_PRODUCTS if x3 else MFMA_F32_PEAK_TFLOPS
+        peak = MFMA_BF16_PEAK_TFLOPS / nprod if x3 else MFMA_F32_PEAK_TFLOPS
         key = "algorithmic_flops_per_launch"
     d = {"kernel": name, "bound": bound, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak,
          "traffic": None, "us_per_launch": us, key: work}
     if bound == "mfma":
-        d["mfma"] = ({"instruction": "v_mfma_f32_32x32x16_bf16", "products_per_fp32_product": X3_PRODUCTS,
-                      "executed_tflops": ach * X3_PRODUCTS, "instruction_peak_tflops": MFMA_BF16_PEAK_TFLOPS,
+        d["mfma"] = ({"instruction": "v_mfma_f32_32x32x16_bf16" if nprod == X3_PRODUCTS else "v_mfma_f32_32x32x16_f16",
+                      "products_per_fp32_product": nprod,
+                      "executed_tflops": ach * nprod, "instruction_peak_tflops": MFMA_BF16_PEAK_TFLOPS,
                       "fp32_instruction_peak_tflops": MFMA_F32_PEAK_TFLOPS} if x3 else
                      {"instruction": "v_mfma_f32_16x16x4_f32", "instruction_peak_tflops": MFMA_F32_PEAK_TFLOPS})
     d.update(extra)
@@ -76,7 +89,7 @@ def gemm_accuracy(device, M=8192, N=512, K=2560):
     L = _lib.lib()
     out, saved = {"shape": [M, N, K], "relative_to": "sum_k |a| |w|"}, _lib.gemm_mode()
     try:
-        for mode in ("x3", "fp32"):
+        for mode in ("x3", "x2", "fp32"):
             _lib.set_gemm_mode(mode)
             check(L.pdgn_gemm_nt(ctypes.c_longlong(M), N, K, ptr(a), K, ptr(w), K, None, None, 0, ptr(c), N, None, stream_of(a)),
                   "pdgn_gemm_nt")
@@ -91,11 +104,11 @@ def _nt_entry(label, M, N, K, device):
     w = torch.randn(N, K, device=device)
     c = torch.empty(M, N, device=device)
     L = _lib.lib()
-    x3 = gemm_mode() == "x3"
+    x3 = gemm_mode() != "fp32"
     # as the step launches it: on the bf16 matrix cores the block's assembled weight arrives pre-split (fused.split_planes, once
     # per iteration) and the kernel is the PW instance of gemm_x3_kernel (pdgn_gemm_nt_ps)
     from .fused import split_planes
-    planes = split_planes(w, False) if x3 else None
+    planes = split_planes(w, False, rows=M) if x3 else None      # (rows: two fp16 parts where the mode in force runs this shape on them)
 
     from .fused import _tail_workspace
 
@@ -104,14 +117,14 @@ def _nt_entry(label, M, N, K, device):
         if planes is not None:
             P = planes.p
             check(L.pdgn_gemm_nt_ps(ctypes.c_longlong(M), N, K, ptr(a), K, ptr(P), P.shape[2], ctypes.c_longlong(P.shape[1] * P.shape[2]),
-                                    None, None, 0, ptr(c), N, None, None, 0, 1, 0, None, 0, stream_of(a)), "pdgn_gemm_nt_ps")
+                                    P.shape[0], None, None, 0, ptr(c), N, None, None, 0, 1, 0, None, 0, stream_of(a)), "pdgn_gemm_nt_ps")
         else:
             check(L.pdgn_gemm_nt(ctypes.c_longlong(M), N, K, ptr(a), K, ptr(w), K, None, None, 0, ptr(c), N, None, stream_of(a)),
                   "pdgn_gemm_nt")
     us = _time_us(run)
     e = _entry("%s (%s, M=%d N=%d K=%d%s)" % ("gemm_x3_kernel" if x3 else "gemm_nt_kernel", label, M, N, K,
                                                "; PW instance = pdgn_gemm_nt_ps, the weight pre-split once per iteration" if planes is not None else ""),
-               "mfma", 2.0 * M * N * K, us, x3=x3, shape=[M, N, K])
+               "mfma", 2.0 * M * N * K, us, x3=x3, two=planes is not None and planes.parts_p == 2, shape=[M, N, K])
     e["algorithmic_bytes_per_launch"] = 4.0 * (M * N + M * K + N * K)
     return e
 
@@ -141,9 +154,10 @@ def conv2_dense_dx_stage4(B, base_points, device):
         check(L.pdgn_gemm_nn(ctypes.c_longlong(M), N, K, ptr(dy), K, ptr(wb), N, None, None, 0, ptr(dx), N, None, stream_of(dy)),
               "pdgn_gemm_nn")
     us = _time_us(run)
-    x3 = gemm_mode() == "x3"
+    x3 = gemm_mode() != "fp32"
     e = _entry("%s<WT> = pdgn_gemm_nn (conv2 dense half input gradient, stage 4, M=%d N=%d K=%d)"
-               % ("gemm_x3_kernel" if x3 else "gemm_nt_kernel", M, N, K), "mfma", 2.0 * M * N * K, us, x3=x3, shape=[M, N, K])
+               % ("gemm_x3_kernel" if x3 else "gemm_nt_kernel", M, N, K), "mfma", 2.0 * M * N * K, us, x3=x3,
+               two=_two_part(M, N, K, (M * K + N * K) * 4), shape=[M, N, K])
     e["algorithmic_bytes_per_launch"] = 4.0 * (M * N + M * K + N * K)
     return e
 
@@ -157,12 +171,12 @@ def weight_grad_stage4(B, base_points, device):
     x = torch.randn(M, K, device=device)
     dw = torch.zeros(N, K, device=device)
     L = _lib.lib()
-    if gemm_mode() == "x3":
+    if gemm_mode() != "fp32":
         def run():
             check(L.pdgn_gemm_tn_big(ctypes.c_longlong(M), N, K, ptr(dy), N, ptr(x), K, ptr(dw), 0, stream_of(dy)), "pdgn_gemm_tn_big")
         us = _time_us(run)
         e = _entry("gemm_x3_kernel<AT,WT> = pdgn_gemm_tn_big (dW of conv2's dense half, stage 4, M=%d N=%d K=%d)" % (M, N, K), "mfma",
-                   2.0 * M * N * K, us, x3=True, shape=[M, N, K])
+                   2.0 * M * N * K, us, x3=True, two=_two_part(N, K, M, (M * N + M * K) * 4), shape=[M, N, K])
         e["algorithmic_bytes_per_launch"] = 4.0 * (M * N + M * K + N * K)
         return e
 
@@ -277,23 +291,30 @@ def conv2_in_step_spans(launch_list, B, base_points):
     that problem (pdgn_gemm_nt_ps_launch_info); the span takes in what belongs to the same call on the same stream: the memset in
     front of it and the stream-K tail launch behind it (560 tiles on 256 CUs: two whole rounds + a tail of 48 tiles).  [] when
     the instance cannot be named (fp32 mode, the 16x16x32 arm)."""
-    if gemm_mode() != "x3":
+    if gemm_mode() == "fp32":
         return []
+    from .fused import two_part
     L = _lib.lib()
-    sym, grid = ctypes.c_void_p(), ctypes.c_int()
-    if L.pdgn_gemm_nt_ps_launch_info(ctypes.c_longlong(B * 8 * base_points), 512, 5120, ctypes.byref(sym), ctypes.byref(grid)) != 0 or not sym.value:
+    M = B * 8 * base_points
+    parts = 2 if two_part(M, 512, 5120, M * 5120 * 4) else 3
+    sym, grid, red, scan = ctypes.c_void_p(), ctypes.c_int(), ctypes.c_void_p(), ctypes.c_void_p()
+    if L.pdgn_gemm_nt_ps_launch_info(ctypes.c_longlong(M), 512, 5120, parts, ctypes.byref(sym), ctypes.byref(grid)) != 0 or not sym.value:
         return []
-    cfg = L.pdgn_gemm_nt_config(ctypes.c_longlong(B * 8 * base_points), 512, 5120, 0)
+    L.pdgn_gemm_aux_symbols(ctypes.byref(red), ctypes.byref(scan))
+    cfg = L.pdgn_gemm_nt_config(ctypes.c_longlong(M), 512, 5120, 0)
     spans = []
     for pos in launch_list.kernel_nodes(sym.value, grid.value):
         first = last = pos
-        if cfg >= 16:                                            # a stream-K tail follows: memset | data-parallel | tail
-            p, kind, _ = launch_list.neighbor(pos, -1)
-            if p >= 0 and kind == 1:
-                first = p
+        p, kind, ksym = launch_list.neighbor(pos, -1)             # in front: the zero-fill of an atomic tail, or the scan of the activations (two parts)
+        if p >= 0 and ((cfg >= 16 and kind == 1) or (kind == 0 and ksym == scan.value)):
+            first = p
+        if cfg >= 16:                                            # a stream-K tail follows: data-parallel | tail | reduce of its partial tiles
             p, kind, _ = launch_list.neighbor(pos, +1)
             if p >= 0 and kind == 0:
                 last = p
+                p2, kind2, ksym2 = launch_list.neighbor(p, +1)
+                if p2 >= 0 and kind2 == 0 and ksym2 == red.value:
+                    last = p2
         spans.append((first, last))
     return spans
 
@@ -317,7 +338,7 @@ def attach_in_step(top, launches_ms):
                      "data-parallel launch + stream-K tail launch, as pdgn_gemm_nt_ps issues them), on the stream the launch list issues "
                      "them on; min %.1f / max %.1f us" % (len(ms), min(ms) * 1e3, max(ms) * 1e3))
     if "mfma" in out and "executed_tflops" in out["mfma"]:
-        out["mfma"] = dict(out["mfma"], executed_tflops=out["achieved"] * X3_PRODUCTS)
+        out["mfma"] = dict(out["mfma"], executed_tflops=out["achieved"] * out["mfma"].get("products_per_fp32_product", X3_PRODUCTS))
     return out
 
 

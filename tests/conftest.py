@@ -30,5 +30,5 @@ def _reset_gemm_switches(request):
     yield
     if request.node.get_closest_marker("gpu") is not None:
         from pdgn_amd import _lib
-        _lib.set_gemm_mode(os.environ.get("PDGN_GEMM", "x3"))
+        _lib.set_gemm_mode(_lib.DEFAULT_GEMM_MODE)
         _lib.set_gemm_config(int(os.environ["PDGN_NT_CFG"]) if os.environ.get("PDGN_NT_CFG") else None)

@@ -471,7 +471,7 @@ def test_gemm_tn_direct(M, N, K):
 
 
 @pytest.mark.parametrize("cfg", [None, 0, 1, 3])
-@pytest.mark.parametrize("gemm", ["x3", "fp32", "x3_16"])
+@pytest.mark.parametrize("gemm", ["x2", "x3", "fp32", "x3_16"])
 @pytest.mark.parametrize("M,N,K", [(35840, 12832, 128), (71680, 1024, 256), (358400, 512, 64), (35840, 512, 5120),
                                    (17920, 256, 2560), (100003, 132, 68), (5000, 64, 128), (40, 128, 64), (8960, 3232, 32)])
 def test_gemm_tn_big_direct(M, N, K, cfg, monkeypatch, gemm):
@@ -805,7 +805,7 @@ def test_config_c4_four_stage_512_to_4096():
 
 
 @pytest.mark.parametrize("cfg", [None, 0, 1, 2, 3])
-@pytest.mark.parametrize("gemm", ["x3", "fp32", "x3_16"])
+@pytest.mark.parametrize("gemm", ["x2", "x3", "fp32", "x3_16"])
 @pytest.mark.parametrize("M,N,K", [(35840, 512, 128), (5000, 132, 36), (129, 8, 4), (71680, 1024, 256), (35840, 512, 5120),
                                    (17920, 64, 6432), (8960, 3232, 32), (1000, 36, 20), (358400, 64, 16)])
 def test_gemm_nt_with_epilogues(M, N, K, cfg, monkeypatch, gemm):
@@ -846,7 +846,7 @@ def test_gemm_nt_with_epilogues(M, N, K, cfg, monkeypatch, gemm):
 
 
 @pytest.mark.parametrize("cfg", [None, 0, 1, 2, 3])
-@pytest.mark.parametrize("gemm", ["x3", "fp32", "x3_16"])
+@pytest.mark.parametrize("gemm", ["x2", "x3", "fp32", "x3_16"])
 @pytest.mark.parametrize("M,N,K", [(35840, 128, 512), (5000, 132, 36), (129, 8, 4), (17920, 2560, 256), (35840, 5120, 512),
                                    (17920, 64, 6432), (1000, 36, 20), (71680, 256, 1024)])
 def test_gemm_nn_input_gradient_form(M, N, K, cfg, monkeypatch, gemm):
@@ -914,26 +914,26 @@ def test_gemm_presplit_second_operand(M, N, K, shape):
     p0, p1 = torch.zeros(nrows, 3 * N, device="cuda"), torch.zeros(nrows, 3 * N, device="cuda")
     wp = ctypes.c_longlong(N * pl.p.shape[2])
     assert L.pdgn_gemm_nt(ctypes.c_longlong(M), N, K, ptr(a), K, ptr(w), K, ptr(bias), ptr(add), N, ptr(c0), N, ptr(p0), stream_of(a)) == 0
-    assert L.pdgn_gemm_nt_ps(ctypes.c_longlong(M), N, K, ptr(a), K, ptr(pl.p), pl.p.shape[2], wp, ptr(bias), ptr(add), N, ptr(c1), N, ptr(p1),
+    assert L.pdgn_gemm_nt_ps(ctypes.c_longlong(M), N, K, ptr(a), K, ptr(pl.p), pl.p.shape[2], wp, 3, ptr(bias), ptr(add), N, ptr(c1), N, ptr(p1),
                              None, 0, 1, 0, None, 0, stream_of(a)) == 0
     assert torch.equal(c0, c1) and torch.equal(p0, p1)          # launches with statistics have no stream-K tail: identical
     assert ((c1.double() - ref).abs() / mag).max().item() < 1e-6
     # plain launch (may carry a stream-K tail with float atomics): equal to rounding
-    assert L.pdgn_gemm_nt_ps(ctypes.c_longlong(M), N, K, ptr(a), K, ptr(pl.p), pl.p.shape[2], wp, None, None, 0, ptr(c1), N, None, None, 0, 1, 0,
+    assert L.pdgn_gemm_nt_ps(ctypes.c_longlong(M), N, K, ptr(a), K, ptr(pl.p), pl.p.shape[2], wp, 3, None, None, 0, ptr(c1), N, None, None, 0, 1, 0,
                              None, 0, stream_of(a)) == 0
     assert ((c1.double() - a.double() @ w.double().t()).abs() / mag).max().item() < 1e-6
     # input gradient through the planes of W^T against pdgn_gemm_nn
     dy = torch.randn(M, N, device="cuda", generator=g)
     d0, d1 = torch.empty(M, K, device="cuda"), torch.empty(M, K, device="cuda")
     assert L.pdgn_gemm_nn(ctypes.c_longlong(M), K, N, ptr(dy), N, ptr(w), K, None, None, 0, ptr(d0), K, None, stream_of(a)) == 0
-    assert L.pdgn_gemm_nt_ps(ctypes.c_longlong(M), K, N, ptr(dy), N, ptr(pl.t), pl.t.shape[2], ctypes.c_longlong(K * pl.t.shape[2]), None, None, 0,
+    assert L.pdgn_gemm_nt_ps(ctypes.c_longlong(M), K, N, ptr(dy), N, ptr(pl.t), pl.t.shape[2], ctypes.c_longlong(K * pl.t.shape[2]), 3, None, None, 0,
                              ptr(d1), K, None, None, 0, 1, 0, None, 0, stream_of(a)) == 0
     refd = dy.double() @ w.double()
     magd = dy.double().abs() @ w.double().abs() + 1.0
     assert ((d1.double() - refd).abs() / magd).max().item() < 1e-6 and ((d0 - d1).abs().double() / magd).max().item() < 1e-6
     # refused where it cannot be what it says: the fp32-instruction mode
     _lib.set_gemm_mode("fp32")
-    assert L.pdgn_gemm_nt_ps(ctypes.c_longlong(M), N, K, ptr(a), K, ptr(pl.p), pl.p.shape[2], wp, None, None, 0, ptr(c1), N, None, None, 0, 1, 0,
+    assert L.pdgn_gemm_nt_ps(ctypes.c_longlong(M), N, K, ptr(a), K, ptr(pl.p), pl.p.shape[2], wp, 3, None, None, 0, ptr(c1), N, None, None, 0, 1, 0,
                              None, 0, stream_of(a)) == -1
     _lib.set_gemm_mode("x3")
 
@@ -998,7 +998,7 @@ def test_linear_cl_with_planes_equals_without():
 
 
 @pytest.mark.parametrize("scale", [1.0, 1e15, 1e-15])
-@pytest.mark.parametrize("M,N,K", [(4099, 132, 100), (35840, 512, 5120), (35840, 256, 128), (8960, 3232, 32)])
+@pytest.mark.parametrize("M,N,K", [(4099, 132, 100), (35840, 512, 5120), (35840, 256, 128), (8960, 3232, 32), (40000, 512, 2560)])
 def test_gemm_x3_is_as_accurate_as_the_fp32_matrix_instructions(M, N, K, scale, monkeypatch):
     """csrc/gemm_x3.hip multiplies fp32 operands as three bf16 parts each (six bf16 MFMA products per fp32 product, fp32
     accumulation).  Against fp64, relative to sum_k |a| |w|: its error stays below 1e-6 and within 1.25x of the error of the
@@ -1017,7 +1017,7 @@ def test_gemm_x3_is_as_accurate_as_the_fp32_matrix_instructions(M, N, K, scale, 
     ref = {"nt": a64 @ w64.t(), "nn": d64 @ w64, "tn": d64.t() @ a64}
     mag = {"nt": a64.abs() @ w64.abs().t(), "nn": d64.abs() @ w64.abs(), "tn": d64.abs().t() @ a64.abs()}
     err = {}
-    for mode in ("x3_32", "x3_16", "fp32"):                   # both bf16 matrix instructions, and the fp32 ones
+    for mode in ("x2", "x3_32", "x3_16", "fp32"):             # two fp16 parts where they pay; both bf16 matrix instructions; the fp32 ones
         _lib.set_gemm_mode(mode)
         C = torch.empty(M, N, device="cuda")
         assert L.pdgn_gemm_nt(ctypes.c_longlong(M), N, K, ptr(A), K, ptr(W), K, None, None, 0, ptr(C), N, None, stream_of(A)) == 0
@@ -1033,7 +1033,7 @@ def test_gemm_x3_is_as_accurate_as_the_fp32_matrix_instructions(M, N, K, scale, 
             err[mode, kind] = ((o.double() - ref[kind]).abs() / mag[kind].clamp_min(1e-300)).max().item()
     for (mode, kind), e in err.items():
         assert e < 1e-6, (mode, kind, e)
-        if mode == "x3_32":                                    # the default: six partial products smallest first
+        if mode in ("x3_32", "x2"):                            # six bf16 partial products smallest first / three fp16 ones (exact products, half the accumulations)
             assert e <= 1.25 * err["fp32", kind] + 2e-8, (mode, kind, e, err["fp32", kind])
         if mode == "x3_16":
             # the 16x16x32 arm adds a chunk's six partial products LARGEST first (the order that lets one set of fragment
@@ -1440,7 +1440,7 @@ def test_point_max_forward_backward(B, N, C):
     assert torch.equal(xg.grad.cpu(), want)
 
 
-@pytest.mark.parametrize("gemm", ["x3", "fp32", "x3_16"])
+@pytest.mark.parametrize("gemm", ["x2", "x3", "fp32", "x3_16"])
 def test_gemm_nt_ex_masked_lanes_in_a_fresh_process(gemm):
     """The extended epilogue on a tile that is wider than the problem (N = 36 < 64) in a FRESH process: lanes past the last column
     are masked with an out-of-range offset, which only works against a BOUNDED buffer descriptor -- the per-group bias table's
@@ -1462,7 +1462,7 @@ def test_gemm_nt_ex_masked_lanes_in_a_fresh_process(gemm):
 
 
 @pytest.mark.parametrize("cfg", [None, 0, 1, 2, 3])
-@pytest.mark.parametrize("gemm", ["x3", "fp32", "x3_16"])
+@pytest.mark.parametrize("gemm", ["x2", "x3", "fp32", "x3_16"])
 @pytest.mark.parametrize("M,N,K,rpg", [(35840, 256, 128, 1024), (5000, 132, 36, 250), (8960, 64, 256, 8960), (1000, 36, 20, 1)])
 def test_gemm_nt_extended_epilogue(M, N, K, rpg, cfg, monkeypatch, gemm):
     """pdgn_gemm_nt_ex through the C ABI, every tile configuration: bias per group of rows + LeakyReLU on the result (the
@@ -1578,3 +1578,77 @@ def test_stream_k_tail_without_atomics(M, N, K):
         assert torch.isfinite(c).all()
     # the Python wrappers hand it over themselves: linear layers through fused.gemm_nt are deterministic now
     assert torch.equal(fused.gemm_nt(a, w, bias), fused.gemm_nt(a, w, bias))
+
+
+
+@pytest.mark.parametrize("M,N,K", [(20000, 512, 2560), (35840, 12832, 128), (17920, 2560, 256)])
+def test_gemm_two_part_planes_and_maxima(M, N, K):
+    """Round 5, mode "x2" (the default): a product whose time is its matrix-core work runs on TWO scaled fp16 parts per value and
+    three fp16 MFMA products (gemm_x3.hip NP = 2).  pdgn_gemm_two_part says where; pdgn_split_f16x2 writes a weight's two planes
+    (scaled by 2^e, e from its largest magnitude) with the exponent behind them -- they reassemble to the weight to 2^-22 of its
+    maximum; the product through the planes equals the unsplit entry point's bit for bit (same parts, same order), with the
+    activations' maxima scanned by the call, handed in from pdgn_absmax_partials, or over the fp32 exponent range; against fp64
+    below 1e-6 of sum |a||w|; two-part planes are refused for a shape the launch model gives another tile."""
+    import ctypes
+    from pdgn_amd import _lib, fused
+    from pdgn_amd._lib import ptr, stream_of
+    L = _lib.lib()
+    _lib.set_gemm_mode("x2")
+    assert fused.two_part(M, N, K, M * K * 4) and not fused.two_part(3000, 256, 8, 0) and not fused.two_part(M, N, K, 1 << 40)
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    for scale in (1.0, 3e-18, 7e12):
+        a = torch.randn(M, K, device="cuda", generator=g) * scale
+        w = torch.randn(N, K, device="cuda", generator=g) * 0.3
+        bias = torch.randn(N, device="cuda", generator=g) * scale
+        pl = fused.split_planes(w, True, rows=M)
+        assert pl.parts_p == 2 and pl.p.shape[:2] == (2, N)
+        h, l = pl.p[0, :, :K].view(torch.float16).double(), pl.p[1, :, :K].view(torch.float16).double()
+        npl = 2 * N * pl.p.shape[2]
+        e = int(pl.p._base[npl:npl + 2].view(torch.int32)[0])      # the exponent, right behind the two planes
+        wmax = w.abs().max().item()
+        assert 2.0 ** 14 <= wmax * 2.0 ** e < 2.0 ** 15
+        assert ((h + l) * 2.0 ** -e - w.double()).abs().max().item() <= 2.0 ** -22 * wmax
+        ref = a.double() @ w.double().t() + bias.double()
+        mag = a.double().abs() @ w.double().abs().t() + abs(scale)
+        c0, c1, c2 = (torch.empty(M, N, device="cuda") for _ in range(3))
+        wp = ctypes.c_longlong(N * pl.p.shape[2])
+        # (a tail workspace with every call: partial tiles summed in a fixed order, so that equal arithmetic gives equal bits)
+        ws = fused._tail_workspace(L, M, N, K, False, a.device)
+        assert L.pdgn_gemm_nt(ctypes.c_longlong(M), N, K, ptr(a), K, ptr(w), K, ptr(bias), None, 0, ptr(c0), N, None, stream_of(a)) == 0
+        ws = fused._tail_workspace(L, M, N, K, False, a.device)
+        assert L.pdgn_gemm_nt_ps(ctypes.c_longlong(M), N, K, ptr(a), K, ptr(pl.p), pl.p.shape[2], wp, 2, ptr(bias), None, 0, ptr(c1), N, None,
+                                 None, 0, 1, 0, None, 0, stream_of(a)) == 0
+        slot = fused.operand_exponent(a)                           # the caller's own scan, handed to the next call
+        assert slot is not None and int(slot.view(torch.int32).max()) == int(a.abs().max().view(torch.int32))
+        ws = fused._tail_workspace(L, M, N, K, False, a.device)
+        assert L.pdgn_gemm_set_operand_scales(ptr(slot), None) == 0
+        assert L.pdgn_gemm_nt_ps(ctypes.c_longlong(M), N, K, ptr(a), K, ptr(pl.p), pl.p.shape[2], wp, 2, ptr(bias), None, 0, ptr(c2), N, None,
+                                 None, 0, 1, 0, None, 0, stream_of(a)) == 0
+        torch.cuda.synchronize()
+        del ws
+        assert torch.equal(c1, c2) and torch.equal(c0, c1)         # same parts, same products, same order: with or without the planes / the hand-over
+        for c in (c0, c1):
+            assert torch.isfinite(c).all() and ((c.double() - ref).abs() / mag).max().item() < 1e-6
+    # three-part planes still serve; two-part ones are refused where the launch model picks another tile
+    small = torch.randn(300, K, device="cuda", generator=g)
+    cs = torch.empty(300, N, device="cuda")
+    if (L.pdgn_gemm_nt_config(ctypes.c_longlong(300), N, K, 0) & 15) != 0:
+        assert L.pdgn_gemm_nt_ps(ctypes.c_longlong(300), N, K, ptr(small), K, ptr(pl.p), pl.p.shape[2], wp, 2, None, None, 0, ptr(cs), N, None,
+                                 None, 0, 1, 0, None, 0, stream_of(a)) == -1
+        assert not fused.planes_fit(pl.p, 300, N, K)
+
+
+def test_bilateral_weighting_emits_its_output_maxima():
+    """want_max: the pass that writes inte = act(BN(u)) * w also leaves the 256 partial maxima of |inte| (what the two-part conv2
+    contraction needs of its first operand) -- the same maximum a scan of the result finds, same result as without."""
+    import torch.nn as nn
+    from pdgn_amd import fused
+    M, k, C = 3000, 10, 64
+    g = torch.Generator(device="cuda").manual_seed(9)
+    x = torch.randn(M * k, C, device="cuda", generator=g) * 2
+    u = torch.randn(M * k // 2, 2 * C, device="cuda", generator=g) * 50
+    bx, bu = nn.BatchNorm2d(C).cuda(), nn.BatchNorm2d(2 * C).cuda()
+    y0 = fused.bilateral_weighting(x, bx, u, bu, True, k)
+    y1, slot = fused.bilateral_weighting(x, bx, u, bu, True, k, want_max=True)
+    assert torch.equal(y0, y1) and slot.shape == (256,)
+    assert int(slot.max()) == int(y1.abs().max().view(torch.int32))

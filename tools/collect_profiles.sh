@@ -17,6 +17,7 @@ python3 tools/main_chain.py $OUT/kt_bench 6 > $OUT/${TAG}_main_chain.txt
 python3 tools/side_queues.py $OUT/kt_bench 6 22 > $OUT/${TAG}_side_queues.txt 2>&1
 python3 tools/wait_gap.py $OUT/kt_bench 2 > $OUT/${TAG}_wait_gap.txt 2>&1
 python3 tools/conv2_in_step.py $OUT/kt_bench > $OUT/${TAG}_conv2_in_step.txt 2>&1
+python3 tools/x3_launches.py $OUT/kt_bench 6 20 > $OUT/${TAG}_x3_launches.txt 2>&1
 MS=$(python3 -c "import json,sys; print(json.load(open(sys.argv[1]))[\"ms_per_step\"])" $OUT/${TAG}_bench_full.json)
 python3 tools/queue_timeline.py $OUT/kt_bench $MS > $OUT/${TAG}_queue_timeline.txt 2>&1
 # the roofline kernels alone
@@ -46,5 +47,7 @@ bash tools/dp_list_ab.sh $OUT/${TAG}_dp_list_ab.txt 3 > /dev/null 2>&1
 python3 tools/glue_owners.py 35 2>&1 | grep -v -E "amdgpu.ids|Warning|_warn" > $OUT/${TAG}_glue_owners.txt
 python3 tools/backward_error.py 2>&1 | grep -v amdgpu.ids > $OUT/${TAG}_backward_error.txt
 python3 tools/spill_table.py > $OUT/${TAG}_spill_table.txt 2>&1
+# stream-K tails: workspace + reduce kernel (default) against the atomic form, alternating in the step
+bash tools/env_ab.sh PDGN_X3_SK_WS "1 0" 3 > $OUT/${TAG}_sk_tails_ab.txt 2>&1
 rm -rf $OUT/kt_bench $OUT/kt_roof $OUT/kt_eval $OUT/pmc $OUT/pmc.*.log $OUT/x3pmc
 ls -la $OUT

@@ -41,7 +41,7 @@ for (m, n, k) in [(35840, 512, 5120), (35840, 12832, 128), (17920, 256, 2560), (
     P, PT = split(w, True)
     c0, c1 = torch.empty(m, n, device=dev), torch.empty(m, n, device=dev)
     nt = lambda: check(L.pdgn_gemm_nt(ctypes.c_longlong(m), n, k, ptr(a), k, ptr(w), k, ptr(b), None, 0, ptr(c0), n, None, stream_of(a)), "nt")
-    ps = lambda: check(L.pdgn_gemm_nt_ps(ctypes.c_longlong(m), n, k, ptr(a), k, ptr(P), P.shape[2], ctypes.c_longlong(P.shape[1] * P.shape[2]),
+    ps = lambda: check(L.pdgn_gemm_nt_ps(ctypes.c_longlong(m), n, k, ptr(a), k, ptr(P), P.shape[2], ctypes.c_longlong(P.shape[1] * P.shape[2]), P.shape[0],
                                          ptr(b), None, 0, ptr(c1), n, None, None, 0, 1, 0, None, 0, stream_of(a)), "ps")
     nt(); ps()
     same = torch.equal(c0, c1)
@@ -51,7 +51,7 @@ for (m, n, k) in [(35840, 512, 5120), (35840, 12832, 128), (17920, 256, 2560), (
     dy = torch.randn(m, n, device=dev)
     d0, d1 = torch.empty(m, k, device=dev), torch.empty(m, k, device=dev)
     nn = lambda: check(L.pdgn_gemm_nn(ctypes.c_longlong(m), k, n, ptr(dy), n, ptr(w), k, None, None, 0, ptr(d0), k, None, stream_of(a)), "nn")
-    pst = lambda: check(L.pdgn_gemm_nt_ps(ctypes.c_longlong(m), k, n, ptr(dy), n, ptr(PT), PT.shape[2], ctypes.c_longlong(PT.shape[1] * PT.shape[2]),
+    pst = lambda: check(L.pdgn_gemm_nt_ps(ctypes.c_longlong(m), k, n, ptr(dy), n, ptr(PT), PT.shape[2], ctypes.c_longlong(PT.shape[1] * PT.shape[2]), PT.shape[0],
                                           None, None, 0, ptr(d1), k, None, None, 0, 1, 0, None, 0, stream_of(a)), "pst")
     if k % 4 == 0 and n % 4 == 0:
         nn(); pst()

@@ -6,6 +6,7 @@
 #endif
 #include "../pdgn_amd/csrc/gemm_x3.hip"
 
+#include <cmath>
 #include <cstdio>
 #include <vector>
 
@@ -43,7 +44,20 @@ int main() {
         hipEventSynchronize(e1);
         float ms = 0.f;
         hipEventElapsedTime(&ms, e0, e1);
-        printf(" %lldx%dx%d %7.1f us %6.1f TF |", m, n, k, ms * 100.f, 2.0 * m * n * k / (ms * 100.0) / 1e6);
+        // a few results against the host's fp64 (rows of A are rows of W: the harness's fill)
+        double worst = 0.0;
+        for (int t = 0; t < 48; ++t) {
+            const long long i = (t * 7919LL) % m;
+            const int j = (t * 104729) % n;
+            float c;
+            hipMemcpy(&c, C + i * n + j, 4, hipMemcpyDeviceToHost);
+            double ref = 0.0, mag = 0.0;
+            const float *ar = h.data() + (size_t)(i % n) * k, *wr = h.data() + (size_t)j * k;
+            for (int q = 0; q < k; ++q) { ref += (double)ar[q] * wr[q]; mag += fabs((double)ar[q] * wr[q]); }
+            const double e = fabs(c - ref) / (mag + 1e-30);
+            worst = e > worst ? e : worst;
+        }
+        printf(" %lldx%dx%d %7.1f us %6.1f TF err %.2e |", m, n, k, ms * 100.f, 2.0 * m * n * k / (ms * 100.0) / 1e6, worst);
         hipFree(A); hipFree(W); hipFree(C);
     }
     printf("\n");
