@@ -77,9 +77,11 @@ def _entry(name, bound, work, us, x3=False, two=False, **extra):
     return d
 
 
-def gemm_accuracy(device, M=8192, N=512, K=2560):
-    """Largest error of pdgn_gemm_nt against fp64, relative to sum_k |a| |w|, for the kernel in use (x3: six bf16 MFMA products
-    per fp32 product) and for the fp32 matrix instructions on the same operands (selected per process, _lib.set_gemm_mode): the live form of tests/test_gpu_deconv.py::test_gemm_x3_is_as_accurate_as_the_fp32_matrix_instructions."""
+def gemm_accuracy(device, M=20000, N=512, K=2560):
+    """Largest error of pdgn_gemm_nt against fp64, relative to sum_k |a| |w|, in each arithmetic mode on the same operands (x2: three
+    fp16 MFMA products of two scaled parts -- the shape is one the two-part form takes; x3: six bf16 products of three parts; fp32:
+    the fp32 matrix instructions; selected per process, _lib.set_gemm_mode): the live form of
+    tests/test_gpu_deconv.py::test_gemm_x3_is_as_accurate_as_the_fp32_matrix_instructions."""
     g = torch.Generator(device=device).manual_seed(1234)
     a = torch.randn(M, K, device=device, generator=g) * (torch.rand(M, 1, device=device, generator=g) * 3)
     w = torch.randn(N, K, device=device, generator=g)
@@ -329,14 +331,17 @@ def attach_in_step(top, launches_ms):
     work = top["algorithmic_flops_per_launch"]
     out = dict(top)
     out["back_to_back"] = {"us_per_launch": top["us_per_launch"], "achieved": top["achieved"], "frac": top["frac"],
-                           "what": "the same launch alone, 20 back to back after 3 (the chip's power limit holds ~1.7 GHz there; "
-                                   "between the iteration's bandwidth-bound kernels it clocks higher)"}
+                           "what": "the same call alone, 20 back to back after 3 (the chip's power limit holds ~1.7 GHz there, between "
+                                   "the iteration's bandwidth-bound kernels it clocks higher; a two-part call scans its first operand's "
+                                   "maxima here, ~150 us of the figure, which the step gets from the producing kernel)"}
     out["us_per_launch"] = us
     out["achieved"] = work / us / 1e6
     out["frac"] = out["achieved"] / out["peak"]
-    out["timing"] = ("HIP events around each of the contraction's %d calls inside the timed steps (one per generator pass and step: memset + "
-                     "data-parallel launch + stream-K tail launch, as pdgn_gemm_nt_ps issues them), on the stream the launch list issues "
-                     "them on; min %.1f / max %.1f us" % (len(ms), min(ms) * 1e3, max(ms) * 1e3))
+    out["timing"] = ("HIP events around each of the contraction's %d calls inside the timed steps (one per generator pass and step: "
+                     "data-parallel launch + stream-K tail launch + the reduce of its partial tiles, as pdgn_gemm_nt_ps issues them; a scan "
+                     "of the activations' maxima in front where the call makes one -- in the step the kernel that writes them leaves "
+                     "the maxima behind), on the stream the launch list issues them on; min %.1f / max %.1f us"
+                     % (len(ms), min(ms) * 1e3, max(ms) * 1e3))
     if "mfma" in out and "executed_tflops" in out["mfma"]:
         out["mfma"] = dict(out["mfma"], executed_tflops=out["achieved"] * out["mfma"].get("products_per_fp32_product", X3_PRODUCTS))
     return out

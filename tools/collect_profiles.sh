@@ -18,6 +18,7 @@ python3 tools/side_queues.py $OUT/kt_bench 6 22 > $OUT/${TAG}_side_queues.txt 2>
 python3 tools/wait_gap.py $OUT/kt_bench 2 > $OUT/${TAG}_wait_gap.txt 2>&1
 python3 tools/conv2_in_step.py $OUT/kt_bench > $OUT/${TAG}_conv2_in_step.txt 2>&1
 python3 tools/x3_launches.py $OUT/kt_bench 6 20 > $OUT/${TAG}_x3_launches.txt 2>&1
+python3 tools/scan_launches.py $OUT/kt_bench 6 > $OUT/${TAG}_scan_launches.txt 2>&1
 MS=$(python3 -c "import json,sys; print(json.load(open(sys.argv[1]))[\"ms_per_step\"])" $OUT/${TAG}_bench_full.json)
 python3 tools/queue_timeline.py $OUT/kt_bench $MS > $OUT/${TAG}_queue_timeline.txt 2>&1
 # the roofline kernels alone
@@ -31,8 +32,9 @@ python3 tools/pmc_roofline.py $OUT/pmc $OUT/${TAG}_pmc_mfma.csv $OUT/traffic.jso
 # every GEMM problem of a step alone; both contraction kernels against fp64; the pre-split second operand
 ALL_CFGS=1 python3 tools/gemm_shapes.py > $OUT/${TAG}_gemm_shapes.txt 2>&1
 python3 tools/x3_check.py 2>&1 | grep -v amdgpu.ids > $OUT/${TAG}_x3_check.txt
+PDGN_GEMM=x3 python3 tools/x3_check.py 2>&1 | grep -v amdgpu.ids >> $OUT/${TAG}_x3_check.txt
 PDGN_GEMM=fp32 python3 tools/x3_check.py 2>&1 | grep -v amdgpu.ids >> $OUT/${TAG}_x3_check.txt
-python3 tools/ps_check.py 2>&1 | grep -v amdgpu.ids > $OUT/${TAG}_presplit_check.txt
+PDGN_GEMM=x3 python3 tools/ps_check.py 2>&1 | grep -v amdgpu.ids > $OUT/${TAG}_presplit_check.txt
 bash tools/x3_pmc.sh $OUT/x3pmc 2>&1 | grep -E "^[abc] \(" > $OUT/${TAG}_x3_pmc.txt
 # where the iteration's time goes, untraced: progress of the issuing stream / D4's / the local-pair loss's chain through one list
 for c in 0 4 5; do python3 -u tools/list_progress.py 10 $c 2>&1 | grep -v amdgpu.ids; done > $OUT/${TAG}_list_progress.txt
@@ -42,11 +44,16 @@ python3 tools/finalize_bench.py 2>&1 | grep -v amdgpu.ids > $OUT/${TAG}_finalize
 python3 bench.py --base-points 256 --steps 10 --warmup 3 --no-cpu-baseline --no-eval-c5 > $OUT/${TAG}_bench_c4.json 2>> $OUT/bench.err
 # round 5: both bf16 matrix instructions (x3_check with the shape forced), the launch list under a one-rank RCCL group, the
 # torch-native / library launches with their owners, the block fixtures' backward error, the register table of the shipped library
-python3 tools/x3_check.py 16 2>&1 | grep -v amdgpu.ids > $OUT/${TAG}_x3_check_16x16x32.txt
+PDGN_GEMM=x3 python3 tools/x3_check.py 16 2>&1 | grep -v amdgpu.ids > $OUT/${TAG}_x3_check_16x16x32.txt
 bash tools/dp_list_ab.sh $OUT/${TAG}_dp_list_ab.txt 3 > /dev/null 2>&1
 python3 tools/glue_owners.py 35 2>&1 | grep -v -E "amdgpu.ids|Warning|_warn" > $OUT/${TAG}_glue_owners.txt
 python3 tools/backward_error.py 2>&1 | grep -v amdgpu.ids > $OUT/${TAG}_backward_error.txt
 python3 tools/spill_table.py > $OUT/${TAG}_spill_table.txt 2>&1
+# the arithmetic modes of the contractions: two fp16 parts where they pay (default) against three bf16 parts everywhere, alternating
+# in the step; every contraction of an iteration alone in both; all three modes against fp64
+bash tools/env_ab.sh PDGN_GEMM "x2 x3" 3 > $OUT/${TAG}_gemm_mode_ab.txt 2>&1
+python3 tools/x2_shapes.py 2>&1 | grep -v amdgpu.ids > $OUT/${TAG}_x2_shapes.txt
+python3 tools/x2_check.py 2>&1 | grep -v amdgpu.ids > $OUT/${TAG}_x2_check.txt
 # stream-K tails: workspace + reduce kernel (default) against the atomic form, alternating in the step
 bash tools/env_ab.sh PDGN_X3_SK_WS "1 0" 3 > $OUT/${TAG}_sk_tails_ab.txt 2>&1
 rm -rf $OUT/kt_bench $OUT/kt_roof $OUT/kt_eval $OUT/pmc $OUT/pmc.*.log $OUT/x3pmc

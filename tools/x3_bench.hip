@@ -1,6 +1,7 @@
 // x3_bench.hip -- pdgn_gemm_nt (gemm_x3.hip) alone, with compile-time ablations (-DX3_ABLATE=n) to see where its time goes.
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -mllvm -pragma-unroll-threshold=200000 -DX3_ABLATE=0 [-DX3_DEFAULT_SHAPE=16] \
-//         -Ipdgn_amd/csrc tools/x3_bench.hip pdgn_amd/csrc/gemm_x3_16.hip -o /tmp/x3b
+//         -Ipdgn_amd/csrc tools/x3_bench.hip pdgn_amd/csrc/gemm_x3_16.hip pdgn_amd/csrc/gemm_x3_h2.hip -o /tmp/x3b
+// PDGN_GEMM=x3: three bf16 parts everywhere; default: two fp16 parts where they pay (the harness provides the scale slots)
 #ifdef X3_DEFAULT_SHAPE                 // -DX3_DEFAULT_SHAPE=16: every instance class on v_mfma_f32_16x16x32_bf16
 #define X3_DEFAULT_MASK (X3_DEFAULT_SHAPE == 16 ? 0xfff : 0)
 #endif
@@ -20,8 +21,12 @@ int fp32_gemm_nt_stat_block_rows(long long, int, int) { return -1; }
 int fp32_gemm_nt_config(long long, int, int, int) { return -1; }
 
 int main() {
+    void *slots = nullptr;                                         // mode 2: the ring of operand-scale slots is the caller's
+    hipMalloc(&slots, 4 << 20);
+    hipMemset(slots, 0, 4 << 20);
+    pdgn_gemm_set_scale_slots(slots, 4 << 20);
     const long long shapes[][3] = {{35840, 512, 5120}, {35840, 12832, 128}, {71680, 1024, 256}, {17920, 256, 2560}};
-    printf("X3_ABLATE=%d CFG=%s |", X3_ABLATE, getenv("PDGN_NT_CFG") ? getenv("PDGN_NT_CFG") : "-");
+    printf("X3_ABLATE=%d mode %d CFG=%s |", X3_ABLATE, pdgn_gemm_set_mode(-1), getenv("PDGN_NT_CFG") ? getenv("PDGN_NT_CFG") : "-");
     for (auto &sh : shapes) {
         const long long m = sh[0];
         const int n = (int)sh[1], k = (int)sh[2];

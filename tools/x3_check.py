@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""pdgn_gemm_nt / nn / tn_big in the running mode (PDGN_GEMM=x3 | fp32) against fp64: error relative to sum_k |a| |w|, and time."""
+"""pdgn_gemm_nt / nn / tn_big in the running mode (PDGN_GEMM=x2 (default) | x3 | fp32) against fp64: error relative to sum_k |a| |w|, and time."""
 import os, sys, ctypes
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -27,7 +27,7 @@ def timeit(fn, n=10):
 
 if len(sys.argv) > 1:
     _lib.set_gemm_shape(int(sys.argv[1]))
-print("mode", os.environ.get("PDGN_GEMM", "x3"), "cfg", os.environ.get("PDGN_NT_CFG", "auto"), "shape", _lib.set_gemm_shape(0))
+print("mode", _lib.gemm_mode(), "cfg", os.environ.get("PDGN_NT_CFG", "auto"), "shape", _lib.set_gemm_shape(0))
 for (m, n, k) in [(1000, 64, 36), (4099, 132, 100), (35840, 512, 5120), (35840, 12832, 128), (71680, 1024, 256), (358400, 512, 64),
                   (17920, 256, 2560), (35840, 256, 128)]:
     a = torch.randn(m, k, device=dev) * torch.rand(m, 1, device=dev) * 3
