@@ -276,6 +276,8 @@ int pdgn_softmax_slots_permute_backward(long long m, int k, int c, const float *
  * (x = h + m + l to 2^-25 |x|) and a product is six bf16 MFMA products accumulated in fp32 (csrc/gemm_x3.hip) -- per product
  * an error of <= 2^-23 |a w|, measured against fp64 below that of the fp32 matrix instructions; no scaling, the fp32
  * exponent range is kept; an infinite operand value yields NaN (inf - inf in the split), where fp32 arithmetic may yield inf.
+ * In the default mode the large products run on TWO scaled fp16 parts and three fp16 MFMA products instead (mode 2 below: same
+ * operands and results, half the matrix-core work, against fp64 below both other forms); PDGN_GEMM=x3 keeps three parts everywhere.
  * PDGN_GEMM=fp32 in the environment at first use, or pdgn_gemm_set_mode(0), selects the fp32 matrix instructions instead
  * (csrc/gemm_nt.hip; 0.6-0.9x the rate).
  * (The reference's Conv2d/Conv1d/Linear forward at models/PDGNet_v2.py:559-625, 835-862, 886-1014 in
@@ -310,8 +312,9 @@ int pdgn_skinny_tn(int R, int N, int K, const float *A, int lda, const float *B,
  * apart; may be NULL) and / or planes_t, the same for the TRANSPOSE (3 x [cols][ld_planes_t]; may be NULL).
  * pdgn_gemm_nt_ps = pdgn_gemm_nt_ex with such planes as the second operand (n x k, pitch ldw, wplane elements between planes;
  * ldw and wplane multiples of 8, the planes 16-byte aligned):
- * forward y = x W^T with W's planes, input gradient dX = dY W with the planes of W^T.  Bit-identical to the unsplit calls; bf16
- * matrix-core mode only (PDGN_ERR_INVALID under pdgn_gemm_set_mode(0)).  No reference counterpart. */
+ * forward y = x W^T with W's planes, input gradient dX = dY W with the planes of W^T.  parts = 3 (these planes) or 2 (the two
+ * fp16 planes of pdgn_split_f16x2, below).  Bit-identical to the unsplit call that runs on the same number of parts; matrix-core
+ * modes only (PDGN_ERR_INVALID under pdgn_gemm_set_mode(0)).  No reference counterpart. */
 int pdgn_split_bf16x3(int rows, int cols, const float *src, int ld_src, unsigned short *planes, int ld_planes,
                       long long plane_stride, unsigned short *planes_t, int ld_planes_t, long long plane_stride_t,
                       pdgn_stream_t stream);
@@ -333,8 +336,8 @@ int pdgn_gemm_nt_ps_launch_info(long long m, int n, int k, int parts, const void
  * partial tiles, the scan of an operand's maxima (mode 2). */
 int pdgn_gemm_aux_symbols(const void **reduce, const void **scan);
 /* Process-wide switches of the dense contractions (read from PDGN_GEMM / PDGN_NT_CFG once, at first use).
- * pdgn_gemm_set_mode: 1 = bf16 matrix cores, three parts, 2 = fp16 matrix cores, two scaled parts (below), 0 = fp32 matrix
- * instructions, < 0 = query; returns the previous mode.
+ * pdgn_gemm_set_mode: 2 = matrix cores, two scaled fp16 parts where that pays and three bf16 parts elsewhere (default; below),
+ * 1 = three bf16 parts everywhere, 0 = fp32 matrix instructions, < 0 = query; returns the previous mode.
  * pdgn_gemm_set_config: -1 = the launch model's pick (default), 0 .. 3 = force a tile configuration (measurement / tests),
  * < -1 = query; returns the previous value.
  * pdgn_gemm_set_shape: the bf16 matrix instruction of the matrix-core mode: 32 = v_mfma_f32_32x32x16_bf16 for every launch, 16 =
@@ -342,23 +345,29 @@ int pdgn_gemm_aux_symbols(const void **reduce, const void **scan);
  * per instance class, 0x1000 | mask = a per-class mask (bit 4 * tile + class; gemm_x3.hip), anything else = query; returns the
  * previous mask.  PDGN_X3_SHAPE / PDGN_X3_SHAPE16_MASK set the process default. */
 int pdgn_gemm_set_mode(int mode);
-/* Mode 2 (round 5; PDGN_GEMM=x2): the same contractions on the fp16 matrix cores with TWO parts per value.  An operand is multiplied
- * by a power of two 2^e, e = 14 - floor(log2 max |x|) over the whole operand (so that nothing leaves fp16's range: max |x| 2^e in
- * [2^14, 2^15)), split as x 2^e = h + l (round-to-nearest fp16 of the value and of the exact remainder: |err| <= 2^-23 |x| for
- * values within 2^-18 of the operand's largest, an absolute 2^-40 max |x| below), a product is the three fp16 MFMA products
- * al wh + ah wl + ah wh accumulated in fp32, and the result is multiplied by 2^-(e_A + e_W) (exact).  Per product |err| <=
- * ~2^-21 |a w| in the worst case, in sums dominated by the fp32 accumulation all modes share (measured against fp64 next to the
- * other two modes: bench.py gemm_accuracy, tests/test_gpu_deconv.py).  Half the matrix-core work of mode 1.
+/* Mode 2 (round 5; the default, PDGN_GEMM=x2): the contractions whose time is their matrix-core work run on the fp16 matrix
+ * cores with TWO parts per value; the others stay on three bf16 parts (mode 1's arithmetic).  pdgn_gemm_two_part(m, n, k,
+ * scan_bytes) says which a call (m, n, k) is when scan_bytes of its operands would still have to be scanned for their maxima: the
+ * 256 x 128 tile, k >= 128, >= 20 GFLOP and at most 4.5 bytes to scan per kflop (measured: tools/x2_shapes.py).
+ * Two parts: an operand is multiplied by a power of two 2^e, e = 14 - floor(log2 max |x|) over the whole operand (so that nothing
+ * leaves fp16's range: max |x| 2^e in [2^14, 2^15)), split as x 2^e = h + l (round-to-nearest fp16 of the value and of the exact
+ * remainder: |err| <= 2^-23 |x| for values within 2^-16 of the operand's largest, an absolute 2^-39 max |x| below), a product is the
+ * three fp16 MFMA products al wh + ah wl + ah wh accumulated in fp32, and the result is multiplied by 2^-(e_A + e_W) (exact).  Per
+ * product |err| <= ~2^-21 |a w| in the worst case; in sums the fp32 accumulation all modes share dominates, of which this form does
+ * half as much: measured against fp64 BELOW the other two modes (bench.py gemm_accuracy, tests/test_gpu_deconv.py, tools/x2_check.py:
+ * all three operand layouts, 1e-20 .. 1e15).  Half the matrix-core work of mode 1.
  * The maxima come from a scan of each operand in front of the launch (x2_absmax_kernel: 256 partial maxima into a 1-KB slot, which
  * every consumer reduces itself: no atomics, nothing to re-arm), the slot taken from a ring the caller provides once:
  * pdgn_gemm_set_scale_slots(device memory, bytes; 1 KB per slot; more slots than launches can be in flight -- the library never
- * allocates); without one the contractions of mode 2 return PDGN_ERR_INVALID.  An operand's maxima can also be computed by the caller
- * (pdgn_absmax_partials into a 1-KB device slot of its own) and handed over for the operands of the calling thread's next
- * contraction call (pdgn_gemm_set_operand_scales: first / second operand as that entry point takes them -- pdgn_gemm_tn_big: dY, X --
- * NULL = scanned by the call; consumed by that call): an activation that feeds several products is scanned once.
- * pdgn_split_f16x2 = pdgn_split_bf16x3 for this mode: two fp16 planes (h | l, already scaled) and the exponent as one int32 right
- * behind them (element offset 2 * plane_stride: the buffer holds 2 * plane_stride + 2 elements); pdgn_gemm_nt_ps takes such planes
- * while mode 2 is in force (the caller keeps planes and mode consistent).  No reference counterpart. */
+ * allocates); without one a two-part call returns PDGN_ERR_INVALID.  An operand's maxima can also be computed by the caller
+ * (pdgn_absmax_partials into a 1-KB device slot of its own), or by the kernel that WRITES the operand
+ * (pdgn_bn_softmax_slots_permute_mul's max_out), and handed over for the operands of the calling thread's next contraction call
+ * (pdgn_gemm_set_operand_scales: first / second operand as that entry point takes them -- pdgn_gemm_tn_big: dY, X -- NULL = scanned
+ * by the call; consumed by that call): an activation that feeds several products is scanned once, or never.
+ * pdgn_split_f16x2 = pdgn_split_bf16x3 for a two-part product: two fp16 planes (h | l, already scaled) and the exponent as one
+ * int32 right behind them (element offset 2 * plane_stride: the buffer holds 2 * plane_stride + 2 elements); pdgn_gemm_nt_ps takes
+ * either kind of planes and is told which (parts = 3 | 2; two-part planes only for a shape the launch model gives the 256 x 128
+ * tile, pdgn_gemm_nt_config, else PDGN_ERR_INVALID).  No reference counterpart. */
 int pdgn_gemm_set_scale_slots(void *slots, long long bytes);
 int pdgn_absmax_partials(long long rows, int cols, const float *src, int ld, unsigned *slot, pdgn_stream_t stream);
 int pdgn_gemm_set_operand_scales(const unsigned *max_a, const unsigned *max_w);

@@ -32,22 +32,30 @@ def lib():
         if got != ABI_VERSION:
             raise PdgnHipError("libpdgn_hip.so ABI %d != expected %d: rebuild" % (got, ABI_VERSION))
         _lib = handle
-        if handle.pdgn_gemm_set_mode(-1) == 2:                     # the default mode (PDGN_GEMM unset or x2)
-            _attach_scale_slots(handle)
+        if handle.pdgn_gemm_set_mode(-1) == 2:                     # the default mode: a ring on the current device now (raw ctypes callers);
+            ensure_scale_slots(handle=handle)                      # the wrappers move it if the contractions run on another one
     return _lib
 
 
-_SCALE_SLOTS = None
+_SCALE_SLOTS = {}               # device index -> the ring handed to the library (one process drives one GPU; kept alive here)
 
 
-def _attach_scale_slots(handle):
-    """Two-part mode (csrc/gemm_x3.hip): the ring of operand-scale slots is the caller's memory -- the library never allocates.
-    4 Ki slots of 1 KB: an iteration is < 10^3 scans inside the library and at most two iterations are in flight."""
-    global _SCALE_SLOTS
-    if _SCALE_SLOTS is None and torch.cuda.is_available():
-        _SCALE_SLOTS = torch.zeros(1 << 20, dtype=torch.int32, device="cuda")
-        check(handle.pdgn_gemm_set_scale_slots(ctypes.c_void_p(_SCALE_SLOTS.data_ptr()), ctypes.c_longlong(_SCALE_SLOTS.numel() * 4)),
-              "pdgn_gemm_set_scale_slots")
+def ensure_scale_slots(device=None, handle=None):
+    """Two-part contractions (csrc/gemm_x3.hip): the ring of operand-scale slots is the caller's memory -- the library never
+    allocates.  4 Ki slots of 1 KB on the device the contractions run on (an iteration is < 10^3 scans inside the library and at
+    most two iterations are in flight); called by the contraction wrappers, so that the ring lives on the device in use whatever
+    device was current when the library was loaded."""
+    if not torch.cuda.is_available():
+        return
+    idx = torch.cuda.current_device() if device is None or device.index is None else device.index
+    if _SCALE_SLOTS.get("attached") == idx:
+        return
+    if idx not in _SCALE_SLOTS:
+        _SCALE_SLOTS[idx] = torch.zeros(1 << 20, dtype=torch.int32, device=torch.device("cuda", idx))
+    t = _SCALE_SLOTS[idx]
+    check((handle or lib()).pdgn_gemm_set_scale_slots(ctypes.c_void_p(t.data_ptr()), ctypes.c_longlong(t.numel() * 4)),
+          "pdgn_gemm_set_scale_slots")
+    _SCALE_SLOTS["attached"] = idx
 
 
 def stream_of(t):
@@ -102,7 +110,7 @@ def set_gemm_mode(mode):
     mode's name ("x3" | "x2" | "fp32").  Pre-split weights (fused.split_planes) belong to the mode they were made in."""
     m = str(mode)
     if m == "x2":
-        _attach_scale_slots(lib())
+        ensure_scale_slots()
     old = lib().pdgn_gemm_set_mode(0 if m.startswith("f") else 2 if m == "x2" else 1)
     if not m.startswith("f"):                                      # (any matrix-core mode without a suffix: the process default's instruction per class)
         lib().pdgn_gemm_set_shape(16 if m.endswith("_16") else 32 if m.endswith("_32") else -1)

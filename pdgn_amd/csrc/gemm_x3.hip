@@ -1014,8 +1014,8 @@ __global__ __launch_bounds__(256) void x3_sk_reduce_kernel(const float *__restri
 }
 // ---- two-part mode (NP = 2): the operands' power-of-two scales.  fp16 holds 2^-14 .. 65504 (2^-24 with subnormals): an operand is
 // multiplied by 2^e, e = 14 - floor(log2(max |x|)), before its split -- max |x| 2^e in [2^14, 2^15): nothing overflows, and a
-// value keeps its full 22 bits while it is within 2^-18 of the operand's largest (smaller ones lose bits to fp16's subnormal
-// spacing: an ABSOLUTE error of at most 2^-40 max |x|).  The maximum is taken by a scan of the operand in front of the launch
+// value keeps its full 22 bits while it is within 2^-16 of the operand's largest (smaller ones lose bits to fp16's subnormal
+// spacing: an ABSOLUTE error of at most 2^-39 max |x|).  The maximum is taken by a scan of the operand in front of the launch
 // (x2_absmax_kernel: one pass at memory speed, the last workgroup to finish turns the maximum into the exponent and re-arms the
 // slot) unless the caller hands one in (pdgn_gemm_set_operand_exponent; a pre-split operand carries its own behind its planes).
 // Slots (1 KB: X2_PARTS partial maxima, gemm_shared.h) come from a ring in a buffer the CALLER provides once

@@ -335,10 +335,17 @@ def two_part(m, n, k, scan_bytes):
     return _lib.gemm_mode() == "x2" and bool(_lib.lib().pdgn_gemm_two_part(ctypes.c_longlong(m), n, k, ctypes.c_longlong(scan_bytes)))
 
 
+def _slots(t):
+    """Before a contraction call: in the default mode the library's scale ring must live on the tensor's device (_lib.ensure_scale_slots)."""
+    if _lib.gemm_mode() == "x2":
+        _lib.ensure_scale_slots(t.device)
+
+
 def split_planes(w, want_t, rows=None):
     """The pre-split planes of a (n, k) fp32 weight (Planes); None where the pre-split path does not apply (fp32-instruction mode,
     sizes that would need padding).  rows: the row count of the activations it will multiply, when known -- it decides between
     three bf16 and two fp16 parts per product (forward: (rows, n, k); input gradient through the transpose: (rows, k, n))."""
+    _slots(w)
     mode = _lib.gemm_mode()
     if not (_PLANES and w.is_cuda and w.dim() == 2 and mode != "fp32") or w.shape[0] % 4 or w.shape[1] % 4 or w.stride(1) != 1:
         return None
@@ -366,20 +373,20 @@ def split_planes(w, want_t, rows=None):
     return Planes(P, PT, (n, k), parts_p, parts_t)
 
 
-_EXP_POOL, _EXP_NEXT = None, 0
+_MAX_POOL, _MAX_NEXT = None, 0
 
 
-def operand_exponent(t):
+def operand_maxima(t):
     """Two-part mode (csrc/gemm_x3.hip, "x2"): the scale of a 2-D fp32 operand -- 256 partial maxima of |t| from ONE scan
     (pdgn_absmax_partials) in a 1-KB slot of a pool -- to hand to every contraction the operand feeds (forward and weight gradient
     of a layer; input and weight gradient for dy) instead of a scan per call.  None in the other modes."""
-    global _EXP_POOL, _EXP_NEXT
+    global _MAX_POOL, _MAX_NEXT
     if _lib.gemm_mode() != "x2" or not t.is_cuda or t.dim() != 2 or t.stride(1) != 1 or t.dtype != F32 or t.shape[1] % 4:
         return None
-    if _EXP_POOL is None:
-        _EXP_POOL = torch.zeros((1 << 12, 256), dtype=torch.int32, device=t.device)   # round-robin: an iteration makes ~200 of them
-    slot = _EXP_POOL[_EXP_NEXT]
-    _EXP_NEXT = (_EXP_NEXT + 1) % _EXP_POOL.shape[0]
+    if _MAX_POOL is None:
+        _MAX_POOL = torch.zeros((1 << 12, 256), dtype=torch.int32, device=t.device)   # round-robin: an iteration makes ~200 of them
+    slot = _MAX_POOL[_MAX_NEXT]
+    _MAX_NEXT = (_MAX_NEXT + 1) % _MAX_POOL.shape[0]
     check(_lib.lib().pdgn_absmax_partials(ctypes.c_longlong(t.shape[0]), t.shape[1], ptr(t), t.stride(0), ptr(slot), stream_of(t)),
           "pdgn_absmax_partials")
     return slot
@@ -387,17 +394,17 @@ def operand_exponent(t):
 
 def _max_slot(device):
     """A 1-KB slot of the pool for a producer kernel that writes its output's partial maxima itself."""
-    global _EXP_POOL, _EXP_NEXT
-    if _EXP_POOL is None:
-        _EXP_POOL = torch.zeros((1 << 12, 256), dtype=torch.int32, device=device)
-    slot = _EXP_POOL[_EXP_NEXT]
-    _EXP_NEXT = (_EXP_NEXT + 1) % _EXP_POOL.shape[0]
+    global _MAX_POOL, _MAX_NEXT
+    if _MAX_POOL is None:
+        _MAX_POOL = torch.zeros((1 << 12, 256), dtype=torch.int32, device=device)
+    slot = _MAX_POOL[_MAX_NEXT]
+    _MAX_NEXT = (_MAX_NEXT + 1) % _MAX_POOL.shape[0]
     return slot
 
 
-def _hand_exponents(L, ea, ew=None):
-    if ea is not None or ew is not None:
-        L.pdgn_gemm_set_operand_scales(ptr(ea), ptr(ew))
+def _hand_maxima(L, ma, mw=None):
+    if ma is not None or mw is not None:
+        L.pdgn_gemm_set_operand_scales(ptr(ma), ptr(mw))
 
 
 def _tail_workspace(L, m, n, k, with_stats, device):
@@ -419,9 +426,10 @@ def planes_fit(P, m, n, k, with_stats=False):
     return P.shape[0] == 3 or (_lib.lib().pdgn_gemm_nt_config(ctypes.c_longlong(m), n, k, 1 if with_stats else 0) & 15) == 0
 
 
-def gemm_nt_planes(a, P, n, k, bias=None, addend=None, want_stats=False, exp_a=None):
+def gemm_nt_planes(a, P, n, k, bias=None, addend=None, want_stats=False, max_a=None):
     """a (m, k) @ W^T for a weight given as its planes P [parts][n][ld] (Planes.p of W, or Planes.t for the product with W itself:
-    then n, k are W^T's; two-part planes: exp_a = a's maxima when the caller has them, operand_exponent); everything else as gemm_nt."""
+    then n, k are W^T's; two-part planes: max_a = a's maxima when the caller has them, operand_maxima); everything else as gemm_nt."""
+    _slots(a)
     m = a.shape[0]
     if GEMM_LOG is not None:
         GEMM_LOG.append(("nt", m, n, k))
@@ -436,19 +444,20 @@ def gemm_nt_planes(a, P, n, k, bias=None, addend=None, want_stats=False, exp_a=N
     if addend is not None:
         addend = _pad_cols(addend)
     ws = _tail_workspace(L, m, n, k, want_stats, a.device)
-    _hand_exponents(L, exp_a)
+    _hand_maxima(L, max_a)
     check(L.pdgn_gemm_nt_ps(ctypes.c_longlong(m), n, k, ptr(ap), ap.stride(0), ptr(P), P.shape[2], ctypes.c_longlong(P.shape[1] * P.shape[2]), P.shape[0],
                             ptr(b), ptr(addend), addend.stride(0) if addend is not None else 0, ptr(out), n, ptr(part), None, 0, 1, 0,
                             None, 0, stream_of(a)), "pdgn_gemm_nt_ps")
     return (out, part) if want_stats else out
 
 
-def gemm_nt(a, w, bias=None, addend=None, want_stats=False, w_transposed=False, exp_a=None):
+def gemm_nt(a, w, bias=None, addend=None, want_stats=False, w_transposed=False, max_a=None):
     """a (m, k) @ w (n, k)^T (+ bias) (+ addend) on pdgn_gemm_nt -- or, with w_transposed, a (m, k) @ w (k, n) on
     pdgn_gemm_nn (the input gradient dy @ W straight from the layer's weight).  Channel counts that are not multiples
     of 4 (the xyz layers: k = 3, the heads' last conv: n = 3) are zero-padded for the launch.  want_stats: also returns
     the BatchNorm partials of the result ((parts, 3n) fp32, block-shifted: per-column sum (x - pv) | sum (x - pv)^2 | pv of
     row blocks of pdgn_gemm_nt_stat_block_rows(m, n, k) rows, pv = the block's first row)."""
+    _slots(a)
     m, k = a.shape
     n = w.shape[1] if w_transposed else w.shape[0]
     if GEMM_LOG is not None:
@@ -478,7 +487,7 @@ def gemm_nt(a, w, bias=None, addend=None, want_stats=False, w_transposed=False, 
     b = bias.detach().contiguous() if bias is not None else None
     fn = L.pdgn_gemm_nn if w_transposed else L.pdgn_gemm_nt
     ws = _tail_workspace(L, m, np_, kp, want_stats, a.device)       # (kept alive to the end of this function: the launch is issued by then)
-    _hand_exponents(L, exp_a)
+    _hand_maxima(L, max_a)
     check(fn(ctypes.c_longlong(m), np_, kp, ptr(ap), ap.stride(0), ptr(wp), wp.stride(0), ptr(b), ptr(addend),
              addend.stride(0) if addend is not None else 0, ptr(out), np_, ptr(part), stream_of(a)),
           "pdgn_gemm_nn" if w_transposed else "pdgn_gemm_nt")
@@ -487,8 +496,9 @@ def gemm_nt(a, w, bias=None, addend=None, want_stats=False, w_transposed=False, 
     return (out, part) if want_stats else out
 
 
-def gemm_tn(dy, x, exp_dy=None, exp_x=None):
+def gemm_tn(dy, x, max_dy=None, max_x=None):
     """dy (m, n)^T @ x (m, k) -> (n, k) on pdgn_gemm_tn (reduction over the rows split over workgroups)."""
+    _slots(dy)
     m, n = dy.shape
     k = x.shape[1]
     if GEMM_LOG is not None:
@@ -502,7 +512,7 @@ def gemm_tn(dy, x, exp_dy=None, exp_x=None):
         # smaller outputs (and, on the fp32 kernels, the two largest ones: conv2's dense half, the per-point GEMM) stay on
         # pdgn_gemm_tn
         dwp = _zeros((dyp.shape[1], xp.shape[1]), dy.device)       # a slice of the backward pass's zero arena: no fill launch here
-        _hand_exponents(_lib.lib(), exp_dy, exp_x)
+        _hand_maxima(_lib.lib(), max_dy, max_x)
         check(_lib.lib().pdgn_gemm_tn_big(ctypes.c_longlong(m), dyp.shape[1], xp.shape[1], ptr(dyp), dyp.stride(0), ptr(xp),
                                           xp.stride(0), ptr(dwp), 1, stream_of(dy)), "pdgn_gemm_tn_big")
         return dwp if (dyp.shape[1] == n and xp.shape[1] == k) else dwp[:n, :k]
@@ -568,7 +578,7 @@ class LinearCL(Function):
         ctx.has_bias = bias is not None
         ctx.has_addend = addend is not None
         ctx.planes_t = None
-        ctx.exp_x = None
+        ctx.max_x = None
         if (planes is not None and x.is_cuda and x.shape[0] >= _PLANES_MIN_ROWS and planes.shape == tuple(weight.shape)
                 and x.shape[1] == weight.shape[1] and x.shape[1] % 4 == 0
                 and planes_fit(planes.p, x.shape[0], weight.shape[0], weight.shape[1], want_stats)):
@@ -577,12 +587,12 @@ class LinearCL(Function):
             ctx.thin = False
             ctx.planes_t = planes.t
             # (a two-part product: x is scanned once, for this product and for its weight gradient)
-            ctx.exp_x = ex = (x_max if x_max is not None else operand_exponent(x)) if planes.parts_p == 2 else None
+            ctx.max_x = xm = (x_max if x_max is not None else operand_maxima(x)) if planes.parts_p == 2 else None
             if want_stats:
-                y, part = gemm_nt_planes(x, planes.p, n, k, bias, addend, want_stats=True, exp_a=ex)
+                y, part = gemm_nt_planes(x, planes.p, n, k, bias, addend, want_stats=True, max_a=xm)
                 ctx.mark_non_differentiable(part)
                 return y, part
-            return gemm_nt_planes(x, planes.p, n, k, bias, addend, exp_a=ex)
+            return gemm_nt_planes(x, planes.p, n, k, bias, addend, max_a=xm)
         ctx.thin = bool(x.is_cuda and x.shape[0] >= _OWN_MIN_ROWS and addend is None and weight.is_contiguous()
                         and _thin_ok(x, weight.shape[0], weight.shape[1]))
         if ctx.thin:
@@ -594,12 +604,12 @@ class LinearCL(Function):
             y = thin_nt(x, weight, k, 1, n, bias)
             return (y, None) if want_stats else y
         if x.is_cuda and x.shape[0] >= _OWN_MIN_ROWS:
-            ex = None                                              # (the library scans both operands itself where two parts pay)
+            xm = None                                              # (the library scans both operands itself where two parts pay)
             if want_stats and weight.shape[0] % 4 == 0:
-                y, part = gemm_nt(x, weight, bias, addend, want_stats=True, exp_a=ex)
+                y, part = gemm_nt(x, weight, bias, addend, want_stats=True, max_a=xm)
                 ctx.mark_non_differentiable(part)
                 return y, part
-            y = gemm_nt(x, weight, bias, addend, exp_a=ex)
+            y = gemm_nt(x, weight, bias, addend, max_a=xm)
             return (y, None) if want_stats else y
         y = torch.nn.functional.linear(x, weight, bias)
         y = y + addend if addend is not None else y
@@ -634,21 +644,21 @@ class LinearCL(Function):
                 db = _zeros((n,), dy.device) if zero_db else group_colsum(dy)[0]
             return dx, dw, db, None, None, None, None
         # two-part products (mode "x2", where they pay): dy is scanned ONCE for the input and the weight gradient
-        ey = None
+        dy_max = None
         if own and _lib.gemm_mode() == "x2" and dy.shape[1] % 4 == 0:
             m_, n_, k_ = dy.shape[0], weight.shape[0], weight.shape[1]
             dx_two = (ctx.needs_input_grad[0] and ctx.planes_t is not None and ctx.planes_t.shape[0] == 2
                       and planes_fit(ctx.planes_t, m_, k_, n_))
-            dw_two = ctx.needs_input_grad[1] and two_part(n_, k_, m_, (0 if dx_two else m_ * n_ * 4) + (0 if ctx.exp_x is not None else m_ * k_ * 4))
+            dw_two = ctx.needs_input_grad[1] and two_part(n_, k_, m_, (0 if dx_two else m_ * n_ * 4) + (0 if ctx.max_x is not None else m_ * k_ * 4))
             if dx_two or dw_two:
-                ey = operand_exponent(dy)
+                dy_max = operand_maxima(dy)
         if ctx.needs_input_grad[0]:
             if ctx.planes_t is not None and own and dy.shape[1] % 4 == 0 and planes_fit(ctx.planes_t, dy.shape[0], weight.shape[1], weight.shape[0]):
-                dx = gemm_nt_planes(dy, ctx.planes_t, weight.shape[1], weight.shape[0], exp_a=ey)      # dX = dY W = dY (W^T)^T
+                dx = gemm_nt_planes(dy, ctx.planes_t, weight.shape[1], weight.shape[0], max_a=dy_max)      # dX = dY W = dY (W^T)^T
             else:
-                dx = gemm_nt(dy, weight, w_transposed=True, exp_a=ey) if own else dy.matmul(weight)
+                dx = gemm_nt(dy, weight, w_transposed=True, max_a=dy_max) if own else dy.matmul(weight)
         if ctx.needs_input_grad[1]:
-            dw = gemm_tn(dy, x, ey, ctx.exp_x) if own else dy.t().matmul(x)
+            dw = gemm_tn(dy, x, dy_max, ctx.max_x) if own else dy.t().matmul(x)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = _zeros((dy.shape[1],), dy.device) if zero_db else group_colsum(dy)[0]
         return dx, dw, db, (dy if ctx.has_addend and ctx.needs_input_grad[3] else None), None, None, None
@@ -750,6 +760,7 @@ def skinny_linear(x, weight):
 def gemm_nt_ex(a, w, ldw, n, bias=None, row_bias=None, rows_per_group=1, act=0, gate=None, w_transposed=False):
     """pdgn_gemm_nt_ex: act(a (m, k) @ W^T + bias + row_bias[row // rows_per_group]) * lrelu'(gate), W given as a data pointer
     with row pitch ldw ((n, k) rows, or (k, n) with w_transposed): a column slice of a wider weight needs no copy."""
+    _slots(a)
     m, k = a.shape
     if GEMM_LOG is not None:
         GEMM_LOG.append(("nn" if w_transposed else "nt", m, n, k))

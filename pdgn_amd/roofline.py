@@ -106,6 +106,7 @@ def _nt_entry(label, M, N, K, device):
     w = torch.randn(N, K, device=device)
     c = torch.empty(M, N, device=device)
     L = _lib.lib()
+    _lib.ensure_scale_slots(torch.device(device))
     x3 = gemm_mode() != "fp32"
     # as the step launches it: on the bf16 matrix cores the block's assembled weight arrives pre-split (fused.split_planes, once
     # per iteration) and the kernel is the PW instance of gemm_x3_kernel (pdgn_gemm_nt_ps)

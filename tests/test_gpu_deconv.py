@@ -1618,7 +1618,7 @@ def test_gemm_two_part_planes_and_maxima(M, N, K):
         ws = fused._tail_workspace(L, M, N, K, False, a.device)
         assert L.pdgn_gemm_nt_ps(ctypes.c_longlong(M), N, K, ptr(a), K, ptr(pl.p), pl.p.shape[2], wp, 2, ptr(bias), None, 0, ptr(c1), N, None,
                                  None, 0, 1, 0, None, 0, stream_of(a)) == 0
-        slot = fused.operand_exponent(a)                           # the caller's own scan, handed to the next call
+        slot = fused.operand_maxima(a)                           # the caller's own scan, handed to the next call
         assert slot is not None and int(slot.view(torch.int32).max()) == int(a.abs().max().view(torch.int32))
         ws = fused._tail_workspace(L, M, N, K, False, a.device)
         assert L.pdgn_gemm_set_operand_scales(ptr(slot), None) == 0

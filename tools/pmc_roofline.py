@@ -51,7 +51,7 @@ def per_launch(d, subs):
 
 def main():
     root, out_csv, out_json = sys.argv[1:4]
-    traffic = {"_meta": {"batch": 35, "base_points": 128, "arch": "gfx950", "recorded": "round 4, profiles/r04_pmc_mfma.csv run"}}
+    traffic = {"_meta": {"batch": 35, "base_points": 128, "arch": "gfx950", "recorded": "round 5, profiles/r05_pmc_mfma.csv run"}}
     lines = ["entry,kernels,us_per_launch,mfma_busy_frac_of_simd_cycles,valu_insts_per_launch,wave_wait_any_frac,"
              "wave_wait_inst_frac,clock_GHz,fetch_MB,write_MB,traffic_MB"]
     for entry, (subs, corr, key) in ENTRIES.items():
