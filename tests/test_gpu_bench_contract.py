@@ -42,9 +42,14 @@ def test_bench_prints_one_json_line_with_roofline_and_cpu_baseline():
     assert d["rccl_ranks"] == 1 and d["ms_per_step_min_rank"] <= d["ms_per_step_max_rank"]
     assert d["executed_flops_per_step"] > 1e12 and 0.0 < d["step_mfma_frac"] < 1.0 and d["algebraic_saving"] > 1.0
     assert r["kernel"].startswith("gemm_x3_kernel") and "Cijk" not in json.dumps(r)      # the roofline names own kernels only
-    assert r["mfma"]["products_per_fp32_product"] == 6 and abs(r["peak"] * 6 - r["mfma"]["instruction_peak_tflops"]) < 1e-6
+    # the dominant contraction runs on two scaled fp16 parts: three fp16 MFMA products per fp32 product, priced against THAT roof
+    np_ = r["mfma"]["products_per_fp32_product"]
+    assert np_ == 3 and r["mfma"]["instruction"] == "v_mfma_f32_32x32x16_f16" and abs(r["peak"] * np_ - r["mfma"]["instruction_peak_tflops"]) < 1e-6
+    assert "back_to_back" in r and r["back_to_back"]["us_per_launch"] > 0 and "timing" in r      # timed inside the steps; alone beside it
     acc = d["gemm_accuracy"]                                     # the arithmetic of the contractions, measured in the same run
-    assert 0.0 < acc["max_error_vs_fp64_x3"] < 1e-6 and acc["max_error_vs_fp64_x3"] <= 1.25 * acc["max_error_vs_fp64_fp32"]
+    for mode in ("x2", "x3"):
+        assert 0.0 < acc["max_error_vs_fp64_" + mode] < 1e-6 and acc["max_error_vs_fp64_" + mode] <= 1.25 * acc["max_error_vs_fp64_fp32"]
+    assert acc["max_error_vs_fp64_x2"] != acc["max_error_vs_fp64_x3"]                           # (the shape is one the two-part form takes)
     c5 = d["eval_c5"]                                            # config C5 rides in the default line
     assert c5["pairs"] == 512 and c5["finite"] is True and c5["pairs_per_s"] > 0 and c5["ms_per_512"] > 0
     assert c5["roofline"]["bound"] == "valu-issue" and 0 < c5["roofline"]["frac"] < 1 and 0 < c5["roofline"]["exp_frac"] < 1
