@@ -144,7 +144,9 @@ int pdgn_knn_graph_transpose(int b, int n, int k, const int32_t *idx, int32_t *r
  * dY's column blocks [off, off+T*C) and [offc, offc+C) is WRITTEN exactly once (no zero-fill). */
 int pdgn_window_gather_sum_backward_csr(int b, int n, int k, int ldy, int T, int P, int C, int off,
                                         int offc, const float *dout, const int32_t *rowptr,
-                                        const int32_t *edges, float *dY, pdgn_stream_t stream);
+                                        const int32_t *edges, float *dY, unsigned *max_out, int max_init, pdgn_stream_t stream);
+/* (max_out, may be NULL: a 1-KB device slot that collects 256 partial maxima of |dY| over the calls that fill one dY -- the first
+ * of them with max_init != 0, which zero-fills the slot -- for the two-part contractions that take dY, pdgn_gemm_set_operand_scales.) */
 
 /* Fused BatchNorm + activation over channels-last (rows x c) activations -- the
  * nn.BatchNorm2d + LeakyReLU/ReLU pairs of models/PDGNet_v2.py:537-545, 561-565, 603-625 in the

@@ -569,7 +569,7 @@ struct NtCfg {
         a.row_bias = epi.row_bias; a.ld_rb = epi.ld_rb; a.rows_per_group = epi.rows_per_group > 0 ? epi.rows_per_group : 1;
         a.rpg_magic = a.rows_per_group > 1 ? (unsigned)(0x100000000ULL / (unsigned)a.rows_per_group) + 1u : 0u;
         a.rb_bytes = epi.row_bias ? (int)((((m + a.rows_per_group - 1) / a.rows_per_group - 1) * (long long)epi.ld_rb + n) * 4) : 0;
-        a.act = epi.act; a.gate = epi.gate; a.ldgate = epi.ldgate; a.sk_split = 0; a.sk_ws = nullptr; a.max_a = a.max_w = nullptr;
+        a.act = epi.act; a.gate = epi.gate; a.ldgate = epi.ldgate; a.sk_split = 0; a.sk_ws = nullptr; a.sk_seg = 0; a.max_a = a.max_w = nullptr;
         a.tiles_m = pl.tiles_m; a.tiles_n = pl.tiles_n; a.kchunks = pl.kchunks;
         a.dbg = 0;
 #ifdef PDGN_NT_DEBUG

@@ -45,8 +45,10 @@ struct NtArgs {
     long long sk_per_wg;              // stream-K launch: (tile, chunk) iterations per workgroup
     int sk_split;                     // > 0 (gemm_x3 only): split-K launch over sk_split tiles: workgroup v takes tile v % sk_split,
                                       // chunks [v / sk_split * sk_per_wg, + sk_per_wg) -- workgroups that run together share panels
-    float *sk_ws;                     // gemm_x3, non-atomic instances with sk_split > 0: workgroup v stores its partial tile (whole,
-                                      // pitch BN) at sk_ws + v * BM * BN instead of adding it into C (stream-K tail without atomics)
+    float *sk_ws;                     // gemm_x3, non-atomic instances: partial tiles (whole, pitch BN) go to this workspace instead of
+                                      // into C (stream-K tail without atomics).  sk_split > 0: workgroup v's one tile at slot v;
+    int sk_seg;                       // sk_seg > 0 (sk_split == 0): the FLATTENED order -- workgroup v takes (tile, chunk) iterations
+                                      // [v sk_per_wg, + sk_per_wg), its i-th tile's part at slot v * sk_seg + i
     int dbg;                          // builds with -DPDGN_NT_DEBUG only (ablation: 1 = stores dropped); always 0 otherwise
     // extended epilogue (pdgn_gemm_nt_ex), applied in this order after bias / addend:
     const float *row_bias;            // + row_bias[(row / rows_per_group) * ld_rb + col]: a bias per GROUP of rows (per sample)

@@ -224,8 +224,9 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_x3_kernel(const NtArgs
             c.ke = min(KC, c.kb + (int)p.sk_per_wg);
             c.valid = c.j == 0 && c.kb < KC;
             c.j++;
-        } else if (ATOMIC) {
+        } else if (ATOMIC || (p.sk_ws && p.sk_seg)) {              // flattened (tile, chunk) order: atomics into C, or partial tiles into the workspace
             c.valid = c.f < c.f1;
+            c.j++;                                                 // (1-based index of the item among this workgroup's)
             if (c.valid) {
                 c.tile = p.tile_begin + (int)(c.f / KC);
                 c.kc = c.kb = (int)(c.f % KC);
@@ -591,7 +592,8 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_x3_kernel(const NtArgs
         const long long mrows = to_ws ? BM : min((long long)BM, p.M - m0);      // (a partial tile is stored whole: rows / columns past
         const int ncols = to_ws ? BN : min(BN, p.N - n0);                       //  the matrix hold zeros and are not read back)
         if (!ATOMIC) {
-            if (to_ws) rsC = __builtin_amdgcn_make_buffer_rsrc((void *)(p.sk_ws + (size_t)v * BM * BN), 0, BM * BN * 4, 0x00020000);
+            if (to_ws) rsC = __builtin_amdgcn_make_buffer_rsrc((void *)(p.sk_ws + (size_t)(p.sk_seg ? v * p.sk_seg + (cp.j - 1) : v) * BM * BN), 0,
+                                                               BM * BN * 4, 0x00020000);
             else rsC = __builtin_amdgcn_make_buffer_rsrc((void *)(p.C + m0 * p.ldc + n0), 0, (int)(mrows * p.ldc * 4), 0x00020000);
 #pragma unroll
             for (int bb = 0; bb < NBB; ++bb)
@@ -982,10 +984,14 @@ static float *x3_take_workspace(size_t floats) {
     return p;
 }
 
-// C tile t of the tail = sum over the S slices ws[(s T + t)] (+ bias + addend); gridDim.y workgroups per tile (BM % (8 * 1) == 0)
+// C tile t of the tail = sum over its parts in the workspace (+ bias + addend); gridDim.y workgroups per tile (BM % (8 * 1) == 0).
+// Aligned form (seg == 0): the S slices ws[s T + t].  Flattened form (seg > 0; per = iterations per workgroup, KC = chunks per
+// tile): the workgroups v0 .. v1 whose iteration ranges meet the tile's, each one's part at slot v seg + (t - its first tile) --
+// in workgroup order: a fixed order of summation either way.
 __global__ __launch_bounds__(256) void x3_sk_reduce_kernel(const float *__restrict__ ws, int S, int T, int BM, int BN, int tile_begin,
                                                            int tiles_m, int tiles_n, long long M, int N, float *__restrict__ C, int ldc,
-                                                           const float *__restrict__ bias, const float *__restrict__ addend, int ldadd) {
+                                                           const float *__restrict__ bias, const float *__restrict__ addend, int ldadd,
+                                                           int seg, long long per, int KC) {
     const int t = blockIdx.x, tile = tile_begin + t;
     const int per_group = NT_GROUP_M * tiles_n;
     const int grp = tile / per_group, r = tile - grp * per_group, first = grp * NT_GROUP_M;
@@ -999,10 +1005,22 @@ __global__ __launch_bounds__(256) void x3_sk_reduce_kernel(const float *__restri
     for (int e = threadIdx.x; e < rows_per * q4; e += 256) {
         const int row = blockIdx.y * rows_per + e / q4, c4 = (e % q4) * 4;
         if (row >= mrows || c4 >= ncols) continue;                  // (N % 4 == 0: a float4 is all in or all out)
-        float4 a = *reinterpret_cast<const float4 *>(ws + ((size_t)t * BM + row) * BN + c4);
-        for (int sl = 1; sl < S; ++sl) {
-            const float4 b = *reinterpret_cast<const float4 *>(ws + (((size_t)sl * T + t) * BM + row) * BN + c4);
-            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        float4 a;
+        if (!seg) {
+            a = *reinterpret_cast<const float4 *>(ws + ((size_t)t * BM + row) * BN + c4);
+            for (int sl = 1; sl < S; ++sl) {
+                const float4 b = *reinterpret_cast<const float4 *>(ws + (((size_t)sl * T + t) * BM + row) * BN + c4);
+                a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+            }
+        } else {
+            const long long f0 = (long long)t * KC, f1 = f0 + KC - 1;
+            const long long v0 = f0 / per, v1 = f1 / per;
+            a = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (long long vv = v0; vv <= v1; ++vv) {
+                const size_t slot = (size_t)(vv * seg + (t - (vv * per) / KC));
+                const float4 b = *reinterpret_cast<const float4 *>(ws + (slot * BM + row) * BN + c4);
+                a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+            }
         }
         if (bias) { const float4 b = *reinterpret_cast<const float4 *>(bias + n0 + c4); a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
         if (addend) {
@@ -1186,18 +1204,39 @@ struct X3Cfg {
         else hipLaunchKernelGGL((gemm_x3_kernel<TM, TN, WM, WN, OCC, ATOMIC, WT, AT, EPI, PW, 32>), dim3(grid), dim3(64 * WM * WN), 0, s, a);
     }
 
-    // floats of workspace the stream-K tail of (m, n, k) wants (0: no tail)
-    static long long tail_floats(long long m, int n, int k, bool allow_sk) {
-        const Plan pl = plan(m, n, k, allow_sk);
-        if (!pl.grid_sk) return 0;
+    // How a stream-K tail (the leftover tiles' k ranges over all CUs) is laid out when its partial tiles go to a workspace.
+    // Aligned: every tile's chunks in s_tail equal slices, workgroup v = (slice, tile): the workgroups that run together read the
+    // same chunks of different tiles.  When the tiles do not divide the CUs well (140 leftover tiles on 256 CUs: one slice each
+    // = 55 % of the chip, the per-point product's input gradient) the FLATTENED order instead: iteration ranges of equal length,
+    // a workgroup's range may span seg tiles.
+    struct Tail {
+        int t_tail, s_tail, per_tail, grid, seg;
+        long long per_flat, floats;
+    };
+    static Tail tail_layout(const Plan &pl) {
+        Tail t = {0, 0, 0, 0, 0, 0, 0};
+        if (!pl.grid_sk) return t;
         const long long T = (long long)pl.tiles_m * pl.tiles_n;
-        const int t_tail = (int)(T - pl.dp_tiles), slots_ = nt_cus() * WG_PER_CU;
-        int s_tail = slots_ / t_tail < 1 ? 1 : slots_ / t_tail;
-        s_tail = s_tail > pl.kchunks ? pl.kchunks : s_tail;
-        const int per_tail = (pl.kchunks + s_tail - 1) / s_tail;
-        s_tail = (pl.kchunks + per_tail - 1) / per_tail;
-        return (long long)s_tail * t_tail * BM * BN;
+        const int slots_ = nt_cus() * WG_PER_CU;
+        t.t_tail = (int)(T - pl.dp_tiles);
+        t.s_tail = slots_ / t.t_tail < 1 ? 1 : slots_ / t.t_tail;
+        t.s_tail = t.s_tail > pl.kchunks ? pl.kchunks : t.s_tail;
+        t.per_tail = (pl.kchunks + t.s_tail - 1) / t.s_tail;
+        t.s_tail = (pl.kchunks + t.per_tail - 1) / t.per_tail;
+        t.grid = t.s_tail * t.t_tail;
+        const long long iters = (long long)t.t_tail * pl.kchunks;
+        if (t.grid * 5 < slots_ * 4 && iters >= (long long)slots_ * 8) {     // under 80 % of the chip, and ranges of >= 8 chunks to hand out
+            t.per_flat = (iters + slots_ - 1) / slots_;
+            t.grid = (int)((iters + t.per_flat - 1) / t.per_flat);
+            t.seg = (int)((t.per_flat + pl.kchunks - 2) / pl.kchunks) + 1;
+            t.floats = (long long)t.grid * t.seg * BM * BN;
+        } else {
+            t.floats = (long long)t.grid * BM * BN;
+        }
+        return t;
     }
+    // floats of workspace the stream-K tail of (m, n, k) wants (0: no tail)
+    static long long tail_floats(long long m, int n, int k, bool allow_sk) { return tail_layout(plan(m, n, k, allow_sk)).floats; }
 
     template <bool WT, bool AT = false>
     static int launch(long long m, int n, int k, const float *A, int lda, const float *W, int ldw, const float *bias,
@@ -1215,6 +1254,7 @@ struct X3Cfg {
         a.act = epi.act; a.gate = epi.gate; a.ldgate = epi.ldgate; a.sk_split = 0;
         a.Wp = Wp; a.wplane = wplane;
         a.sk_ws = nullptr;
+        a.sk_seg = 0;
         a.max_a = a.max_w = nullptr;
         // two parts or three: pre-split planes say it themselves; otherwise where it pays (x2_pays: mode 2, this tile, enough
         // matrix-core work per byte that still has to be scanned for its maximum)
@@ -1248,17 +1288,8 @@ struct X3Cfg {
         }
         // stream-K tail: the leftover tiles' k range in S slices, partial tiles to the workspace + a reduce (no atomics); the atomic
         // form (zero-fill + fp32 atomics into C) when there is no workspace
-        const int t_tail = pl.grid_sk ? (int)(T - pl.dp_tiles) : 0;
-        int s_tail = 0, per_tail = 0;
-        float *ws = nullptr;
-        if (t_tail > 0 && !AT) {
-            const int slots_ = nt_cus() * WG_PER_CU;
-            s_tail = slots_ / t_tail < 1 ? 1 : slots_ / t_tail;
-            s_tail = s_tail > pl.kchunks ? pl.kchunks : s_tail;
-            per_tail = (pl.kchunks + s_tail - 1) / s_tail;
-            s_tail = (pl.kchunks + per_tail - 1) / per_tail;
-            ws = x3_take_workspace((size_t)s_tail * t_tail * BM * BN);
-        }
+        const Tail tl = tail_layout(pl);
+        float *ws = (tl.t_tail > 0 && !AT) ? x3_take_workspace((size_t)tl.floats) : nullptr;
         if (pl.grid_sk && !ws) {
             const long long r0 = (long long)(pl.dp_tiles / (NT_GROUP_M * pl.tiles_n)) * NT_GROUP_M * BM;
             if (!prezeroed && hipMemsetAsync(C + r0 * ldc, 0, (size_t)(m - r0) * ldc * sizeof(float), s) != hipSuccess) return pdgn_launch_status();
@@ -1273,12 +1304,13 @@ struct X3Cfg {
             else go<false, WT, AT, false>(pl.grid_dp, s, a, two);
         }
         if (pl.grid_sk && ws) {
-            a.tile_begin = pl.dp_tiles; a.tile_end = (int)T; a.sk_split = t_tail; a.sk_per_wg = per_tail; a.sk_ws = ws;
+            a.tile_begin = pl.dp_tiles; a.tile_end = (int)T; a.sk_ws = ws;
+            a.sk_split = tl.seg ? 0 : tl.t_tail; a.sk_seg = tl.seg; a.sk_per_wg = tl.seg ? tl.per_flat : tl.per_tail;
             a.bias = nullptr; a.addend = nullptr;                  // (the reduce adds them)
-            if (CAN_PW && Wp) go<false, false, false, false, CAN_PW>(s_tail * t_tail, s, a, two);
-            else go<false, WT, AT, false>(s_tail * t_tail, s, a, two);
-            hipLaunchKernelGGL(x3_sk_reduce_kernel, dim3(t_tail, 8), dim3(256), 0, s, ws, s_tail, t_tail, BM, BN, pl.dp_tiles, pl.tiles_m,
-                               pl.tiles_n, m, n, C, ldc, bias, addend, ldadd);
+            if (CAN_PW && Wp) go<false, false, false, false, CAN_PW>(tl.grid, s, a, two);
+            else go<false, WT, AT, false>(tl.grid, s, a, two);
+            hipLaunchKernelGGL(x3_sk_reduce_kernel, dim3(tl.t_tail, 8), dim3(256), 0, s, ws, tl.s_tail, tl.t_tail, BM, BN, pl.dp_tiles, pl.tiles_m,
+                               pl.tiles_n, m, n, C, ldc, bias, addend, ldadd, tl.seg, tl.per_flat, pl.kchunks);
         } else if (pl.grid_sk) {
             a.tile_begin = pl.dp_tiles; a.tile_end = (int)T; a.sk_per_wg = pl.sk_per_wg;
             if (CAN_PW && Wp) go<true, false, false, false, CAN_PW>(pl.grid_sk, s, a, two);

@@ -475,13 +475,25 @@ __global__ __launch_bounds__(WGS_THREADS) void csr_fill_kernel(long long total, 
     edges[b * nk + pos] = (r / k) * 32 + (r % k);
 }
 
+// max_out (the adjoint kernels; may be NULL): 256 partial maxima of |dY| as bit patterns -- what the two-part contractions that take
+// dY (the per-point product's input and weight gradient, gemm_x3.hip) would otherwise scan its 1.8 GB for.  One atomic max per wave,
+// entry = (workgroup * waves + wave) % 256; the launcher of a dY's FIRST spec zero-fills the slot.
+__device__ __forceinline__ void wgs_emit_max(const float __attribute__((ext_vector_type(4))) v, unsigned *__restrict__ max_out) {
+    unsigned m = max(max(__float_as_uint(v[0]) & 0x7fffffffu, __float_as_uint(v[1]) & 0x7fffffffu),
+                     max(__float_as_uint(v[2]) & 0x7fffffffu, __float_as_uint(v[3]) & 0x7fffffffu));
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(max_out + ((blockIdx.x * (WGS_THREADS / 64) + (threadIdx.x >> 6)) & 255), m);
+}
+
 __global__ __launch_bounds__(WGS_THREADS) void wgs_bwd_csr_kernel(
     long long total, int n, int k, int ldy, int T, int P, int CV, int off, int offc,
     const float *__restrict__ dout, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ edges,
-    float *__restrict__ dY) {
+    float *__restrict__ dY, unsigned *__restrict__ max_out) {
     typedef float vec_t __attribute__((ext_vector_type(4)));
     long long e = (long long)blockIdx.x * WGS_THREADS + threadIdx.x;
-    if (e >= total) return;
+    vec_t acc = {0.f, 0.f, 0.f, 0.f};
+    if (e < total) {
     const int TT = offc >= 0 ? T + 1 : T;
     const int cv = (int)(e % CV);
     long long r = e / CV;
@@ -490,23 +502,24 @@ __global__ __launch_bounds__(WGS_THREADS) void wgs_bwd_csr_kernel(
     const long long b = bj / n;
     const int j = (int)(bj - b * n);
     const int C = CV * 4, c = cv * 4;
-    vec_t acc = {0.f, 0.f, 0.f, 0.f};
     if (t == T) {                                             // centre columns
         const float *src = dout + bj * P * C + c;
         for (int p = 0; p < P; ++p) acc += *reinterpret_cast<const vec_t *>(src + (size_t)p * C);
         *reinterpret_cast<vec_t *>(dY + bj * ldy + offc + c) = acc;
-        return;
+    } else {
+        const int32_t *R = rowptr + b * (n + 1);
+        const int32_t *E = edges + b * (long long)n * k;
+        const int e1 = R[j + 1];
+        for (int q = R[j]; q < e1; ++q) {
+            const int rec = E[q];
+            const int p = (rec & 31) - t;
+            if (p >= 0 && p < P)
+                acc += *reinterpret_cast<const vec_t *>(dout + ((b * n + (rec >> 5)) * P + p) * C + c);
+        }
+        *reinterpret_cast<vec_t *>(dY + bj * ldy + off + t * C + c) = acc;
     }
-    const int32_t *R = rowptr + b * (n + 1);
-    const int32_t *E = edges + b * (long long)n * k;
-    const int e1 = R[j + 1];
-    for (int q = R[j]; q < e1; ++q) {
-        const int rec = E[q];
-        const int p = (rec & 31) - t;
-        if (p >= 0 && p < P)
-            acc += *reinterpret_cast<const vec_t *>(dout + ((b * n + (rec >> 5)) * P + p) * C + c);
     }
-    *reinterpret_cast<vec_t *>(dY + bj * ldy + off + t * C + c) = acc;
+    if (max_out) wgs_emit_max(acc, max_out);                   // (every lane of the wave gets here)
 }
 
 // The adjoint in the task mapping of wgs_fwd_xcd_kernel.  A WAVE owns one source point j of a (sample, 64-channel
@@ -519,7 +532,7 @@ template <int TT, int CW>
 __global__ __launch_bounds__(WGS_THREADS) void wgs_bwd_csr_xcd_kernel(
     int ntasks, int bpt, int n, int k, int ldy, int T, int P, int CV, int nchunk, int off, int offc,
     const float *__restrict__ dout, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ edges,
-    float *__restrict__ dY) {
+    float *__restrict__ dY, unsigned *__restrict__ max_out) {
     typedef wgs_vec_t vec_t;
     constexpr int MAXT = TT ? TT : 8, JB = WGS_THREADS / 64, WGS_EL = 64 / CW;   // source points per block; edge lanes per column
     const int seq = blockIdx.x >> 3;
@@ -579,14 +592,29 @@ __global__ __launch_bounds__(WGS_THREADS) void wgs_bwd_csr_xcd_kernel(
         for (int m = CW; m < 64; m <<= 1) v += __shfl_xor(v, m);
         ctr[i] = v;
     }
-    if (!cok) return;
-    const unsigned oj = wgs_mul24(j, ldy4) + cb;
+    if (cok) {
+        const unsigned oj = wgs_mul24(j, ldy4) + cb;
 #pragma unroll
-    for (int t = 0; t < MAXT; ++t)                             // the stores are dealt out over the edge lanes as well
-        if ((TT || t < T) && (t % WGS_EL) == el)
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(wgs_u4_t, acc[t]), rsY, (int)oj, (int)((unsigned)off * 4u + t * C4), 0);
-    if (offc >= 0 && el == WGS_EL - 1)
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(wgs_u4_t, ctr), rsY, (int)oj, (int)((unsigned)offc * 4u), 0);
+        for (int t = 0; t < MAXT; ++t)                         // the stores are dealt out over the edge lanes as well
+            if ((TT || t < T) && (t % WGS_EL) == el)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(wgs_u4_t, acc[t]), rsY, (int)oj, (int)((unsigned)off * 4u + t * C4), 0);
+        if (offc >= 0 && el == WGS_EL - 1)
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(wgs_u4_t, ctr), rsY, (int)oj, (int)((unsigned)offc * 4u), 0);
+    }
+    if (max_out) {                                             // (wave-uniform: j < n) the totals every lane holds -> one atomic per wave
+        vec_t m = zero;
+        if (cok) {
+#pragma unroll
+            for (int t = 0; t < MAXT; ++t)
+                if (TT || t < T)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) m[i] = fmaxf(m[i], fabsf(acc[t][i]));
+            if (offc >= 0)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) m[i] = fmaxf(m[i], fabsf(ctr[i]));
+        }
+        wgs_emit_max(m, max_out);
+    }
 }
 
 extern "C" int pdgn_knn_graph_transpose(int b, int n, int k, const int32_t *idx, int32_t *rowptr,
@@ -607,10 +635,12 @@ extern "C" int pdgn_knn_graph_transpose(int b, int n, int k, const int32_t *idx,
 
 extern "C" int pdgn_window_gather_sum_backward_csr(int b, int n, int k, int ldy, int T, int P, int C, int off,
                                                    int offc, const float *dout, const int32_t *rowptr,
-                                                   const int32_t *edges, float *dY, pdgn_stream_t stream) {
+                                                   const int32_t *edges, float *dY, unsigned *max_out, int max_init,
+                                                   pdgn_stream_t stream) {
     if (!wgs_ok(b, n, k, ldy, T, P, C, off, offc) || C % 4 || ldy % 4 || off % 4 || (offc >= 0 && offc % 4) || k > 31)
         return PDGN_ERR_INVALID;
     if (b == 0) return 0;
+    if (max_out && max_init && hipMemsetAsync(max_out, 0, 256 * sizeof(unsigned), (hipStream_t)stream) != hipSuccess) return pdgn_launch_status();
     static const int xcd = getenv("PDGN_WGS_XCD") ? atoi(getenv("PDGN_WGS_XCD")) : 1;
     if (xcd && (T <= 8 || T == 10) && (long long)n * T * (C / 4) >= 65536 && wgs_slabs_ok(n, k, ldy, P, C)) {
         static const int cw = wgs_cw("PDGN_WGS_BCW", 64);
@@ -620,13 +650,13 @@ extern "C" int pdgn_window_gather_sum_backward_csr(int b, int n, int k, int ldy,
 #define WGS_CALL(W)                                                                                                           \
     if (T == 6)                                                                                                               \
         hipLaunchKernelGGL((wgs_bwd_csr_xcd_kernel<6, W>), dim3((unsigned)blocks), dim3(WGS_THREADS), 0, (hipStream_t)stream, \
-                           ntasks, bpt, n, k, ldy, T, P, CV, nchunk, off, offc, dout, rowptr, edges, dY);                     \
+                           ntasks, bpt, n, k, ldy, T, P, CV, nchunk, off, offc, dout, rowptr, edges, dY, max_out);                     \
     else if (T == 10)                                                                                                         \
         hipLaunchKernelGGL((wgs_bwd_csr_xcd_kernel<10, W>), dim3((unsigned)blocks), dim3(WGS_THREADS), 0, (hipStream_t)stream,\
-                           ntasks, bpt, n, k, ldy, T, P, CV, nchunk, off, offc, dout, rowptr, edges, dY);                     \
+                           ntasks, bpt, n, k, ldy, T, P, CV, nchunk, off, offc, dout, rowptr, edges, dY, max_out);                     \
     else                                                                                                                      \
         hipLaunchKernelGGL((wgs_bwd_csr_xcd_kernel<0, W>), dim3((unsigned)blocks), dim3(WGS_THREADS), 0, (hipStream_t)stream, \
-                           ntasks, bpt, n, k, ldy, T, P, CV, nchunk, off, offc, dout, rowptr, edges, dY)
+                           ntasks, bpt, n, k, ldy, T, P, CV, nchunk, off, offc, dout, rowptr, edges, dY, max_out)
             WGS_DISPATCH_CW(cw, WGS_CALL);
 #undef WGS_CALL
             return pdgn_launch_status();
@@ -635,6 +665,6 @@ extern "C" int pdgn_window_gather_sum_backward_csr(int b, int n, int k, int ldy,
     const int TT = offc >= 0 ? T + 1 : T;
     const long long total = (long long)b * n * TT * (C / 4);
     hipLaunchKernelGGL(wgs_bwd_csr_kernel, dim3(cdiv(total, WGS_THREADS)), dim3(WGS_THREADS), 0, (hipStream_t)stream,
-                       total, n, k, ldy, T, P, C / 4, off, offc, dout, rowptr, edges, dY);
+                       total, n, k, ldy, T, P, C / 4, off, offc, dout, rowptr, edges, dY, max_out);
     return pdgn_launch_status();
 }

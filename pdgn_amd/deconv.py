@@ -30,7 +30,7 @@ from . import streams as _streams
 from ._lib import check, ptr, require, stream_of
 from .fused import (Planes, split_planes, skinny_linear, _zeros, bilateral_weighting, bn_act,  # noqa: F401
                     small_sequential, bn_act_maxpool, bn_softmax_slots_permute, flush_bn_counters,  # noqa: F401
-                    has_zero_colsum, linear_cl, softmax_slots_permute, DenseInput, group_colsum)
+                    has_zero_colsum, linear_cl, softmax_slots_permute, DenseInput, group_colsum, mark_maxima, _max_slot)
 from .fused import _STATS_MAX as STATS_MAX  # noqa: F401
 
 F32, I32 = torch.float32, torch.int32
@@ -159,18 +159,25 @@ class EdgeGatherSum(Function):
             # atomic-free path: the specs tile dY completely, each element is written once
             rowptr, edges = transposed_graph(idx)
             dY = torch.empty((b, n, ldy), dtype=F32, device=idx.device)
+            # a LARGE dY leaves with its partial maxima (the kernels that write it compute them on the way): the two-part
+            # contractions of the layer below -- the per-point product's input and weight gradient -- would scan it otherwise
+            dmax = _max_slot(idx.device) if (_lib.gemm_mode() == "x2" and b * n * ldy >= (1 << 24)) else None
+            first = 1
             for (T, P, C, off, offc), dout, hb in zip(ctx.specs, douts, ctx.has_bias):
                 hb = 3 if hb == 1 and has_zero_colsum(dout) else hb
                 dout = dout.contiguous()
                 check(L.pdgn_window_gather_sum_backward_csr(b, n, k, ldy, T, P, C, off, offc, ptr(dout), ptr(rowptr),
-                                                            ptr(edges), ptr(dY), stream_of(dout)),
+                                                            ptr(edges), ptr(dY), ptr(dmax), first, stream_of(dout)),
                       "pdgn_window_gather_sum_backward_csr")
+                first = 0
                 if hb == 2 and offc >= 0:
                     # per-sample bias: sum over (n, p) of dout = sum over n of the centre columns the kernel just
                     # wrote (dY[b,j,offc+c] = sum_p dout[b,j,p,c]) -- P times less data than dout itself
                     dbias.append(group_colsum(dY.view(b * n, ldy)[:, offc:offc + C], n))
                 else:
                     dbias.append(_dbias(dout, hb))
+            if dmax is not None:
+                mark_maxima(dY, dmax)
             return (dY, None, None) + tuple(dbias)
         dY = torch.zeros((b, n, ldy), dtype=F32, device=idx.device)
         for (T, P, C, off, offc), dout, hb in zip(ctx.specs, douts, ctx.has_bias):
@@ -367,7 +374,7 @@ class PointDeconv(nn.Module):
         want_t = torch.is_grad_enabled() and WcatV.requires_grad
         with torch.no_grad():
             rows = getattr(self, "_rows_hint", None)               # B * N of the last forward: decides three bf16 / two fp16 parts
-            pv = split_planes(WcatV.detach(), want_t, rows)
+            pv = split_planes(WcatV.detach(), want_t, rows, dy_maxima_free=True)      # (its dY comes from EdgeGatherSum.backward, with maxima)
             pb = split_planes(Wb.detach(), want_t, rows)
         return WcatC, WcatV, Wb, pv, pb
 

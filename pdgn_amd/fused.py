@@ -44,6 +44,27 @@ def has_zero_colsum(dy):
 def clear_zero_colsum():
     _ZERO_COLSUM.clear()
     _INPUT_GRADS.clear()
+    _GRAD_MAXIMA.clear()
+
+
+# A third side channel of the same kind: a backward that WRITES a large gradient (EdgeGatherSum's dY, 1.8 GB at stage 4) leaves its
+# partial maxima in a 1-KB slot (csrc/gemm_shared.h X2_PARTS) for the two-part contractions of the layer that receives it
+# (LinearCL.backward: input and weight gradient of the per-point product) -- they would scan the whole tensor otherwise.  Keyed
+# and validated like _ZERO_COLSUM; taken once.
+_GRAD_MAXIMA = {}
+
+
+def mark_maxima(g, slot):
+    _GRAD_MAXIMA[g.data_ptr()] = (weakref.ref(g), slot)
+
+
+def take_maxima(dy):
+    ent = _GRAD_MAXIMA.pop(dy.data_ptr(), None)
+    if ent is None:
+        return None
+    src = ent[0]()
+    return ent[1] if src is not None and (src is dy or dy._base is src or (dy._base is not None and dy._base is src._base)) \
+        and dy.numel() == src.numel() else None
 
 
 # A second side channel of the same kind: BNActMaxPool's backward, when the dense layer in front of it is frozen, computes
@@ -341,10 +362,11 @@ def _slots(t):
         _lib.ensure_scale_slots(t.device)
 
 
-def split_planes(w, want_t, rows=None):
+def split_planes(w, want_t, rows=None, dy_maxima_free=False):
     """The pre-split planes of a (n, k) fp32 weight (Planes); None where the pre-split path does not apply (fp32-instruction mode,
     sizes that would need padding).  rows: the row count of the activations it will multiply, when known -- it decides between
-    three bf16 and two fp16 parts per product (forward: (rows, n, k); input gradient through the transpose: (rows, k, n))."""
+    three bf16 and two fp16 parts per product (forward: (rows, n, k); input gradient through the transpose: (rows, k, n));
+    dy_maxima_free: the layer's output gradient arrives with its maxima (mark_maxima: nothing to scan for the input gradient)."""
     _slots(w)
     mode = _lib.gemm_mode()
     if not (_PLANES and w.is_cuda and w.dim() == 2 and mode != "fp32") or w.shape[0] % 4 or w.shape[1] % 4 or w.stride(1) != 1:
@@ -352,7 +374,7 @@ def split_planes(w, want_t, rows=None):
     n, k = w.shape
     ldp, ldt = (k + 7) // 8 * 8, (n + 7) // 8 * 8
     parts_p = 2 if rows and two_part(rows, n, k, rows * k * 4) else 3           # (the activations are scanned, the weight brings its exponent)
-    parts_t = 2 if rows and want_t and two_part(rows, k, n, rows * n * 4) else 3
+    parts_t = 2 if rows and want_t and two_part(rows, k, n, 0 if dy_maxima_free else rows * n * 4) else 3
 
     def planes(parts, rows_, ld):                                  # [parts][rows][ld] (+ 16 B: two-part planes keep the exponent there)
         buf = torch.empty(parts * rows_ * ld + 8, dtype=torch.int16, device=w.device)
@@ -647,10 +669,12 @@ class LinearCL(Function):
         dy_max = None
         if own and _lib.gemm_mode() == "x2" and dy.shape[1] % 4 == 0:
             m_, n_, k_ = dy.shape[0], weight.shape[0], weight.shape[1]
+            dy_max = take_maxima(dy)                               # left behind by the backward that wrote dy (EdgeGatherSum), or None
             dx_two = (ctx.needs_input_grad[0] and ctx.planes_t is not None and ctx.planes_t.shape[0] == 2
                       and planes_fit(ctx.planes_t, m_, k_, n_))
-            dw_two = ctx.needs_input_grad[1] and two_part(n_, k_, m_, (0 if dx_two else m_ * n_ * 4) + (0 if ctx.max_x is not None else m_ * k_ * 4))
-            if dx_two or dw_two:
+            dw_two = ctx.needs_input_grad[1] and two_part(n_, k_, m_, (0 if (dx_two or dy_max is not None) else m_ * n_ * 4) +
+                                                          (0 if ctx.max_x is not None else m_ * k_ * 4))
+            if dy_max is None and (dx_two or dw_two):
                 dy_max = operand_maxima(dy)
         if ctx.needs_input_grad[0]:
             if ctx.planes_t is not None and own and dy.shape[1] % 4 == 0 and planes_fit(ctx.planes_t, dy.shape[0], weight.shape[1], weight.shape[0]):

@@ -1526,7 +1526,8 @@ def test_head_mlp_vs_torch(B, M, Fo, nc):
         assert (a.double() - b).abs().max().item() < tol * (20 if n.startswith("d") and n != "dx" else 1), n
 
 
-@pytest.mark.parametrize("M,N,K", [(35840, 512, 5120), (17920, 256, 2560), (9000, 132, 1284), (4100, 64, 6432), (8960, 128, 1280)])
+@pytest.mark.parametrize("M,N,K", [(35840, 512, 5120), (17920, 256, 2560), (9000, 132, 1284), (4100, 64, 6432), (8960, 128, 1280),
+                                   (36000, 128, 2048), (35840, 128, 12832), (20100, 132, 900)])      # (the last three: the flattened layout)
 def test_stream_k_tail_without_atomics(M, N, K):
     """Round 5: a launch whose tiles do not fill the last round of workgroups finishes its leftover tiles as split-K partial tiles
     in a caller-provided workspace + a reduce kernel (csrc/gemm_x3.hip: pdgn_gemm_tail_workspace_floats / pdgn_gemm_set_tail_workspace)
@@ -1652,3 +1653,31 @@ def test_bilateral_weighting_emits_its_output_maxima():
     y1, slot = fused.bilateral_weighting(x, bx, u, bu, True, k, want_max=True)
     assert torch.equal(y0, y1) and slot.shape == (256,)
     assert int(slot.max()) == int(y1.abs().max().view(torch.int32))
+
+
+@pytest.mark.parametrize("B,N,k,specs", [(3, 300, 10, ((6, 5, 16, 0, 96), (10, 1, 8, 112, 192), (1, 10, 4, 200, 204))),
+                                         (2, 1024, 10, ((6, 5, 128, 0, 768), (10, 1, 64, 896, 1536)))])
+def test_gather_sum_adjoint_leaves_the_maxima_of_dy(B, N, k, specs):
+    """The kernels that WRITE dY (one call per spec into the same tensor) collect 256 partial maxima of |dY| in one slot, the first
+    call zero-filling it: the same maximum a scan of the finished dY finds -- both kernel forms (the per-wave task kernel for the
+    large specs, the per-element one for the small) -- and dY itself is unchanged."""
+    import ctypes
+    from pdgn_amd import _lib
+    from pdgn_amd._lib import ptr, stream_of
+    from pdgn_amd.deconv import transposed_graph
+    L = _lib.lib()
+    ldy = sum(T * C + (C if offc >= 0 else 0) for (T, P, C, off, offc) in specs)
+    g = torch.Generator(device="cuda").manual_seed(N + ldy)
+    idx = torch.randint(0, N, (B, N, k), device="cuda", generator=g, dtype=torch.int32)
+    idx[:, :, 0] = 3
+    rowptr, edges = transposed_graph(idx)
+    douts = [torch.randn(B, N, P, C, device="cuda", generator=g) * (10.0 ** i) for i, (T, P, C, off, offc) in enumerate(specs)]
+    res = []
+    for slot in (None, torch.full((256,), 7, dtype=torch.int32, device="cuda")):       # (garbage in the slot: the first call clears it)
+        dY = torch.full((B, N, ldy), float("nan"), device="cuda")
+        for i, ((T, P, C, off, offc), dout) in enumerate(zip(specs, douts)):
+            assert L.pdgn_window_gather_sum_backward_csr(B, N, k, ldy, T, P, C, off, offc, ptr(dout), ptr(rowptr), ptr(edges), ptr(dY),
+                                                         ptr(slot), 1 if i == 0 else 0, stream_of(dY)) == 0
+        res.append(dY)
+    assert torch.equal(res[0], res[1]) and torch.isfinite(res[1]).all()
+    assert int(slot.max()) == int(res[1].abs().max().view(torch.int32))

@@ -30,7 +30,7 @@ rowptr = torch.empty(b, n + 1, dtype=torch.int32, device="cuda"); edges = torch.
 scr2 = torch.empty(2 * b * n, dtype=torch.int32, device="cuda")
 L.pdgn_knn_graph_transpose(b, n, k, ptr(idx), ptr(rowptr), ptr(edges), ptr(scr2), stream_of(Y))
 dout = torch.randn(b, n, P, C, device="cuda"); dY = torch.empty(b, n, ldy, device="cuda")
-e = t(lambda: L.pdgn_window_gather_sum_backward_csr(b, n, k, ldy, T, P, C, 0, T * C, ptr(dout), ptr(rowptr), ptr(edges), ptr(dY), stream_of(Y)))
+e = t(lambda: L.pdgn_window_gather_sum_backward_csr(b, n, k, ldy, T, P, C, 0, T * C, ptr(dout), ptr(rowptr), ptr(edges), ptr(dY), None, 0, stream_of(Y)))
 print("wgs_bwd_csr %.1f us" % e)
 # conv2's neighbour half at stage 4: T = k = 10 taps, one position, C = 2*Fout = 512
 T2, P2, C2 = 10, 1, 512
@@ -38,5 +38,5 @@ ldy2 = T2 * C2 + C2
 Y2 = torch.randn(b, n, ldy2, device="cuda"); out2 = torch.empty(b, n, P2, C2, device="cuda")
 dout2 = torch.randn(b, n, P2, C2, device="cuda"); dY2 = torch.empty(b, n, ldy2, device="cuda")
 f2 = t(lambda: L.pdgn_window_gather_sum(b, n, k, ldy2, T2, P2, C2, 0, T2 * C2, ptr(Y2), ptr(idx), ptr(bias), C, ptr(out2), stream_of(Y)))
-g2 = t(lambda: L.pdgn_window_gather_sum_backward_csr(b, n, k, ldy2, T2, P2, C2, 0, T2 * C2, ptr(dout2), ptr(rowptr), ptr(edges), ptr(dY2), stream_of(Y)))
+g2 = t(lambda: L.pdgn_window_gather_sum_backward_csr(b, n, k, ldy2, T2, P2, C2, 0, T2 * C2, ptr(dout2), ptr(rowptr), ptr(edges), ptr(dY2), None, 0, stream_of(Y)))
 print("conv2 half (T=10, P=1, C=512): wgs_fwd %.1f us | wgs_bwd_csr %.1f us" % (f2, g2))
