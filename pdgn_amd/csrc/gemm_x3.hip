@@ -160,6 +160,18 @@ __device__ __forceinline__ float x3_row_sum(float v) {
 // weight by pdgn_split_bf16x3 with the same round-to-nearest remainders the loader computes: its quads are loaded part by part
 // (8 B per part and lane) and go to LDS as they are -- none of the 22 vector instructions per quad, a third of the split work
 // of a 256 x 128 tile.  Same parts, same products, same order: results are bit-identical to the unsplit operand's.
+// NP: parts per operand value.  3: the bf16 form above.  2 (round 5, MS = 32 only): each operand is multiplied by a power of two
+// 2^e, e = 14 - floor(log2 max |x|) over the WHOLE operand (exact; max |x| 2^e in [2^14, 2^15): inside fp16's range), and split
+// as x 2^e = h + l with h = rn16(x 2^e), l = rn16 of the exact remainder: 22 + 1 significant bits while |x| is within 2^-16 of
+// the operand's largest value, an absolute 2^-39 max |x| below (fp16's subnormal spacing).  A product is THREE partial products
+// on v_mfma_f32_32x32x16_f16 -- al wh + ah wl + ah wh, each exact in the fp32 accumulator's input -- and the accumulators are
+// multiplied by 2^-e_A, then 2^-e_W in front of the epilogue (exact).  Half the matrix-core work, two thirds of the LDS image,
+// 7 instead of 11 vector instructions per pair of values in the split; per product |err| <~ 2^-21 |a w| in the worst case
+// (al wl dropped + the two representation errors), in a sum far below the fp32 accumulation's own rounding, of which this
+// form does half as much: against fp64 its results are the closest of the three forms (tools/x2_check.py).  The maxima
+// arrive as 256 partial maxima per operand (p.max_a / p.max_w: x2_absmax_kernel, or the kernel that wrote the operand),
+// reduced by every workgroup itself in its prologue; a pre-split second operand (two fp16 planes, already scaled) carries its
+// exponent behind its planes.  Which launches take this form: x2_pays (host side).
 template <int TM, int TN, int WM, int WN, int OCC, bool ATOMIC, bool WT, bool AT, bool EPI = false, bool PW = false, int MS = 32, int NP = 3>
 __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_x3_kernel(const NtArgs p) {
     static_assert(!PW || (!WT && !AT), "pre-split second operand: row-major (N x K) planes only");
@@ -187,7 +199,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_x3_kernel(const NtArgs
     const int v = xcd * gq + min(xcd, gr) + (pid >> 3);
 
     const int KC = p.kchunks;
-    // NP = 2: the operands' power-of-two scales (p.exps: exponent of A, of W; fp16 holds 2^-14 .. 2^16) and the result's
+    // NP = 2: the operands' power-of-two scales (from their partial maxima) and the result's
     float scA = 1.f, scW = 1.f, unA = 1.f, unW = 1.f;
     if (NP == 2) {
         static_assert(NP != 2 || NTH == X2_PARTS, "one partial maximum per thread");
