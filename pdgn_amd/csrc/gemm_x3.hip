@@ -986,13 +986,15 @@ static bool x3_shape16(int cfg_index, bool atomic, bool epi, bool pw);
 // The workspace is the CALLER's (kernels never allocate, and an allocation under a stream capture would end the capture):
 // pdgn_gemm_tail_workspace_floats says how much a problem's tail wants, pdgn_gemm_set_tail_workspace hands a buffer to the NEXT
 // contraction call of the calling thread (thread-local, consumed by that call); without one the atomic form runs.
-static thread_local float *x3_tail_ws = nullptr;
+static thread_local float *x3_tail_ws = nullptr;            // handed in for the NEXT contraction call (pdgn_gemm_set_tail_workspace)
 static thread_local long long x3_tail_ws_floats = 0;
+static thread_local float *x3_cur_ws;                       // ... taken into the call in progress (X3Handover, below)
+static thread_local long long x3_cur_ws_floats;
 static float *x3_take_workspace(size_t floats) {
     static const bool off = [] { const char *e = getenv("PDGN_X3_SK_WS"); return e && e[0] == '0'; }();   // 0: the atomic tails (A/B)
-    float *p = (!off && x3_tail_ws && (size_t)x3_tail_ws_floats >= floats) ? x3_tail_ws : nullptr;
-    x3_tail_ws = nullptr;
-    x3_tail_ws_floats = 0;
+    float *p = (!off && x3_cur_ws && (size_t)x3_cur_ws_floats >= floats) ? x3_cur_ws : nullptr;
+    x3_cur_ws = nullptr;
+    x3_cur_ws_floats = 0;
     return p;
 }
 
@@ -1128,6 +1130,23 @@ const unsigned *x2_scan(const float *X, long long rows, int cols, int ld, hipStr
     return sl;
 }
 static thread_local const unsigned *x2_next_max_a = nullptr, *x2_next_max_w = nullptr;     // handed in for the NEXT contraction call's operands
+
+// What the caller handed over for "the next contraction call" (a tail workspace, operand maxima) belongs to THAT call, whether it
+// launches anything or returns an error first: every public entry point opens with an X3Handover, which takes the pending
+// hand-overs into the call (x3_cur_*: what launch() consumes) and leaves nothing behind for a later call to pick up by mistake.
+static thread_local const unsigned *x2_cur_max_a = nullptr, *x2_cur_max_w = nullptr;
+struct X3Handover {
+    X3Handover() {
+        x3_cur_ws = x3_tail_ws; x3_cur_ws_floats = x3_tail_ws_floats;
+        x2_cur_max_a = x2_next_max_a; x2_cur_max_w = x2_next_max_w;
+        x3_tail_ws = nullptr; x3_tail_ws_floats = 0;
+        x2_next_max_a = x2_next_max_w = nullptr;
+    }
+    ~X3Handover() {
+        x3_cur_ws = nullptr; x3_cur_ws_floats = 0;
+        x2_cur_max_a = x2_cur_max_w = nullptr;
+    }
+};
 
 // gemm_x3_16.hip: instance (tile cfg, flags = ATOMIC | WT << 1 | AT << 2 | EPI << 3 | PW << 4) of gemm_x3_kernel<..., 16>
 void x3_launch16(int cfg, int flags, int grid, hipStream_t s, const NtArgs &a);
@@ -1270,8 +1289,8 @@ struct X3Cfg {
         a.max_a = a.max_w = nullptr;
         // two parts or three: pre-split planes say it themselves; otherwise where it pays (x2_pays: mode 2, this tile, enough
         // matrix-core work per byte that still has to be scanned for its maximum)
-        const unsigned *hand_a = x2_next_max_a, *hand_w = x2_next_max_w;
-        x2_next_max_a = x2_next_max_w = nullptr;
+        const unsigned *hand_a = x2_cur_max_a, *hand_w = x2_cur_max_w;
+        x2_cur_max_a = x2_cur_max_w = nullptr;
         const bool two = Wp ? parts == 2
                             : x2_pays(CFG, m, n, k, (hand_a ? 0 : (long long)m * k * 4) + (hand_w ? 0 : (long long)n * k * 4));
         if (two && CFG != 0) return PDGN_ERR_INVALID;              // (two-part planes for a problem the other tiles take: x2_pays said no)
@@ -1463,6 +1482,7 @@ static int x3_dispatch(long long m, int n, int k, const float *A, int lda, const
 extern "C" int pdgn_gemm_nt(long long m, int n, int k, const float *A, int lda, const float *W, int ldw,
                             const float *bias, const float *addend, int ldadd, float *C, int ldc, float *stat_part,
                             pdgn_stream_t stream) {
+    const X3Handover handover;                                 // (pending workspace / maxima belong to this call, even if it is refused)
     if (!x3_mode()) return fp32_gemm_nt(m, n, k, A, lda, W, ldw, bias, addend, ldadd, C, ldc, stat_part, stream);
     if (!x3_args_ok(m, n, k, lda, ldw, ldadd, ldc, addend, false)) return PDGN_ERR_INVALID;
     return x3_dispatch<false>(m, n, k, A, lda, W, ldw, bias, addend, ldadd, C, ldc, stat_part, (hipStream_t)stream);
@@ -1473,6 +1493,7 @@ extern "C" int pdgn_gemm_nt(long long m, int n, int k, const float *A, int lda, 
 extern "C" int pdgn_gemm_nn(long long m, int n, int k, const float *A, int lda, const float *Wt, int ldw,
                             const float *bias, const float *addend, int ldadd, float *C, int ldc, float *stat_part,
                             pdgn_stream_t stream) {
+    const X3Handover handover;                                 // (pending workspace / maxima belong to this call, even if it is refused)
     if (!x3_mode()) return fp32_gemm_nn(m, n, k, A, lda, Wt, ldw, bias, addend, ldadd, C, ldc, stat_part, stream);
     if (!x3_args_ok(m, n, k, lda, ldw, ldadd, ldc, addend, true)) return PDGN_ERR_INVALID;
     return x3_dispatch<true>(m, n, k, A, lda, Wt, ldw, bias, addend, ldadd, C, ldc, stat_part, (hipStream_t)stream);
@@ -1487,6 +1508,7 @@ extern "C" int pdgn_gemm_nt_ex(long long m, int n, int k, const float *A, int ld
                                const float *addend, int ldadd, float *C, int ldc, float *stat_part, const float *row_bias,
                                int ld_rb, int rows_per_group, int act, const float *gate, int ldgate, int transposed_w,
                                pdgn_stream_t stream) {
+    const X3Handover handover;                                 // (pending workspace / maxima belong to this call, even if it is refused)
     if (!x3_mode())
         return fp32_gemm_nt_ex(m, n, k, A, lda, W, ldw, bias, addend, ldadd, C, ldc, stat_part, row_bias, ld_rb, rows_per_group,
                                act, gate, ldgate, transposed_w, stream);
@@ -1509,6 +1531,7 @@ extern "C" int pdgn_gemm_nt_ps(long long m, int n, int k, const float *A, int ld
                                long long wplane, int parts, const float *bias, const float *addend, int ldadd, float *C, int ldc,
                                float *stat_part, const float *row_bias, int ld_rb, int rows_per_group, int act, const float *gate,
                                int ldgate, pdgn_stream_t stream) {
+    const X3Handover handover;                                 // (pending workspace / maxima belong to this call, even if it is refused)
     if (!x3_mode() || !Wplanes || (parts != 3 && parts != 2)) return PDGN_ERR_INVALID;
     if (!x3_args_ok(m, n, k, lda, ldw, ldadd, ldc, addend, false)) return PDGN_ERR_INVALID;
     if (wplane < (long long)(n - 1) * ldw + k || wplane >= (1LL << 28) || ldw % 8 || wplane % 8 || ((uintptr_t)Wplanes & 15))
@@ -1581,6 +1604,7 @@ extern "C" int pdgn_gemm_aux_symbols(const void **reduce, const void **scan) {
 // small ones.
 extern "C" int pdgn_gemm_tn_big(long long m, int n, int k, const float *dY, int ldy, const float *X, int ldx, float *dW,
                                 int dw_is_zero, pdgn_stream_t stream) {
+    const X3Handover handover;                                 // (pending workspace / maxima belong to this call, even if it is refused)
     if (!x3_mode()) return fp32_gemm_tn_big(m, n, k, dY, ldy, X, ldx, dW, stream);       // (zero-fills dW itself in any case)
     if (m < 1 || n < 4 || k < 4 || n % 4 || k % 4 || ldy % 4 || ldx % 4 || ldy < n || ldx < k || ldy >= (1 << 19) ||
         ldx >= (1 << 19) || m > 0x7fffffffLL * 16)

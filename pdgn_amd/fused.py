@@ -63,8 +63,11 @@ def take_maxima(dy):
     if ent is None:
         return None
     src = ent[0]()
-    return ent[1] if src is not None and (src is dy or dy._base is src or (dy._base is not None and dy._base is src._base)) \
-        and dy.numel() == src.numel() else None
+    # the same elements: the marked tensor itself, or a view of the same storage that starts where it starts, has as many
+    # elements and is, like it, contiguous (a reshape)
+    same = src is not None and (src is dy or (dy.numel() == src.numel() and dy.is_contiguous() and src.is_contiguous()
+                                              and (dy._base is src or (dy._base is not None and dy._base is src._base))))
+    return ent[1] if same else None
 
 
 # A second side channel of the same kind: BNActMaxPool's backward, when the dense layer in front of it is frozen, computes

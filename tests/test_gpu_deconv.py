@@ -1681,3 +1681,32 @@ def test_gather_sum_adjoint_leaves_the_maxima_of_dy(B, N, k, specs):
         res.append(dY)
     assert torch.equal(res[0], res[1]) and torch.isfinite(res[1]).all()
     assert int(slot.max()) == int(res[1].abs().max().view(torch.int32))
+
+
+def test_handovers_belong_to_the_next_call_only():
+    """A tail workspace and operand maxima handed over for "the next contraction call" are consumed by THAT call even when it is
+    refused: a later call must not pick them up.  Here the refused call gets maxima of zero (exponent 126: every product would
+    overflow) and a workspace that is then freed; the valid call after it scans its operands itself and is right."""
+    import ctypes
+    from pdgn_amd import _lib, fused
+    from pdgn_amd._lib import ptr, stream_of
+    L = _lib.lib()
+    _lib.set_gemm_mode("x2")
+    M, N, K = 20000, 512, 2560
+    g = torch.Generator(device="cuda").manual_seed(11)
+    a = torch.randn(M, K, device="cuda", generator=g)
+    w = torch.randn(N, K, device="cuda", generator=g)
+    c = torch.empty(M, N, device="cuda")
+    zeros = torch.zeros(256, dtype=torch.int32, device="cuda")
+    ws = fused._tail_workspace(L, M, N, K, False, a.device)
+    assert L.pdgn_gemm_set_operand_scales(ptr(zeros), ptr(zeros)) == 0
+    assert L.pdgn_gemm_nt(ctypes.c_longlong(M), 3, K, ptr(a), K, ptr(w), K, None, None, 0, ptr(c), N, None, stream_of(a)) == -1     # n % 4: refused
+    del ws
+    assert L.pdgn_gemm_nt(ctypes.c_longlong(M), N, K, ptr(a), K, ptr(w), K, None, None, 0, ptr(c), N, None, stream_of(a)) == 0
+    ref = a.double() @ w.double().t()
+    mag = a.double().abs() @ w.double().abs().t()
+    assert torch.isfinite(c).all() and ((c.double() - ref).abs() / mag).max().item() < 1e-6
+    # ... and handed-over maxima ARE used by the call they are meant for (zero maxima: the scaled operands overflow fp16)
+    assert L.pdgn_gemm_set_operand_scales(ptr(zeros), ptr(zeros)) == 0
+    assert L.pdgn_gemm_nt(ctypes.c_longlong(M), N, K, ptr(a), K, ptr(w), K, None, None, 0, ptr(c), N, None, stream_of(a)) == 0
+    assert not torch.isfinite(c).all()
