@@ -73,20 +73,26 @@ __device__ __forceinline__ int x2_exponent(unsigned maxbits) {     // (NaN / Inf
     const int e = 14 - ((int)(maxbits >> 23) - 127);
     return e > 126 ? 126 : (e < -126 ? -126 : e);
 }
-// max over the workgroup's 256 threads of two values each; scratch: 8 words of LDS; every thread must call (two barriers)
+// max over the workgroup's threads (a multiple of 64, at most 512) of two values each; scratch: 16 words of LDS; every thread must
+// call (two barriers)
 __device__ __forceinline__ void x2_block_max2(unsigned &a, unsigned &b, unsigned *scratch) {
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) {
         a = max(a, (unsigned)__shfl_xor((int)a, o));
         b = max(b, (unsigned)__shfl_xor((int)b, o));
     }
+    const int nw = (int)(blockDim.x >> 6);
     if ((threadIdx.x & 63) == 0) {
         scratch[threadIdx.x >> 6] = a;
-        scratch[4 + (threadIdx.x >> 6)] = b;
+        scratch[8 + (threadIdx.x >> 6)] = b;
     }
     __syncthreads();
-    a = max(max(scratch[0], scratch[1]), max(scratch[2], scratch[3]));
-    b = max(max(scratch[4], scratch[5]), max(scratch[6], scratch[7]));
+    a = scratch[0];
+    b = scratch[8];
+    for (int i = 1; i < nw; ++i) {
+        a = max(a, scratch[i]);
+        b = max(b, scratch[8 + i]);
+    }
     __syncthreads();
 }
 

@@ -185,7 +185,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_x3_kernel(const NtArgs
     constexpr int PART_A = BM * 64, PART_W = BN * 64, STAGE = NP * (PART_A + PART_W);
     // STG: the result leaves through a per-wave LDS staging block (32 rows x 128 B) so that a store instruction covers whole
     // 128-B lines (8 rows) instead of 32 B of each of 32 rows -- for the one-workgroup-per-CU tiles, whose LDS has the room
-    constexpr bool STG = OCC == 1 && !ATOMIC && !(X3_ABLATE & 128);
+    constexpr bool STG = OCC == 1 && !ATOMIC && !(X3_ABLATE & 128) && 2 * STAGE + NW * 4096 <= 160 * 1024;      // (and the CU's 160 KB hold it)
     __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * STAGE + (STG ? NW * 4096 : 0)];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -202,8 +202,9 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_x3_kernel(const NtArgs
     // NP = 2: the operands' power-of-two scales (from their partial maxima) and the result's
     float scA = 1.f, scW = 1.f, unA = 1.f, unW = 1.f;
     if (NP == 2) {
-        static_assert(NP != 2 || NTH == X2_PARTS, "one partial maximum per thread");
-        unsigned ma = p.max_a ? p.max_a[tid] : 0x47000000u, mw = (!PW && p.max_w) ? p.max_w[tid] : 0x47000000u;      // (none: 2^15, e = 0)
+        static_assert(NP != 2 || NTH >= X2_PARTS, "one partial maximum per thread");
+        const bool mine = tid < X2_PARTS;
+        unsigned ma = p.max_a ? (mine ? p.max_a[tid] : 0u) : 0x47000000u, mw = (!PW && p.max_w) ? (mine ? p.max_w[tid] : 0u) : 0x47000000u;      // (none: 2^15, e = 0)
         x2_block_max2(ma, mw, reinterpret_cast<unsigned *>(smem));
         const int ea = __builtin_amdgcn_readfirstlane(x2_exponent(ma));
         const int ew = PW ? __builtin_amdgcn_readfirstlane(*reinterpret_cast<const int *>(p.Wp + 2 * p.wplane))
@@ -1151,8 +1152,8 @@ struct X3Handover {
 // gemm_x3_16.hip: instance (tile cfg, flags = ATOMIC | WT << 1 | AT << 2 | EPI << 3 | PW << 4) of gemm_x3_kernel<..., 16>
 void x3_launch16(int cfg, int flags, int grid, hipStream_t s, const NtArgs &a);
 // gemm_x3_h2.hip: the same of gemm_x3_kernel<..., 32, 2> (two fp16 parts), and an instance's host symbol
-void x3_launch_h2(int flags, int grid, hipStream_t s, const NtArgs &a);
-const void *x3_symbol_h2(int flags);
+void x3_launch_h2(int flags, int grid, hipStream_t s, const NtArgs &a, bool eight_waves);
+const void *x3_symbol_h2(int flags, bool eight_waves);
 // Where the two-part form pays (measured, tools/x2_shapes.py: every contraction of an iteration alone in both forms): it halves
 // the matrix-core work of a launch and needs the operands' maxima first -- a pass over every operand that does not bring them
 // along.  On the 256 x 128 tile, with a reduction of at least 128 and >= 20 GFLOP, the products are the larger part of the
@@ -1230,7 +1231,7 @@ struct X3Cfg {
         // the matrix instruction is chosen per instance class (tile, atomic / extended epilogue / pre-split operand): nt_switches().shape16
         // (the 16x16x32 instances live in their own translation unit, gemm_x3_16.hip: the two compile side by side)
         const int flags = (ATOMIC ? 1 : 0) | (WT ? 2 : 0) | (AT ? 4 : 0) | (EPI ? 8 : 0) | (PW ? 16 : 0);
-        if (two_part) x3_launch_h2(flags, grid, s, a);             // (256 x 128 tiles only: x2_pays)
+        if (two_part) x3_launch_h2(flags, grid, s, a, a.stat_part == nullptr);      // (256 x 128 tiles only: x2_pays; eight waves unless BatchNorm partials are emitted)
         else if (x3_shape16(CFG, ATOMIC, EPI, PW)) x3_launch16(CFG, flags, grid, s, a);
         else hipLaunchKernelGGL((gemm_x3_kernel<TM, TN, WM, WN, OCC, ATOMIC, WT, AT, EPI, PW, 32>), dim3(grid), dim3(64 * WM * WN), 0, s, a);
     }
@@ -1353,6 +1354,8 @@ struct X3Cfg {
 
 typedef X3Cfg<2, 2, 2, 2, 1, 660, 1> X3Square;   // 128 x 128, 4 waves of 64 x 64 (96 KB of LDS): one per CU
 typedef X3Cfg<4, 2, 2, 2, 1, 760, 0> X3Big;      // 256 x 128, 4 waves of 128 x 64 (144 KB of LDS): one per CU, one wave per SIMD
+// (the bf16 form as eight waves of 64 x 64 -- what the two-part form runs on, gemm_x3_h2.hip -- has no room for the result staging
+// (147 + 32 KB of LDS) and measured 1055 -> 1027 us on conv2's dense half, 860 -> 905 on the per-point product: not built)
 typedef X3Cfg<2, 1, 2, 2, 2, 540, 2> X3Narrow;   // 128 x 64, 4 waves of 64 x 32 (72 KB of LDS): two per CU
 
 NtSwitches &nt_switches() {
@@ -1576,7 +1579,7 @@ extern "C" int pdgn_gemm_nt_ps_launch_info(long long m, int n, int k, int parts,
     if (parts == 2) {
         if (cfg != 0) return PDGN_ERR_INVALID;
         *grid = X3Big::plan(m, n, k, true).grid_dp;
-        *sym = x3_symbol_h2(16);
+        *sym = x3_symbol_h2(16, true);
     } else if (cfg == 0) {
         *grid = X3Big::plan(m, n, k, true).grid_dp;
         if (!s16) *sym = (const void *)gemm_x3_kernel<4, 2, 2, 2, 1, false, false, false, false, true, 32>;

@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void split_f16x2_kernel(int rows, int cols, co
     __shared__ unsigned short tile[2][32][33];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
-    __shared__ unsigned red[8];
+    __shared__ unsigned red[16];
     unsigned mx = maxima[threadIdx.x], unused = 0;                // X2_PARTS = 256 = the workgroup
     x2_block_max2(mx, unused, red);
     const int e = x2_exponent(mx);

@@ -17,7 +17,7 @@ def _x3_class(name):
     tm, tn, wm, wn, occ = (int(v) for v in a[:5])
     atomic, wt, at, epi, pw = (v == "true" for v in a[5:10])
     ms = int(a[10]) if len(a) > 10 else 32
-    tile = {(4, 2, 1): 0, (2, 2, 1): 1, (2, 1, 2): 2}[(tm, tn, occ)]
+    tile = {(4, 2, 2, 1): 0, (2, 2, 4, 1): 0, (2, 2, 2, 1): 1, (2, 1, 2, 2): 2}[(tm, tn, wm, occ)]      # (the 256 x 128 tile: four waves of 128 x 64 or eight of 64 x 64)
     return tile, (3 if epi else 2 if atomic else 1 if pw else 0), ms
 
 
