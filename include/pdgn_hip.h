@@ -353,7 +353,8 @@ int pdgn_gemm_set_mode(int mode);
  * 256 x 128 tile, k >= 128, >= 20 GFLOP and at most 4.5 bytes to scan per kflop (measured: tools/x2_shapes.py).
  * Two parts: an operand is multiplied by a power of two 2^e, e = 14 - floor(log2 max |x|) over the whole operand (so that nothing
  * leaves fp16's range: max |x| 2^e in [2^14, 2^15)), split as x 2^e = h + l (round-to-nearest fp16 of the value and of the exact
- * remainder: |err| <= 2^-23 |x| for values within 2^-16 of the operand's largest, an absolute 2^-39 max |x| below), a product is the
+ * remainder: |err| <= 2^-23 |x| for values within 2^-16 of the operand's largest, an absolute 2^-39 max |x| below -- a norm-wise
+ * bound per operand, as for any block-scaled format; mode 1 needs no scale and keeps every value's own 24 bits), a product is the
  * three fp16 MFMA products al wh + ah wl + ah wh accumulated in fp32, and the result is multiplied by 2^-(e_A + e_W) (exact).  Per
  * product |err| <= ~2^-21 |a w| in the worst case; in sums the fp32 accumulation all modes share dominates, of which this form does
  * half as much: measured against fp64 BELOW the other two modes (bench.py gemm_accuracy, tests/test_gpu_deconv.py, tools/x2_check.py:
