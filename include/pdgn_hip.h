@@ -330,6 +330,10 @@ int pdgn_gemm_nt_ps(long long m, int n, int k, const float *A, int lda, const un
  * consumes it -- the tail stores partial tiles there and a small kernel adds them into C (deterministic, no zero-fill); without one
  * it adds them with fp32 atomics.  The buffer must stay valid until that call's launches have run.  No reference counterpart. */
 long long pdgn_gemm_tail_workspace_floats(long long m, int n, int k, int with_stats);
+/* The same for pdgn_gemm_tn_big (dW = dY^T X: few output tiles, the reduction over the m rows split in k slices): with a workspace of
+ * this many floats handed over the same way the slices' partial tiles are summed in a fixed order (no atomics, no zero-fill of dW,
+ * bit-identical from run to run); 0: the call does not split. */
+long long pdgn_gemm_tn_big_workspace_floats(long long m, int n, int k);
 int pdgn_gemm_set_tail_workspace(float *ws, long long floats);
 /* The kernel instance (host symbol; NULL for the 16x16x32 arm) and grid of the plain data-parallel launch of pdgn_gemm_nt_ps(m, n, k)
  * under the switches in force: for measurements that look that launch up in a recorded iteration.  Host-side only. */

@@ -1017,26 +1017,44 @@ __global__ __launch_bounds__(256) void x3_sk_reduce_kernel(const float *__restri
     const int mrows = (int)min((long long)BM, M - m0), ncols = min(BN, N - n0);
     const int q4 = BN / 4;
     const int rows_per = BM / (int)gridDim.y;                     // gridDim.y workgroups share a tile by rows (48 tiles alone fill a fifth of the chip)
-    for (int e = threadIdx.x; e < rows_per * q4; e += 256) {
+    const int ne = rows_per * q4;                                  // float4 elements of this workgroup
+    // few elements per workgroup (few tiles, many slices: a 256 x 128 weight gradient summed over 128 slices): G threads share an
+    // element, thread g takes the slices g, g + G, ... in order and the G partial sums are added in g order -- a fixed order still
+    const int G = (!seg && ne < 256) ? 256 / ne : 1;
+    __shared__ float4 red[256];
+    for (int e0 = 0; e0 < ne; e0 += 256 / G) {
+        const int e = e0 + (int)threadIdx.x % (256 / G), g = (int)threadIdx.x / (256 / G);
         const int row = blockIdx.y * rows_per + e / q4, c4 = (e % q4) * 4;
-        if (row >= mrows || c4 >= ncols) continue;                  // (N % 4 == 0: a float4 is all in or all out)
-        float4 a;
-        if (!seg) {
-            a = *reinterpret_cast<const float4 *>(ws + ((size_t)t * BM + row) * BN + c4);
-            for (int sl = 1; sl < S; ++sl) {
+        const bool in = e < ne && row < mrows && c4 < ncols;       // (N % 4 == 0: a float4 is all in or all out)
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (in && !seg) {
+            bool have = false;
+#pragma unroll 4                                                   // (several slices' loads in flight; the additions keep their order)
+            for (int sl = g; sl < S; sl += G) {
                 const float4 b = *reinterpret_cast<const float4 *>(ws + (((size_t)sl * T + t) * BM + row) * BN + c4);
-                a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+                if (!have) { a = b; have = true; }
+                else { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
             }
-        } else {
+        } else if (in) {
             const long long f0 = (long long)t * KC, f1 = f0 + KC - 1;
             const long long v0 = f0 / per, v1 = f1 / per;
-            a = make_float4(0.f, 0.f, 0.f, 0.f);
             for (long long vv = v0; vv <= v1; ++vv) {
                 const size_t slot = (size_t)(vv * seg + (t - (vv * per) / KC));
                 const float4 b = *reinterpret_cast<const float4 *>(ws + (slot * BM + row) * BN + c4);
                 a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
             }
         }
+        if (G > 1) {                                               // (uniform over the workgroup)
+            red[threadIdx.x] = a;
+            __syncthreads();
+            if (g == 0)
+                for (int gg = 1; gg < G; ++gg) {
+                    const float4 b = red[gg * (256 / G) + (int)threadIdx.x];
+                    a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+                }
+            __syncthreads();
+        }
+        if (!in || g != 0) continue;
         if (bias) { const float4 b = *reinterpret_cast<const float4 *>(bias + n0 + c4); a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
         if (addend) {
             const float4 b = *reinterpret_cast<const float4 *>(addend + (m0 + row) * ldadd + n0 + c4);
@@ -1148,6 +1166,14 @@ struct X3Handover {
         x2_cur_max_a = x2_cur_max_w = nullptr;
     }
 };
+
+// workgroups per tile of x3_sk_reduce_kernel: 8, more when there are few tiles (a weight gradient of 2 tiles in 128 slices is 128
+// dependent loads per thread: 64 us with 16 workgroups)
+static int x3_reduce_split(int tiles) {
+    int y = 8;
+    while (tiles * y < 512 && y < 64) y *= 2;
+    return y;
+}
 
 // gemm_x3_16.hip: instance (tile cfg, flags = ATOMIC | WT << 1 | AT << 2 | EPI << 3 | PW << 4) of gemm_x3_kernel<..., 16>
 void x3_launch16(int cfg, int flags, int grid, hipStream_t s, const NtArgs &a);
@@ -1269,6 +1295,21 @@ struct X3Cfg {
     }
     // floats of workspace the stream-K tail of (m, n, k) wants (0: no tail)
     static long long tail_floats(long long m, int n, int k, bool allow_sk) { return tail_layout(plan(m, n, k, allow_sk)).floats; }
+    // weight gradients (split-K over few output tiles): the number of NON-EMPTY k slices per tile, and the workspace their partial
+    // tiles want (0: the launch is not a split-K one)
+    static int at_slices(const Plan &pl) {
+        const long long T = (long long)pl.tiles_m * pl.tiles_n;
+        const int slots = nt_cus() * WG_PER_CU;
+        const int S = (int)(slots / T) < pl.kchunks ? (int)(slots / T) : pl.kchunks;
+        const int per = (pl.kchunks + S - 1) / S;
+        return (pl.kchunks + per - 1) / per;
+    }
+    static long long at_floats(long long m, int n, int k) {
+        const Plan pl = plan(m, n, k, true);
+        const long long T = (long long)pl.tiles_m * pl.tiles_n;
+        if (T > nt_cus() * WG_PER_CU || !nt_switches().splitk) return 0;
+        return (long long)at_slices(pl) * T * BM * BN;
+    }
 
     template <bool WT, bool AT = false>
     static int launch(long long m, int n, int k, const float *A, int lda, const float *W, int ldw, const float *bias,
@@ -1313,8 +1354,19 @@ struct X3Cfg {
             // panel is fetched from HBM once per tile (conv2's dense half: 4.4 GB for 0.8 GB of operands).
             const int slots = nt_cus() * WG_PER_CU;
             const int S = (int)(slots / T) < pl.kchunks ? (int)(slots / T) : pl.kchunks;
-            if (!prezeroed && hipMemsetAsync(C, 0, (size_t)m * ldc * sizeof(float), s) != hipSuccess) return pdgn_launch_status();
             a.tile_begin = 0; a.tile_end = (int)T; a.sk_split = (int)T; a.sk_per_wg = (pl.kchunks + S - 1) / S;
+            // with a workspace (pdgn_gemm_tn_big_workspace_floats): the slices' partial tiles go there and x3_sk_reduce_kernel sums
+            // them in slice order -- no atomics, no zero-fill, the same bits every run; without one: fp32 atomics into a zeroed dW
+            const int s_ws = at_slices(pl);
+            float *ws = x3_take_workspace((size_t)s_ws * T * BM * BN);
+            if (ws) {
+                a.sk_ws = ws;
+                go<false, WT, AT, false>((int)T * s_ws, s, a, two);
+                hipLaunchKernelGGL(x3_sk_reduce_kernel, dim3((int)T, x3_reduce_split((int)T)), dim3(256), 0, s, ws, s_ws, (int)T, BM, BN, 0, pl.tiles_m, pl.tiles_n, m, n,
+                                   C, ldc, nullptr, nullptr, 0, 0, 0LL, pl.kchunks);
+                return pdgn_launch_status();
+            }
+            if (!prezeroed && hipMemsetAsync(C, 0, (size_t)m * ldc * sizeof(float), s) != hipSuccess) return pdgn_launch_status();
             go<true, WT, AT, false>((int)T * S, s, a, two);
             return pdgn_launch_status();
         }
@@ -1341,7 +1393,7 @@ struct X3Cfg {
             a.bias = nullptr; a.addend = nullptr;                  // (the reduce adds them)
             if (CAN_PW && Wp) go<false, false, false, false, CAN_PW>(tl.grid, s, a, two);
             else go<false, WT, AT, false>(tl.grid, s, a, two);
-            hipLaunchKernelGGL(x3_sk_reduce_kernel, dim3(tl.t_tail, 8), dim3(256), 0, s, ws, tl.s_tail, tl.t_tail, BM, BN, pl.dp_tiles, pl.tiles_m,
+            hipLaunchKernelGGL(x3_sk_reduce_kernel, dim3(tl.t_tail, x3_reduce_split(tl.t_tail)), dim3(256), 0, s, ws, tl.s_tail, tl.t_tail, BM, BN, pl.dp_tiles, pl.tiles_m,
                                pl.tiles_n, m, n, C, ldc, bias, addend, ldadd, tl.seg, tl.per_flat, pl.kchunks);
         } else if (pl.grid_sk) {
             a.tile_begin = pl.dp_tiles; a.tile_end = (int)T; a.sk_per_wg = pl.sk_per_wg;
@@ -1619,6 +1671,18 @@ extern "C" int pdgn_gemm_tn_big(long long m, int n, int k, const float *dY, int 
         case 0: return X3Big::launch<true, true>(n, k, (int)m, dY, ldy, X, ldx, nullptr, nullptr, 0, dW, k, nullptr, s, NtEpi(), dw_is_zero != 0);
         case 2: return X3Narrow::launch<true, true>(n, k, (int)m, dY, ldy, X, ldx, nullptr, nullptr, 0, dW, k, nullptr, s, NtEpi(), dw_is_zero != 0);
         default: return X3Square::launch<true, true>(n, k, (int)m, dY, ldy, X, ldx, nullptr, nullptr, 0, dW, k, nullptr, s, NtEpi(), dw_is_zero != 0);
+    }
+}
+
+// Floats of workspace with which pdgn_gemm_tn_big(m, n, k) sums its k slices without atomics (pdgn_gemm_set_tail_workspace hands the
+// buffer to the next call, as for the stream-K tails); 0: that call does not split (or runs on the fp32 instructions).
+extern "C" long long pdgn_gemm_tn_big_workspace_floats(long long m, int n, int k) {
+    if (!x3_mode() || m < 1 || n < 4 || k < 4) return 0;
+    const int red = (int)(m > 0x7fffffff ? 0x7fffffff : m);
+    switch (x3_pick(n, k, red, false)) {
+        case 0: return X3Big::at_floats(n, k, red);
+        case 2: return X3Narrow::at_floats(n, k, red);
+        default: return X3Square::at_floats(n, k, red);
     }
 }
 

@@ -536,10 +536,18 @@ def gemm_tn(dy, x, max_dy=None, max_x=None):
         # transposed balances them better than pdgn_gemm_tn's split (measured, tools/gemm_shapes.py: 0.70-0.94x its time);
         # smaller outputs (and, on the fp32 kernels, the two largest ones: conv2's dense half, the per-point GEMM) stay on
         # pdgn_gemm_tn
-        dwp = _zeros((dyp.shape[1], xp.shape[1]), dy.device)       # a slice of the backward pass's zero arena: no fill launch here
-        _hand_maxima(_lib.lib(), max_dy, max_x)
+        L = _lib.lib()
+        L.pdgn_gemm_tn_big_workspace_floats.restype = ctypes.c_longlong
+        need = L.pdgn_gemm_tn_big_workspace_floats(ctypes.c_longlong(m), dyp.shape[1], xp.shape[1])
+        if need > 0:                                               # the k slices' partial tiles: summed in a fixed order, no atomics
+            ws = torch.empty(need, dtype=F32, device=dy.device)
+            check(L.pdgn_gemm_set_tail_workspace(ptr(ws), ctypes.c_longlong(need)), "pdgn_gemm_set_tail_workspace")
+            dwp = torch.empty((dyp.shape[1], xp.shape[1]), dtype=F32, device=dy.device)
+        else:
+            dwp = _zeros((dyp.shape[1], xp.shape[1]), dy.device)   # a slice of the backward pass's zero arena: no fill launch here
+        _hand_maxima(L, max_dy, max_x)
         check(_lib.lib().pdgn_gemm_tn_big(ctypes.c_longlong(m), dyp.shape[1], xp.shape[1], ptr(dyp), dyp.stride(0), ptr(xp),
-                                          xp.stride(0), ptr(dwp), 1, stream_of(dy)), "pdgn_gemm_tn_big")
+                                          xp.stride(0), ptr(dwp), 0 if need > 0 else 1, stream_of(dy)), "pdgn_gemm_tn_big")      # (not zero-filled when the workspace form is expected: the atomic form, should the library take it after all, fills it itself)
         return dwp if (dyp.shape[1] == n and xp.shape[1] == k) else dwp[:n, :k]
     if dyp.stride(0) != dyp.shape[1]:
         dyp = dyp.contiguous()

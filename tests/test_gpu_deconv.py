@@ -1710,3 +1710,38 @@ def test_handovers_belong_to_the_next_call_only():
     assert L.pdgn_gemm_set_operand_scales(ptr(zeros), ptr(zeros)) == 0
     assert L.pdgn_gemm_nt(ctypes.c_longlong(M), N, K, ptr(a), K, ptr(w), K, None, None, 0, ptr(c), N, None, stream_of(a)) == 0
     assert not torch.isfinite(c).all()
+
+
+@pytest.mark.parametrize("M,N,K", [(35840, 512, 5120), (35840, 12832, 128), (17920, 256, 2560), (40000, 128, 64), (100003, 132, 68)])
+def test_weight_gradient_slices_without_atomics(M, N, K):
+    """pdgn_gemm_tn_big with a workspace (pdgn_gemm_tn_big_workspace_floats + pdgn_gemm_set_tail_workspace): the k slices' partial tiles
+    are summed by the reduce kernel in slice order -- against fp64, against the atomic form, bit-identical from run to run, dW not
+    zero-filled by anyone (poisoned with NaN here)."""
+    import ctypes
+    from pdgn_amd import _lib
+    from pdgn_amd._lib import ptr, stream_of
+    L = _lib.lib()
+    L.pdgn_gemm_tn_big_workspace_floats.restype = ctypes.c_longlong
+    need = L.pdgn_gemm_tn_big_workspace_floats(ctypes.c_longlong(M), N, K)
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    x = torch.randn(M, K, device="cuda", generator=g)
+    dy = torch.randn(M, N, device="cuda", generator=g)
+    rows = min(M, 20000)
+    ref = dy[:rows].double().t() @ x[:rows].double()
+    mag = dy[:rows].double().abs().t() @ x[:rows].double().abs() + 1.0
+
+    def run(with_ws, m):
+        dw = torch.full((N, K), float("nan"), device="cuda")
+        n_ = L.pdgn_gemm_tn_big_workspace_floats(ctypes.c_longlong(m), N, K)
+        ws = torch.empty(max(n_, 1), device="cuda")
+        if with_ws and n_:
+            assert L.pdgn_gemm_set_tail_workspace(ptr(ws), ctypes.c_longlong(n_)) == 0
+        assert L.pdgn_gemm_tn_big(ctypes.c_longlong(m), N, K, ptr(dy), N, ptr(x), K, ptr(dw), 0, stream_of(dy)) == 0
+        torch.cuda.synchronize()
+        return dw
+    a, b, c = run(True, rows), run(True, rows), run(False, rows)
+    assert ((a.double() - ref).abs() / mag).max().item() < 1e-6 and ((c.double() - ref).abs() / mag).max().item() < 1e-6
+    if need:
+        assert torch.equal(a, b), "slices summed in a fixed order"
+    full = run(True, M)
+    assert torch.isfinite(full).all()
