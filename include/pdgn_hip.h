@@ -373,12 +373,17 @@ int pdgn_gemm_set_mode(int mode);
  * by the call; consumed by that call): an activation that feeds several products is scanned once, or never.
  * pdgn_split_f16x2 = pdgn_split_bf16x3 for a two-part product: two fp16 planes (h | l, already scaled) and the exponent as one
  * int32 right behind them (element offset 2 * plane_stride: the buffer holds 2 * plane_stride + 2 elements); pdgn_gemm_nt_ps takes
- * either kind of planes and is told which (parts = 3 | 2; two-part planes only for a shape the launch model gives the 256 x 128
- * tile, pdgn_gemm_nt_config, else PDGN_ERR_INVALID).  No reference counterpart. */
+ * either kind of planes and is told which (parts = 3 | 2).  No reference counterpart. */
 int pdgn_gemm_set_scale_slots(void *slots, long long bytes);
 int pdgn_absmax_partials(long long rows, int cols, const float *src, int ld, unsigned *slot, pdgn_stream_t stream);
 int pdgn_gemm_set_operand_scales(const unsigned *max_a, const unsigned *max_w);
 int pdgn_gemm_two_part(long long m, int n, int k, long long scan_bytes);
+/* The same question for a product against PRE-SPLIT planes (which kind to make: pdgn_split_f16x2 or _bf16x3): with nothing to
+ * convert for the weight the two-part loop is ahead from ~2 GFLOP on, k >= 32; two-part planes run on the 256 x 128 tile whatever
+ * pdgn_gemm_nt_config says for three parts (a launch with stat_part: only where that IS the pick, else PDGN_ERR_INVALID), and their
+ * tail workspace is pdgn_gemm_nt_ps_workspace_floats(m, n, k, parts, with_stats). */
+int pdgn_gemm_two_part_planes(long long m, int n, int k, long long scan_bytes);
+long long pdgn_gemm_nt_ps_workspace_floats(long long m, int n, int k, int parts, int with_stats);
 int pdgn_split_f16x2(int rows, int cols, const float *src, int ld_src, unsigned short *planes, int ld_planes,
                      long long plane_stride, unsigned short *planes_t, int ld_planes_t, long long plane_stride_t,
                      pdgn_stream_t stream);

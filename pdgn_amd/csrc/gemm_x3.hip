@@ -1504,6 +1504,18 @@ static int x3_pick(long long m, int n, int k, bool stats) {
     return best;
 }
 
+// Whether a product against PRE-SPLIT planes should use two-part ones (pdgn_split_f16x2) when scan_bytes of the activations would
+// still have to be scanned for their maxima: with nothing to convert for the weight the eight-wave two-part loop on the 256 x 128
+// tile is ahead of every three-part tile from ~2 GFLOP on (tools/cfg_probe.py: 17920 x 256 x 2560 153 -> 98 us, 35840 x 512 x 256
+// 68 -> 47, 17920 x 6432 x 64 136 -> 107), as long as the scan stays under 4.5 bytes per kflop.
+extern "C" int pdgn_gemm_two_part_planes(long long m, int n, int k, long long scan_bytes) {
+    if (nt_switches().mode != 2 || m < 256 || n < 4 || k < 32) return 0;
+    const double flops = 2.0 * (double)m * n * k;
+    return (flops >= 2e9 && (double)scan_bytes <= 4.5e-3 * flops) ? 1 : 0;
+}
+// The tail workspace of pdgn_gemm_nt_ps(m, n, k) for planes of `parts` parts (two-part planes always run on the 256 x 128 tile).
+extern "C" long long pdgn_gemm_nt_ps_workspace_floats(long long m, int n, int k, int parts, int with_stats);
+
 // Whether the contraction (m, n, k) runs on two parts under the switches in force when scan_bytes of its operands still have to be
 // scanned for their maxima (x2_pays): what a caller that pre-splits a weight (pdgn_split_f16x2 or _bf16x3) or hands maxima over asks first.
 extern "C" int pdgn_gemm_two_part(long long m, int n, int k, long long scan_bytes) {
@@ -1521,8 +1533,14 @@ template <bool WT>
 static int x3_dispatch(long long m, int n, int k, const float *A, int lda, const float *W, int ldw, const float *bias,
                        const float *addend, int ldadd, float *C, int ldc, float *stat_part, hipStream_t s,
                        const NtEpi &epi = NtEpi(), const unsigned short *Wp = nullptr, long long wplane = 0, int parts = 3) {
-    const int cfg = x3_pick(m, n, k, stat_part != nullptr || epi.any());
-    if (Wp && parts == 2 && cfg != 0) return PDGN_ERR_INVALID;    // two-part planes: only where the launch model picks the 256 x 128 tile (pdgn_gemm_nt_config)
+    // two-part planes run on the 256 x 128 tile whatever the launch model would pick for three parts (with the maxima handed in
+    // and nothing to convert for the weight the eight-wave two-part loop is ahead from ~2 GFLOP on: tools/cfg_probe.py); a
+    // launch that emits BatchNorm partials keeps the geometry pdgn_gemm_nt_stat_rows / _stat_block_rows promised
+    int cfg = x3_pick(m, n, k, stat_part != nullptr || epi.any());
+    if (Wp && parts == 2) {
+        if (stat_part && cfg != 0) return PDGN_ERR_INVALID;
+        cfg = 0;
+    }
     switch (cfg) {
         case 0: return X3Big::launch<WT>(m, n, k, A, lda, W, ldw, bias, addend, ldadd, C, ldc, stat_part, s, epi, false, Wp, wplane, parts);
         case 2: return X3Narrow::launch<WT>(m, n, k, A, lda, W, ldw, bias, addend, ldadd, C, ldc, stat_part, s, epi, false, Wp, wplane, parts);
@@ -1613,6 +1631,11 @@ extern "C" long long pdgn_gemm_tail_workspace_floats(long long m, int n, int k, 
         default: return X3Square::tail_floats(m, n, k, sk);
     }
 }
+extern "C" long long pdgn_gemm_nt_ps_workspace_floats(long long m, int n, int k, int parts, int with_stats) {
+    if (!x3_mode() || m < 1 || n < 4 || k < 4) return 0;
+    if (parts == 2) return with_stats ? 0 : X3Big::tail_floats(m, n, k, true);
+    return pdgn_gemm_tail_workspace_floats(m, n, k, with_stats);
+}
 extern "C" int pdgn_gemm_set_tail_workspace(float *ws, long long floats) {
     if (floats < 0 || ((uintptr_t)ws & 15)) return PDGN_ERR_INVALID;
     x3_tail_ws = ws;
@@ -1629,7 +1652,6 @@ extern "C" int pdgn_gemm_nt_ps_launch_info(long long m, int n, int k, int parts,
     const bool s16 = x3_shape16(cfg, false, false, true);
     *sym = nullptr;
     if (parts == 2) {
-        if (cfg != 0) return PDGN_ERR_INVALID;
         *grid = X3Big::plan(m, n, k, true).grid_dp;
         *sym = x3_symbol_h2(16, true);
     } else if (cfg == 0) {

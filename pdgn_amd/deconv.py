@@ -375,7 +375,7 @@ class PointDeconv(nn.Module):
         with torch.no_grad():
             rows = getattr(self, "_rows_hint", None)               # B * N of the last forward: decides three bf16 / two fp16 parts
             pv = split_planes(WcatV.detach(), want_t, rows, dy_maxima_free=True)      # (its dY comes from EdgeGatherSum.backward, with maxima)
-            pb = split_planes(Wb.detach(), want_t, rows)
+            pb = split_planes(Wb.detach(), want_t, rows, x_maxima_free=self.bilateral and self.softmax)      # (inte arrives with its maxima: bilateral_weighting's want_max)
         return WcatC, WcatV, Wb, pv, pb
 
     def preassemble(self, Fc):

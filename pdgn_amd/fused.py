@@ -359,25 +359,32 @@ def two_part(m, n, k, scan_bytes):
     return _lib.gemm_mode() == "x2" and bool(_lib.lib().pdgn_gemm_two_part(ctypes.c_longlong(m), n, k, ctypes.c_longlong(scan_bytes)))
 
 
+def two_part_planes(m, n, k, scan_bytes):
+    """Whether the product (m, n, k) against PRE-SPLIT planes should use two-part ones when scan_bytes of the activations still have
+    to be scanned (csrc/gemm_x3.hip pdgn_gemm_two_part_planes: from ~2 GFLOP on, the 256 x 128 eight-wave tile)."""
+    return _lib.gemm_mode() == "x2" and bool(_lib.lib().pdgn_gemm_two_part_planes(ctypes.c_longlong(m), n, k, ctypes.c_longlong(scan_bytes)))
+
+
 def _slots(t):
     """Before a contraction call: in the default mode the library's scale ring must live on the tensor's device (_lib.ensure_scale_slots)."""
     if _lib.gemm_mode() == "x2":
         _lib.ensure_scale_slots(t.device)
 
 
-def split_planes(w, want_t, rows=None, dy_maxima_free=False):
+def split_planes(w, want_t, rows=None, dy_maxima_free=False, x_maxima_free=False):
     """The pre-split planes of a (n, k) fp32 weight (Planes); None where the pre-split path does not apply (fp32-instruction mode,
     sizes that would need padding).  rows: the row count of the activations it will multiply, when known -- it decides between
     three bf16 and two fp16 parts per product (forward: (rows, n, k); input gradient through the transpose: (rows, k, n));
-    dy_maxima_free: the layer's output gradient arrives with its maxima (mark_maxima: nothing to scan for the input gradient)."""
+    dy_maxima_free / x_maxima_free: the layer's output gradient / its input arrives with its maxima (mark_maxima, linear_cl's
+    x_max: nothing to scan)."""
     _slots(w)
     mode = _lib.gemm_mode()
     if not (_PLANES and w.is_cuda and w.dim() == 2 and mode != "fp32") or w.shape[0] % 4 or w.shape[1] % 4 or w.stride(1) != 1:
         return None
     n, k = w.shape
     ldp, ldt = (k + 7) // 8 * 8, (n + 7) // 8 * 8
-    parts_p = 2 if rows and two_part(rows, n, k, rows * k * 4) else 3           # (the activations are scanned, the weight brings its exponent)
-    parts_t = 2 if rows and want_t and two_part(rows, k, n, 0 if dy_maxima_free else rows * n * 4) else 3
+    parts_p = 2 if rows and two_part_planes(rows, n, k, 0 if x_maxima_free else rows * k * 4) else 3    # (the weight brings its exponent)
+    parts_t = 2 if rows and want_t and two_part_planes(rows, k, n, 0 if dy_maxima_free else rows * n * 4) else 3
 
     def planes(parts, rows_, ld):                                  # [parts][rows][ld] (+ 16 B: two-part planes keep the exponent there)
         buf = torch.empty(parts * rows_ * ld + 8, dtype=torch.int16, device=w.device)
@@ -432,12 +439,17 @@ def _hand_maxima(L, ma, mw=None):
         L.pdgn_gemm_set_operand_scales(ptr(ma), ptr(mw))
 
 
-def _tail_workspace(L, m, n, k, with_stats, device):
+def _tail_workspace(L, m, n, k, with_stats, device, parts=None):
     """The stream-K tail of the next contraction call without atomics (csrc/gemm_x3.hip): a buffer for its partial tiles, handed to
     the library for that ONE call.  Returned so that the caller keeps it alive until its launch is issued (stream-ordered reuse
-    by the caching allocator is safe: the next user runs behind this call on the same stream)."""
-    L.pdgn_gemm_tail_workspace_floats.restype = ctypes.c_longlong
-    need = L.pdgn_gemm_tail_workspace_floats(ctypes.c_longlong(m), n, k, 1 if with_stats else 0)
+    by the caching allocator is safe: the next user runs behind this call on the same stream).  parts: of the pre-split planes the
+    call multiplies (two-part planes run on the 256 x 128 tile whatever the launch model picks)."""
+    if parts is not None:
+        L.pdgn_gemm_nt_ps_workspace_floats.restype = ctypes.c_longlong
+        need = L.pdgn_gemm_nt_ps_workspace_floats(ctypes.c_longlong(m), n, k, parts, 1 if with_stats else 0)
+    else:
+        L.pdgn_gemm_tail_workspace_floats.restype = ctypes.c_longlong
+        need = L.pdgn_gemm_tail_workspace_floats(ctypes.c_longlong(m), n, k, 1 if with_stats else 0)
     if need <= 0:
         return None
     ws = torch.empty(need, dtype=F32, device=device)
@@ -446,9 +458,10 @@ def _tail_workspace(L, m, n, k, with_stats, device):
 
 
 def planes_fit(P, m, n, k, with_stats=False):
-    """Whether planes P can serve the product (m, n, k): three-part planes always; two-part ones only where the launch model
-    picks the tile their instances exist for (the shape they were made for: split_planes' rows)."""
-    return P.shape[0] == 3 or (_lib.lib().pdgn_gemm_nt_config(ctypes.c_longlong(m), n, k, 1 if with_stats else 0) & 15) == 0
+    """Whether planes P can serve the product (m, n, k): three-part planes always; two-part ones (which run on the 256 x 128 tile
+    whatever the launch model picks) unless the launch emits BatchNorm partials and the model's pick -- whose geometry the
+    partials' consumers were told -- is another tile."""
+    return P.shape[0] == 3 or not with_stats or (_lib.lib().pdgn_gemm_nt_config(ctypes.c_longlong(m), n, k, 1) & 15) == 0
 
 
 def gemm_nt_planes(a, P, n, k, bias=None, addend=None, want_stats=False, max_a=None):
@@ -468,7 +481,7 @@ def gemm_nt_planes(a, P, n, k, bias=None, addend=None, want_stats=False, max_a=N
     b = bias.detach().contiguous() if bias is not None else None
     if addend is not None:
         addend = _pad_cols(addend)
-    ws = _tail_workspace(L, m, n, k, want_stats, a.device)
+    ws = _tail_workspace(L, m, n, k, want_stats, a.device, parts=P.shape[0])
     _hand_maxima(L, max_a)
     check(L.pdgn_gemm_nt_ps(ctypes.c_longlong(m), n, k, ptr(ap), ap.stride(0), ptr(P), P.shape[2], ctypes.c_longlong(P.shape[1] * P.shape[2]), P.shape[0],
                             ptr(b), ptr(addend), addend.stride(0) if addend is not None else 0, ptr(out), n, ptr(part), None, 0, 1, 0,

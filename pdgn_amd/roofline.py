@@ -116,7 +116,7 @@ def _nt_entry(label, M, N, K, device):
     from .fused import _tail_workspace
 
     def run():
-        ws = _tail_workspace(L, M, N, K, False, device)            # the stream-K tail without atomics, as the step's calls run it
+        ws = _tail_workspace(L, M, N, K, False, device, parts=planes.p.shape[0] if planes is not None else None)      # the stream-K tail without atomics, as the step's calls run it
         if planes is not None:
             P = planes.p
             check(L.pdgn_gemm_nt_ps(ctypes.c_longlong(M), N, K, ptr(a), K, ptr(P), P.shape[2], ctypes.c_longlong(P.shape[1] * P.shape[2]),
@@ -299,7 +299,8 @@ def conv2_in_step_spans(launch_list, B, base_points):
     from .fused import two_part
     L = _lib.lib()
     M = B * 8 * base_points
-    parts = 2 if two_part(M, 512, 5120, M * 5120 * 4) else 3
+    from .fused import two_part_planes
+    parts = 2 if two_part_planes(M, 512, 5120, 0) else 3          # (the step's planes: inte arrives with its maxima)
     sym, grid, red, scan = ctypes.c_void_p(), ctypes.c_int(), ctypes.c_void_p(), ctypes.c_void_p()
     if L.pdgn_gemm_nt_ps_launch_info(ctypes.c_longlong(M), 512, 5120, parts, ctypes.byref(sym), ctypes.byref(grid)) != 0 or not sym.value:
         return []

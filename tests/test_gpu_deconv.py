@@ -1630,13 +1630,51 @@ def test_gemm_two_part_planes_and_maxima(M, N, K):
         assert torch.equal(c1, c2) and torch.equal(c0, c1)         # same parts, same products, same order: with or without the planes / the hand-over
         for c in (c0, c1):
             assert torch.isfinite(c).all() and ((c.double() - ref).abs() / mag).max().item() < 1e-6
-    # three-part planes still serve; two-part ones are refused where the launch model picks another tile
+    # two-part planes run on the 256 x 128 tile whatever the launch model would pick for three parts -- here for 300 rows -- unless
+    # the launch emits BatchNorm partials, whose geometry is the pick's
     small = torch.randn(300, K, device="cuda", generator=g)
     cs = torch.empty(300, N, device="cuda")
-    if (L.pdgn_gemm_nt_config(ctypes.c_longlong(300), N, K, 0) & 15) != 0:
+    if (L.pdgn_gemm_nt_config(ctypes.c_longlong(300), N, K, 1) & 15) != 0:
         assert L.pdgn_gemm_nt_ps(ctypes.c_longlong(300), N, K, ptr(small), K, ptr(pl.p), pl.p.shape[2], wp, 2, None, None, 0, ptr(cs), N, None,
+                                 None, 0, 1, 0, None, 0, stream_of(a)) == 0
+        refs = small.double() @ w.double().t()
+        mags = small.double().abs() @ w.double().abs().t() + 1.0
+        assert ((cs.double() - refs).abs() / mags).max().item() < 1e-6
+        L.pdgn_gemm_nt_stat_rows.restype = ctypes.c_longlong
+        part = torch.empty(L.pdgn_gemm_nt_stat_rows(ctypes.c_longlong(300), N, K), 3 * N, device="cuda")
+        assert L.pdgn_gemm_nt_ps(ctypes.c_longlong(300), N, K, ptr(small), K, ptr(pl.p), pl.p.shape[2], wp, 2, None, None, 0, ptr(cs), N, ptr(part),
                                  None, 0, 1, 0, None, 0, stream_of(a)) == -1
-        assert not fused.planes_fit(pl.p, 300, N, K)
+        assert fused.planes_fit(pl.p, 300, N, K) and not fused.planes_fit(pl.p, 300, N, K, True)
+    # which planes to make: from ~2 GFLOP on when the activations' maxima are free, never for a handful of rows or a short reduction
+    assert fused.two_part_planes(17920, 256, 2560, 0) and fused.two_part_planes(35840, 512, 256, 0) and fused.two_part_planes(17920, 6432, 64, 17920 * 64 * 4)
+    assert not fused.two_part_planes(17920, 256, 2560, 17920 * 2560 * 4) and not fused.two_part_planes(200, 256, 2560, 0) and not fused.two_part_planes(17920, 256, 16, 0)
+
+
+@pytest.mark.parametrize("M,N,K", [(17920, 256, 2560), (8960, 128, 1280), (17920, 6432, 64), (17920, 64, 6432), (4100, 132, 260)])
+def test_two_part_planes_on_the_big_tile_for_mid_size_products(M, N, K):
+    """Two-part planes + handed-in maxima on shapes the launch model gives other tiles for three parts (conv2's dense half and the
+    per-point product at stages 2-3, an input gradient with a long reduction, a ragged one): through LinearCL forward and backward
+    against fp64, tail workspaces included."""
+    from pdgn_amd import _lib, fused
+    _lib.set_gemm_mode("x2")
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    x = torch.randn(M, K, device="cuda", generator=g)
+    w = torch.randn(N, K, device="cuda", generator=g) * 0.2
+    add = torch.randn(M, N, device="cuda", generator=g)
+    dy = torch.randn(M, N, device="cuda", generator=g)
+    pl = fused.split_planes(w, True, rows=M, dy_maxima_free=True, x_maxima_free=True)
+    if 2.0 * M * N * K >= 2e9:
+        assert pl.parts_p == 2 and pl.parts_t == 2
+    xg, wg = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    y = fused.linear_cl(xg, wg, None, add, planes=pl, x_max=fused.operand_maxima(x) if pl.parts_p == 2 else None)
+    y.backward(dy)
+    x64, w64 = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    y64 = x64 @ w64.t() + add.double()
+    y64.backward(dy.double())
+    for name, got, ref, mag in (("y", y.detach(), y64.detach(), x.double().abs() @ w.double().abs().t() + 1.0),
+                                ("dx", xg.grad, x64.grad, dy.double().abs() @ w.double().abs() + 1.0),
+                                ("dw", wg.grad, w64.grad, dy.double().abs().t() @ x.double().abs() + 1.0)):
+        assert ((got.double() - ref).abs() / mag).max().item() < 2e-6, name
 
 
 def test_bilateral_weighting_emits_its_output_maxima():
