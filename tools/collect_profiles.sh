@@ -54,6 +54,7 @@ python3 tools/spill_table.py > $OUT/${TAG}_spill_table.txt 2>&1
 bash tools/env_ab.sh PDGN_GEMM "x2 x3" 3 > $OUT/${TAG}_gemm_mode_ab.txt 2>&1
 python3 tools/x2_shapes.py 2>&1 | grep -v amdgpu.ids > $OUT/${TAG}_x2_shapes.txt
 python3 tools/x2_check.py 2>&1 | grep -v amdgpu.ids > $OUT/${TAG}_x2_check.txt
+python3 tools/cfg_probe.py 2>&1 | grep -v amdgpu.ids > $OUT/${TAG}_cfg_probe.txt
 python3 tools/operand_range.py 2>&1 | grep -v amdgpu.ids > $OUT/${TAG}_operand_range.txt
 # stream-K tails: workspace + reduce kernel (default) against the atomic form, alternating in the step
 bash tools/env_ab.sh PDGN_X3_SK_WS "1 0" 3 > $OUT/${TAG}_sk_tails_ab.txt 2>&1
