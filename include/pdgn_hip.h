@@ -5,8 +5,14 @@
  * Every entry point takes plain device pointers + sizes + a hipStream_t (passed as
  * void*), launches asynchronously on that stream, never allocates, never synchronises,
  * and returns 0 on success, a hipError_t value (>0) on a launch failure, or
- * PDGN_ERR_INVALID (-1) when an argument is out of the supported range.  The library
- * keeps no global state and is safe to call from one process per GPU.
+ * PDGN_ERR_INVALID (-1) when an argument is out of the supported range.  The pointops /
+ * structural-loss / BatchNorm / gather entry points keep no state.  The dense contractions
+ * (pdgn_gemm_*) have state, all of it listed at pdgn_gemm_set_mode below: process-wide
+ * switches (arithmetic mode, forced tile, matrix instruction: set once from the
+ * environment, changed only by tests / tools), a process-wide arena for the two-part
+ * mode's own scans (pdgn_gemm_set_scale_slots), and THREAD-LOCAL hand-overs (operand
+ * maxima, tail workspace) that belong to the calling thread's next contraction call.
+ * One process per GPU, contraction calls from one thread at a time per hand-over.
  *
  * All tensors are contiguous, batch-major; float = fp32, idx = int32 -- exactly the
  * layouts of the reference launchers cited per function (paths relative to the
@@ -145,8 +151,9 @@ int pdgn_knn_graph_transpose(int b, int n, int k, const int32_t *idx, int32_t *r
 int pdgn_window_gather_sum_backward_csr(int b, int n, int k, int ldy, int T, int P, int C, int off,
                                         int offc, const float *dout, const int32_t *rowptr,
                                         const int32_t *edges, float *dY, unsigned *max_out, int max_init, pdgn_stream_t stream);
-/* (max_out, may be NULL: a 1-KB device slot that collects 256 partial maxima of |dY| over the calls that fill one dY -- the first
- * of them with max_init != 0, which zero-fills the slot -- for the two-part contractions that take dY, pdgn_gemm_set_operand_scales.) */
+/* (max_out, may be NULL: uint32[b n], the maximum of |dY| (bit pattern) over every row (b, j) of dY, collected over the calls that
+ * fill one dY -- the first of them passes max_init = 1 and the array is zero-filled; atomic max, order-independent -- for
+ * pdgn_gemm_set_operand_scales: the per-point product's input gradient takes dY as its first operand and scales it row by row.) */
 
 /* Fused BatchNorm + activation over channels-last (rows x c) activations -- the
  * nn.BatchNorm2d + LeakyReLU/ReLU pairs of models/PDGNet_v2.py:537-545, 561-565, 603-625 in the
@@ -255,8 +262,9 @@ int pdgn_bn_softmax_slots_permute(long long m, int k, int c, int act, const floa
 int pdgn_bn_softmax_slots_permute_mul(long long m, int k, int c, int act, const float *x, const float *stats,
                                       int act_u, const float *u, const float *stats_u, float *w, float *y,
                                       unsigned *max_out, pdgn_stream_t stream);
-/* (max_out, may be NULL: a 1-KB device slot that receives 256 partial maxima of |y| -- what pdgn_absmax_partials would compute by a
- * pass over y -- for the two-part contraction that consumes y, pdgn_gemm_set_operand_scales; the call zero-fills it.) */
+/* (max_out, may be NULL: uint32[m], the maximum of |y| (bit pattern) over each point's k c outputs = the row maxima of y as the
+ * (m, k c) first operand of conv2's dense half -- what pdgn_absmax_rows_cols would compute by a pass over y; zero-filled by the
+ * call, atomic max.) */
 /* Adjoint of pdgn_bn_softmax_slots_permute_mul in two passes over (x, u, w, dy): BatchNorm_u backward, slot-softmax
  * backward and BatchNorm_x backward with dW / dh kept in registers.  scratch: pdgn_bilateral_scratch_floats(m,k,c)
  * floats; bsums_x (2c) = [sum dz_x | sum dz_x*xhat] (= dbeta, dgamma of BN_x), bsums_u (4c) likewise for BN_u;
@@ -355,27 +363,37 @@ int pdgn_gemm_set_mode(int mode);
  * cores with TWO parts per value; the others stay on three bf16 parts (mode 1's arithmetic).  pdgn_gemm_two_part(m, n, k,
  * scan_bytes) says which a call (m, n, k) is when scan_bytes of its operands would still have to be scanned for their maxima: the
  * 256 x 128 tile, k >= 128, >= 20 GFLOP and at most 4.5 bytes to scan per kflop (measured: tools/x2_shapes.py).
- * Two parts: an operand is multiplied by a power of two 2^e, e = 14 - floor(log2 max |x|) over the whole operand (so that nothing
- * leaves fp16's range: max |x| 2^e in [2^14, 2^15)), split as x 2^e = h + l (round-to-nearest fp16 of the value and of the exact
- * remainder: |err| <= 2^-23 |x| for values within 2^-16 of the operand's largest, an absolute 2^-39 max |x| below -- a norm-wise
- * bound per operand, as for any block-scaled format; mode 1 needs no scale and keeps every value's own 24 bits), a product is the
- * three fp16 MFMA products al wh + ah wl + ah wh accumulated in fp32, and the result is multiplied by 2^-(e_A + e_W) (exact).  Per
- * product |err| <= ~2^-21 |a w| in the worst case; in sums the fp32 accumulation all modes share dominates, of which this form does
- * half as much: measured against fp64 BELOW the other two modes (bench.py gemm_accuracy, tests/test_gpu_deconv.py, tools/x2_check.py:
- * all three operand layouts, 1e-20 .. 1e15).  Half the matrix-core work of mode 1.
- * The maxima come from a scan of each operand in front of the launch (x2_absmax_kernel: 256 partial maxima into a 1-KB slot, which
- * every consumer reduces itself: no atomics, nothing to re-arm), the slot taken from a ring the caller provides once:
- * pdgn_gemm_set_scale_slots(device memory, bytes; 1 KB per slot; more slots than launches can be in flight -- the library never
- * allocates); without one a two-part call returns PDGN_ERR_INVALID.  An operand's maxima can also be computed by the caller
- * (pdgn_absmax_partials into a 1-KB device slot of its own), or by the kernel that WRITES the operand
- * (pdgn_bn_softmax_slots_permute_mul's max_out), and handed over for the operands of the calling thread's next contraction call
- * (pdgn_gemm_set_operand_scales: first / second operand as that entry point takes them -- pdgn_gemm_tn_big: dY, X -- NULL = scanned
- * by the call; consumed by that call): an activation that feeds several products is scanned once, or never.
- * pdgn_split_f16x2 = pdgn_split_bf16x3 for a two-part product: two fp16 planes (h | l, already scaled) and the exponent as one
- * int32 right behind them (element offset 2 * plane_stride: the buffer holds 2 * plane_stride + 2 elements); pdgn_gemm_nt_ps takes
- * either kind of planes and is told which (parts = 3 | 2).  No reference counterpart. */
+ * Two parts (round 6: scaled PER ROW; one scale per operand until then): every ROW of each operand as the kernel sees it -- row m
+ * of A, row n of W; for an operand given transposed the COLUMNS of the matrix in memory: pdgn_gemm_nn's Wt, both operands of
+ * pdgn_gemm_tn_big -- is multiplied by a power of two 2^e_r, e_r = 14 - floor(log2 max |x| over that row) (so that nothing leaves
+ * fp16's range), split as x 2^e = h + l (round-to-nearest fp16 of the value and of the exact remainder: |err| <= 2^-23 |x| for
+ * values within 2^-16 of THEIR ROW's largest, an absolute 2^-39 of the row's maximum below; mode 1 needs no scale and keeps every
+ * value's own 24 bits), a product is the three fp16 MFMA products al wh + ah wl + ah wh accumulated in fp32, and C[m, n] is
+ * multiplied by 2^-e_A[m] 2^-e_W[n] (exact).  An output row therefore depends on its own input row's scale only: the input gradient
+ * of a point with a small output gradient is as accurate, relative to that row, as any other's (tests/test_gpu_deconv.py::
+ * test_two_part_rows_spanning_thirty_binades).  Per product |err| <= ~2^-21 |a w| in the worst case; in sums the fp32 accumulation
+ * all modes share dominates, of which this form does half as much: measured against fp64 BELOW the other two modes (bench.py
+ * gemm_accuracy, tools/x2_check.py: all three operand layouts, 1e-20 .. 1e15).  Half the matrix-core work of mode 1.
+ * The maxima are arrays of bit patterns of |x| (uint32; unsigned order = magnitude order: producers combine them with integer /
+ * atomic max in any order).  They come from a scan in front of the launch (x2_maxima_kernel: one pass, row and / or column
+ * maxima) into an arena the caller provides once -- pdgn_gemm_set_scale_slots(device memory, bytes; handed out round-robin in 1-KB
+ * units, 4 bytes per kernel-side row: it must hold the arrays of every launch that can be in flight; the library never
+ * allocates); without one a two-part call that has to scan returns PDGN_ERR_INVALID -- or from the caller: pdgn_absmax_rows_cols
+ * (rowmax[rows] and / or colmax[cols] of a matrix in one pass), or the kernel that WRITES the operand
+ * (pdgn_bn_softmax_slots_permute_mul's and pdgn_window_gather_sum_backward_csr's max_out: row maxima), handed over for the operands of
+ * the calling thread's NEXT contraction call (pdgn_gemm_set_operand_scales(max_a, max_w): the kernel-side rows of the first /
+ * second operand as that entry point takes them -- _nt / _nt_ps: rows of A, rows of W; _nn: rows of A, columns of Wt; _tn_big:
+ * columns of dY, columns of X; NULL = scanned by the call; consumed by that call; finite upper bounds serve as well): an
+ * activation that feeds several products is scanned once, or never.
+ * pdgn_split_f16x2 = pdgn_split_bf16x3 for a two-part product: two fp16 planes (h | l, every row scaled by its own power of two) and
+ * the rows' maxima as uint32[rows] right behind them (element offset 2 * plane_stride: the buffer holds 2 * plane_stride + 2 * rows
+ * elements; plane_stride >= rows * ld_planes, a multiple of 8); the transposed planes' rows are the matrix's columns.
+ * pdgn_gemm_nt_ps takes either kind of planes and is told which (parts = 3 | 2).  No reference counterpart.
+ * State: the mode / tile / instruction switches are process-wide; the arena is process-wide; the hand-overs (operand maxima, tail
+ * workspace) are THREAD-LOCAL and belong to the calling thread's next contraction call only, whether it launches or is refused. */
 int pdgn_gemm_set_scale_slots(void *slots, long long bytes);
-int pdgn_absmax_partials(long long rows, int cols, const float *src, int ld, unsigned *slot, pdgn_stream_t stream);
+int pdgn_absmax_rows_cols(long long rows, int cols, const float *src, int ld, unsigned *rowmax, unsigned *colmax,
+                          pdgn_stream_t stream);
 int pdgn_gemm_set_operand_scales(const unsigned *max_a, const unsigned *max_w);
 int pdgn_gemm_two_part(long long m, int n, int k, long long scan_bytes);
 /* The same question for a product against PRE-SPLIT planes (which kind to make: pdgn_split_f16x2 or _bf16x3): with nothing to

@@ -10,7 +10,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "libpdgn_hip.so")
-ABI_VERSION = 23
+ABI_VERSION = 24
 _lib = None
 
 
@@ -41,17 +41,18 @@ _SCALE_SLOTS = {}               # device index -> the ring handed to the library
 
 
 def ensure_scale_slots(device=None, handle=None):
-    """Two-part contractions (csrc/gemm_x3.hip): the ring of operand-scale slots is the caller's memory -- the library never
-    allocates.  4 Ki slots of 1 KB on the device the contractions run on (an iteration is < 10^3 scans inside the library and at
-    most two iterations are in flight); called by the contraction wrappers, so that the ring lives on the device in use whatever
-    device was current when the library was loaded."""
+    """Two-part contractions (csrc/gemm_x3.hip): the arena of the library's own operand-maxima scans is the caller's memory -- the
+    library never allocates.  64 MB on the device the contractions run on, used round-robin (a scanned operand takes 4 bytes per
+    kernel-side row: at most 0.3 MB; an iteration makes a few dozen scans inside the library and at most two iterations are in
+    flight); called by the contraction wrappers, so that the arena lives on the device in use whatever device was current when the
+    library was loaded."""
     if not torch.cuda.is_available():
         return
     idx = torch.cuda.current_device() if device is None or device.index is None else device.index
     if _SCALE_SLOTS.get("attached") == idx:
         return
     if idx not in _SCALE_SLOTS:
-        _SCALE_SLOTS[idx] = torch.zeros(1 << 20, dtype=torch.int32, device=torch.device("cuda", idx))
+        _SCALE_SLOTS[idx] = torch.zeros(1 << 24, dtype=torch.int32, device=torch.device("cuda", idx))
     t = _SCALE_SLOTS[idx]
     check((handle or lib()).pdgn_gemm_set_scale_slots(ctypes.c_void_p(t.data_ptr()), ctypes.c_longlong(t.numel() * 4)),
           "pdgn_gemm_set_scale_slots")

@@ -60,41 +60,27 @@ struct NtArgs {
     int ldgate;
     const unsigned short *Wp;         // gemm_x3, PW instances: the second operand pre-split into three bf16 planes [N][ldw]
     long long wplane;                 // elements between the planes
-    const unsigned *max_a, *max_w;    // gemm_x3, two-part (fp16) instances: X2_PARTS partial maxima (bit patterns of |x|) of each operand,
-                                      // which is multiplied by 2^e, e = x2_exponent(their maximum), before the split (pre-split
-                                      // second operand: its exponent sits behind its two planes instead)
+    const unsigned *max_a, *max_w;    // gemm_x3, two-part (fp16) instances: the maximum of |x| (bit pattern) of every ROW of each operand as the
+                                      // kernel sees it (M entries / N entries: for an operand given transposed, of every column of the
+                                      // matrix in memory); row r is multiplied by 2^e_r, e_r = x2_exponent(its maximum), before the split and
+                                      // the result by 2^-e_A[row] 2^-e_W[column] (pre-split second operand: its rows' maxima sit behind
+                                      // its two planes; the host points max_w there)
 };
 
-// Two-part mode: an operand's scale.  A scan (x2_absmax_kernel, gemm_x3.hip) leaves X2_PARTS partial maxima of |x| (as bit patterns:
-// unsigned order = magnitude order; unused entries zero) in a 1-KB slot; every consumer reduces them itself (one load per thread of
-// a 256-thread workgroup) -- no atomics, no fences, nothing to re-arm.  e = 14 - floor(log2 max): max |x| 2^e in [2^14, 2^15).
-#define X2_PARTS 256
+// Two-part mode: an operand's scales -- one power of two PER ROW of the operand as the kernel sees it (round 6; one per operand until
+// then: a block-scaled format whose block was the whole matrix).  The maxima travel as bit patterns of |x| (unsigned order =
+// magnitude order, so producers combine them with integer max / atomicMax in any order: deterministic); e = 14 - floor(log2 max):
+// max |x| 2^e in [2^14, 2^15) -- nothing overflows fp16, and a value keeps 22 bits while it is within 2^-16 of ITS ROW's largest.
 __device__ __forceinline__ int x2_exponent(unsigned maxbits) {     // (NaN / Inf: the largest exponent field; the products carry them)
     const int e = 14 - ((int)(maxbits >> 23) - 127);
     return e > 126 ? 126 : (e < -126 ? -126 : e);
 }
-// max over the workgroup's threads (a multiple of 64, at most 512) of two values each; scratch: 16 words of LDS; every thread must
-// call (two barriers)
-__device__ __forceinline__ void x2_block_max2(unsigned &a, unsigned &b, unsigned *scratch) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) {
-        a = max(a, (unsigned)__shfl_xor((int)a, o));
-        b = max(b, (unsigned)__shfl_xor((int)b, o));
-    }
-    const int nw = (int)(blockDim.x >> 6);
-    if ((threadIdx.x & 63) == 0) {
-        scratch[threadIdx.x >> 6] = a;
-        scratch[8 + (threadIdx.x >> 6)] = b;
-    }
-    __syncthreads();
-    a = scratch[0];
-    b = scratch[8];
-    for (int i = 1; i < nw; ++i) {
-        a = max(a, scratch[i]);
-        b = max(b, scratch[8 + i]);
-    }
-    __syncthreads();
+__device__ __forceinline__ int x2_scale_field(unsigned maxbits) {  // exponent field of 2^e: 127 + e = 268 - field(max), clamped like x2_exponent
+    const int f = 268 - (int)(maxbits >> 23);
+    return f < 1 ? 1 : (f > 253 ? 253 : f);
 }
+__device__ __forceinline__ float x2_scale(unsigned maxbits) { return __int_as_float(x2_scale_field(maxbits) << 23); }          // 2^e
+__device__ __forceinline__ float x2_unscale(unsigned maxbits) { return __int_as_float((254 - x2_scale_field(maxbits)) << 23); }  // 2^-e
 
 // ------------------------------------------------------------------ host side
 struct NtDev {

@@ -160,18 +160,20 @@ __device__ __forceinline__ float x3_row_sum(float v) {
 // weight by pdgn_split_bf16x3 with the same round-to-nearest remainders the loader computes: its quads are loaded part by part
 // (8 B per part and lane) and go to LDS as they are -- none of the 22 vector instructions per quad, a third of the split work
 // of a 256 x 128 tile.  Same parts, same products, same order: results are bit-identical to the unsplit operand's.
-// NP: parts per operand value.  3: the bf16 form above.  2 (round 5, MS = 32 only): each operand is multiplied by a power of two
-// 2^e, e = 14 - floor(log2 max |x|) over the WHOLE operand (exact; max |x| 2^e in [2^14, 2^15): inside fp16's range), and split
-// as x 2^e = h + l with h = rn16(x 2^e), l = rn16 of the exact remainder: 22 + 1 significant bits while |x| is within 2^-16 of
-// the operand's largest value, an absolute 2^-39 max |x| below (fp16's subnormal spacing).  A product is THREE partial products
-// on v_mfma_f32_32x32x16_f16 -- al wh + ah wl + ah wh, each exact in the fp32 accumulator's input -- and the accumulators are
-// multiplied by 2^-e_A, then 2^-e_W in front of the epilogue (exact).  Half the matrix-core work, two thirds of the LDS image,
-// 7 instead of 11 vector instructions per pair of values in the split; per product |err| <~ 2^-21 |a w| in the worst case
-// (al wl dropped + the two representation errors), in a sum far below the fp32 accumulation's own rounding, of which this
-// form does half as much: against fp64 its results are the closest of the three forms (tools/x2_check.py).  The maxima
-// arrive as 256 partial maxima per operand (p.max_a / p.max_w: x2_absmax_kernel, or the kernel that wrote the operand),
-// reduced by every workgroup itself in its prologue; a pre-split second operand (two fp16 planes, already scaled) carries its
-// exponent behind its planes.  Which launches take this form: x2_pays (host side).
+// NP: parts per operand value.  3: the bf16 form above.  2 (round 5, MS = 32 only): each ROW of each operand (as the kernel sees
+// it: a transposed operand's rows are the columns of the matrix in memory) is multiplied by a power of two 2^e_r, e_r = 14 -
+// floor(log2 max |x| over that row) (exact; max |x| 2^e_r in [2^14, 2^15): inside fp16's range), and split as x 2^e = h + l with
+// h = rn16(x 2^e), l = rn16 of the exact remainder: 22 + 1 significant bits while |x| is within 2^-16 of ITS ROW's largest value,
+// an absolute 2^-39 of the row's maximum below (fp16's subnormal spacing).  (Round 5 scaled the whole operand by one power of two:
+// a row 2^-26 below the operand's maximum -- a point with a small gradient -- kept 12 bits.  Round 6: per row.)  A product is
+// THREE partial products on v_mfma_f32_32x32x16_f16 -- al wh + ah wl + ah wh, each exact in the fp32 accumulator's input -- and
+// C[m, n] is multiplied by 2^-e_A[m], then 2^-e_W[n] in front of the epilogue (exact).  Half the matrix-core work, two thirds of the
+// LDS image, 7 instead of 11 vector instructions per pair of values in the split; per product |err| <~ 2^-21 |a w| in the worst
+// case (al wl dropped + the two representation errors), in a sum far below the fp32 accumulation's own rounding, of which this
+// form does half as much: against fp64 its results are the closest of the three forms (tools/x2_check.py).  The row maxima
+// arrive as arrays of bit patterns (p.max_a[M] / p.max_w[N]: x2_maxima_kernel, the caller, or the kernel that wrote the operand;
+// a pre-split second operand -- two fp16 planes, already scaled row by row -- carries its rows' maxima behind its planes).
+// Which launches take this form: x2_pays (host side).
 template <int TM, int TN, int WM, int WN, int OCC, bool ATOMIC, bool WT, bool AT, bool EPI = false, bool PW = false, int MS = 32, int NP = 3>
 __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_x3_kernel(const NtArgs p) {
     static_assert(!PW || (!WT && !AT), "pre-split second operand: row-major (N x K) planes only");
@@ -185,8 +187,12 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_x3_kernel(const NtArgs
     constexpr int PART_A = BM * 64, PART_W = BN * 64, STAGE = NP * (PART_A + PART_W);
     // STG: the result leaves through a per-wave LDS staging block (32 rows x 128 B) so that a store instruction covers whole
     // 128-B lines (8 rows) instead of 32 B of each of 32 rows -- for the one-workgroup-per-CU tiles, whose LDS has the room
-    constexpr bool STG = OCC == 1 && !ATOMIC && !(X3_ABLATE & 128) && 2 * STAGE + NW * 4096 <= 160 * 1024;      // (and the CU's 160 KB hold it)
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * STAGE + (STG ? NW * 4096 : 0)];
+    // NP = 2: the item's un-scales 2^-e of its BM rows and BN columns (finish_item reads them from here: held in registers they
+    // would be 2 + 32 values per lane over a whole item)
+    constexpr int UNT = NP == 2 ? (BM + BN) * 4 : 0;
+    constexpr bool STG = OCC == 1 && !ATOMIC && !(X3_ABLATE & 128) && 2 * STAGE + NW * 4096 + UNT <= 160 * 1024;      // (and the CU's 160 KB hold it)
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * STAGE + (STG ? NW * 4096 : 0) + UNT];
+    float *const untab = reinterpret_cast<float *>(smem + 2 * STAGE + (STG ? NW * 4096 : 0));     // [BM row un-scales | BN column un-scales]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -199,21 +205,6 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_x3_kernel(const NtArgs
     const int v = xcd * gq + min(xcd, gr) + (pid >> 3);
 
     const int KC = p.kchunks;
-    // NP = 2: the operands' power-of-two scales (from their partial maxima) and the result's
-    float scA = 1.f, scW = 1.f, unA = 1.f, unW = 1.f;
-    if (NP == 2) {
-        static_assert(NP != 2 || NTH >= X2_PARTS, "one partial maximum per thread");
-        const bool mine = tid < X2_PARTS;
-        unsigned ma = p.max_a ? (mine ? p.max_a[tid] : 0u) : 0x47000000u, mw = (!PW && p.max_w) ? (mine ? p.max_w[tid] : 0u) : 0x47000000u;      // (none: 2^15, e = 0)
-        x2_block_max2(ma, mw, reinterpret_cast<unsigned *>(smem));
-        const int ea = __builtin_amdgcn_readfirstlane(x2_exponent(ma));
-        const int ew = PW ? __builtin_amdgcn_readfirstlane(*reinterpret_cast<const int *>(p.Wp + 2 * p.wplane))
-                          : __builtin_amdgcn_readfirstlane(x2_exponent(mw));
-        scA = __int_as_float((127 + ea) << 23);
-        scW = __int_as_float((127 + ew) << 23);
-        unA = __int_as_float((127 - ea) << 23);                    // (|e| <= 126: x2_exponent; applied one after the other: the
-        unW = __int_as_float((127 - ew) << 23);                    //  product of the two may be outside fp32's range, the result is not)
-    }
     // tile index -> (tile row, tile column), grouped: NT_GROUP_M tile rows are walked column by column (gemm_nt.hip)
     auto decode = [&](int tile, int &tm, int &tn) {
         const int per_group = NT_GROUP_M * p.tiles_n;
@@ -319,6 +310,13 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_x3_kernel(const NtArgs
     __amdgpu_buffer_rsrc_t rsA, rsW;                               // descriptors of the load cursor's chunk
     long long ld_m0 = 0;
     int ld_n0 = 0, ld_mrows = 0, ld_nrows = 0;
+    // NP = 2: the power-of-two scale of each ROW the thread converts (row-major operand: one per quad; transposed: the CU rows of
+    // its units; a pre-split second operand arrives scaled).  scA / scW belong to the item whose chunk sits in the raw registers;
+    // the maxima of the load cursor's NEXT item are fetched (nxA / nxW) when that item's first chunk is about to be loaded and
+    // become the scales once the last chunk of the item before has been converted (the chunk loop's hooks, below).
+    constexpr int NSA = NP == 2 ? (AT ? CUA : QA) : 1, NSW = (NP == 2 && !PW) ? (WT ? CUW : QW) : 1;
+    float scA[NSA], scW[NSW];
+    unsigned nxA[NSA], nxW[NSW];
     auto make_srds = [&](int tile) {
         int tm, tn;
         decode(tile, tm, tn);
@@ -328,6 +326,50 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_x3_kernel(const NtArgs
         ld_nrows = min(BN, p.N - ld_n0);
     };
     make_srds(ld.tile);
+    // the row maxima of the load cursor's tile (rows past the operand read as 0: scale 2^126 of values that are zero)
+    auto fetch_maxima = [&]() {
+        if (NP != 2) return;
+        int lane_ = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+        asm volatile("" : "+v"(lane_));
+        const int tid_ = wave * 64 + lane_;
+        const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void *)(p.max_a + ld_m0), 0, ld_mrows * 4, 0x00020000);
+        if (!AT) {
+#pragma unroll
+            for (int j = 0; j < NSA; ++j) nxA[j] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rA, (unsigned)(wave * 8 + (lane_ >> 3) + j * NW * 8) * 4u, 0, 0);
+        } else if (CUA == 4) {
+            const u32x4 x = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rA, (unsigned)(tid_ % (BM / CUA)) * 16u, 0, 0));
+#pragma unroll
+            for (int j = 0; j < NSA; ++j) nxA[j] = x[j];
+        } else {
+            typedef unsigned u32x2_ __attribute__((ext_vector_type(2)));
+            const u32x2_ x = __builtin_bit_cast(u32x2_, __builtin_amdgcn_raw_buffer_load_b64(rA, (unsigned)(tid_ % (BM / CUA)) * 8u, 0, 0));
+#pragma unroll
+            for (int j = 0; j < NSA; ++j) nxA[j] = x[j];
+        }
+        if (PW) return;
+        const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void *)(p.max_w + ld_n0), 0, ld_nrows * 4, 0x00020000);
+        if (!WT) {
+#pragma unroll
+            for (int j = 0; j < NSW; ++j) nxW[j] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rW, (unsigned)(wave * 8 + (lane_ >> 3) + j * NW * 8) * 4u, 0, 0);
+        } else if (CUW == 4) {
+            const u32x4 x = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rW, (unsigned)(tid_ % (BN / CUW)) * 16u, 0, 0));
+#pragma unroll
+            for (int j = 0; j < NSW; ++j) nxW[j] = x[j];
+        } else {
+            typedef unsigned u32x2_ __attribute__((ext_vector_type(2)));
+            const u32x2_ x = __builtin_bit_cast(u32x2_, __builtin_amdgcn_raw_buffer_load_b64(rW, (unsigned)(tid_ % (BN / CUW)) * 8u, 0, 0));
+#pragma unroll
+            for (int j = 0; j < NSW; ++j) nxW[j] = x[j];
+        }
+    };
+    auto adopt_scales = [&]() {                                    // the fetched maxima become the conversion's scales
+        if (NP != 2) return;
+#pragma unroll
+        for (int j = 0; j < NSA; ++j) scA[j] = x2_scale(nxA[j]);
+        if (PW) return;
+#pragma unroll
+        for (int j = 0; j < NSW; ++j) scW[j] = x2_scale(nxW[j]);
+    };
     int ld_k0 = 0;
     bool kokA = true, kokW = true;
     auto issue_begin = [&]() {                                     // the load cursor's chunk; past the end of the sequence: empty descriptors
@@ -419,7 +461,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_x3_kernel(const NtArgs
         }
         if (NP == 2) {
             // scaled into fp16's range (exact: a power of two), h = rn16, l = rn16 of the exact remainder
-            const float sc = q < QA ? scA : scW;
+            const float sc = q < QA ? scA[AT ? q % CUA : q] : scW[PW ? 0 : (WT ? (q - QA) % CUW : q - QA)];      // the quad's row
             const float a2 = a * sc, b2 = b * sc;
             const unsigned h = x2_cvt_pk(a2, b2);
             const f16x2 hh = __builtin_bit_cast(f16x2, h);
@@ -595,12 +637,34 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_x3_kernel(const NtArgs
         const int n0 = tn * BN;
         const bool to_ws = !ATOMIC && p.sk_ws != nullptr;
         if (NP == 2) {
+            // out of the scaled domain: row m by 2^-e_A[m], column n by 2^-e_W[n] (exact; one after the other: the product of the two
+            // factors may be outside fp32's range, the result is not).  The factors come from the item's table in LDS
+            // (store_unscales, written behind the barrier of the item's first chunk).
+            if (!ATOMIC) {
+                float ua[TM];
 #pragma unroll
-            for (int a = 0; a < TM; ++a)
+                for (int a = 0; a < TM; ++a) ua[a] = untab[mloc0 + 32 * a];
 #pragma unroll
-                for (int b = 0; b < TN; ++b)
+                for (int bb = 0; bb < NBB; ++bb) {
+                    const f32x4 uw = *reinterpret_cast<const f32x4 *>(untab + BM + nloc0 + coloff(bb));
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[a][b][r] = acc[a][b][r] * unA * unW;
+                    for (int a = 0; a < TM; ++a) set4(a, bb, (get4(a, bb) * ua[a]) * uw);
+                }
+            } else {                                               // operands swapped: D row 8 q + 4 lg + r = activation row, D column li = weight row
+                const int mla = wm * 32 * TM + 4 * lg, nla = wn * 32 * TN + li;
+#pragma unroll
+                for (int b = 0; b < TN; ++b) {
+                    const float uw = untab[BM + nla + 32 * b];
+#pragma unroll
+                    for (int a = 0; a < TM; ++a)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const f32x4 ua4 = *reinterpret_cast<const f32x4 *>(untab + mla + 32 * a + 8 * q);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) acc[a][b][4 * q + r] = (acc[a][b][4 * q + r] * ua4[r]) * uw;
+                        }
+                }
+            }
         }
         const long long mrows = to_ws ? BM : min((long long)BM, p.M - m0);      // (a partial tile is stored whole: rows / columns past
         const int ncols = to_ws ? BN : min(BN, p.N - n0);                       //  the matrix hold zeros and are not read back)
@@ -912,7 +976,43 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_x3_kernel(const NtArgs
     };
 
     // ---- prologue: chunk 0 converted into stage 0, chunk 1 in the raw registers, the first fragments read
+    // NP = 2: the un-scales of the compute cursor's item -- its rows' and columns' maxima are fetched at the top of the item's first
+    // chunk, one entry (or two) per thread, and written to the table in LDS behind that chunk (behind its barrier: every wave has
+    // left the previous item's finish_item by then)
+    constexpr int NUN = NP == 2 ? (BM + BN + NTH - 1) / NTH : 1;
+    unsigned unb[NUN];
+    auto fetch_unscales = [&]() {
+        if (NP != 2) return;
+        int tm, tn;
+        decode(cp.tile, tm, tn);
+        const long long m0 = (long long)tm * BM;
+        const int n0 = tn * BN;
+        const int mrows = (int)min((long long)BM, p.M - m0), ncols = min(BN, p.N - n0);
+        const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void *)(p.max_a + m0), 0, mrows * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void *)(p.max_w + n0), 0, ncols * 4, 0x00020000);
+        int lane_ = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+        asm volatile("" : "+v"(lane_));
+#pragma unroll
+        for (int i = 0; i < NUN; ++i) {
+            const int e = wave * 64 + lane_ + i * NTH;
+            unb[i] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rA, e < BM ? (unsigned)e * 4u : NT_OOB, 0, 0) |
+                     (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rW, e >= BM ? (unsigned)(e - BM) * 4u : NT_OOB, 0, 0);
+        }
+    };
+    auto store_unscales = [&]() {
+        if (NP != 2) return;
+        int lane_ = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+        asm volatile("" : "+v"(lane_));
+#pragma unroll
+        for (int i = 0; i < NUN; ++i) {
+            const int e = wave * 64 + lane_ + i * NTH;
+            if (e < BM + BN) untab[e] = x2_unscale(unb[i]);
+        }
+    };
+
     issue_begin();
+    fetch_maxima();                                                // (the first item's scales)
+    adopt_scales();
 #pragma unroll
     for (int q = 0; q < NQ; ++q) load_quad(q);
     advance_load();
@@ -921,6 +1021,10 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_x3_kernel(const NtArgs
         conv_pair(q, 0);
         conv_pair(q, 1);
         conv_write(0, q);
+    }
+    if (NP == 2 && ld.valid && ld.kc == ld.kb) {                   // (a one-chunk item: the second chunk of the sequence opens the next one)
+        fetch_maxima();
+        adopt_scales();
     }
     issue_begin();
 #pragma unroll
@@ -942,25 +1046,40 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_x3_kernel(const NtArgs
     while (cp.valid) {
         // the item's first chunk is peeled off the loop: one code path per loop body, so the loop-carried registers (raw
         // values in flight, accumulators) need no copies at a merge
+        // NP = 2: when the chunk about to be loaded opens an item, that item's row maxima are fetched now and become the conversion's
+        // scales behind this chunk (whose conversion tasks still split the item before)
+        const bool open0 = NP == 2 && ld.valid && ld.kc == ld.kb;
+        if (open0) fetch_maxima();
+        fetch_unscales();
         issue_begin();                                             // the chunk the conversion tasks reload the registers with
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (MS == 32) chunk(std::true_type(), stage);
         else chunk16(std::true_type(), stage);
         __builtin_amdgcn_sched_barrier(0);
+        if (open0) adopt_scales();
+        store_unscales();
         advance_load();
         stage ^= 1;
         cp.kc++;
         while (cp.kc != cp.ke) {
+            const bool open1 = NP == 2 && ld.valid && ld.kc == ld.kb;
+            if (open1) fetch_maxima();
             issue_begin();
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (MS == 32) chunk(std::false_type(), stage);
             else chunk16(std::false_type(), stage);
             __builtin_amdgcn_sched_barrier(0);
+            if (open1) adopt_scales();
             advance_load();
             stage ^= 1;
             cp.kc++;
         }
         __builtin_amdgcn_sched_barrier(0);
+        if (NP == 2 && cp.ke - cp.kb == 1) {                       // (a one-chunk item: its table was written behind its only barrier)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
         finish_item();
         __builtin_amdgcn_sched_barrier(0);
         next_item(cp);
@@ -1063,90 +1182,122 @@ __global__ __launch_bounds__(256) void x3_sk_reduce_kernel(const float *__restri
         *reinterpret_cast<float4 *>(C + (m0 + row) * ldc + n0 + c4) = a;
     }
 }
-// ---- two-part mode (NP = 2): the operands' power-of-two scales.  fp16 holds 2^-14 .. 65504 (2^-24 with subnormals): an operand is
-// multiplied by 2^e, e = 14 - floor(log2(max |x|)), before its split -- max |x| 2^e in [2^14, 2^15): nothing overflows, and a
-// value keeps its full 22 bits while it is within 2^-16 of the operand's largest (smaller ones lose bits to fp16's subnormal
-// spacing: an ABSOLUTE error of at most 2^-39 max |x|).  The maximum is taken by a scan of the operand in front of the launch
-// (x2_absmax_kernel: one pass at memory speed, the last workgroup to finish turns the maximum into the exponent and re-arms the
-// slot) unless the caller hands one in (pdgn_gemm_set_operand_exponent; a pre-split operand carries its own behind its planes).
-// Slots (1 KB: X2_PARTS partial maxima, gemm_shared.h) come from a ring in a buffer the CALLER provides once
-// (pdgn_gemm_set_scale_slots: the library never allocates; a launch takes the next slot, so the buffer must hold more slots than
-// launches can be in flight).
-__global__ __launch_bounds__(1024) void x2_absmax_kernel(const float *__restrict__ X, long long rows, int cols, int ld, int vec,
-                                                         unsigned *__restrict__ slot) {
-    // a workgroup takes one contiguous range of 16-B units (4-B units when the operand is not 16-B addressable); a row-major
-    // operand without gaps is one flat array, otherwise the (row, column) of a thread's unit is tracked by increments
-    unsigned mx = 0;
-    const int cu = vec ? cols >> 2 : cols;                         // units per row
-    const long long total = rows * cu;
-    long long per = (total + gridDim.x - 1) / gridDim.x;
-    per = (per + 1023) / 1024 * 1024;
-    long long i = (long long)blockIdx.x * per + threadIdx.x;
-    const long long end = min(total, (long long)(blockIdx.x + 1) * per);
-    if (vec && ld == cols) {
-        const uint4 *__restrict__ P = reinterpret_cast<const uint4 *>(X);
-        for (; i + 3072 < end; i += 4096) {                        // four loads in flight per thread, 64 KB per workgroup
-            const uint4 a = P[i], b = P[i + 1024], c = P[i + 2048], d = P[i + 3072];
-            mx = max(mx, max(max(a.x & 0x7fffffffu, a.y & 0x7fffffffu), max(a.z & 0x7fffffffu, a.w & 0x7fffffffu)));
-            mx = max(mx, max(max(b.x & 0x7fffffffu, b.y & 0x7fffffffu), max(b.z & 0x7fffffffu, b.w & 0x7fffffffu)));
-            mx = max(mx, max(max(c.x & 0x7fffffffu, c.y & 0x7fffffffu), max(c.z & 0x7fffffffu, c.w & 0x7fffffffu)));
-            mx = max(mx, max(max(d.x & 0x7fffffffu, d.y & 0x7fffffffu), max(d.z & 0x7fffffffu, d.w & 0x7fffffffu)));
+// ---- two-part mode (NP = 2): the operands' power-of-two scales, ONE PER ROW of each operand as the kernel sees it (round 6: per
+// operand until then).  fp16 holds 2^-14 .. 65504 (2^-24 with subnormals): row r is multiplied by 2^e_r, e_r = 14 - floor(log2(max
+// |x| over the row)), before its split -- max 2^e in [2^14, 2^15): nothing overflows, and a value keeps its full 22 bits while it
+// is within 2^-16 of ITS ROW's largest (smaller ones lose bits to fp16's subnormal spacing: an absolute error of at most 2^-39 of
+// the row's maximum).  C[m, n] leaves the scaled domain by 2^-e_A[m] 2^-e_W[n] in the epilogue (exact).  For an operand given
+// transposed (the input gradient's weight, both operands of a weight gradient) the kernel's rows are the COLUMNS of the matrix in
+// memory: a weight gradient dW[n, k] = sum_r dY[r, n] X[r, k] scales dY per column n and X per column k.
+// The maxima (bit patterns of |x|: unsigned order = magnitude order, so they combine by integer max in any order) come from
+// x2_maxima_kernel (one pass at memory speed: row maxima and / or column maxima), from the caller (pdgn_gemm_set_operand_scales),
+// or from the kernel that wrote the operand; a pre-split operand carries its rows' maxima behind its planes.  The library's own
+// scans take their arrays from an arena the CALLER provides once (pdgn_gemm_set_scale_slots: the library never allocates; it is
+// used round-robin, so it must hold the arrays of all launches that can be in flight).
+template <int NU>
+__global__ __launch_bounds__(1024) void x2_maxima_kernel(const float *__restrict__ X, long long rows, int cols, int ld, int slab_units,
+                                                         long long rows_per_wg, unsigned *__restrict__ rowmax,
+                                                         unsigned *__restrict__ colmax, int row_atomic) {
+    // a workgroup takes rows_per_wg consecutive rows of one slab of 64 NU 16-B column units; a WAVE takes every 16th of them, lane l
+    // the units l, l + 64, ... of the slab: its columns are the same for every row (running column maxima in registers)
+    extern __shared__ unsigned x2_cmax[];                          // [4 slab_units] when colmax
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int u0 = blockIdx.y * slab_units, nu = min(slab_units, cols / 4 - u0);
+    const long long r0 = (long long)blockIdx.x * rows_per_wg, r1 = min(rows, r0 + rows_per_wg);
+    if (colmax) {
+        for (int i = threadIdx.x; i < 4 * nu; i += 1024) x2_cmax[i] = 0u;
+        __syncthreads();
+    }
+    uint4 cm[NU];
+#pragma unroll
+    for (int i = 0; i < NU; ++i) cm[i] = make_uint4(0u, 0u, 0u, 0u);
+    for (long long r = r0 + wave; r < r1; r += 16) {
+        const uint4 *__restrict__ P = reinterpret_cast<const uint4 *>(X + r * ld) + u0;
+        uint4 v[NU];
+#pragma unroll
+        for (int i = 0; i < NU; ++i) v[i] = lane + 64 * i < nu ? P[lane + 64 * i] : make_uint4(0u, 0u, 0u, 0u);
+        unsigned rm = 0u;
+#pragma unroll
+        for (int i = 0; i < NU; ++i) {
+            v[i].x &= 0x7fffffffu; v[i].y &= 0x7fffffffu; v[i].z &= 0x7fffffffu; v[i].w &= 0x7fffffffu;
+            rm = max(rm, max(max(v[i].x, v[i].y), max(v[i].z, v[i].w)));
+            cm[i].x = max(cm[i].x, v[i].x); cm[i].y = max(cm[i].y, v[i].y); cm[i].z = max(cm[i].z, v[i].z); cm[i].w = max(cm[i].w, v[i].w);
         }
-        for (; i < end; i += 1024) {
-            const uint4 a = P[i];
-            mx = max(mx, max(max(a.x & 0x7fffffffu, a.y & 0x7fffffffu), max(a.z & 0x7fffffffu, a.w & 0x7fffffffu)));
-        }
-    } else if (i < end) {
-        long long r = i / cu;
-        int c = (int)(i - r * cu);
-        for (; i < end; i += 1024) {
-            if (vec) {
-                const uint4 a = *reinterpret_cast<const uint4 *>(X + r * ld + 4 * c);
-                mx = max(mx, max(max(a.x & 0x7fffffffu, a.y & 0x7fffffffu), max(a.z & 0x7fffffffu, a.w & 0x7fffffffu)));
-            } else {
-                mx = max(mx, __float_as_uint(X[r * ld + c]) & 0x7fffffffu);
-            }
-            c += 1024;
-            if (c >= cu) {
-                const int q = c / cu;
-                r += q;
-                c -= q * cu;
+        if (rowmax) {
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) rm = max(rm, (unsigned)__shfl_xor((int)rm, o));
+            if (lane == 0) {
+                if (row_atomic) atomicMax(rowmax + r, rm);         // (several slabs: the launcher zero-filled the array)
+                else rowmax[r] = rm;
             }
         }
     }
+    if (!colmax) return;
 #pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, o));
-    __shared__ unsigned wmx[16];
-    if ((threadIdx.x & 63) == 0) wmx[threadIdx.x >> 6] = mx;
+    for (int i = 0; i < NU; ++i)
+        if (lane + 64 * i < nu) {
+            unsigned *c = x2_cmax + 4 * (lane + 64 * i);
+            atomicMax(c, cm[i].x); atomicMax(c + 1, cm[i].y); atomicMax(c + 2, cm[i].z); atomicMax(c + 3, cm[i].w);
+        }
     __syncthreads();
-    if (threadIdx.x < 16) {
-        mx = wmx[threadIdx.x];
-#pragma unroll
-        for (int o = 8; o >= 1; o >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, o));
-        if (threadIdx.x == 0) slot[blockIdx.x] = mx;
-    }
-    if (blockIdx.x == 0 && threadIdx.x >= gridDim.x && threadIdx.x < X2_PARTS) slot[threadIdx.x] = 0u;      // the entries no workgroup writes
+    for (int i = threadIdx.x; i < 4 * nu; i += 1024) atomicMax(colmax + 4 * u0 + i, x2_cmax[i]);
 }
-static int x2_scan_launch(const float *X, long long rows, int cols, int ld, unsigned *slot, hipStream_t s) {
-    const int vec = (cols % 4 == 0 && ld % 4 == 0 && ((uintptr_t)X & 15) == 0) ? 1 : 0;
-    const long long units = rows * (vec ? cols / 4 : cols);
-    long long g = (units + 4095) / 4096;                           // 64 KB per workgroup and pass; at most one workgroup per CU and X2_PARTS in all
-    const int cap = nt_cus() < X2_PARTS ? nt_cus() : X2_PARTS;
-    g = g < 1 ? 1 : (g > cap ? cap : g);
-    hipLaunchKernelGGL(x2_absmax_kernel, dim3((int)g), dim3(1024), 0, s, X, rows, cols, ld, vec, slot);
+// rowmax[rows] and / or colmax[cols] of |X| (rows x cols, pitch ld; cols, ld multiples of 4, X 16-byte aligned) on stream s
+static int x2_maxima_launch(const float *X, long long rows, int cols, int ld, unsigned *rowmax, unsigned *colmax, hipStream_t s) {
+    if (rows < 1 || cols < 4 || cols % 4 || ld % 4 || ld < cols || ((uintptr_t)X & 15) || (!rowmax && !colmax)) return PDGN_ERR_INVALID;
+    const int units = cols / 4;
+    // units per lane: 1, 2, 4 or 8 (2048 columns per slab: 64 registers of values and running column maxima); wider matrices in several slabs
+    const int per = (units + 63) / 64;
+    const int NU = per <= 1 ? 1 : per <= 2 ? 2 : per <= 4 ? 4 : 8;
+    const int slab = 64 * NU, slabs = (units + slab - 1) / slab;
+    const int cus = nt_cus();
+    long long wgs = (rows + 15) / 16;                              // at least one row per wave
+    const long long cap = colmax ? (long long)cus / slabs + 1 : 8LL * cus;    // column maxima: every workgroup ends with 4 slab atomics per column unit
+    wgs = wgs < 1 ? 1 : (wgs > cap ? cap : wgs);
+    const long long rpw = ((rows + wgs - 1) / wgs + 15) / 16 * 16;
+    wgs = (rows + rpw - 1) / rpw;
+    if (wgs > 0x7fffffffLL || slabs > 65535) return PDGN_ERR_INVALID;
+    const int row_atomic = rowmax && slabs > 1;
+    if (row_atomic && hipMemsetAsync(rowmax, 0, (size_t)rows * 4, s) != hipSuccess) return pdgn_launch_status();
+    if (colmax && hipMemsetAsync(colmax, 0, (size_t)cols * 4, s) != hipSuccess) return pdgn_launch_status();
+    const size_t lds = colmax ? (size_t)slab * 16 : 0;
+#define X2_MAX_CALL(N_)                                                                                                         \
+    hipLaunchKernelGGL((x2_maxima_kernel<N_>), dim3((unsigned)wgs, (unsigned)slabs), dim3(1024), lds, s, X, rows, cols, ld, slab, rpw, \
+                       rowmax, colmax, row_atomic)
+    switch (NU) {
+        case 1: X2_MAX_CALL(1); break;
+        case 2: X2_MAX_CALL(2); break;
+        case 4: X2_MAX_CALL(4); break;
+        default: X2_MAX_CALL(8); break;
+    }
+#undef X2_MAX_CALL
     return pdgn_launch_status();
 }
+int x2_maxima_launch_ext(const float *X, long long rows, int cols, int ld, unsigned *rowmax, unsigned *colmax, hipStream_t s) {      // (split.hip)
+    return x2_maxima_launch(X, rows, cols, ld, rowmax, colmax, s);
+}
+// the caller's arena for the library's own scans: bytes handed out round-robin in 1-KB units
 static std::atomic<unsigned *> x2_ring{nullptr};
 static std::atomic<unsigned> x2_ring_slots{0};
-// the partial maxima of (rows x cols, pitch ld) on stream s: a device pointer valid for the launches that follow on s (NULL: no ring)
-const unsigned *x2_scan(const float *X, long long rows, int cols, int ld, hipStream_t s) {
-    static std::atomic<unsigned> next{0};
+static unsigned *x2_arena_take(long long entries) {
+    static std::atomic<unsigned long long> next{0};
     unsigned *ring = x2_ring.load();
     const unsigned slots = x2_ring_slots.load();
-    if (!ring || !slots) return nullptr;
-    unsigned *sl = ring + (size_t)(next.fetch_add(1) % slots) * X2_PARTS;
-    if (x2_scan_launch(X, rows, cols, ld, sl, s) != 0) return nullptr;
-    return sl;
+    const unsigned long long need = (unsigned long long)(entries + 255) / 256;
+    if (!ring || !slots || need > slots) return nullptr;
+    for (;;) {
+        const unsigned long long at = next.fetch_add(need);
+        const unsigned long long pos = at % slots;
+        if (pos + need <= slots) return ring + (size_t)pos * 256;  // (a range that would wrap is skipped: the next take starts over)
+    }
+}
+// the maxima of the kernel-side rows of an operand (rows x cols in memory, pitch ld) on stream s: of its rows, or -- bycol: the
+// operand is given transposed -- of its columns.  A device pointer valid for the launches that follow on s (NULL: no arena)
+const unsigned *x2_scan(const float *X, long long rows, int cols, int ld, bool bycol, hipStream_t s) {
+    unsigned *out = x2_arena_take(bycol ? cols : rows);
+    if (!out) return nullptr;
+    if (x2_maxima_launch(X, rows, cols, ld, bycol ? nullptr : out, bycol ? out : nullptr, s) != 0) return nullptr;
+    return out;
 }
 static thread_local const unsigned *x2_next_max_a = nullptr, *x2_next_max_w = nullptr;     // handed in for the NEXT contraction call's operands
 
@@ -1188,7 +1339,7 @@ const void *x3_symbol_h2(int flags, bool eight_waves);
 // would have to read more than 4.5 bytes per kflop for the maxima keeps three parts (the per-point product's input gradient:
 // 1.8 GB of dY for 118 GFLOP).
 static bool x2_pays(int cfg, long long m, int n, int k, long long scan_bytes) {
-    if (nt_switches().mode != 2 || cfg != 0 || k < 128) return false;
+    if (nt_switches().mode != 2 || cfg != 0 || k < 128 || m >= (1LL << 28)) return false;
     const double flops = 2.0 * (double)m * n * k;
     return flops >= 2e10 && (double)scan_bytes <= 4.5e-3 * flops;
 }
@@ -1337,9 +1488,11 @@ struct X3Cfg {
                             : x2_pays(CFG, m, n, k, (hand_a ? 0 : (long long)m * k * 4) + (hand_w ? 0 : (long long)n * k * 4));
         if (two && CFG != 0) return PDGN_ERR_INVALID;              // (two-part planes for a problem the other tiles take: x2_pays said no)
         if (two) {
-            a.max_a = hand_a ? hand_a : x2_scan(A, AT ? (long long)k : m, AT ? (int)m : k, lda, s);
-            if (!Wp) a.max_w = hand_w ? hand_w : x2_scan(W, WT ? k : n, WT ? n : k, ldw, s);
-            if (!a.max_a || (!Wp && !a.max_w)) return PDGN_ERR_INVALID;     // (no slots: pdgn_gemm_set_scale_slots)
+            // per-row maxima of each operand as the kernel sees it (a transposed operand: the columns of the matrix in memory)
+            a.max_a = hand_a ? hand_a : x2_scan(A, AT ? (long long)k : m, AT ? (int)m : k, lda, AT, s);
+            if (Wp) a.max_w = reinterpret_cast<const unsigned *>(Wp + 2 * wplane);      // (behind the two planes: pdgn_split_f16x2)
+            else a.max_w = hand_w ? hand_w : x2_scan(W, WT ? k : n, WT ? n : k, ldw, WT, s);
+            if (!a.max_a || !a.max_w) return PDGN_ERR_INVALID;     // (no arena: pdgn_gemm_set_scale_slots)
         }
         a.tiles_m = pl.tiles_m; a.tiles_n = pl.tiles_n; a.kchunks = pl.kchunks;
         a.dbg = 0;
@@ -1441,24 +1594,29 @@ extern "C" int pdgn_gemm_set_mode(int mode) {
     return old;
 }
 
-// Two-part mode: the ring of scale slots (1 KB each; device memory that stays the library's to use until replaced; NULL / 0
-// detaches).  Without one the contractions of mode 2 are refused (-1) unless both operands' maxima are handed in.
+// Two-part mode: the arena of the library's own maxima scans (device memory that stays the library's to use until replaced; NULL / 0
+// detaches; used round-robin in 1-KB units: an operand of r kernel-side rows takes 4 r bytes).  Without one the contractions of
+// mode 2 are refused (-1) unless both operands' maxima are handed in.
 extern "C" int pdgn_gemm_set_scale_slots(void *slots, long long bytes) {
     if (bytes < 0 || ((uintptr_t)slots & 15)) return PDGN_ERR_INVALID;
-    const long long n = bytes / (X2_PARTS * 4);
+    const long long n = bytes / 1024;
     x2_ring_slots.store(0);
     x2_ring.store((unsigned *)slots);
     x2_ring_slots.store(slots ? (unsigned)(n > 0x7fffffff ? 0x7fffffff : n) : 0u);
     return 0;
 }
 
-// Two-part mode: the partial maxima of an fp32 matrix (rows x cols, pitch ld) into a caller's 1-KB slot (256 words, device) on
-// `stream`, and the hand-over of such slots for the operands of the calling thread's next contraction call (first / second as that
-// entry point takes them; NULL: scanned by the call), which then does not scan them: an activation that feeds several products --
-// forward, weight gradient -- is scanned once.
-extern "C" int pdgn_absmax_partials(long long rows, int cols, const float *src, int ld, unsigned *slot, pdgn_stream_t stream) {
-    if (rows < 1 || cols < 1 || ld < cols || !src || !slot) return PDGN_ERR_INVALID;
-    return x2_scan_launch(src, rows, cols, ld, slot, (hipStream_t)stream);
+// Two-part mode: the maxima of |x| (bit patterns) of every row (rowmax[rows]; may be NULL) and / or every column (colmax[cols]; may
+// be NULL) of an fp32 matrix (rows x cols, pitch ld; cols and ld multiples of 4, src 16-byte aligned) in ONE pass on `stream`, and
+// the hand-over of such arrays for the operands of the calling thread's next contraction call: max_a[i] / max_w[j] = the maximum
+// of row i of the first / row j of the second operand AS THAT ENTRY POINT'S KERNEL SEES THEM -- pdgn_gemm_nt / _nt_ps: rows of A
+// (m) and rows of W (n); pdgn_gemm_nn: rows of A (m) and COLUMNS of Wt (n); pdgn_gemm_tn_big: columns of dY (n) and columns of X
+// (k).  NULL: scanned by the call.  Upper bounds are as good as maxima as long as they are finite (a bound 2^b above the row's
+// maximum costs b of the 16 binades over which a value keeps its full 22 bits).
+extern "C" int pdgn_absmax_rows_cols(long long rows, int cols, const float *src, int ld, unsigned *rowmax, unsigned *colmax,
+                                     pdgn_stream_t stream) {
+    if (!src) return PDGN_ERR_INVALID;
+    return x2_maxima_launch(src, rows, cols, ld, rowmax, colmax, (hipStream_t)stream);
 }
 extern "C" int pdgn_gemm_set_operand_scales(const unsigned *max_a, const unsigned *max_w) {
     x2_next_max_a = max_a;
@@ -1671,7 +1829,7 @@ extern "C" int pdgn_gemm_nt_ps_launch_info(long long m, int n, int k, int parts,
 // tail's partial tiles; the scan of an operand's maxima): for measurements that take a whole call out of a recorded iteration.
 extern "C" int pdgn_gemm_aux_symbols(const void **reduce, const void **scan) {
     if (reduce) *reduce = (const void *)x3_sk_reduce_kernel;
-    if (scan) *scan = (const void *)x2_absmax_kernel;
+    if (scan) *scan = (const void *)x2_maxima_kernel<8>;       // (the instance a scan of conv2's first operand takes: 5120 columns in slabs of 2048)
     return 0;
 }
 

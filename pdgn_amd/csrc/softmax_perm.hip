@@ -93,8 +93,9 @@ __global__ __launch_bounds__(SP_THREADS) void bn_softmax_perm_fwd_kernel(long lo
 // x (M, k, C) raw conv_all.3 output, u (M, k/2, 2C) raw inte_conv_hk output -- already in w's layout, so the thread
 // that owns channel pair c of point m holds exactly the float4s of u it has to scale.  w is written only when the
 // backward pass will need it (w_out != NULL); y always.  Neither activated tensor makes an extra HBM round trip.
-// max_out (may be NULL): 256 partial maxima of |y| as bit patterns (entry = workgroup % 256, combined with atomic max; zero-filled
-// by the launcher) -- what the two-part contraction that consumes y (conv2's dense half, gemm_x3.hip) would otherwise scan y for.
+// max_out (may be NULL): uint32[M], the maximum of |y| (bit pattern) over each point's k C outputs -- the ROW maxima of y as the
+// (M, k C) first operand of conv2's dense half (combined with atomic max: order-independent; zero-filled by the launcher) -- what
+// the two-part contraction that consumes y (gemm_x3.hip: one power-of-two scale per row) would otherwise scan y for.
 template <int KT>
 __global__ __launch_bounds__(SP_THREADS) void bn_softmax_perm_mul_fwd_kernel(
     long long total2, int k_rt, int C, int act, const float *__restrict__ x, const float *__restrict__ stats,
@@ -157,16 +158,14 @@ __global__ __launch_bounds__(SP_THREADS) void bn_softmax_perm_mul_fwd_kernel(
         }
     }
     if (max_out) {                                                 // (uniform: every thread of the workgroup gets here)
+        // y viewed as the (M, k C) operand of conv2's dense half: the maximum of |y| over ROW m (all slots and channels of point m)
+        const int C2 = C / 2;
+        if ((C2 & 63) == 0) {                                      // a wave lies inside one point: one atomic per wave
 #pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) ymax = max(ymax, (unsigned)__shfl_xor((int)ymax, o));
-        __shared__ unsigned wmax[SP_THREADS / 64];
-        if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = ymax;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            unsigned m = wmax[0];
-#pragma unroll
-            for (int i = 1; i < SP_THREADS / 64; ++i) m = max(m, wmax[i]);
-            atomicMax(max_out + (blockIdx.x & 255), m);
+            for (int o = 32; o >= 1; o >>= 1) ymax = max(ymax, (unsigned)__shfl_xor((int)ymax, o));
+            if ((threadIdx.x & 63) == 0 && e < total2) atomicMax(max_out + e / C2, ymax);
+        } else if (e < total2) {
+            atomicMax(max_out + e / C2, ymax);
         }
     }
 }
@@ -226,7 +225,7 @@ extern "C" int pdgn_bn_softmax_slots_permute_mul(long long m, int k, int c, int 
     const long long total2 = m * (c / 2);
     const dim3 grid(cdiv(total2, SP_THREADS)), block(SP_THREADS);
     hipStream_t s = (hipStream_t)stream;
-    if (max_out && hipMemsetAsync(max_out, 0, 256 * sizeof(unsigned), s) != hipSuccess) return pdgn_launch_status();
+    if (max_out && hipMemsetAsync(max_out, 0, (size_t)m * sizeof(unsigned), s) != hipSuccess) return pdgn_launch_status();
     if (k == 10)
         hipLaunchKernelGGL(bn_softmax_perm_mul_fwd_kernel<10>, grid, block, 0, s, total2, k, c, act, x, stats, act_u, u, stats_u, w, y, max_out);
     else if (k == 20)

@@ -75,12 +75,14 @@ extern "C" int pdgn_split_bf16x3(int rows, int cols, const float *src, int ld_sr
 }
 
 
-// ---- two scaled fp16 parts (gemm_x3.hip, two-part mode): x 2^e = h + l, e = 14 - floor(log2 max |x|) from a scan of the matrix;
-// planes [2][rows][ld] fp16 (h | l) and the exponent as ONE int32 right behind them (element offset 2 plane_stride: the
-// contraction reads it from there), the same for the transpose.  Exactly the loader's arithmetic (gemm_x3.hip conv_pair).
+// ---- two scaled fp16 parts (gemm_x3.hip, two-part mode): row r of the planes holds x 2^e_r = h + l, e_r = 14 - floor(log2 max |x|
+// over that row) (gemm_shared.h x2_scale); planes [2][rows][ld] fp16 (h | l) and the rows' maxima (bit patterns of |x|, uint32[rows])
+// right behind them (element offset 2 plane_stride: the contraction reads its second operand's scales from there).  The transposed
+// planes' rows are the matrix's COLUMNS: scaled by the column maxima, which sit behind THEM.  Exactly the loader's arithmetic
+// (gemm_x3.hip conv_pair).
 typedef _Float16 sp_f16x2 __attribute__((ext_vector_type(2)));
 #include "gemm_shared.h"
-const unsigned *x2_scan(const float *X, long long rows, int cols, int ld, hipStream_t s);      // gemm_x3.hip
+int x2_maxima_launch_ext(const float *X, long long rows, int cols, int ld, unsigned *rowmax, unsigned *colmax, hipStream_t s);      // gemm_x3.hip
 
 __device__ __forceinline__ void sp_split2(float a, float sc, unsigned short &h, unsigned short &l) {
     const float a2 = a * sc;
@@ -93,56 +95,59 @@ __device__ __forceinline__ void sp_split2(float a, float sc, unsigned short &h, 
 }
 
 __global__ __launch_bounds__(256) void split_f16x2_kernel(int rows, int cols, const float *__restrict__ src, int lds_,
-                                                          const unsigned *__restrict__ maxima, unsigned short *__restrict__ P, int ldp,
-                                                          long long pstride, unsigned short *__restrict__ PT, int ldpt,
-                                                          long long ptstride) {
+                                                          unsigned short *__restrict__ P, int ldp, long long pstride,
+                                                          unsigned short *__restrict__ PT, int ldpt, long long ptstride) {
     __shared__ unsigned short tile[2][32][33];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
-    __shared__ unsigned red[16];
-    unsigned mx = maxima[threadIdx.x], unused = 0;                // X2_PARTS = 256 = the workgroup
-    x2_block_max2(mx, unused, red);
-    const int e = x2_exponent(mx);
-    const float sc = __int_as_float((127 + e) << 23);
-    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
-        if (P) *reinterpret_cast<int *>(P + 2 * pstride) = e;
-        if (PT) *reinterpret_cast<int *>(PT + 2 * ptstride) = e;
-    }
+    const unsigned *__restrict__ rmax = P ? reinterpret_cast<const unsigned *>(P + 2 * pstride) : nullptr;      // [rows], written by the scan in front
+    const unsigned *__restrict__ cmax = PT ? reinterpret_cast<const unsigned *>(PT + 2 * ptstride) : nullptr;   // [cols]
+    const int c = c0 + tx;
+    const float scc = (PT && c < cols) ? x2_scale(cmax[c]) : 0.f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int r = r0 + ty + 8 * i, c = c0 + tx;
+        const int r = r0 + ty + 8 * i;
+        const bool in = r < rows && c < cols;
+        const float v = in ? src[(size_t)r * lds_ + c] : 0.f;
         unsigned short h = 0, l = 0;
-        if (r < rows && c < cols) sp_split2(src[(size_t)r * lds_ + c], sc, h, l);
-        if (P && r < rows && c < ldp) {
+        if (P && in) sp_split2(v, x2_scale(rmax[r]), h, l);
+        if (P && r < rows && c < ldp) {                            // (pad columns [cols, ld) hold zeros: a K tail must not multiply 0 by garbage)
             P[(size_t)r * ldp + c] = h;
             P[pstride + (size_t)r * ldp + c] = l;
         }
-        tile[0][ty + 8 * i][tx] = h;
-        tile[1][ty + 8 * i][tx] = l;
+        unsigned short ht = 0, lt = 0;
+        if (PT && in) sp_split2(v, scc, ht, lt);
+        tile[0][ty + 8 * i][tx] = ht;
+        tile[1][ty + 8 * i][tx] = lt;
     }
     if (!PT) return;
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int c = c0 + ty + 8 * i, r = r0 + tx;
-        if (c < cols && r < ldpt) {
-            PT[(size_t)c * ldpt + r] = tile[0][tx][ty + 8 * i];
-            PT[ptstride + (size_t)c * ldpt + r] = tile[1][tx][ty + 8 * i];
+        const int cc = c0 + ty + 8 * i, r = r0 + tx;
+        if (cc < cols && r < ldpt) {
+            PT[(size_t)cc * ldpt + r] = tile[0][tx][ty + 8 * i];
+            PT[ptstride + (size_t)cc * ldpt + r] = tile[1][tx][ty + 8 * i];
         }
     }
 }
 
-// src (rows x cols, pitch ld_src) -> planes (2 x [rows][ld_planes] fp16, plane_stride elements apart, + one int32 at element
-// 2 plane_stride: the buffer holds 2 plane_stride + 2 elements; plane_stride a multiple of 8) and / or the same of the transpose.
+// src (rows x cols, pitch ld_src; cols and ld_src multiples of 4, 16-byte aligned) -> planes (2 x [rows][ld_planes] fp16,
+// plane_stride elements apart, + the rows' maxima as uint32[rows] at element 2 plane_stride: the buffer holds 2 plane_stride + 2
+// rows elements; plane_stride >= rows * ld_planes and a multiple of 8) and / or the same of the transpose (its rows = the
+// columns: 2 plane_stride_t + 2 cols elements).
 extern "C" int pdgn_split_f16x2(int rows, int cols, const float *src, int ld_src, unsigned short *planes, int ld_planes,
                                 long long plane_stride, unsigned short *planes_t, int ld_planes_t, long long plane_stride_t,
                                 pdgn_stream_t stream) {
     if (rows < 1 || cols < 1 || ld_src < cols || (!planes && !planes_t)) return PDGN_ERR_INVALID;
-    if (planes && (ld_planes < cols || plane_stride < (long long)(rows - 1) * ld_planes + cols || plane_stride % 2)) return PDGN_ERR_INVALID;
-    if (planes_t && (ld_planes_t < rows || plane_stride_t < (long long)(cols - 1) * ld_planes_t + rows || plane_stride_t % 2)) return PDGN_ERR_INVALID;
-    const unsigned *e = x2_scan(src, rows, cols, ld_src, (hipStream_t)stream);
-    if (!e) return PDGN_ERR_INVALID;                             // (no scale slots: pdgn_gemm_set_scale_slots)
+    // (the kernel fills the pad columns of every row, the last one's too: the planes must hold whole rows, and the
+    // maxima behind them start on a 16-byte boundary)
+    if (planes && (ld_planes < cols || plane_stride < (long long)rows * ld_planes || plane_stride % 8)) return PDGN_ERR_INVALID;
+    if (planes_t && (ld_planes_t < rows || plane_stride_t < (long long)cols * ld_planes_t || plane_stride_t % 8)) return PDGN_ERR_INVALID;
+    const int st = x2_maxima_launch_ext(src, rows, cols, ld_src, planes ? reinterpret_cast<unsigned *>(planes + 2 * plane_stride) : nullptr,
+                                        planes_t ? reinterpret_cast<unsigned *>(planes_t + 2 * plane_stride_t) : nullptr, (hipStream_t)stream);
+    if (st != 0) return st;
     hipLaunchKernelGGL(split_f16x2_kernel, dim3(cdiv(cols, 32), cdiv(rows, 32)), dim3(256), 0, (hipStream_t)stream, rows, cols, src,
-                       ld_src, e, planes, ld_planes, plane_stride, planes_t, ld_planes_t, plane_stride_t);
+                       ld_src, planes, ld_planes, plane_stride, planes_t, ld_planes_t, plane_stride_t);
     return pdgn_launch_status();
 }

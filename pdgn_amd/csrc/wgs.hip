@@ -475,15 +475,13 @@ __global__ __launch_bounds__(WGS_THREADS) void csr_fill_kernel(long long total, 
     edges[b * nk + pos] = (r / k) * 32 + (r % k);
 }
 
-// max_out (the adjoint kernels; may be NULL): 256 partial maxima of |dY| as bit patterns -- what the two-part contractions that take
-// dY (the per-point product's input and weight gradient, gemm_x3.hip) would otherwise scan its 1.8 GB for.  One atomic max per wave,
-// entry = (workgroup * waves + wave) % 256; the launcher of a dY's FIRST spec zero-fills the slot.
-__device__ __forceinline__ void wgs_emit_max(const float __attribute__((ext_vector_type(4))) v, unsigned *__restrict__ max_out) {
-    unsigned m = max(max(__float_as_uint(v[0]) & 0x7fffffffu, __float_as_uint(v[1]) & 0x7fffffffu),
-                     max(__float_as_uint(v[2]) & 0x7fffffffu, __float_as_uint(v[3]) & 0x7fffffffu));
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
-    if ((threadIdx.x & 63) == 0) atomicMax(max_out + ((blockIdx.x * (WGS_THREADS / 64) + (threadIdx.x >> 6)) & 255), m);
+// max_out (the adjoint kernels; may be NULL): uint32[b n], the maximum of |dY| (bit pattern) over each ROW (b, j) of dY -- what the
+// two-part contractions that take dY as their first operand (the per-point product's input gradient, gemm_x3.hip: one power-of-two
+// scale per row) would otherwise scan its 1.8 GB for.  Atomic max (order-independent); the launcher of a dY's FIRST spec
+// zero-fills the array.
+__device__ __forceinline__ unsigned wgs_absmax4(const float __attribute__((ext_vector_type(4))) v) {
+    return max(max(__float_as_uint(v[0]) & 0x7fffffffu, __float_as_uint(v[1]) & 0x7fffffffu),
+               max(__float_as_uint(v[2]) & 0x7fffffffu, __float_as_uint(v[3]) & 0x7fffffffu));
 }
 
 __global__ __launch_bounds__(WGS_THREADS) void wgs_bwd_csr_kernel(
@@ -518,8 +516,8 @@ __global__ __launch_bounds__(WGS_THREADS) void wgs_bwd_csr_kernel(
         }
         *reinterpret_cast<vec_t *>(dY + bj * ldy + off + t * C + c) = acc;
     }
+    if (max_out) atomicMax(max_out + bj, wgs_absmax4(acc));       // (the small shapes' kernel: one atomic per 16 B written)
     }
-    if (max_out) wgs_emit_max(acc, max_out);                   // (every lane of the wave gets here)
 }
 
 // The adjoint in the task mapping of wgs_fwd_xcd_kernel.  A WAVE owns one source point j of a (sample, 64-channel
@@ -613,7 +611,10 @@ __global__ __launch_bounds__(WGS_THREADS) void wgs_bwd_csr_xcd_kernel(
 #pragma unroll
                 for (int i = 0; i < 4; ++i) m[i] = fmaxf(m[i], fabsf(ctr[i]));
         }
-        wgs_emit_max(m, max_out);
+        unsigned mm = wgs_absmax4(m);
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) mm = max(mm, (unsigned)__shfl_xor((int)mm, o));
+        if (lane == 0) atomicMax(max_out + (size_t)b * n + j, mm);
     }
 }
 
@@ -640,7 +641,7 @@ extern "C" int pdgn_window_gather_sum_backward_csr(int b, int n, int k, int ldy,
     if (!wgs_ok(b, n, k, ldy, T, P, C, off, offc) || C % 4 || ldy % 4 || off % 4 || (offc >= 0 && offc % 4) || k > 31)
         return PDGN_ERR_INVALID;
     if (b == 0) return 0;
-    if (max_out && max_init && hipMemsetAsync(max_out, 0, 256 * sizeof(unsigned), (hipStream_t)stream) != hipSuccess) return pdgn_launch_status();
+    if (max_out && max_init && hipMemsetAsync(max_out, 0, (size_t)b * n * sizeof(unsigned), (hipStream_t)stream) != hipSuccess) return pdgn_launch_status();
     static const int xcd = getenv("PDGN_WGS_XCD") ? atoi(getenv("PDGN_WGS_XCD")) : 1;
     if (xcd && (T <= 8 || T == 10) && (long long)n * T * (C / 4) >= 65536 && wgs_slabs_ok(n, k, ldy, P, C)) {
         static const int cw = wgs_cw("PDGN_WGS_BCW", 64);

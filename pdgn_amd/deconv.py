@@ -30,7 +30,7 @@ from . import streams as _streams
 from ._lib import check, ptr, require, stream_of
 from .fused import (Planes, split_planes, skinny_linear, _zeros, bilateral_weighting, bn_act,  # noqa: F401
                     small_sequential, bn_act_maxpool, bn_softmax_slots_permute, flush_bn_counters,  # noqa: F401
-                    has_zero_colsum, linear_cl, softmax_slots_permute, DenseInput, group_colsum, mark_maxima, _max_slot)
+                    has_zero_colsum, linear_cl, softmax_slots_permute, DenseInput, group_colsum, mark_maxima, row_maxima_buffer)
 from .fused import _STATS_MAX as STATS_MAX  # noqa: F401
 
 F32, I32 = torch.float32, torch.int32
@@ -159,9 +159,9 @@ class EdgeGatherSum(Function):
             # atomic-free path: the specs tile dY completely, each element is written once
             rowptr, edges = transposed_graph(idx)
             dY = torch.empty((b, n, ldy), dtype=F32, device=idx.device)
-            # a LARGE dY leaves with its partial maxima (the kernels that write it compute them on the way): the two-part
-            # contractions of the layer below -- the per-point product's input and weight gradient -- would scan it otherwise
-            dmax = _max_slot(idx.device) if (_lib.gemm_mode() == "x2" and b * n * ldy >= (1 << 24)) else None
+            # a LARGE dY leaves with its ROW maxima (the kernels that write it compute them on the way): the two-part input
+            # gradient of the layer below -- the per-point product, which scales dY row by row -- would scan it otherwise
+            dmax = row_maxima_buffer(b * n, idx.device) if (_lib.gemm_mode() == "x2" and b * n * ldy >= (1 << 24)) else None
             first = 1
             for (T, P, C, off, offc), dout, hb in zip(ctx.specs, douts, ctx.has_bias):
                 hb = 3 if hb == 1 and has_zero_colsum(dout) else hb

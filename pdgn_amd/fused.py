@@ -344,7 +344,8 @@ _PLANES = os.environ.get("PDGN_PLANES", "1") == "1"            # A/B switch: 0 =
 class Planes:
     """A weight's parts as planes, written ONCE per weight instead of by every workgroup's loader of the contraction kernel:
     three bf16 parts (x = h + m + l, csrc/split.hip) as [3][rows][ld], or -- for a contraction that runs on two parts
-    (pdgn_gemm_two_part) -- two scaled fp16 parts [2][rows][ld] with the exponent behind them (int16 storage either way);
+    (pdgn_gemm_two_part) -- two fp16 parts [2][rows][ld], every row scaled by its own power of two, with the rows' maxima behind
+    them (int16 storage either way);
     `t` = the same for the transpose (the input-gradient product dX = dY W is the NT product against W^T) or None.
     parts_p / parts_t: 3 or 2."""
     __slots__ = ("p", "t", "shape", "parts_p", "parts_t")
@@ -379,15 +380,16 @@ def split_planes(w, want_t, rows=None, dy_maxima_free=False, x_maxima_free=False
     x_max: nothing to scan)."""
     _slots(w)
     mode = _lib.gemm_mode()
-    if not (_PLANES and w.is_cuda and w.dim() == 2 and mode != "fp32") or w.shape[0] % 4 or w.shape[1] % 4 or w.stride(1) != 1:
+    if (not (_PLANES and w.is_cuda and w.dim() == 2 and mode != "fp32") or w.shape[0] % 4 or w.shape[1] % 4 or w.stride(1) != 1
+            or w.stride(0) % 4 or w.data_ptr() % 16):
         return None
     n, k = w.shape
     ldp, ldt = (k + 7) // 8 * 8, (n + 7) // 8 * 8
     parts_p = 2 if rows and two_part_planes(rows, n, k, 0 if x_maxima_free else rows * k * 4) else 3    # (the weight brings its exponent)
     parts_t = 2 if rows and want_t and two_part_planes(rows, k, n, 0 if dy_maxima_free else rows * n * 4) else 3
 
-    def planes(parts, rows_, ld):                                  # [parts][rows][ld] (+ 16 B: two-part planes keep the exponent there)
-        buf = torch.empty(parts * rows_ * ld + 8, dtype=torch.int16, device=w.device)
+    def planes(parts, rows_, ld):                                  # [parts][rows][ld] (+ 4 B per row: two-part planes keep their rows' maxima there)
+        buf = torch.empty(parts * rows_ * ld + 2 * rows_ + 8, dtype=torch.int16, device=w.device)
         return buf[:parts * rows_ * ld].view(parts, rows_, ld)
     P = planes(parts_p, n, ldp)
     PT = planes(parts_t, k, ldt) if want_t else None
@@ -405,33 +407,31 @@ def split_planes(w, want_t, rows=None, dy_maxima_free=False, x_maxima_free=False
     return Planes(P, PT, (n, k), parts_p, parts_t)
 
 
-_MAX_POOL, _MAX_NEXT = None, 0
+def _maxima_ok(t):
+    return (_lib.gemm_mode() == "x2" and t.is_cuda and t.dim() == 2 and t.stride(1) == 1 and t.dtype == F32 and t.shape[1] % 4 == 0
+            and t.stride(0) % 4 == 0 and t.data_ptr() % 16 == 0)
 
 
-def operand_maxima(t):
-    """Two-part mode (csrc/gemm_x3.hip, "x2"): the scale of a 2-D fp32 operand -- 256 partial maxima of |t| from ONE scan
-    (pdgn_absmax_partials) in a 1-KB slot of a pool -- to hand to every contraction the operand feeds (forward and weight gradient
-    of a layer; input and weight gradient for dy) instead of a scan per call.  None in the other modes."""
-    global _MAX_POOL, _MAX_NEXT
-    if _lib.gemm_mode() != "x2" or not t.is_cuda or t.dim() != 2 or t.stride(1) != 1 or t.dtype != F32 or t.shape[1] % 4:
-        return None
-    if _MAX_POOL is None:
-        _MAX_POOL = torch.zeros((1 << 12, 256), dtype=torch.int32, device=t.device)   # round-robin: an iteration makes ~200 of them
-    slot = _MAX_POOL[_MAX_NEXT]
-    _MAX_NEXT = (_MAX_NEXT + 1) % _MAX_POOL.shape[0]
-    check(_lib.lib().pdgn_absmax_partials(ctypes.c_longlong(t.shape[0]), t.shape[1], ptr(t), t.stride(0), ptr(slot), stream_of(t)),
-          "pdgn_absmax_partials")
-    return slot
+def operand_maxima(t, rows=True, cols=False):
+    """Two-part mode (csrc/gemm_x3.hip, "x2"): the scales of a 2-D fp32 operand are one power of two per ROW of the operand as the
+    contraction kernel sees it, derived from that row's largest magnitude.  This is ONE scan (pdgn_absmax_rows_cols) that leaves
+    the row maxima (int32 (rows,): bit patterns of |x|) and / or the column maxima ((cols,): what a product that takes the
+    operand TRANSPOSED -- a weight gradient -- needs) in tensors of their own, to hand to every contraction the operand feeds
+    instead of a scan per call.  Returns rowmax, colmax, or the pair when both are asked for; None in the other modes.
+    (Round 5 kept 256 partial maxima per operand in slots of one process-wide ring; the arrays are ordinary tensors now: they
+    live as long as their users hold them, on the operand's device -- ADVICE r5.)"""
+    if not _maxima_ok(t) or not (rows or cols):
+        return (None, None) if (rows and cols) else None
+    rm = torch.empty((t.shape[0],), dtype=torch.int32, device=t.device) if rows else None
+    cm = torch.empty((t.shape[1],), dtype=torch.int32, device=t.device) if cols else None
+    check(_lib.lib().pdgn_absmax_rows_cols(ctypes.c_longlong(t.shape[0]), t.shape[1], ptr(t), t.stride(0), ptr(rm), ptr(cm),
+                                            stream_of(t)), "pdgn_absmax_rows_cols")
+    return (rm, cm) if (rows and cols) else (rm if rows else cm)
 
 
-def _max_slot(device):
-    """A 1-KB slot of the pool for a producer kernel that writes its output's partial maxima itself."""
-    global _MAX_POOL, _MAX_NEXT
-    if _MAX_POOL is None:
-        _MAX_POOL = torch.zeros((1 << 12, 256), dtype=torch.int32, device=device)
-    slot = _MAX_POOL[_MAX_NEXT]
-    _MAX_NEXT = (_MAX_NEXT + 1) % _MAX_POOL.shape[0]
-    return slot
+def row_maxima_buffer(rows, device):
+    """An int32 (rows,) tensor for a producer kernel that writes its output's row maxima itself (it zero-fills it first)."""
+    return torch.empty((rows,), dtype=torch.int32, device=device)
 
 
 def _hand_maxima(L, ma, mw=None):
@@ -535,7 +535,8 @@ def gemm_nt(a, w, bias=None, addend=None, want_stats=False, w_transposed=False, 
 
 
 def gemm_tn(dy, x, max_dy=None, max_x=None):
-    """dy (m, n)^T @ x (m, k) -> (n, k) on pdgn_gemm_tn (reduction over the rows split over workgroups)."""
+    """dy (m, n)^T @ x (m, k) -> (n, k) on pdgn_gemm_tn (reduction over the rows split over workgroups).  max_dy / max_x: the COLUMN
+    maxima of dy / x (operand_maxima(..., cols=True)) for a two-part product, or None (the library scans where two parts pay)."""
     _slots(dy)
     m, n = dy.shape
     k = x.shape[1]
@@ -632,7 +633,7 @@ class LinearCL(Function):
             n, k = weight.shape
             ctx.thin = False
             ctx.planes_t = planes.t
-            # (a two-part product: x is scanned once, for this product and for its weight gradient)
+            # (a two-part product scales x row by row: its row maxima from the producer, or one scan)
             ctx.max_x = xm = (x_max if x_max is not None else operand_maxima(x)) if planes.parts_p == 2 else None
             if want_stats:
                 y, part = gemm_nt_planes(x, planes.p, n, k, bias, addend, want_stats=True, max_a=xm)
@@ -689,24 +690,32 @@ class LinearCL(Function):
             elif want_db:
                 db = _zeros((n,), dy.device) if zero_db else group_colsum(dy)[0]
             return dx, dw, db, None, None, None, None
-        # two-part products (mode "x2", where they pay): dy is scanned ONCE for the input and the weight gradient
-        dy_max = None
+        # two-part products (mode "x2", where they pay): the input gradient dX = dY W scales dY row by row, the weight gradient
+        # dW = dY^T X scales dY and X column by column (its kernel takes both transposed); dy is scanned ONCE for both
+        dy_rows = dy_cols = x_cols = None
         if own and _lib.gemm_mode() == "x2" and dy.shape[1] % 4 == 0:
             m_, n_, k_ = dy.shape[0], weight.shape[0], weight.shape[1]
-            dy_max = take_maxima(dy)                               # left behind by the backward that wrote dy (EdgeGatherSum), or None
+            dy_rows = take_maxima(dy)                              # left behind by the backward that wrote dy (EdgeGatherSum), or None
             dx_two = (ctx.needs_input_grad[0] and ctx.planes_t is not None and ctx.planes_t.shape[0] == 2
                       and planes_fit(ctx.planes_t, m_, k_, n_))
-            dw_two = ctx.needs_input_grad[1] and two_part(n_, k_, m_, (0 if (dx_two or dy_max is not None) else m_ * n_ * 4) +
-                                                          (0 if ctx.max_x is not None else m_ * k_ * 4))
-            if dy_max is None and (dx_two or dw_two):
-                dy_max = operand_maxima(dy)
+            scan_dy_rows = dx_two and dy_rows is None
+            xs = x if x.stride(1) == 1 else None
+            dw_two = (ctx.needs_input_grad[1] and xs is not None and _maxima_ok(dy) and _maxima_ok(xs)
+                      and two_part(n_, k_, m_, (0 if scan_dy_rows else m_ * n_ * 4) + m_ * k_ * 4))
+            if scan_dy_rows or dw_two:
+                r_, c_ = operand_maxima(dy, rows=True, cols=True) if (scan_dy_rows and dw_two) else \
+                    ((operand_maxima(dy), None) if scan_dy_rows else (None, operand_maxima(dy, rows=False, cols=True)))
+                dy_rows = r_ if scan_dy_rows else dy_rows
+                dy_cols = c_
+            if dw_two:
+                x_cols = operand_maxima(xs, rows=False, cols=True)
         if ctx.needs_input_grad[0]:
             if ctx.planes_t is not None and own and dy.shape[1] % 4 == 0 and planes_fit(ctx.planes_t, dy.shape[0], weight.shape[1], weight.shape[0]):
-                dx = gemm_nt_planes(dy, ctx.planes_t, weight.shape[1], weight.shape[0], max_a=dy_max)      # dX = dY W = dY (W^T)^T
+                dx = gemm_nt_planes(dy, ctx.planes_t, weight.shape[1], weight.shape[0], max_a=dy_rows)      # dX = dY W = dY (W^T)^T
             else:
-                dx = gemm_nt(dy, weight, w_transposed=True, max_a=dy_max) if own else dy.matmul(weight)
+                dx = gemm_nt(dy, weight, w_transposed=True, max_a=dy_rows) if own else dy.matmul(weight)      # (where two parts pay the library scans what is not handed in)
         if ctx.needs_input_grad[1]:
-            dw = gemm_tn(dy, x, dy_max, ctx.max_x) if own else dy.t().matmul(x)
+            dw = gemm_tn(dy, x, dy_cols, x_cols) if own else dy.t().matmul(x)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = _zeros((dy.shape[1],), dy.device) if zero_db else group_colsum(dy)[0]
         return dx, dw, db, (dy if ctx.has_addend and ctx.needs_input_grad[3] else None), None, None, None
@@ -1002,7 +1011,7 @@ class BilateralWeighting(Function):
         w = torch.empty((m, k // 2, 2 * C), dtype=F32, device=x.device) if need_w else None
         y = torch.empty_like(u)
         # want_max: y's partial maxima come out of the same pass (the two-part contraction that takes y would scan it otherwise)
-        ymax = _max_slot(x.device) if want_max else None
+        ymax = row_maxima_buffer(m, x.device) if want_max else None     # y as the (m, k C) operand of conv2's dense half: its ROW maxima
         check(L.pdgn_bn_softmax_slots_permute_mul(ctypes.c_longlong(m), k, C, act, ptr(x), ptr(stats_x), act, ptr(u),
                                                   ptr(stats_u), ptr(w), ptr(y), ptr(ymax), stream_of(x)),
               "pdgn_bn_softmax_slots_permute_mul")

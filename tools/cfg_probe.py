@@ -26,7 +26,7 @@ def t(fn, it=20):
 def planes2(w):
     n, k = w.shape
     ld = (k + 7) // 8 * 8
-    buf = torch.empty(2 * n * ld + 8, dtype=torch.int16, device=w.device)
+    buf = torch.empty(2 * n * ld + 2 * n + 8, dtype=torch.int16, device=w.device)     # (+ the rows' maxima behind the planes)
     P = buf[:2 * n * ld].view(2, n, ld)
     check(L.pdgn_split_f16x2(n, k, ptr(w), k, ptr(P), ld, ctypes.c_longlong(n * ld), None, 0, ctypes.c_longlong(0), stream_of(w)), "split")
     return P
