@@ -30,10 +30,12 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 matrix peak (v_mfma_f32_32x32x2_f32 / 16x16x4_f32)
 _GEMM_ENV = os.environ.get("PDGN_GEMM", "")                      # (the library reads the same variable at first use)
 GEMM_ARITHMETIC = ("fp32 matrix instructions (PDGN_GEMM=fp32)" if _GEMM_ENV.startswith("f") else
-                   "fp32 operands, results and accumulation; each product = three fp16 MFMA partial products of the operands' two-way "
-                   "fp16 splits after an exact power-of-two scaling by the operand's largest magnitude (csrc/gemm_x3.hip, NP = 2): "
-                   "against fp64 below the fp32 matrix instructions' error (gemm_accuracy; tests/test_gpu_deconv.py); "
-                   "PDGN_GEMM=x3 / fp32 select the three-part bf16 form / the fp32 instructions" if not _GEMM_ENV.startswith("x3") else
+                   "fp32 operands, results and accumulation; the large contractions: each product = three fp16 MFMA partial products of "
+                   "the operands' two-way fp16 splits after an exact power-of-two scaling of every operand ROW by that row's largest "
+                   "magnitude (csrc/gemm_x3.hip, NP = 2; per row since round 6, per operand before), the others six bf16 products of "
+                   "three-way bf16 splits: against fp64 below the fp32 matrix instructions' error, also row by row (gemm_accuracy, "
+                   "gemm_accuracy.row_scaled; tests/test_gpu_deconv.py); ms_per_step_x3 = the same step with three bf16 parts "
+                   "everywhere (PDGN_GEMM=x3); PDGN_GEMM=fp32 selects the fp32 instructions" if not _GEMM_ENV.startswith("x3") else
                    "fp32 operands, results and accumulation; each product = six bf16 MFMA partial products of the operands' "
                    "three-way bf16 splits (csrc/gemm_x3.hip): error per product <= 2^-23, against fp64 below the fp32 matrix "
                    "instructions' (tests/test_gpu_deconv.py); PDGN_GEMM=fp32 selects those instructions")
@@ -62,6 +64,7 @@ def parse():
                          "from C on the eager schedule's streams (trainer.capture_list, csrc/replay.hip); eager: every "
                          "launch issued from Python")
     ap.add_argument("--no-roofline", action="store_true", help="skip the roofline kernels (for clean rocprof traces)")
+    ap.add_argument("--no-x3-leg", action="store_true", help="skip the extra 10-step loop on three bf16 parts everywhere (ms_per_step_x3)")
     ap.add_argument("--eval", action="store_true", help="time config C5 (Chamfer + EMD, 512 pairs of 2048 points)")
     ap.add_argument("--eval-pairs", type=int, default=512)
     ap.add_argument("--no-eval-c5", action="store_true", help="leave the C5 sub-object (eval_c5) out of the default line")
@@ -370,7 +373,10 @@ def eval_main(args):
 
 def main():
     args = parse()
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+    # (PDGN_FORCE_DIST=1 with one GPU: the SAME child-launch path -- this process starts torch.distributed.run before anything has
+    # touched a GPU, the child builds a one-rank RCCL group and issues the launch list with the collectives as host points -- so that
+    # the N-rank code runs on the one-GPU boxes too: tests/test_gpu_bench_contract.py)
+    if (args.gpus > 1 or os.environ.get("PDGN_FORCE_DIST") == "1") and "WORLD_SIZE" not in os.environ and args.backend != "gloo-stub" and not args.eval:
         self_launch(args)                                        # does not return
     if args.backend == "gloo-stub":
         return stub_main(args)
@@ -396,6 +402,36 @@ def main():
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
+
+
+def x3_leg(args, device, reals, zs, steps=10, warmup=3):
+    """The same iteration with every contraction on three bf16 parts (six bf16 MFMA products per fp32 product: the arithmetic that
+    needs no operand scale at all, PDGN_GEMM=x3), from a second trainer built in that mode, issued as a launch list like the
+    headline: ms per step (VERDICT r5 next #1d: the reference-equivalent-precision number beside the headline)."""
+    import torch
+    from pdgn_amd import _lib
+    from pdgn_amd.trainer import PDGNTrainer
+    old = _lib.set_gemm_mode("x3")
+    try:
+        torch.manual_seed(9999)
+        tr = PDGNTrainer(device=device, base_points=args.base_points)
+        tr.train()
+        for _ in range(2):
+            tr.step(reals, *zs[0])
+        step = lambda z: tr.step(reals, *z)
+        if getattr(args, "issue", "eager") == "list" and getattr(tr, "overlap", False):
+            tr.capture_list(reals, *zs[0])
+            step = lambda z: tr.step_list(None, *z)
+        for i in range(warmup):
+            step(zs[i % len(zs)])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step(zs[(warmup + i) % len(zs)])
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps * 1e3
+    finally:
+        _lib.set_gemm_mode(old)
 
 
 def measure_and_report(args, trainer, reals, zs, world, rank, device, res):
@@ -520,6 +556,13 @@ def measure_and_report(args, trainer, reals, zs, world, rank, device, res):
             line["step_frac_of_fp32_instruction_peak"] = total / (ms * 1e-3) / (MFMA_F32_PEAK_TFLOPS * 1e12)
             line["direct_form_flops_per_step"] = DIRECT_FORM_FLOPS_PER_SAMPLE * B
             line["algebraic_saving"] = DIRECT_FORM_FLOPS_PER_SAMPLE * B / total if total else None
+        if world == 1 and not graphed and not getattr(args, "no_x3_leg", False) and not args.no_roofline:      # (traces run with --no-roofline: one trainer's kernels only)
+            try:
+                from pdgn_amd import _lib as _l
+                if _l.gemm_mode() == "x2":
+                    line["ms_per_step_x3"] = x3_leg(args, device, reals, zs)
+            except Exception as e:                               # never lose the headline number
+                line["ms_per_step_x3"] = {"error": repr(e)}
         if not args.no_roofline:
             try:
                 from pdgn_amd import roofline

@@ -370,22 +370,28 @@ extern "C" int pdgn_replay_chain_neighbor(void *plan_, int pos, int dir, int *ki
 extern "C" int pdgn_replay_time_spans(void *plan_, const int *first, const int *last, int n, int slots) {
     RPlan *plan = (RPlan *)plan_;
     if (!plan || n < 0 || slots < 0 || (n > 0 && (!first || !last))) return PDGN_ERR_INVALID;
-    for (auto &r : plan->nodes) r.tstart = r.tstop = -1;
-    for (auto ev : plan->time_ev) if (ev) (void)hipEventDestroy(ev);
-    plan->time_ev.clear();
-    plan->time_count.assign((size_t)n, 0);
-    plan->time_slots = n ? slots : 0;
+    // (validate every span and build the events BEFORE anything of the plan changes -- a refused call, or an event that
+    // cannot be created, leaves the plan with no timing at all, never with tags that index a missing event)
     const int N = (int)plan->nodes.size();
-    for (int i = 0; i < n; ++i) {
+    for (int i = 0; i < n; ++i)
         if (first[i] < 0 || last[i] >= N || first[i] > last[i] || plan->nodes[first[i]].chain != plan->nodes[last[i]].chain)
             return PDGN_ERR_INVALID;
+    std::vector<hipEvent_t> events((size_t)n * slots * 2, nullptr);
+    for (auto &ev : events) {
+        const hipError_t e = hipEventCreate(&ev);
+        if (e != hipSuccess) {
+            for (auto made : events) if (made) (void)hipEventDestroy(made);
+            return (int)e;
+        }
+    }
+    for (auto &r : plan->nodes) r.tstart = r.tstop = -1;
+    for (auto ev : plan->time_ev) if (ev) (void)hipEventDestroy(ev);
+    plan->time_ev.swap(events);
+    plan->time_count.assign((size_t)n, 0);
+    plan->time_slots = n ? slots : 0;
+    for (int i = 0; i < n; ++i) {
         plan->nodes[first[i]].tstart = i;
         plan->nodes[last[i]].tstop = i;
-    }
-    plan->time_ev.assign((size_t)n * slots * 2, nullptr);
-    for (auto &ev : plan->time_ev) {
-        hipError_t e = hipEventCreate(&ev);
-        if (e != hipSuccess) return (int)e;
     }
     return 0;
 }

