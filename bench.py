@@ -536,6 +536,8 @@ def measure_and_report(args, trainer, reals, zs, world, rank, device, res):
                        "parallelism": "dp%d" % world, "losses_finite": finite, "hipgraph": graphed,
                        # list: every launch of the iteration re-issued from C (csrc/replay.hip), one iteration in flight
                        "issue": issue,
+                       # the collective backend the gradient all-reduces ran on (None: one process, no process group)
+                       "process_group": dist.get_backend() if dist.is_initialized() else None,
                        # how one fp32 product of the dense contractions is formed
                        "gemm_arithmetic": GEMM_ARITHMETIC},
         }

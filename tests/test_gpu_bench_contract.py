@@ -110,5 +110,6 @@ def test_bench_n_rank_launch_path_on_one_gpu():
     for d in (s, r):
         assert d["n_gpus"] == 1 and d["rccl_ranks"] == 1 and d["config"]["issue"] == "list" and d["config"]["losses_finite"] is True
         assert d["config"]["global_batch"] == 35 and abs(d["value"] - 35 * 2048 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+    assert s["config"]["process_group"] is None and r["config"]["process_group"] == "nccl"       # (= RCCL on ROCm)
     assert r["config"]["parallelism"] == "dp1" and r["executed_flops_per_step"] == s["executed_flops_per_step"]
     assert r["ms_per_step"] <= s["ms_per_step"] + 1.0, (r["ms_per_step"], s["ms_per_step"])
