@@ -1838,6 +1838,57 @@ def test_gemm_two_part_planes_and_maxima(M, N, K):
     assert not fused.two_part_planes(17920, 256, 2560, 17920 * 2560 * 4) and not fused.two_part_planes(200, 256, 2560, 0) and not fused.two_part_planes(17920, 256, 16, 0)
 
 
+@pytest.mark.parametrize("M,N,K", [(35840, 12832, 128), (17920, 6432, 64), (17920, 3232, 32), (9001, 2028, 64), (4099, 4100, 128), (300000, 512, 64)])
+def test_row_panel_kernel_of_the_short_reductions(M, N, K):
+    """csrc/gemm_rp.hip (round 6): the products with a short reduction and a wide result -- the per-point tap product of a block,
+    35840 x 12832 x 128 at stage 4 -- on two-part planes with a plain epilogue run on the row-panel kernel (A resident in registers
+    as fragments, weight tiles streamed through LDS, XCD-partitioned).  Same scaling, same split, same three partial products in
+    the same order as gemm_x3.hip's two-part form: where pdgn_gemm_nt takes two parts itself the results are bit-identical;
+    everywhere against fp64 below 1e-6 of every element's own sum |a||w| -- with the rows of both operands spanning 2^-30 .. 1,
+    ragged row / column counts, panels that end inside a workgroup's range."""
+    import ctypes
+    from pdgn_amd import _lib, fused
+    from pdgn_amd._lib import ptr, stream_of
+    L = _lib.lib()
+    _lib.set_gemm_mode("x2")
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    a = torch.randn(M, K, device="cuda", generator=g) * _spread(M, g)[:, None]
+    w = torch.randn(N, K, device="cuda", generator=g) * 0.3 * _spread(N, g)[:, None]
+    pl = fused.split_planes(w, False, rows=M, x_maxima_free=True)
+    assert pl.parts_p == 2
+    L.pdgn_gemm_nt_ps_workspace_floats.restype = ctypes.c_longlong
+    assert L.pdgn_gemm_nt_ps_workspace_floats(ctypes.c_longlong(M), N, K, 2, 0) == 0      # (the row-panel kernel: no stream-K tail)
+    c = torch.full((M, N), float("nan"), device="cuda")
+    wp = ctypes.c_longlong(N * pl.p.shape[2])
+    am = fused.operand_maxima(a)
+    for hand in (True, False):                                   # A's row maxima handed in / scanned by the call
+        c.fill_(float("nan"))
+        if hand:
+            assert L.pdgn_gemm_set_operand_scales(ptr(am), None) == 0
+        assert L.pdgn_gemm_nt_ps(ctypes.c_longlong(M), N, K, ptr(a), K, ptr(pl.p), pl.p.shape[2], wp, 2, None, None, 0, ptr(c), N, None,
+                                 None, 0, 1, 0, None, 0, stream_of(a)) == 0
+        torch.cuda.synchronize()
+        assert torch.isfinite(c).all()
+        rows = torch.cat([torch.arange(0, min(M, 3000), device="cuda"), torch.arange(max(0, M - 3000), M, device="cuda")])
+        ref = a[rows].double() @ w.double().t()
+        mag = (a[rows].double().abs() @ w.double().abs().t()).clamp_min(1e-300)
+        assert ((c[rows].double() - ref).abs() / mag).max().item() < 1e-6
+    if fused.two_part(M, N, K, 0):                               # the tile kernel's two-part form on the same operands: the same bits
+        c0 = torch.empty(M, N, device="cuda")
+        wm = fused.operand_maxima(w)
+        ws = fused._tail_workspace(L, M, N, K, False, a.device)
+        assert L.pdgn_gemm_set_operand_scales(ptr(am), ptr(wm)) == 0
+        assert L.pdgn_gemm_nt(ctypes.c_longlong(M), N, K, ptr(a), K, ptr(w), K, None, None, 0, ptr(c0), N, None, stream_of(a)) == 0
+        torch.cuda.synchronize()
+        del ws
+        assert torch.equal(c0, c)
+    # through LinearCL: forward on the row-panel kernel, the gradients on the tile kernels
+    xg, wg = a.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    pl2 = fused.split_planes(w, True, rows=M, dy_maxima_free=True, x_maxima_free=True)
+    y = fused.linear_cl(xg, wg, planes=pl2, x_max=am)
+    assert torch.equal(y.detach(), c)
+
+
 @pytest.mark.parametrize("M,N,K", [(17920, 256, 2560), (8960, 128, 1280), (17920, 6432, 64), (17920, 64, 6432), (4100, 132, 260)])
 def test_two_part_planes_on_the_big_tile_for_mid_size_products(M, N, K):
     """Two-part planes + handed-in maxima on shapes the launch model gives other tiles for three parts (conv2's dense half and the
