@@ -46,7 +46,7 @@ __device__ __forceinline__ rp_f32x16 rp_mfma(const u32x4 a, const u32x4 b, const
 }
 __device__ __forceinline__ unsigned rp_sw(unsigned r) { return (r >> 2) & 3u; }      // gemm_x3.hip x3_sw<32>
 
-template <int K, int AUX, bool DIRECT>
+template <int K, int AUX, bool PIPE>
 __global__ __launch_bounds__(512, 1) void gemm_rp_kernel(const RpArgs p) {
     static_assert(K == 32 || K == 64 || K == 128, "reduction lengths of the per-point products");
     constexpr int KS = K / 16, KC = K / 32;                         // k steps of 16; 32-deep chunks of the LDS image
@@ -108,8 +108,7 @@ __global__ __launch_bounds__(512, 1) void gemm_rp_kernel(const RpArgs p) {
 
     // ---- A: this wave's 32 rows of the panel as fragments (lane (li, lg) of k step s: row li, k = 16 s + 8 lg .. + 7)
     u32x4 afh[KS], afl[KS];
-    int ua_e[DIRECT ? 1 : 4];                                      // un-scale exponents -e_A of the rows this lane STORES: its fragment row li
-                                                                   // (direct stores), or rows 8 j + (lane >> 3) of the staged read-back
+    int ua_e[4];                                                   // un-scale exponents -e_A of the rows this lane STORES: rows 8 j + (lane >> 3) of the staged read-back
     __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc((void *)p.C, 0, 0, 0x00020000);
     auto load_a = [&](int panel) {
         const long long m0 = (long long)panel * BM + 32 * wave;
@@ -127,13 +126,9 @@ __global__ __launch_bounds__(512, 1) void gemm_rp_kernel(const RpArgs p) {
         }
         const int f = x2_scale_field(mb);
         const float sc = __int_as_float(f << 23);
-        if (DIRECT) {
-            ua_e[0] = 127 - f;
-        } else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                ua_e[j] = 127 - x2_scale_field((unsigned)__builtin_amdgcn_raw_buffer_load_b32(rsMA, (unsigned)(8 * j + (lane >> 3)) * 4u, 0, 0));
-        }
+        for (int j = 0; j < 4; ++j)
+            ua_e[j] = 127 - x2_scale_field((unsigned)__builtin_amdgcn_raw_buffer_load_b32(rsMA, (unsigned)(8 * j + (lane >> 3)) * 4u, 0, 0));
 #pragma unroll
         for (int s = 0; s < KS; ++s)
 #pragma unroll
@@ -163,6 +158,44 @@ __global__ __launch_bounds__(512, 1) void gemm_rp_kernel(const RpArgs p) {
     const unsigned w_rd = (unsigned)(li * 64 + ((lg ^ rp_sw(li)) * 16));       // fragment read: row li of a 32-row block, column 2 (s & 1) + lg of chunk s / 2
     const unsigned stg_wr = (unsigned)(li * 128), stg_sw = (unsigned)(li & 7);
     const unsigned stg_rd = (unsigned)((lane >> 3) * 128 + (((lane & 7) ^ (lane >> 3)) * 16));
+    // ---- a finished tile's result: out of the scaled domain (exact: 2^-(e_A[row] + e_W[column]) as one ldexp), through the wave's
+    // staging block, out as whole 128-B lines.  In four parts -- per 32 x 32 block: accumulators -> staging block; read back row-major
+    // (lane l: row 8 j + (l >> 3), columns 4 (l & 7) .. + 3 -- the same four columns for every j: one set of column exponents per
+    // block, the row exponents in registers since load_a), un-scale, store -- so that (PIPE) the parts of tile t - 1 sit BETWEEN
+    // the matrix instructions of tile t: all eight waves of a workgroup reach the barrier of a step together, and with the result
+    // written behind the products every SIMD's matrix pipe stood idle while its two waves stored (measured: 436 us, the products
+    // alone 170).
+    struct Done {
+        rp_f32x16 acc[2];
+        i32x4 ec[2];                                               // column exponents of the lane's read-back columns, per block
+        int ua[4];
+        int n0;
+        __amdgpu_buffer_rsrc_t rsC;
+    };
+    auto out_part = [&](const Done &d, int part) {
+        const int b = part >> 1;
+        if ((part & 1) == 0) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                *reinterpret_cast<u32x4 *>(stg + stg_wr + (((unsigned)(2 * q + lg) ^ stg_sw) * 16)) =
+                    (u32x4){__float_as_uint(d.acc[b][4 * q]), __float_as_uint(d.acc[b][4 * q + 1]), __float_as_uint(d.acc[b][4 * q + 2]), __float_as_uint(d.acc[b][4 * q + 3])};
+            return;
+        }
+        const int nl = d.n0 + 32 * b + 4 * (lane & 7);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const f32x4 x = *reinterpret_cast<const f32x4 *>(stg + stg_rd + j * 1024);
+            u32x4 v;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = __float_as_uint(__builtin_ldexpf(x[r], d.ua[j] + d.ec[b][r]));
+            const unsigned off = nl < p.N ? (unsigned)((8 * j + (lane >> 3)) * p.ldc + nl) * 4u : NT_OOB;
+            __builtin_amdgcn_raw_buffer_store_b128(v, d.rsC, off, 0, AUX);
+        }
+    };
+    Done prev;
+    bool have_prev = false;
+    prev.n0 = 0;
+    prev.rsC = rsC;
     int buf = 0;
     for (; t < t1; ++t) {
         const unsigned char *Wt = smem + buf * WTILE;
@@ -191,10 +224,31 @@ __global__ __launch_bounds__(512, 1) void gemm_rp_kernel(const RpArgs p) {
             // block, columns 8 q + 4 lg + (0 .. 3) in registers 4 q .. 4 q + 3
 #pragma unroll
             for (int b = 0; b < 2; ++b) acc[b] = rp_mfma(wh[s & 1][b], afl[s], acc[b]);
+            // the previous tile's result, a part per k step (KS = 2: two)
+            if (PIPE && have_prev) {
+#pragma unroll
+                for (int part = 0; part < 4; ++part)
+                    if ((part * KS) / 4 == s) out_part(prev, part);
+            }
 #pragma unroll
             for (int b = 0; b < 2; ++b) acc[b] = rp_mfma(wl[s & 1][b], afh[s], acc[b]);
 #pragma unroll
             for (int b = 0; b < 2; ++b) acc[b] = rp_mfma(wh[s & 1][b], afh[s], acc[b]);
+        }
+        // this tile leaves during the next step's products (PIPE), or now
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            prev.acc[b] = acc[b];
+            prev.ec[b] = *reinterpret_cast<const i32x4 *>(colexp + buf * BN + 32 * b + 4 * (lane & 7));
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) prev.ua[j] = ua_e[j];
+        prev.n0 = (c0 + ct) * BN;
+        prev.rsC = rsC;
+        have_prev = true;
+        if (!PIPE) {
+#pragma unroll
+            for (int part = 0; part < 4; ++part) out_part(prev, part);
         }
         // the next tile's planes (in registers since the last step) into the other buffer: every wave left that buffer at the
         // barrier that ended the previous step; then the loads of the tile after next
@@ -203,42 +257,6 @@ __global__ __launch_bounds__(512, 1) void gemm_rp_kernel(const RpArgs p) {
         if (more) write_w(buf ^ 1);
         const bool more2 = t + 2 < t1;
         if (more2) load_w(next_ct(nct));
-        // ---- this tile's result: out of the scaled domain (exact: 2^-(e_A[row] + e_W[column]) as one ldexp), through the wave's
-        // staging block, out as whole 128-B lines
-        const int n0 = (c0 + ct) * BN;
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            if (DIRECT) {
-                // straight from the accumulators: 32 B of each of 32 rows per store (measurement arm: no staging traffic through LDS)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const i32x4 ec = *reinterpret_cast<const i32x4 *>(colexp + buf * BN + 32 * b + 8 * q + 4 * lg);
-                    u32x4 v;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = __float_as_uint(__builtin_ldexpf(acc[b][4 * q + r], ua_e[0] + ec[r]));
-                    const int nl = n0 + 32 * b + 8 * q + 4 * lg;
-                    __builtin_amdgcn_raw_buffer_store_b128(v, rsC, nl < p.N ? (unsigned)(li * p.ldc + nl) * 4u : NT_OOB, 0, AUX);
-                }
-                continue;
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                *reinterpret_cast<u32x4 *>(stg + stg_wr + (((unsigned)(2 * q + lg) ^ stg_sw) * 16)) =
-                    (u32x4){__float_as_uint(acc[b][4 * q]), __float_as_uint(acc[b][4 * q + 1]), __float_as_uint(acc[b][4 * q + 2]), __float_as_uint(acc[b][4 * q + 3])};
-            // read back row-major: lane l holds row 8 j + (l >> 3), columns 4 (l & 7) .. + 3 -- the SAME four columns for every j, so
-            // the column exponents are one LDS read per block and the row exponents sit in registers since load_a
-            const i32x4 ec = *reinterpret_cast<const i32x4 *>(colexp + buf * BN + 32 * b + 4 * (lane & 7));
-            const int nl = n0 + 32 * b + 4 * (lane & 7);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const f32x4 x = *reinterpret_cast<const f32x4 *>(stg + stg_rd + j * 1024);
-                u32x4 v;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = __float_as_uint(__builtin_ldexpf(x[r], ua_e[j] + ec[r]));
-                const unsigned off = nl < p.N ? (unsigned)((8 * j + (lane >> 3)) * p.ldc + nl) * 4u : NT_OOB;
-                __builtin_amdgcn_raw_buffer_store_b128(v, rsC, off, 0, AUX);
-            }
-        }
         // next step: the same panel's next tile, or the next panel
         if (more && nct == 0) {
             ++panel;
@@ -250,17 +268,19 @@ __global__ __launch_bounds__(512, 1) void gemm_rp_kernel(const RpArgs p) {
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     }
+    if (PIPE && have_prev) {
+#pragma unroll
+        for (int part = 0; part < 4; ++part) out_part(prev, part);
+    }
 }
 
 // ------------------------------------------------------------------ host side
 template <int K>
-static void rp_go(int grid, hipStream_t s, const RpArgs &a, int aux, bool direct) {
-    if (direct) {
-        if (aux == 2) hipLaunchKernelGGL((gemm_rp_kernel<K, 2, true>), dim3(grid), dim3(512), 0, s, a);
-        else hipLaunchKernelGGL((gemm_rp_kernel<K, 0, true>), dim3(grid), dim3(512), 0, s, a);
-    } else if (aux == 16) hipLaunchKernelGGL((gemm_rp_kernel<K, 16, false>), dim3(grid), dim3(512), 0, s, a);
-    else if (aux == 2) hipLaunchKernelGGL((gemm_rp_kernel<K, 2, false>), dim3(grid), dim3(512), 0, s, a);
-    else hipLaunchKernelGGL((gemm_rp_kernel<K, 0, false>), dim3(grid), dim3(512), 0, s, a);
+static void rp_go(int grid, hipStream_t s, const RpArgs &a, int aux, bool pipe) {
+    if (!pipe) hipLaunchKernelGGL((gemm_rp_kernel<K, 2, false>), dim3(grid), dim3(512), 0, s, a);
+    else if (aux == 16) hipLaunchKernelGGL((gemm_rp_kernel<K, 16, true>), dim3(grid), dim3(512), 0, s, a);
+    else if (aux == 2) hipLaunchKernelGGL((gemm_rp_kernel<K, 2, true>), dim3(grid), dim3(512), 0, s, a);
+    else hipLaunchKernelGGL((gemm_rp_kernel<K, 0, true>), dim3(grid), dim3(512), 0, s, a);
 }
 
 // Whether pdgn_gemm_nt_ps(m, n, k) with two-part planes and a plain epilogue takes this kernel: a short reduction, a result at
@@ -290,11 +310,17 @@ int rp_launch(long long m, int n, int k, const float *A, int lda, const unsigned
     a.rgroups = 8 / cs;
     const int cus = nt_cus();
     a.wg_per_xcd = cus >= 8 ? cus / 8 : 1;
-    static const int aux = [] { const char *e = getenv("PDGN_RP_STORE"); return e ? atoi(e) : 2; }();      // 0 plain, 2 nt (default: measured +4 %), 16 sc1
-    static const bool direct = [] { const char *e = getenv("PDGN_RP_DIRECT"); return e && e[0] == '1'; }();  // measurement: unstaged stores
+    // store policy: a result beyond what the 256-MB Infinity Cache keeps is streamed (nt: 447 -> 422 us at 1.84 GB); a smaller one is
+    // left where its consumer -- the gather kernel that follows -- finds it (plain: 49.9 -> 40.6 us at 232 MB).  PDGN_RP_STORE = 0 | 2 | 16
+    // forces plain / nt / sc1 (measurement)
+    static const int aux_env = [] { const char *e = getenv("PDGN_RP_STORE"); return e ? atoi(e) : -1; }();
+    const int aux = aux_env >= 0 ? aux_env : ((double)m * n * 4 > 2.5e8 ? 2 : 0);
+    // (unstaged stores -- 32 B of each of 32 rows per instruction -- measured 510 us against 436 staged, and 2207 with nt: partial lines
+    // written around the L2 are read-modify-writes at the memory; not built)
+    static const bool pipe = [] { const char *e = getenv("PDGN_RP_PIPE"); return !(e && e[0] == '0'); }();   // 0: a tile's result behind its products (A/B)
     const int grid = 8 * a.wg_per_xcd;
-    if (k == 128) rp_go<128>(grid, s, a, aux, direct);
-    else if (k == 64) rp_go<64>(grid, s, a, aux, direct);
-    else rp_go<32>(grid, s, a, aux, direct);
+    if (k == 128) rp_go<128>(grid, s, a, aux, pipe);
+    else if (k == 64) rp_go<64>(grid, s, a, aux, pipe);
+    else rp_go<32>(grid, s, a, aux, pipe);
     return pdgn_launch_status();
 }

@@ -153,8 +153,17 @@ def conv2_dense_stage4(B, base_points, device):
 
 
 def per_point_stage4(B, base_points, device):
-    """The per-point GEMM of stage 4: Y (M x 12832) = X (M x 128) Wcat^T, all taps of inte_conv_hk / conv2 / conv_fea."""
-    return _nt_entry("per-point GEMM, stage 4", B * 8 * base_points, 12832, 128, device)
+    """The per-point GEMM of stage 4: Y (M x 12832) = X (M x 128) Wcat^T, all taps of inte_conv_hk / conv2 / conv_fea.  63 flop per
+    byte: under the two-part form's matrix roof (833 TFLOP/s) this launch is bound by its 1.84 GB of result STORES, not by its
+    118 GFLOP (it was priced as `mfma`) -- bound "hbm", algorithmic bytes = result + both operands.  Round 6: on
+    the row-panel kernel (csrc/gemm_rp.hip) in the default mode."""
+    M, N, K = B * 8 * base_points, 12832, 128
+    e = _nt_entry("per-point GEMM, stage 4", M, N, K, device)
+    rp = gemm_mode() == "x2"
+    h = _entry(e["kernel"].replace("gemm_x3_kernel", "gemm_rp_kernel<128>") if rp else e["kernel"], "hbm", 4.0 * (M * N + M * K + N * K),
+               e["us_per_launch"], shape=[M, N, K])
+    h["mfma_view"] = {"achieved_tflops": e["achieved"], "frac_of_matrix_roof": e["frac"], "peak_tflops": e["peak"]}
+    return h
 
 
 def conv2_dense_dx_stage4(B, base_points, device):

@@ -13,7 +13,7 @@ import csv, glob, json, os, sys
 
 ENTRIES = {   # entry function -> (kernel-name substrings whose dispatches belong to it, FETCH correction, roofline key prefix)
     "conv2_dense_stage4": (["gemm_x3_kernel", "gemm_nt_kernel"], 2.0, "gemm_x3_kernel (conv2 dense half forward"),
-    "per_point_stage4": (["gemm_x3_kernel", "gemm_nt_kernel"], 2.0, "gemm_x3_kernel (per-point GEMM"),
+    "per_point_stage4": (["gemm_rp_kernel", "gemm_x3_kernel", "gemm_nt_kernel"], 2.0, "gemm_rp_kernel<128> (per-point GEMM"),
     "conv2_dense_dx_stage4": (["gemm_x3_kernel", "gemm_nt_kernel"], 2.0, "gemm_x3_kernel<WT> = pdgn_gemm_nn (conv2 dense half input gradient"),
     "weight_grad_stage4": (["gemm_x3_kernel", "gemm_tn_kernel"], 2.0, "gemm_x3_kernel<AT,WT> = pdgn_gemm_tn_big"),
     "bn_act_backward_stage4": (["cl_bwd_reduce_kernel", "cl_bwd_apply_kernel"], 2.0, "cl_bwd_reduce + cl_bwd_apply"),
@@ -51,7 +51,7 @@ def per_launch(d, subs):
 
 def main():
     root, out_csv, out_json = sys.argv[1:4]
-    traffic = {"_meta": {"batch": 35, "base_points": 128, "arch": "gfx950", "recorded": "round 5, profiles/r05_pmc_mfma.csv run"}}
+    traffic = {"_meta": {"batch": 35, "base_points": 128, "arch": "gfx950", "recorded": "round 6, profiles/r06_pmc_mfma.csv run"}}
     lines = ["entry,kernels,us_per_launch,mfma_busy_frac_of_simd_cycles,valu_insts_per_launch,wave_wait_any_frac,"
              "wave_wait_inst_frac,clock_GHz,fetch_MB,write_MB,traffic_MB"]
     for entry, (subs, corr, key) in ENTRIES.items():

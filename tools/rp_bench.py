@@ -37,4 +37,4 @@ for (m, n, k) in [(35840, 12832, 128), (17920, 6432, 64), (17920, 3232, 32), (35
     am = fused.operand_maxima(a)
     us = t(lambda: fused.gemm_nt_planes(a, pl.p, n, k, max_a=am))
     out.append("%dx%dx%d %.1f us %.2f TB/s" % (m, n, k, us, m * n * 4.0 / us / 1e6))
-print("RP=%s STORE=%s CSLABS=%s DIRECT=%s | " % (os.environ.get("PDGN_RP", "1"), os.environ.get("PDGN_RP_STORE", "2"), os.environ.get("PDGN_RP_CSLABS", "auto"), os.environ.get("PDGN_RP_DIRECT", "0")) + " | ".join(out))
+print("RP=%s STORE=%s CSLABS=%s PIPE=%s | " % (os.environ.get("PDGN_RP", "1"), os.environ.get("PDGN_RP_STORE", "2"), os.environ.get("PDGN_RP_CSLABS", "auto"), os.environ.get("PDGN_RP_PIPE", "1")) + " | ".join(out))
