@@ -376,7 +376,8 @@ def main():
     # (PDGN_FORCE_DIST=1 with one GPU: the SAME child-launch path -- this process starts torch.distributed.run before anything has
     # touched a GPU, the child builds a one-rank RCCL group and issues the launch list with the collectives as host points -- so that
     # the N-rank code runs on the one-GPU boxes too: tests/test_gpu_bench_contract.py)
-    if (args.gpus > 1 or os.environ.get("PDGN_FORCE_DIST") == "1") and "WORLD_SIZE" not in os.environ and args.backend != "gloo-stub" and not args.eval:
+    forced = os.environ.get("PDGN_FORCE_DIST") == "1" and args.backend != "gloo-stub" and not args.eval
+    if (args.gpus > 1 or forced) and "WORLD_SIZE" not in os.environ:
         self_launch(args)                                        # does not return
     if args.backend == "gloo-stub":
         return stub_main(args)

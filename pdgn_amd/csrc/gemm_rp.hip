@@ -35,6 +35,8 @@ struct RpArgs {
     int panels, ctiles;               // row panels of 256, column tiles of 64
     int rgroups, cslabs;              // rgroups * cslabs == 8: XCD x = (row group x / cslabs, column slab x % cslabs)
     int wg_per_xcd;
+    float *stat_part;                 // STATS: ceil(M / 32) rows of [3 N] floats, per-column sum (x - pv) | sum (x - pv)^2 | pv of every 32-row block
+                                      // of C (pv: the block's first row), the layout pdgn_bn_stats_from_gemm_partials reads
 };
 
 __device__ __forceinline__ unsigned rp_cvt_pk(float a, float b) {
@@ -46,7 +48,7 @@ __device__ __forceinline__ rp_f32x16 rp_mfma(const u32x4 a, const u32x4 b, const
 }
 __device__ __forceinline__ unsigned rp_sw(unsigned r) { return (r >> 2) & 3u; }      // gemm_x3.hip x3_sw<32>
 
-template <int K, int AUX, bool PIPE>
+template <int K, int AUX, bool PIPE, bool STATS = false>
 __global__ __launch_bounds__(512, 1) void gemm_rp_kernel(const RpArgs p) {
     static_assert(K == 32 || K == 64 || K == 128, "reduction lengths of the per-point products");
     constexpr int KS = K / 16, KC = K / 32;                         // k steps of 16; 32-deep chunks of the LDS image
@@ -109,10 +111,14 @@ __global__ __launch_bounds__(512, 1) void gemm_rp_kernel(const RpArgs p) {
     // ---- A: this wave's 32 rows of the panel as fragments (lane (li, lg) of k step s: row li, k = 16 s + 8 lg .. + 7)
     u32x4 afh[KS], afl[KS];
     int ua_e[4];                                                   // un-scale exponents -e_A of the rows this lane STORES: rows 8 j + (lane >> 3) of the staged read-back
+    int cur_mrows = 0;                                             // rows of this wave's block of the current panel inside the matrix
+    long long cur_prow = 0;
     __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc((void *)p.C, 0, 0, 0x00020000);
     auto load_a = [&](int panel) {
         const long long m0 = (long long)panel * BM + 32 * wave;
         const int mrows = (int)max(0LL, min(32LL, p.M - m0));
+        cur_mrows = mrows;
+        cur_prow = (long long)panel * 8 + wave;
         const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void *)(p.A + m0 * p.lda), 0,
                                                                             mrows > 0 ? (int)(((long long)(mrows - 1) * p.lda + K) * 4) : 0, 0x00020000);
         const __amdgpu_buffer_rsrc_t rsMA = __builtin_amdgcn_make_buffer_rsrc((void *)(p.max_a + m0), 0, mrows * 4, 0x00020000);
@@ -170,6 +176,8 @@ __global__ __launch_bounds__(512, 1) void gemm_rp_kernel(const RpArgs p) {
         i32x4 ec[2];                                               // column exponents of the lane's read-back columns, per block
         int ua[4];
         int n0;
+        int mrows;                                                 // rows of this wave's block inside the matrix (0 .. 32)
+        long long prow;                                            // STATS: the block's partial row
         __amdgpu_buffer_rsrc_t rsC;
     };
     auto out_part = [&](const Done &d, int part) {
@@ -182,19 +190,52 @@ __global__ __launch_bounds__(512, 1) void gemm_rp_kernel(const RpArgs p) {
             return;
         }
         const int nl = d.n0 + 32 * b + 4 * (lane & 7);
+        f32x4 val[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const f32x4 x = *reinterpret_cast<const f32x4 *>(stg + stg_rd + j * 1024);
-            u32x4 v;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = __float_as_uint(__builtin_ldexpf(x[r], d.ua[j] + d.ec[b][r]));
+            for (int r = 0; r < 4; ++r) val[j][r] = __builtin_ldexpf(x[r], d.ua[j] + d.ec[b][r]);
             const unsigned off = nl < p.N ? (unsigned)((8 * j + (lane >> 3)) * p.ldc + nl) * 4u : NT_OOB;
-            __builtin_amdgcn_raw_buffer_store_b128(v, d.rsC, off, 0, AUX);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, val[j]), d.rsC, off, 0, AUX);
+        }
+        if (STATS) {
+            // BatchNorm partials of the block's 32 rows, shifted by its first row (gemm_x3.hip's stat_part: sum (x - pv), sum (x - pv)^2,
+            // pv; combined in fp64 by cl_finalize_blocks_*).  In the read-back layout a lane holds rows 8 j + (l >> 3) of four columns:
+            // four rows in registers, then over the eight lanes of equal l & 7 (xor 8, 16, 32); row 0 sits in lanes 0 .. 7.
+            float pv[4], cs[4] = {0.f, 0.f, 0.f, 0.f}, cq[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pv[r] = __shfl(val[0][r], lane & 7);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (8 * j + (lane >> 3) < d.mrows) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float dd = val[j][r] - pv[r];
+                        cs[r] += dd;
+                        cq[r] = __fmaf_rn(dd, dd, cq[r]);
+                    }
+                }
+#pragma unroll
+            for (int o = 8; o <= 32; o <<= 1)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    cs[r] += __shfl_xor(cs[r], o);
+                    cq[r] += __shfl_xor(cq[r], o);
+                }
+            if (lane < 8 && nl < p.N && d.mrows > 0) {
+                float *P = p.stat_part + d.prow * 3 * p.N + nl;
+                *reinterpret_cast<float4 *>(P) = make_float4(cs[0], cs[1], cs[2], cs[3]);
+                *reinterpret_cast<float4 *>(P + p.N) = make_float4(cq[0], cq[1], cq[2], cq[3]);
+                *reinterpret_cast<float4 *>(P + 2 * p.N) = make_float4(pv[0], pv[1], pv[2], pv[3]);
+            }
         }
     };
     Done prev;
     bool have_prev = false;
     prev.n0 = 0;
+    prev.mrows = 0;
+    prev.prow = 0;
     prev.rsC = rsC;
     int buf = 0;
     for (; t < t1; ++t) {
@@ -244,6 +285,8 @@ __global__ __launch_bounds__(512, 1) void gemm_rp_kernel(const RpArgs p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) prev.ua[j] = ua_e[j];
         prev.n0 = (c0 + ct) * BN;
+        prev.mrows = cur_mrows;
+        prev.prow = cur_prow;
         prev.rsC = rsC;
         have_prev = true;
         if (!PIPE) {
@@ -277,7 +320,10 @@ __global__ __launch_bounds__(512, 1) void gemm_rp_kernel(const RpArgs p) {
 // ------------------------------------------------------------------ host side
 template <int K>
 static void rp_go(int grid, hipStream_t s, const RpArgs &a, int aux, bool pipe) {
-    if (!pipe) hipLaunchKernelGGL((gemm_rp_kernel<K, 2, false>), dim3(grid), dim3(512), 0, s, a);
+    if (a.stat_part) {
+        if (aux == 2) hipLaunchKernelGGL((gemm_rp_kernel<K, 2, true, true>), dim3(grid), dim3(512), 0, s, a);
+        else hipLaunchKernelGGL((gemm_rp_kernel<K, 0, true, true>), dim3(grid), dim3(512), 0, s, a);
+    } else if (!pipe) hipLaunchKernelGGL((gemm_rp_kernel<K, 2, false>), dim3(grid), dim3(512), 0, s, a);
     else if (aux == 16) hipLaunchKernelGGL((gemm_rp_kernel<K, 16, true>), dim3(grid), dim3(512), 0, s, a);
     else if (aux == 2) hipLaunchKernelGGL((gemm_rp_kernel<K, 2, true>), dim3(grid), dim3(512), 0, s, a);
     else hipLaunchKernelGGL((gemm_rp_kernel<K, 0, true>), dim3(grid), dim3(512), 0, s, a);
@@ -287,14 +333,15 @@ static void rp_go(int grid, hipStream_t s, const RpArgs &a, int aux, bool pipe) 
 // least ~64 MB wide enough that the stores are what the launch costs.  PDGN_RP=0: never (A/B switch).
 bool rp_takes(long long m, int n, int k) {
     static const bool off = [] { const char *e = getenv("PDGN_RP"); return e && e[0] == '0'; }();
-    return !off && (k == 32 || k == 64 || k == 128) && n >= 512 && m >= 4096 && (double)m * n >= 1.6e7 && m < (1LL << 28);
+    return !off && (k == 32 || k == 64 || k == 128) && n >= 128 && m >= 4096 && (double)m * n >= 1.6e7 && m < (1LL << 28);
 }
 
 // C (m x n, pitch ldc) = A (m x k, pitch lda) W^T for two-part planes Wp [2][n][ldw] (pdgn_split_f16x2: the rows' maxima behind
 // them), max_a = A's row maxima.  Returns 0, or a launch error.
 int rp_launch(long long m, int n, int k, const float *A, int lda, const unsigned short *Wp, int ldw, long long wplane, float *C, int ldc,
-              const unsigned *max_a, hipStream_t s) {
+              const unsigned *max_a, float *stat_part, hipStream_t s) {
     RpArgs a;
+    a.stat_part = stat_part;
     a.M = m; a.N = n; a.lda = lda; a.ldw = ldw; a.ldc = ldc; a.A = A; a.Wp = Wp; a.wplane = wplane; a.C = C;
     a.max_a = max_a;
     a.max_w = reinterpret_cast<const unsigned *>(Wp + 2 * wplane);

@@ -1329,7 +1329,7 @@ static int x3_reduce_split(int tiles) {
 // gemm_rp.hip: the row-panel kernel of the short-reduction, wide-result products on two-part planes
 bool rp_takes(long long m, int n, int k);
 int rp_launch(long long m, int n, int k, const float *A, int lda, const unsigned short *Wp, int ldw, long long wplane, float *C, int ldc,
-              const unsigned *max_a, hipStream_t s);
+              const unsigned *max_a, float *stat_part, hipStream_t s);
 // gemm_x3_16.hip: instance (tile cfg, flags = ATOMIC | WT << 1 | AT << 2 | EPI << 3 | PW << 4) of gemm_x3_kernel<..., 16>
 void x3_launch16(int cfg, int flags, int grid, hipStream_t s, const NtArgs &a);
 // gemm_x3_h2.hip: the same of gemm_x3_kernel<..., 32, 2> (two fp16 parts), and an instance's host symbol
@@ -1775,12 +1775,12 @@ extern "C" int pdgn_gemm_nt_ps(long long m, int n, int k, const float *A, int ld
         (gate && (ldgate < n || ldgate % 4)) || m >= (1LL << 31) || (row_bias && m * rows_per_group >= (1LL << 32)) ||
         (row_bias && rows_per_group >= 1 && ((m + rows_per_group - 1) / rows_per_group) * (long long)ld_rb * 4 >= (long long)NT_OOB))
         return PDGN_ERR_INVALID;
-    if (parts == 2 && x3_mode() == 2 && !bias && !addend && !stat_part && !row_bias && !act && !gate && rp_takes(m, n, k)) {
+    if (parts == 2 && x3_mode() == 2 && !bias && !addend && !row_bias && !act && !gate && rp_takes(m, n, k)) {
         // a short reduction and a wide result: the row-panel kernel (gemm_rp.hip: A resident in registers, the weight tiles streamed,
         // the same two-part arithmetic bit for bit)
         const unsigned *ma = x2_cur_max_a ? x2_cur_max_a : x2_scan(A, m, k, lda, false, (hipStream_t)stream);
         if (!ma) return PDGN_ERR_INVALID;                          // (no arena: pdgn_gemm_set_scale_slots)
-        return rp_launch(m, n, k, A, lda, Wplanes, ldw, wplane, C, ldc, ma, (hipStream_t)stream);
+        return rp_launch(m, n, k, A, lda, Wplanes, ldw, wplane, C, ldc, ma, stat_part, (hipStream_t)stream);      // (stat_part: one partial row per 32 rows, pdgn_gemm_nt_ps_stat_rows)
     }
     NtEpi e;
     e.row_bias = row_bias; e.ld_rb = ld_rb; e.rows_per_group = rows_per_group > 0 ? rows_per_group : 1; e.act = act; e.gate = gate;
@@ -1802,7 +1802,7 @@ extern "C" long long pdgn_gemm_tail_workspace_floats(long long m, int n, int k, 
 }
 extern "C" long long pdgn_gemm_nt_ps_workspace_floats(long long m, int n, int k, int parts, int with_stats) {
     if (!x3_mode() || m < 1 || n < 4 || k < 4) return 0;
-    if (parts == 2 && !with_stats && rp_takes(m, n, k)) return 0;         // (the row-panel kernel has no tail)
+    if (parts == 2 && rp_takes(m, n, k)) return 0;                        // (the row-panel kernel has no tail)
     if (parts == 2) return with_stats ? 0 : X3Big::tail_floats(m, n, k, true);
     return pdgn_gemm_tail_workspace_floats(m, n, k, with_stats);
 }
@@ -1876,6 +1876,17 @@ extern "C" long long pdgn_gemm_tn_big_workspace_floats(long long m, int n, int k
         case 2: return X3Narrow::at_floats(n, k, red);
         default: return X3Square::at_floats(n, k, red);
     }
+}
+
+// The same two questions for pdgn_gemm_nt_ps with `parts`-part planes, bias / addend / epilogue extras absent (`plain` != 0): a
+// short-reduction product on two-part planes runs on the row-panel kernel (gemm_rp.hip), whose partial rows cover 32 rows each.
+extern "C" long long pdgn_gemm_nt_ps_stat_rows(long long m, int n, int k, int parts, int plain) {
+    if (x3_mode() == 2 && parts == 2 && plain && m >= 1 && rp_takes(m, n, k)) return (m + 31) / 32;
+    return pdgn_gemm_nt_stat_rows(m, n, k);
+}
+extern "C" int pdgn_gemm_nt_ps_stat_block_rows(long long m, int n, int k, int parts, int plain) {
+    if (x3_mode() == 2 && parts == 2 && plain && m >= 1 && rp_takes(m, n, k)) return 32;
+    return pdgn_gemm_nt_stat_block_rows(m, n, k);
 }
 
 // Number of [3n] partial-statistics rows pdgn_gemm_nt writes for this problem (tile rows x waves along m).

@@ -363,7 +363,7 @@ class PointDeconv(nn.Module):
     # `preassemble` builds them ahead of a pass (the trainer: once per iteration, for BOTH generator passes, off the issuing
     # stream); forward_cl takes them from there while the parameters' versions still match, else builds them on the spot.
     def _weights_key(self, Fc):
-        ws = [self.inte_conv_hk[0].weight, self.conv2.conv.weight] + ([self.conv_fea[0].weight] if self.bilateral else [])
+        ws = [self.inte_conv_hk[0].weight, self.conv2.conv.weight] + ([self.conv_fea[0].weight, self.conv_all[3].weight] if self.bilateral else [])
         return (Fc, getattr(self, "_rows_hint", None)) + tuple((w.data_ptr(), w._version) for w in ws)
 
     def _assemble_now(self, Fc):
@@ -376,7 +376,14 @@ class PointDeconv(nn.Module):
             rows = getattr(self, "_rows_hint", None)               # B * N of the last forward: decides three bf16 / two fp16 parts
             pv = split_planes(WcatV.detach(), want_t, rows, dy_maxima_free=True)      # (its dY comes from EdgeGatherSum.backward, with maxima)
             pb = split_planes(Wb.detach(), want_t, rows, x_maxima_free=self.bilateral and self.softmax)      # (inte arrives with its maxima: bilateral_weighting's want_max)
-        return WcatC, WcatV, Wb, pv, pb
+            # the edge-level layer in front of the bilateral weighting (conv_all.3: rows * k edges x 2F x 64): forward planes only --
+            # a short reduction with a wide result, the row-panel kernel's case (csrc/gemm_rp.hip), BatchNorm partials included
+            # (x_maxima_free: the scan of its 64-channel input -- 4 % of the result's bytes -- is not what decides here)
+            pa3 = (split_planes(_w2d(self.conv_all[3]).detach(), False, rows * self.k if rows else None, x_maxima_free=True)
+                   if self.bilateral and _lib.gemm_mode() == "x2" else None)
+            if pa3 is not None and pa3.parts_p != 2:
+                pa3 = None
+        return WcatC, WcatV, Wb, pv, pb, pa3
 
     def preassemble(self, Fc):
         """Build the block's GEMM operands now (under the caller's grad mode, on the current stream)."""
@@ -417,11 +424,11 @@ class PointDeconv(nn.Module):
         elif idx.dtype != I32:
             idx = idx.to(I32)
         idx = idx.contiguous()
-        planes_v = planes_b = None
+        planes_v = planes_b = planes_a3 = None
         if xt.is_cuda:
             T = k // 2 + 1
             P = k - T + 1
-            WcatC, WcatV, Wb, planes_v, planes_b = self.assembled(Fc if const is not None else 0)
+            WcatC, WcatV, Wb, planes_v, planes_b, planes_a3 = self.assembled(Fc if const is not None else 0)
         else:                                                          # host tests: the same algebra in torch ops
             Wcat, Wb, T, P = self._assemble()
             WcatC, WcatV = (Wcat[:, :Fc], Wcat[:, Fc:].contiguous()) if const is not None else (None, Wcat)
@@ -465,7 +472,7 @@ class PointDeconv(nn.Module):
             # in training the GEMMs' epilogues emit the BatchNorm statistics of their outputs: no statistics pass
             h, ph = linear_cl(h, _w2d(self.conv_all[0]), None, None, training)
             h = bn_act(h, self.conv_all[1], training, pre_bias=self.conv_all[0].bias, partials=ph)
-            h, ph = linear_cl(h, _w2d(self.conv_all[3]), None, None, training)
+            h, ph = linear_cl(h, _w2d(self.conv_all[3]), None, None, training, planes=planes_a3)
             if self.softmax:
                 # conv_all.4 + LeakyReLU + softmax over the k slots + interleave w[b,n,s=P*j+p,c'] -> [b,n,p,o=2c'+j]
                 # (:623-625, :634-641) AND inte = LeakyReLU(BN(inte_pre)) * w (:637, :642): one pass over both raw tensors

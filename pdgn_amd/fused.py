@@ -457,11 +457,20 @@ def _tail_workspace(L, m, n, k, with_stats, device, parts=None):
     return ws
 
 
-def planes_fit(P, m, n, k, with_stats=False):
+def _rp_stats(m, n, k, parts, plain):
+    """Whether pdgn_gemm_nt_ps(m, n, k) on `parts`-part planes runs on the row-panel kernel (csrc/gemm_rp.hip: short reductions on
+    two-part planes, no bias / addend): its BatchNorm partials cover 32 rows each."""
+    return parts == 2 and plain and _lib.lib().pdgn_gemm_nt_ps_stat_block_rows(ctypes.c_longlong(m), n, k, 2, 1) == 32 \
+        and _lib.lib().pdgn_gemm_nt_stat_block_rows(ctypes.c_longlong(m), n, k) != 32
+
+
+def planes_fit(P, m, n, k, with_stats=False, plain=False):
     """Whether planes P can serve the product (m, n, k): three-part planes always; two-part ones (which run on the 256 x 128 tile
-    whatever the launch model picks) unless the launch emits BatchNorm partials and the model's pick -- whose geometry the
-    partials' consumers were told -- is another tile."""
-    return P.shape[0] == 3 or not with_stats or (_lib.lib().pdgn_gemm_nt_config(ctypes.c_longlong(m), n, k, 1) & 15) == 0
+    whatever the launch model picks, or -- short reductions without bias / addend: plain -- on the row-panel kernel) unless the
+    launch emits BatchNorm partials and neither the row-panel kernel takes it nor the model's pick -- whose geometry the partials'
+    consumers were told -- is the 256 x 128 tile."""
+    return (P.shape[0] == 3 or not with_stats or _rp_stats(m, n, k, P.shape[0], plain)
+            or (_lib.lib().pdgn_gemm_nt_config(ctypes.c_longlong(m), n, k, 1) & 15) == 0)
 
 
 def gemm_nt_planes(a, P, n, k, bias=None, addend=None, want_stats=False, max_a=None):
@@ -476,8 +485,9 @@ def gemm_nt_planes(a, P, n, k, bias=None, addend=None, want_stats=False, max_a=N
     out = torch.empty((m, n), dtype=F32, device=a.device)
     part = None
     if want_stats:
-        L.pdgn_gemm_nt_stat_rows.restype = ctypes.c_longlong
-        part = torch.empty((L.pdgn_gemm_nt_stat_rows(ctypes.c_longlong(m), n, k), 3 * n), dtype=F32, device=a.device)
+        L.pdgn_gemm_nt_ps_stat_rows.restype = ctypes.c_longlong
+        part = torch.empty((L.pdgn_gemm_nt_ps_stat_rows(ctypes.c_longlong(m), n, k, P.shape[0], 1 if (bias is None and addend is None) else 0),
+                            3 * n), dtype=F32, device=a.device)
     b = bias.detach().contiguous() if bias is not None else None
     if addend is not None:
         addend = _pad_cols(addend)
@@ -614,6 +624,13 @@ def thin_tn(dy, x, want_db):
     return dw, db
 
 
+def _planes_taken(x, weight, planes, want_stats, plain):
+    """Whether LinearCL's forward multiplies against the pre-split planes (the same question stat_block_rows asks)."""
+    return (planes is not None and x.is_cuda and x.shape[0] >= _PLANES_MIN_ROWS and planes.shape == tuple(weight.shape)
+            and x.shape[1] == weight.shape[1] and x.shape[1] % 4 == 0
+            and planes_fit(planes.p, x.shape[0], weight.shape[0], weight.shape[1], want_stats, plain))
+
+
 class LinearCL(Function):
     """y = x @ W^T (+ b) (+ addend) for point-major rows x (M, C_in): the reference's Conv2d / Conv1d / Linear layers
     (models/PDGNet_v2.py:559-625, 835-862, 886-1014) as row-matrix products on the hand-written MFMA kernels (see above)."""
@@ -626,9 +643,7 @@ class LinearCL(Function):
         ctx.has_addend = addend is not None
         ctx.planes_t = None
         ctx.max_x = None
-        if (planes is not None and x.is_cuda and x.shape[0] >= _PLANES_MIN_ROWS and planes.shape == tuple(weight.shape)
-                and x.shape[1] == weight.shape[1] and x.shape[1] % 4 == 0
-                and planes_fit(planes.p, x.shape[0], weight.shape[0], weight.shape[1], want_stats)):
+        if _planes_taken(x, weight, planes, want_stats, bias is None and addend is None):
             # the weight arrives pre-split (Planes): no split work for it in the kernel, forward and input gradient
             n, k = weight.shape
             ctx.thin = False
@@ -893,15 +908,18 @@ def linear_cl(x2d, weight, bias=None, addend=None, want_stats=None, planes=None,
         return LinearCL.apply(x2d, weight, bias, addend, False, planes, x_max)
     if want_stats:
         y, part = LinearCL.apply(x2d, weight, bias, addend, True, planes, x_max)
-        return y, ((part, stat_block_rows(x2d, weight, addend)) if part is not None else None)
+        return y, ((part, stat_block_rows(x2d, weight, addend, planes, bias)) if part is not None else None)
     return LinearCL.apply(x2d, weight, bias, addend, False, planes, x_max), None
 
 
-def stat_block_rows(x2d, weight, addend=None):
+def stat_block_rows(x2d, weight, addend=None, planes=None, bias=None):
     """Rows of y = x2d weight^T each partial-statistics row of LinearCL's epilogue covers: the same question the launch asked
     (the same deterministic launch model on the same padded sizes), so the block size travels with the partials as a value."""
     L = _lib.lib()
     n, k = weight.shape
+    plain = bias is None and addend is None
+    if _planes_taken(x2d, weight, planes, True, plain):
+        return int(L.pdgn_gemm_nt_ps_stat_block_rows(ctypes.c_longlong(x2d.shape[0]), n, k, planes.p.shape[0], 1 if plain else 0))
     if addend is None and weight.is_contiguous() and _thin_ok(x2d, n, k):
         return int(L.pdgn_thin_stat_block_rows())
     return int(L.pdgn_gemm_nt_stat_block_rows(ctypes.c_longlong(x2d.shape[0]), (n + 3) // 4 * 4, (k + 3) // 4 * 4))

@@ -1889,6 +1889,36 @@ def test_row_panel_kernel_of_the_short_reductions(M, N, K):
     assert torch.equal(y.detach(), c)
 
 
+@pytest.mark.parametrize("ratio", [0.0, 300.0])
+@pytest.mark.parametrize("M,N,K", [(40960, 512, 64), (40999, 516, 64), (179200, 256, 64), (20000, 1024, 128)])
+def test_row_panel_kernel_emits_batchnorm_partials(M, N, K, ratio):
+    """The row-panel kernel with stat_part (the edge-level layer in front of the bilateral weighting, conv_all.3: 358400 x 512 x 64
+    at stage 4): one partial row per 32 rows of the result -- sum (x - pv), sum (x - pv)^2, pv with pv the block's first row --
+    through linear_cl(want_stats=True, planes=two-part planes) -> bn_act(partials=...) against fp64: normalised output at 1e-4, also
+    with |mean| >> std (ratio: the weight rows get a common offset direction), ragged row / column counts, the result itself equal
+    to the call without partials, running statistics."""
+    import torch.nn as nn
+    from pdgn_amd import _lib, fused
+    _lib.set_gemm_mode("x2")
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    x = torch.randn(M, K, device="cuda", generator=g) + (1.0 if ratio else 0.0)
+    w = torch.randn(N, K, device="cuda", generator=g) / K ** 0.5 + ratio / K
+    pl = fused.split_planes(w, False, rows=M, x_maxima_free=True)
+    assert pl.parts_p == 2
+    y0 = fused.linear_cl(x, w, planes=pl)
+    y, part = fused.linear_cl(x, w, None, None, True, planes=pl)
+    assert part is not None and part[1] == 32 and part[0].shape == ((M + 31) // 32, 3 * N)
+    assert torch.equal(y, y0)
+    bn = nn.BatchNorm1d(N).cuda().train()
+    out = fused.bn_act(y, bn, True, act="none", partials=part)
+    y64 = y.double()
+    want = (y64 - y64.mean(0)) / torch.sqrt(y64.var(0, unbiased=False) + bn.eps)
+    err = (out.double() - want).abs().max().item()
+    assert err < 1e-4 * max(1.0, want.abs().max().item()), (M, N, K, ratio, err)
+    np.testing.assert_allclose(bn.running_var.cpu().numpy(), (0.9 + 0.1 * y64.var(0, unbiased=True)).float().cpu().numpy(), rtol=1e-4)
+    np.testing.assert_allclose(bn.running_mean.cpu().numpy(), (0.1 * y64.mean(0)).float().cpu().numpy(), rtol=1e-4, atol=1e-6)
+
+
 @pytest.mark.parametrize("M,N,K", [(17920, 256, 2560), (8960, 128, 1280), (17920, 6432, 64), (17920, 64, 6432), (4100, 132, 260)])
 def test_two_part_planes_on_the_big_tile_for_mid_size_products(M, N, K):
     """Two-part planes + handed-in maxima on shapes the launch model gives other tiles for three parts (conv2's dense half and the
