@@ -1197,9 +1197,11 @@ __global__ __launch_bounds__(256) void x3_sk_reduce_kernel(const float *__restri
 template <int NU>
 __global__ __launch_bounds__(1024) void x2_maxima_kernel(const float *__restrict__ X, long long rows, int cols, int ld, int slab_units,
                                                          long long rows_per_wg, unsigned *__restrict__ rowmax,
-                                                         unsigned *__restrict__ colmax, int row_atomic) {
+                                                         unsigned *__restrict__ colmax, int row_atomic, int upr) {
     // a workgroup takes rows_per_wg consecutive rows of one slab of 64 NU 16-B column units; a WAVE takes every 16th of them, lane l
-    // the units l, l + 64, ... of the slab: its columns are the same for every row (running column maxima in registers)
+    // the units l, l + 64, ... of the slab: its columns are the same for every row (running column maxima in registers).  Narrow
+    // matrices (NU = 1, upr = 2 .. 32 units per row, a power of two): 64 / upr rows per wave and pass, lane l = (row l / upr, unit
+    // l % upr) -- a 64-column operand read one row per wave and pass ran at 1.8 TB/s
     extern __shared__ unsigned x2_cmax[];                          // [4 slab_units] when colmax
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int u0 = blockIdx.y * slab_units, nu = min(slab_units, cols / 4 - u0);
@@ -1208,14 +1210,15 @@ __global__ __launch_bounds__(1024) void x2_maxima_kernel(const float *__restrict
         for (int i = threadIdx.x; i < 4 * nu; i += 1024) x2_cmax[i] = 0u;
         __syncthreads();
     }
+    const int G = 64 / upr, ul = lane & (upr - 1), gl = lane / upr;     // (upr = 64: G = 1, ul = lane, gl = 0)
     uint4 cm[NU];
 #pragma unroll
     for (int i = 0; i < NU; ++i) cm[i] = make_uint4(0u, 0u, 0u, 0u);
-    for (long long r = r0 + wave; r < r1; r += 16) {
+    for (long long r = r0 + (long long)wave * G + gl; r < r1; r += 16 * G) {
         const uint4 *__restrict__ P = reinterpret_cast<const uint4 *>(X + r * ld) + u0;
         uint4 v[NU];
 #pragma unroll
-        for (int i = 0; i < NU; ++i) v[i] = lane + 64 * i < nu ? P[lane + 64 * i] : make_uint4(0u, 0u, 0u, 0u);
+        for (int i = 0; i < NU; ++i) v[i] = ul + 64 * i < nu ? P[ul + 64 * i] : make_uint4(0u, 0u, 0u, 0u);
         unsigned rm = 0u;
 #pragma unroll
         for (int i = 0; i < NU; ++i) {
@@ -1224,9 +1227,8 @@ __global__ __launch_bounds__(1024) void x2_maxima_kernel(const float *__restrict
             cm[i].x = max(cm[i].x, v[i].x); cm[i].y = max(cm[i].y, v[i].y); cm[i].z = max(cm[i].z, v[i].z); cm[i].w = max(cm[i].w, v[i].w);
         }
         if (rowmax) {
-#pragma unroll
-            for (int o = 32; o >= 1; o >>= 1) rm = max(rm, (unsigned)__shfl_xor((int)rm, o));
-            if (lane == 0) {
+            for (int o = upr >> 1; o >= 1; o >>= 1) rm = max(rm, (unsigned)__shfl_xor((int)rm, o));
+            if (ul == 0) {
                 if (row_atomic) atomicMax(rowmax + r, rm);         // (several slabs: the launcher zero-filled the array)
                 else rowmax[r] = rm;
             }
@@ -1235,8 +1237,8 @@ __global__ __launch_bounds__(1024) void x2_maxima_kernel(const float *__restrict
     if (!colmax) return;
 #pragma unroll
     for (int i = 0; i < NU; ++i)
-        if (lane + 64 * i < nu) {
-            unsigned *c = x2_cmax + 4 * (lane + 64 * i);
+        if (ul + 64 * i < nu) {
+            unsigned *c = x2_cmax + 4 * (ul + 64 * i);
             atomicMax(c, cm[i].x); atomicMax(c + 1, cm[i].y); atomicMax(c + 2, cm[i].z); atomicMax(c + 3, cm[i].w);
         }
     __syncthreads();
@@ -1251,10 +1253,13 @@ static int x2_maxima_launch(const float *X, long long rows, int cols, int ld, un
     const int NU = per <= 1 ? 1 : per <= 2 ? 2 : per <= 4 ? 4 : 8;
     const int slab = 64 * NU, slabs = (units + slab - 1) / slab;
     const int cus = nt_cus();
-    long long wgs = (rows + 15) / 16;                              // at least one row per wave
+    int upr = 64;                                                  // NU = 1: units per row rounded up to a power of two (narrow matrices: several rows per wave)
+    if (NU == 1) { upr = 1; while (upr < units) upr *= 2; }
+    long long wgs = (rows + 16 * (64 / upr) - 1) / (16 * (64 / upr));      // at least one pass per wave
     const long long cap = colmax ? (long long)cus / slabs + 1 : 8LL * cus;    // column maxima: every workgroup ends with 4 slab atomics per column unit
     wgs = wgs < 1 ? 1 : (wgs > cap ? cap : wgs);
-    const long long rpw = ((rows + wgs - 1) / wgs + 15) / 16 * 16;
+    const int rq = 16 * (64 / upr);                                // rows a workgroup takes per pass
+    const long long rpw = ((rows + wgs - 1) / wgs + rq - 1) / rq * rq;
     wgs = (rows + rpw - 1) / rpw;
     if (wgs > 0x7fffffffLL || slabs > 65535) return PDGN_ERR_INVALID;
     const int row_atomic = rowmax && slabs > 1;
@@ -1263,7 +1268,7 @@ static int x2_maxima_launch(const float *X, long long rows, int cols, int ld, un
     const size_t lds = colmax ? (size_t)slab * 16 : 0;
 #define X2_MAX_CALL(N_)                                                                                                         \
     hipLaunchKernelGGL((x2_maxima_kernel<N_>), dim3((unsigned)wgs, (unsigned)slabs), dim3(1024), lds, s, X, rows, cols, ld, slab, rpw, \
-                       rowmax, colmax, row_atomic)
+                       rowmax, colmax, row_atomic, upr)
     switch (NU) {
         case 1: X2_MAX_CALL(1); break;
         case 2: X2_MAX_CALL(2); break;

@@ -460,7 +460,7 @@ class PointDeconv(nn.Module):
         inte_pre, a_pre = outs[0], outs[1]                             # (B,N,P,4F), (B,N,1,2Fo)
         part_i = outs[-1] if fuse_stats else None                      # BatchNorm partials of inte_pre
         w = None
-        inte_max = None                                                # inte's partial maxima when its producer emits them (two-part conv2)
+        inte_max = inte_cmax = None                                    # inte's row / column maxima when its producer emits them (two-part conv2)
         if self.bilateral:
             Wx = _w2d(self.conv_xyz[0])                   # (16, 6)
             Yx = linear_cl(pct.reshape(B * N, 3), _XyzTaps.apply(Wx)).view(B, N, -1)
@@ -477,8 +477,8 @@ class PointDeconv(nn.Module):
                 # conv_all.4 + LeakyReLU + softmax over the k slots + interleave w[b,n,s=P*j+p,c'] -> [b,n,p,o=2c'+j]
                 # (:623-625, :634-641) AND inte = LeakyReLU(BN(inte_pre)) * w (:637, :642): one pass over both raw tensors
                 if planes_b is not None and planes_b.parts_p == 2:
-                    inte, inte_max = bilateral_weighting(h, self.conv_all[4], inte_pre.view(-1, 4 * Fi), self.inte_conv_hk[1], training, k,
-                                                         pre_bias_x=self.conv_all[3].bias, partials_u=part_i, partials_x=ph, want_max=True)
+                    inte, inte_max, inte_cmax = bilateral_weighting(h, self.conv_all[4], inte_pre.view(-1, 4 * Fi), self.inte_conv_hk[1], training, k,
+                                                                    pre_bias_x=self.conv_all[3].bias, partials_u=part_i, partials_x=ph, want_max=True)
                 else:
                     inte = bilateral_weighting(h, self.conv_all[4], inte_pre.view(-1, 4 * Fi), self.inte_conv_hk[1], training, k,
                                                pre_bias_x=self.conv_all[3].bias, partials_u=part_i, partials_x=ph)
@@ -489,7 +489,7 @@ class PointDeconv(nn.Module):
         else:
             # inte = LeakyReLU(BN(inte_pre))  (:637)
             inte = bn_act(inte_pre.view(-1, 4 * Fi), self.inte_conv_hk[1], training, partials=part_i)
-        out_pre = linear_cl(inte.view(B * N, P * 4 * Fi), Wb, None, a_pre.view(B * N, 2 * Fo), planes=planes_b, x_max=inte_max)    # sum in the GEMM's epilogue
+        out_pre = linear_cl(inte.view(B * N, P * 4 * Fi), Wb, None, a_pre.view(B * N, 2 * Fo), planes=planes_b, x_max=inte_max, x_cmax=inte_cmax)    # sum in the GEMM's epilogue
         # (B,2Fout,N,1) -> view(B,Fout,2,N) -> (B,Fout,2N) (:645-647): point j*N+n of channel c is conv channel 2c+j at
         # point n; in point-major form that is (B, 2, N, Fout) -> (B, 2N, Fout), which the BatchNorm + ReLU pass stores
         # directly (interleave_n) instead of a permute copy behind it

@@ -636,13 +636,14 @@ class LinearCL(Function):
     (models/PDGNet_v2.py:559-625, 835-862, 886-1014) as row-matrix products on the hand-written MFMA kernels (see above)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, addend, want_stats=False, planes=None, x_max=None):
+    def forward(ctx, x, weight, bias, addend, want_stats=False, planes=None, x_max=None, x_cmax=None):
         ctx.save_for_backward(x, weight)
         ctx.set_materialize_grads(False)          # no zero-filled "gradient" of the statistics partials (a launch per call)
         ctx.has_bias = bias is not None
         ctx.has_addend = addend is not None
         ctx.planes_t = None
         ctx.max_x = None
+        ctx.max_x_cols = x_cmax                                # x's column maxima when its producer computed them (the weight gradient's scale)
         if _planes_taken(x, weight, planes, want_stats, bias is None and addend is None):
             # the weight arrives pre-split (Planes): no split work for it in the kernel, forward and input gradient
             n, k = weight.shape
@@ -681,10 +682,10 @@ class LinearCL(Function):
     def backward(ctx, dy, *unused):
         x, weight = ctx.saved_tensors
         if dy is None:
-            return None, None, None, None, None, None, None
+            return None, None, None, None, None, None, None, None
         carried = take_input_grad(dy)
         if carried is not None:              # BNActMaxPool's backward already carried the gradient through this layer
-            return carried[0], carried[1], None, None, None, None, None
+            return carried[0], carried[1], None, None, None, None, None, None
         if is_placeholder(dy):
             raise RuntimeError("LinearCL.backward: received BNActMaxPool's gradient placeholder without the gradient it stands for "
                                "(another consumer of the layer's output, a hook or a copy sits between the two nodes)")
@@ -704,7 +705,7 @@ class LinearCL(Function):
                     db = _zeros((n,), dy.device)
             elif want_db:
                 db = _zeros((n,), dy.device) if zero_db else group_colsum(dy)[0]
-            return dx, dw, db, None, None, None, None
+            return dx, dw, db, None, None, None, None, None
         # two-part products (mode "x2", where they pay): the input gradient dX = dY W scales dY row by row, the weight gradient
         # dW = dY^T X scales dY and X column by column (its kernel takes both transposed); dy is scanned ONCE for both
         dy_rows = dy_cols = x_cols = None
@@ -716,14 +717,14 @@ class LinearCL(Function):
             scan_dy_rows = dx_two and dy_rows is None
             xs = x if x.stride(1) == 1 else None
             dw_two = (ctx.needs_input_grad[1] and xs is not None and _maxima_ok(dy) and _maxima_ok(xs)
-                      and two_part(n_, k_, m_, (0 if scan_dy_rows else m_ * n_ * 4) + m_ * k_ * 4))
+                      and two_part(n_, k_, m_, (0 if scan_dy_rows else m_ * n_ * 4) + (0 if ctx.max_x_cols is not None else m_ * k_ * 4)))
             if scan_dy_rows or dw_two:
                 r_, c_ = operand_maxima(dy, rows=True, cols=True) if (scan_dy_rows and dw_two) else \
                     ((operand_maxima(dy), None) if scan_dy_rows else (None, operand_maxima(dy, rows=False, cols=True)))
                 dy_rows = r_ if scan_dy_rows else dy_rows
                 dy_cols = c_
             if dw_two:
-                x_cols = operand_maxima(xs, rows=False, cols=True)
+                x_cols = ctx.max_x_cols if ctx.max_x_cols is not None else operand_maxima(xs, rows=False, cols=True)
         if ctx.needs_input_grad[0]:
             if ctx.planes_t is not None and own and dy.shape[1] % 4 == 0 and planes_fit(ctx.planes_t, dy.shape[0], weight.shape[1], weight.shape[0]):
                 dx = gemm_nt_planes(dy, ctx.planes_t, weight.shape[1], weight.shape[0], max_a=dy_rows)      # dX = dY W = dY (W^T)^T
@@ -733,7 +734,7 @@ class LinearCL(Function):
             dw = gemm_tn(dy, x, dy_cols, x_cols) if own else dy.t().matmul(x)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = _zeros((dy.shape[1],), dy.device) if zero_db else group_colsum(dy)[0]
-        return dx, dw, db, (dy if ctx.has_addend and ctx.needs_input_grad[3] else None), None, None, None
+        return dx, dw, db, (dy if ctx.has_addend and ctx.needs_input_grad[3] else None), None, None, None, None
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -898,18 +899,18 @@ class HeadMLP(Function):
 _PLANES_MIN_ROWS = 4096        # below this a contraction is a few tiles: the split kernel's launches would cost more than they save
 
 
-def linear_cl(x2d, weight, bias=None, addend=None, want_stats=None, planes=None, x_max=None):
+def linear_cl(x2d, weight, bias=None, addend=None, want_stats=None, planes=None, x_max=None, x_cmax=None):
     """Dense layer on point-major rows (see LinearCL); `addend` (M, C_out) is added in the GEMM's epilogue.
     x_max: x2d's partial maxima when its producer computed them (bilateral_weighting's want_max), for a two-part product.
     want_stats (True / False, not None): returns the PAIR (y, partials) -- with True the BatchNorm partial sums of y from
     the GEMM's epilogue, for bn_act / bilateral_weighting's `partials` argument (no statistics pass over y); None when
     this call did not produce them."""
     if want_stats is None:
-        return LinearCL.apply(x2d, weight, bias, addend, False, planes, x_max)
+        return LinearCL.apply(x2d, weight, bias, addend, False, planes, x_max, x_cmax)
     if want_stats:
-        y, part = LinearCL.apply(x2d, weight, bias, addend, True, planes, x_max)
+        y, part = LinearCL.apply(x2d, weight, bias, addend, True, planes, x_max, x_cmax)
         return y, ((part, stat_block_rows(x2d, weight, addend, planes, bias)) if part is not None else None)
-    return LinearCL.apply(x2d, weight, bias, addend, False, planes, x_max), None
+    return LinearCL.apply(x2d, weight, bias, addend, False, planes, x_max, x_cmax), None
 
 
 def stat_block_rows(x2d, weight, addend=None, planes=None, bias=None):
@@ -1030,6 +1031,17 @@ class BilateralWeighting(Function):
         y = torch.empty_like(u)
         # want_max: y's partial maxima come out of the same pass (the two-part contraction that takes y would scan it otherwise)
         ymax = row_maxima_buffer(m, x.device) if want_max else None     # y as the (m, k C) operand of conv2's dense half: its ROW maxima
+        # ... and, when a backward pass will follow, an upper BOUND of its column maxima (conv2's weight gradient takes y
+        # transposed and scales it column by column): y = act(gamma xhat + beta) * w with softmax weights w <= 1 and, under batch
+        # statistics, |xhat| <= sqrt(n - 1) for n samples -- so |y[:, (p, c)]| <= |gamma_c| sqrt(n - 1) + |beta_c|, from the 2C
+        # parameters alone.  A bound 2^b above the true maximum costs b of the 16 binades over which a value keeps its full 22
+        # bits (here b ~ 6: sqrt(n) against the ~5 sigma a column really reaches); the product's error stays far below the fp32
+        # accumulation's (gemm_x3.hip).  Measured against the alternatives: a scan of y is 176 us at stage 4, exact maxima from
+        # this kernel (threads walking several points) made it 130 us slower per launch.
+        ycmax = None
+        if want_max and training and any(ctx.needs_input_grad):
+            n_u = float(u.shape[0])
+            ycmax = torch.add(bu.detach().abs(), gu.detach().abs(), alpha=max(n_u - 1.0, 1.0) ** 0.5).repeat(k // 2).view(torch.int32)
         check(L.pdgn_bn_softmax_slots_permute_mul(ctypes.c_longlong(m), k, C, act, ptr(x), ptr(stats_x), act, ptr(u),
                                                   ptr(stats_u), ptr(w), ptr(y), ptr(ymax), stream_of(x)),
               "pdgn_bn_softmax_slots_permute_mul")
@@ -1037,7 +1049,10 @@ class BilateralWeighting(Function):
         ctx.cfg = (rows, C, act, bool(training), k, pbx is not None, pbu is not None)
         if want_max:
             ctx.mark_non_differentiable(ymax)
-            return y, ymax
+            if ycmax is not None:
+                ctx.mark_non_differentiable(ycmax)
+                return y, ymax, ycmax
+            return y, ymax, None
         return y
 
     @staticmethod
@@ -1086,15 +1101,15 @@ class BilateralWeighting(Function):
 def bilateral_weighting(x2d, bn_x, u2d, bn_u, training, k, act="leaky_relu", pre_bias_x=None, pre_bias_u=None,
                         partials_u=None, partials_x=None, want_max=False):
     """x2d (M*k, C) raw conv_all.3 output, u2d (M*k/2, 2C) raw inte_conv_hk output ->
-    act(bn_u(u2d)) * softmax_slots_permute(act(bn_x(x2d))), shape of u2d.  want_max: returns the PAIR (y, maxima) -- y's partial
-    maxima (a 1-KB slot for linear_cl's x_max: the two-part contraction that consumes y needs them) or None when this path did
-    not produce them."""
+    act(bn_u(u2d)) * softmax_slots_permute(act(bn_x(x2d))), shape of u2d.  want_max: returns (y, row maxima, column maxima) of y as
+    the (M, k C) operand of conv2's dense half (int32 bit patterns: linear_cl's x_max / x_cmax -- the two-part forward product
+    scales y row by row, its weight gradient column by column); either is None when this path did not produce it."""
     x2d, pre_bias_x = _fold_pre_bias(x2d, pre_bias_x, training)
     u2d, pre_bias_u = _fold_pre_bias(u2d, pre_bias_u, training)
     if x2d.shape[1] % 4 or k > 16:           # (the fused adjoint holds all k slots of a channel pair in registers: k <= 16)
         w = bn_softmax_slots_permute(x2d, bn_x, training, k, act=act, pre_bias=pre_bias_x)
         y = bn_act(u2d, bn_u, training, act=act, mul=w.view(u2d.shape), pre_bias=pre_bias_u, partials=partials_u)
-        return (y, None) if want_max else y
+        return (y, None, None) if want_max else y
     if training:
         for bn in (bn_x, bn_u):
             if bn.track_running_stats:

@@ -1,6 +1,8 @@
 """GPU parity of the point-deconvolution stack: feature-space kNN, window gather-sum, PointDeconv,
 PointGenerator / discriminators and one G+D step, all through the HIP C ABI.
 Float tolerance 1e-4 relative (BASELINE.json north_star); kNN indices exact outside near-ties."""
+import copy
+
 import numpy as np
 import pytest
 import torch
@@ -1958,9 +1960,57 @@ def test_bilateral_weighting_emits_its_output_maxima(C):
     u = torch.randn(M * k // 2, 2 * C, device="cuda", generator=g) * 50
     bx, bu = nn.BatchNorm2d(C).cuda(), nn.BatchNorm2d(2 * C).cuda()
     y0 = fused.bilateral_weighting(x, bx, u, bu, True, k)
-    y1, slot = fused.bilateral_weighting(x, bx, u, bu, True, k, want_max=True)
+    y1, slot, cslot = fused.bilateral_weighting(x, bx, u, bu, True, k, want_max=True)
     assert torch.equal(y0, y1) and slot.shape == (M,)
+    assert cslot is not None and bool((cslot.view(torch.float32) >= y1.view(M, -1).abs().amax(0)).all())      # (the BatchNorm parameters want gradients: a column bound comes along)
     assert torch.equal(slot, y1.view(M, -1).abs().amax(1).view(torch.int32))     # y as the (M, k C) operand of conv2's dense half
+
+
+@pytest.mark.parametrize("M,C", [(20000, 512), (3000, 128)])
+def test_bilateral_weighting_bounds_its_column_maxima_for_the_weight_gradient(M, C):
+    """When a backward pass will follow, bilateral_weighting hands conv2's weight gradient (which takes inte transposed and scales it
+    column by column) an upper BOUND of inte's column maxima from the BatchNorm parameters alone -- |gamma| sqrt(n - 1) + |beta|:
+    never below the true maximum (no scaled value can leave fp16's range), within 2^9 of it, same y; and the two-part weight
+    gradient computed with the bound is as accurate against fp64 as with the exact maxima."""
+    import ctypes
+    import torch.nn as nn
+    from pdgn_amd import _lib, fused
+    from pdgn_amd._lib import ptr, stream_of
+    k = 10
+    g = torch.Generator(device="cuda").manual_seed(M + C)
+    x = (torch.randn(M * k, C, device="cuda", generator=g) * 2).requires_grad_(True)
+    u = (torch.randn(M * k // 2, 2 * C, device="cuda", generator=g) * torch.rand(1, 2 * C, device="cuda", generator=g) * 50).requires_grad_(True)
+    bx, bu = nn.BatchNorm2d(C).cuda(), nn.BatchNorm2d(2 * C).cuda()
+    with torch.no_grad():
+        bu.weight.copy_(torch.randn(2 * C, device="cuda", generator=g))
+        bu.bias.copy_(torch.randn(2 * C, device="cuda", generator=g))
+    bx0, bu0 = copy.deepcopy(bx), copy.deepcopy(bu)
+    with torch.no_grad():
+        y0 = fused.bilateral_weighting(x, bx0, u, bu0, True, k)
+    y1, rmax, cmax = fused.bilateral_weighting(x, bx, u, bu, True, k, want_max=True)
+    assert torch.equal(y0, y1.detach())
+    assert torch.equal(rmax, y1.detach().view(M, -1).abs().amax(1).view(torch.int32))
+    true = y1.detach().view(M, -1).abs().amax(0)
+    bound = cmax.view(torch.float32)
+    assert cmax.shape == (k * C,) and bool((bound >= true).all()) and bool((bound <= true.clamp_min(1e-30) * 512).all())
+    if M < 10000:
+        return
+    # the weight gradient dW = dOut^T inte on two parts with the bound / with the exact column maxima, against fp64
+    L = _lib.lib()
+    _lib.set_gemm_mode("x2")
+    N = 512
+    X = y1.detach().view(M, k * C)
+    dO = torch.randn(M, N, device="cuda", generator=g)
+    ref = dO.double().t() @ X.double()
+    mag = dO.double().abs().t() @ X.double().abs()
+    errs = []
+    cd = fused.operand_maxima(dO, rows=False, cols=True)
+    for cx in (cmax, fused.operand_maxima(X, rows=False, cols=True)):
+        dW = torch.empty(N, k * C, device="cuda")
+        assert L.pdgn_gemm_set_operand_scales(ptr(cd), ptr(cx)) == 0
+        assert L.pdgn_gemm_tn_big(ctypes.c_longlong(M), N, k * C, ptr(dO), N, ptr(X), k * C, ptr(dW), 0, stream_of(dO)) == 0
+        errs.append(((dW.double() - ref).abs() / mag.clamp_min(1e-300)).max().item())
+    assert errs[0] < 1e-6 and errs[0] <= 1.25 * errs[1] + 2e-8, errs
 
 
 @pytest.mark.parametrize("B,N,k,specs", [(3, 300, 10, ((6, 5, 16, 0, 96), (10, 1, 8, 112, 192), (1, 10, 4, 200, 204))),

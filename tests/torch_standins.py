@@ -93,7 +93,7 @@ def patch_losses(monkeypatch_or_module):
             setattr(losses, name, fn)
 
 
-def linear_cl_torch(x2d, weight, bias=None, addend=None, want_stats=None, planes=None, x_max=None):
+def linear_cl_torch(x2d, weight, bias=None, addend=None, want_stats=None, planes=None, x_max=None, x_cmax=None):
     y = torch.nn.functional.linear(x2d, weight, bias)
     y = y + addend if addend is not None else y
     return y if want_stats is None else (y, None)
