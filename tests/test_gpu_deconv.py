@@ -1992,7 +1992,10 @@ def test_bilateral_weighting_bounds_its_column_maxima_for_the_weight_gradient(M,
     assert torch.equal(rmax, y1.detach().view(M, -1).abs().amax(1).view(torch.int32))
     true = y1.detach().view(M, -1).abs().amax(0)
     bound = cmax.view(torch.float32)
-    assert cmax.shape == (k * C,) and bool((bound >= true).all()) and bool((bound <= true.clamp_min(1e-30) * 512).all())
+    # (never below; and not absurdly above: sqrt(n) / (the ~4.5 sigma a column reaches x the softmax weight of its largest entry):
+    # 2^7 .. 2^11 here -- of the 16 binades over which a value keeps 22 bits, 5 .. 9 remain, and the dW check below says what that costs)
+    assert cmax.shape == (k * C,) and bool((bound >= true).all()) and bool((bound <= true.clamp_min(1e-30) * 65536).all()), \
+        float((bound / true.clamp_min(1e-30)).max())
     if M < 10000:
         return
     # the weight gradient dW = dOut^T inte on two parts with the bound / with the exact column maxima, against fp64
@@ -2010,6 +2013,7 @@ def test_bilateral_weighting_bounds_its_column_maxima_for_the_weight_gradient(M,
         assert L.pdgn_gemm_set_operand_scales(ptr(cd), ptr(cx)) == 0
         assert L.pdgn_gemm_tn_big(ctypes.c_longlong(M), N, k * C, ptr(dO), N, ptr(X), k * C, ptr(dW), 0, stream_of(dO)) == 0
         errs.append(((dW.double() - ref).abs() / mag.clamp_min(1e-300)).max().item())
+    print('dW error with the bound / with exact column maxima:', errs, 'bound / true max up to', float((bound / true.clamp_min(1e-30)).max()))
     assert errs[0] < 1e-6 and errs[0] <= 1.25 * errs[1] + 2e-8, errs
 
 
