@@ -31,7 +31,7 @@ struct RpArgs {
     const unsigned short *Wp;         // two fp16 planes [2][N][ldw], wplane elements apart
     long long wplane;
     float *C;
-    const unsigned *max_a, *max_w;    // row maxima (bit patterns) of A (M) and of W (N: behind the planes)
+    const unsigned *max_w;            // row maxima (bit patterns) of W (N: behind the planes); A's are taken in the kernel
     int panels, ctiles;               // row panels of 256, column tiles of 64
     int rgroups, cslabs;              // rgroups * cslabs == 8: XCD x = (row group x / cslabs, column slab x % cslabs)
     int wg_per_xcd;
@@ -121,8 +121,6 @@ __global__ __launch_bounds__(512, 1) void gemm_rp_kernel(const RpArgs p) {
         cur_prow = (long long)panel * 8 + wave;
         const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void *)(p.A + m0 * p.lda), 0,
                                                                             mrows > 0 ? (int)(((long long)(mrows - 1) * p.lda + K) * 4) : 0, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rsMA = __builtin_amdgcn_make_buffer_rsrc((void *)(p.max_a + m0), 0, mrows * 4, 0x00020000);
-        const unsigned mb = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rsMA, (unsigned)li * 4u, 0, 0);
         f32x4 raw[2 * KS];
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
@@ -130,11 +128,19 @@ __global__ __launch_bounds__(512, 1) void gemm_rp_kernel(const RpArgs p) {
             raw[2 * s] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, off, 0, 0));
             raw[2 * s + 1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, off == NT_OOB ? NT_OOB : off + 16u, 0, 0));
         }
+        // the row's maximum is taken HERE: the two lanes (li, 0) and (li, 1) hold the whole row between them -- no scan of A in
+        // front of the launch, no maxima to hand in (the exact maximum, as a scan finds it: the same scale, the same bits)
+        unsigned mb = 0u;
+#pragma unroll
+        for (int i = 0; i < 2 * KS; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mb = max(mb, __float_as_uint(raw[i][r]) & 0x7fffffffu);
+        mb = max(mb, (unsigned)__shfl_xor((int)mb, 32));
         const int f = x2_scale_field(mb);
         const float sc = __int_as_float(f << 23);
+        // un-scale exponents of the rows this lane STORES (rows 8 j + (lane >> 3) of the staged read-back): from the lanes that hold them
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            ua_e[j] = 127 - x2_scale_field((unsigned)__builtin_amdgcn_raw_buffer_load_b32(rsMA, (unsigned)(8 * j + (lane >> 3)) * 4u, 0, 0));
+        for (int j = 0; j < 4; ++j) ua_e[j] = 127 - __shfl(f, 8 * j + (lane >> 3));
 #pragma unroll
         for (int s = 0; s < KS; ++s)
 #pragma unroll
@@ -337,13 +343,12 @@ bool rp_takes(long long m, int n, int k) {
 }
 
 // C (m x n, pitch ldc) = A (m x k, pitch lda) W^T for two-part planes Wp [2][n][ldw] (pdgn_split_f16x2: the rows' maxima behind
-// them), max_a = A's row maxima.  Returns 0, or a launch error.
+// them); A's row maxima are taken in the kernel (a wave holds whole rows).  Returns 0, or a launch error.
 int rp_launch(long long m, int n, int k, const float *A, int lda, const unsigned short *Wp, int ldw, long long wplane, float *C, int ldc,
-              const unsigned *max_a, float *stat_part, hipStream_t s) {
+              float *stat_part, hipStream_t s) {
     RpArgs a;
     a.stat_part = stat_part;
     a.M = m; a.N = n; a.lda = lda; a.ldw = ldw; a.ldc = ldc; a.A = A; a.Wp = Wp; a.wplane = wplane; a.C = C;
-    a.max_a = max_a;
     a.max_w = reinterpret_cast<const unsigned *>(Wp + 2 * wplane);
     a.panels = cdiv(m, 256);
     a.ctiles = cdiv(n, 64);

@@ -1334,7 +1334,7 @@ static int x3_reduce_split(int tiles) {
 // gemm_rp.hip: the row-panel kernel of the short-reduction, wide-result products on two-part planes
 bool rp_takes(long long m, int n, int k);
 int rp_launch(long long m, int n, int k, const float *A, int lda, const unsigned short *Wp, int ldw, long long wplane, float *C, int ldc,
-              const unsigned *max_a, float *stat_part, hipStream_t s);
+              float *stat_part, hipStream_t s);
 // gemm_x3_16.hip: instance (tile cfg, flags = ATOMIC | WT << 1 | AT << 2 | EPI << 3 | PW << 4) of gemm_x3_kernel<..., 16>
 void x3_launch16(int cfg, int flags, int grid, hipStream_t s, const NtArgs &a);
 // gemm_x3_h2.hip: the same of gemm_x3_kernel<..., 32, 2> (two fp16 parts), and an instance's host symbol
@@ -1783,9 +1783,8 @@ extern "C" int pdgn_gemm_nt_ps(long long m, int n, int k, const float *A, int ld
     if (parts == 2 && x3_mode() == 2 && !bias && !addend && !row_bias && !act && !gate && rp_takes(m, n, k)) {
         // a short reduction and a wide result: the row-panel kernel (gemm_rp.hip: A resident in registers, the weight tiles streamed,
         // the same two-part arithmetic bit for bit)
-        const unsigned *ma = x2_cur_max_a ? x2_cur_max_a : x2_scan(A, m, k, lda, false, (hipStream_t)stream);
-        if (!ma) return PDGN_ERR_INVALID;                          // (no arena: pdgn_gemm_set_scale_slots)
-        return rp_launch(m, n, k, A, lda, Wplanes, ldw, wplane, C, ldc, ma, stat_part, (hipStream_t)stream);      // (stat_part: one partial row per 32 rows, pdgn_gemm_nt_ps_stat_rows)
+        // (A's row maxima: taken inside the kernel -- handed-in ones are not needed and not read)
+        return rp_launch(m, n, k, A, lda, Wplanes, ldw, wplane, C, ldc, stat_part, (hipStream_t)stream);      // (stat_part: one partial row per 32 rows, pdgn_gemm_nt_ps_stat_rows)
     }
     NtEpi e;
     e.row_bias = row_bias; e.ld_rb = ld_rb; e.rows_per_group = rows_per_group > 0 ? rows_per_group : 1; e.act = act; e.gate = gate;

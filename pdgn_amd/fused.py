@@ -457,7 +457,7 @@ def _tail_workspace(L, m, n, k, with_stats, device, parts=None):
     return ws
 
 
-def _rp_stats(m, n, k, parts, plain):
+def _rp_takes(m, n, k, parts, plain):
     """Whether pdgn_gemm_nt_ps(m, n, k) on `parts`-part planes runs on the row-panel kernel (csrc/gemm_rp.hip: short reductions on
     two-part planes, no bias / addend): its BatchNorm partials cover 32 rows each."""
     return parts == 2 and plain and _lib.lib().pdgn_gemm_nt_ps_stat_block_rows(ctypes.c_longlong(m), n, k, 2, 1) == 32 \
@@ -469,7 +469,7 @@ def planes_fit(P, m, n, k, with_stats=False, plain=False):
     whatever the launch model picks, or -- short reductions without bias / addend: plain -- on the row-panel kernel) unless the
     launch emits BatchNorm partials and neither the row-panel kernel takes it nor the model's pick -- whose geometry the partials'
     consumers were told -- is the 256 x 128 tile."""
-    return (P.shape[0] == 3 or not with_stats or _rp_stats(m, n, k, P.shape[0], plain)
+    return (P.shape[0] == 3 or not with_stats or _rp_takes(m, n, k, P.shape[0], plain)
             or (_lib.lib().pdgn_gemm_nt_config(ctypes.c_longlong(m), n, k, 1) & 15) == 0)
 
 
@@ -649,8 +649,12 @@ class LinearCL(Function):
             n, k = weight.shape
             ctx.thin = False
             ctx.planes_t = planes.t
-            # (a two-part product scales x row by row: its row maxima from the producer, or one scan)
-            ctx.max_x = xm = (x_max if x_max is not None else operand_maxima(x)) if planes.parts_p == 2 else None
+            # (a two-part product scales x row by row: its row maxima from the producer, or one scan -- or, on the row-panel kernel,
+            # taken inside the launch: a wave holds whole rows)
+            xm = None
+            if planes.parts_p == 2 and not _rp_takes(x.shape[0], n, k, 2, bias is None and addend is None):
+                xm = x_max if x_max is not None else operand_maxima(x)
+            ctx.max_x = xm
             if want_stats:
                 y, part = gemm_nt_planes(x, planes.p, n, k, bias, addend, want_stats=True, max_a=xm)
                 ctx.mark_non_differentiable(part)
