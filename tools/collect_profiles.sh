@@ -1,8 +1,8 @@
 #!/bin/bash
 # Everything under profiles/ for one round, on one MI355X box (run through gpurun from the repo root):
-#   bash tools/collect_profiles.sh gpurun_out/prof r05
+#   bash tools/collect_profiles.sh gpurun_out/prof r06
 set -u
-OUT=${1:-gpurun_out/prof}; TAG=${2:-r05}
+OUT=${1:-gpurun_out/prof}; TAG=${2:-r06}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 # the bench line as the driver runs it (launch-list issue, cpu_baseline at B = 35), and the same with every launch issued from Python
@@ -58,5 +58,12 @@ python3 tools/cfg_probe.py 2>&1 | grep -v amdgpu.ids > $OUT/${TAG}_cfg_probe.txt
 python3 tools/operand_range.py 2>&1 | grep -v amdgpu.ids > $OUT/${TAG}_operand_range.txt
 # stream-K tails: workspace + reduce kernel (default) against the atomic form, alternating in the step
 bash tools/env_ab.sh PDGN_X3_SK_WS "1 0" 3 > $OUT/${TAG}_sk_tails_ab.txt 2>&1
+# round 6: the row-panel kernel of the short-reduction products alone (against the tile kernel; store policies) and in the step; the
+# F = 128, N = 512 block of the imported reference in the three arithmetic modes
+for rp in 1 0; do PDGN_RP=$rp python3 tools/rp_bench.py 2>&1 | grep -v amdgpu.ids; done > $OUT/${TAG}_rp_bench.txt
+for st in 0 2 16; do PDGN_RP_STORE=$st python3 tools/rp_bench.py 2>&1 | grep -v amdgpu.ids; done >> $OUT/${TAG}_rp_bench.txt
+PDGN_RP_PIPE=0 python3 tools/rp_bench.py 2>&1 | grep -v amdgpu.ids >> $OUT/${TAG}_rp_bench.txt
+bash tools/env_ab.sh PDGN_RP "1 0" 3 > $OUT/${TAG}_rp_ab.txt 2>&1
+python3 tools/block_big_error.py 2>&1 | grep -v amdgpu.ids > $OUT/${TAG}_block_big_error.txt
 rm -rf $OUT/kt_bench $OUT/kt_roof $OUT/kt_eval $OUT/pmc $OUT/pmc.*.log $OUT/x3pmc
 ls -la $OUT
