@@ -1350,7 +1350,8 @@ const void *x3_symbol_h2(int flags, bool eight_waves);
 static bool x2_pays(int cfg, long long m, int n, int k, long long scan_bytes) {
     if (nt_switches().mode != 2 || cfg != 0 || k < 128 || m >= (1LL << 28)) return false;
     const double flops = 2.0 * (double)m * n * k;
-    return flops >= 2e10 && (double)scan_bytes <= 4.5e-3 * flops;
+    static const double min_flops = [] { const char *e = getenv("PDGN_X2_MIN_GFLOP"); return (e && *e) ? atof(e) * 1e9 : 2e10; }();   // (measurement)
+    return flops >= min_flops && (double)scan_bytes <= 4.5e-3 * flops;
 }
 
 template <int TM, int TN, int WM, int WN, int OCC, int RATE, int CFG>      // RATE: fp32-equivalent kflop / us a CU sustains on this tile's loop
