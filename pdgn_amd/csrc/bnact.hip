@@ -278,18 +278,61 @@ __global__ __launch_bounds__(FIN_CH * FIN_PL) void cl_finalize_blocks_slice_kern
     scratch[((size_t)blockIdx.y * 2 + 1) * C + c] = red2[0][cl];
 }
 
+// The same for 64-channel multiples (round 6): a workgroup takes 64 CONSECUTIVE channels (a wave reads 256 contiguous bytes of a
+// partial row: the four-channel form above touches 16 B of every row per workgroup) on four part lanes; more, shorter slices.  The
+// row-panel kernel's partials (gemm_rp.hip: one row per 32 rows of the result, 11200 x [3 x 512] for the stage-4 edge-level layer) took
+// 100 us in the four-channel form.
+__global__ __launch_bounds__(256) void cl_finalize_blocks_slice64_kernel(
+    long long R, int C, int nparts, int rpp, int per_slice, const float *__restrict__ part, double *__restrict__ scratch) {
+    __shared__ double red[4][64], red2[4][64];
+    const int cl = threadIdx.x & 63, pl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    double a = 0, b = 0;
+    const double inv_full = 1.0 / (double)rpp;
+    const int pmax_all = (int)min((long long)nparts, (R + rpp - 1) / rpp);
+    const int p0 = blockIdx.y * per_slice, pmax = min(pmax_all, p0 + per_slice);
+#pragma unroll 4
+    for (int p = p0 + pl; p < pmax; p += 4) {
+        const long long left = R - (long long)p * rpp;
+        const bool full = left >= rpp;
+        const double n = (double)(full ? rpp : left), inv = full ? inv_full : 1.0 / (double)left;
+        const float *q = part + (size_t)p * 3 * C + c;
+        const double s = (double)q[0], sq = (double)q[C], pv = (double)q[2 * C];
+        const double mb = pv + s * inv;
+        a += n * mb;
+        b += (sq - s * s * inv) + n * mb * mb;
+    }
+    red[pl][cl] = a;
+    red2[pl][cl] = b;
+    __syncthreads();
+    if (pl == 0) {                                                // (in lane order: a fixed order of summation)
+        scratch[((size_t)blockIdx.y * 2) * C + c] = ((red[0][cl] + red[1][cl]) + red[2][cl]) + red[3][cl];
+        scratch[((size_t)blockIdx.y * 2 + 1) * C + c] = ((red2[0][cl] + red2[1][cl]) + red2[2][cl]) + red2[3][cl];
+    }
+}
+
 __global__ void cl_finalize_blocks_join_kernel(long long R, int C, int slices, float eps, float momentum,
                                                const double *__restrict__ scratch, const float *__restrict__ gamma,
                                                const float *__restrict__ beta, const float *__restrict__ pre_bias,
                                                float *__restrict__ running_mean, float *__restrict__ running_var,
                                                float *__restrict__ stats) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+    // 64 channels x 4 lanes per workgroup (blockDim = 256): lane l adds slices l, l + 4, ... in order, the four sums meet in lane
+    // order -- a fixed order of summation; a single lane walking 128 slices was 128 dependent loads
+    __shared__ double ra[4][64], rb[4][64];
+    const int cl = threadIdx.x & 63, pl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
     double a = 0, b = 0;
-    for (int s = 0; s < slices; ++s) {
-        a += scratch[((size_t)s * 2) * C + c];
-        b += scratch[((size_t)s * 2 + 1) * C + c];
-    }
+    if (c < C)
+        for (int s = pl; s < slices; s += 4) {
+            a += scratch[((size_t)s * 2) * C + c];
+            b += scratch[((size_t)s * 2 + 1) * C + c];
+        }
+    ra[pl][cl] = a;
+    rb[pl][cl] = b;
+    __syncthreads();
+    if (pl != 0 || c >= C) return;
+    a = ((ra[0][cl] + ra[1][cl]) + ra[2][cl]) + ra[3][cl];
+    b = ((rb[0][cl] + rb[1][cl]) + rb[2][cl]) + rb[3][cl];
     const double mean = a / (double)R;
     double var = b / (double)R - mean * mean;
     var = var < 0 ? 0 : var;
@@ -312,6 +355,13 @@ static inline int fb_slices(int c, long long nparts) {           // 0: the one-l
     // enough workgroups (c / 4 channel groups x slices ~ 512) with at least two passes of the 64 part lanes each; measured
     // (tools/finalize_bench.py): 5600 x 64 channels 35 -> 14 us with 32 slices; 2800 x 512 is no faster sliced 32 ways (25 -> 30)
     if (nparts < 512) return 0;
+    if (c % 64 == 0) {                                              // the 64-channel form: ~16 partial rows per part lane, at most 128 slices
+        // (tools/finalize_bench.py, round 6: 11200 x 512: 87 -> 36 us, 5600 x 256: 44 -> 17, 2800 x 512: 25 -> 12, 5600 x 64: 33 -> 16;
+        //  below ~1400 rows one launch is as fast: 560 x 512 5.5 vs 10 us)
+        if (nparts < 1400) return 0;
+        long long s64 = nparts / 64;
+        return (int)(s64 < 2 ? 2 : (s64 > 128 ? 128 : s64));
+    }
     long long s = 512 / (c / 4 > 0 ? c / 4 : 1);
     s = s > 32 ? 32 : s;
     while (s > 1 && nparts / s < 128) s >>= 1;
@@ -585,9 +635,13 @@ extern "C" int pdgn_bn_stats_from_gemm_partials(long long rows, int c, long long
     const int slices = scratch ? fb_slices(c, nparts) : 0;
     if (slices > 1) {
         const int per = (int)((nparts + slices - 1) / slices);
-        hipLaunchKernelGGL(cl_finalize_blocks_slice_kernel, dim3(cdiv(c, FIN_CH), slices), dim3(FIN_CH * FIN_PL), 0,
-                           (hipStream_t)stream, rows, c, (int)nparts, block_rows, per, partials, scratch);
-        hipLaunchKernelGGL(cl_finalize_blocks_join_kernel, dim3(cdiv(c, 64)), dim3(64), 0, (hipStream_t)stream, rows, c, slices,
+        if (c % 64 == 0)
+            hipLaunchKernelGGL(cl_finalize_blocks_slice64_kernel, dim3(c / 64, slices), dim3(256), 0, (hipStream_t)stream, rows, c, (int)nparts,
+                               block_rows, per, partials, scratch);
+        else
+            hipLaunchKernelGGL(cl_finalize_blocks_slice_kernel, dim3(cdiv(c, FIN_CH), slices), dim3(FIN_CH * FIN_PL), 0,
+                               (hipStream_t)stream, rows, c, (int)nparts, block_rows, per, partials, scratch);
+        hipLaunchKernelGGL(cl_finalize_blocks_join_kernel, dim3(cdiv(c, 64)), dim3(256), 0, (hipStream_t)stream, rows, c, slices,
                            eps, momentum, (const double *)scratch, gamma, beta, pre_bias, running_mean, running_var, stats);
         return pdgn_launch_status();
     }

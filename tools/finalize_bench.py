@@ -7,7 +7,7 @@ from pdgn_amd import _lib
 from pdgn_amd._lib import ptr, stream_of
 L = _lib.lib()
 L.pdgn_bn_blocks_scratch_doubles.restype = ctypes.c_longlong
-for rows, C, block in [(35840, 512, 128), (35840, 512, 64), (71680, 256, 64), (179200, 256, 128), (358400, 64, 64), (358400, 512, 128), (17920, 1024, 64)]:
+for rows, C, block in [(35840, 512, 128), (35840, 512, 64), (71680, 256, 64), (179200, 256, 128), (358400, 64, 64), (358400, 512, 128), (358400, 512, 32), (179200, 256, 32), (17920, 1024, 64)]:
     nparts = -(-rows // block)
     part = torch.randn(nparts, 3 * C, device="cuda")
     g = torch.ones(C, device="cuda"); b = torch.zeros(C, device="cuda"); rm = torch.zeros(C, device="cuda"); rv = torch.ones(C, device="cuda")
