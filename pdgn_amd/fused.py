@@ -48,9 +48,9 @@ def clear_zero_colsum():
 
 
 # A third side channel of the same kind: a backward that WRITES a large gradient (EdgeGatherSum's dY, 1.8 GB at stage 4) leaves its
-# partial maxima in a 1-KB slot (csrc/gemm_shared.h X2_PARTS) for the two-part contractions of the layer that receives it
-# (LinearCL.backward: input and weight gradient of the per-point product) -- they would scan the whole tensor otherwise.  Keyed
-# and validated like _ZERO_COLSUM; taken once.
+# ROW maxima (an int32 (rows,) tensor of bit patterns, csrc/wgs.hip) for the two-part contraction of the layer that receives it
+# (LinearCL.backward: the input gradient of the per-point product scales dY row by row) -- it would scan the whole tensor otherwise.
+# Keyed and validated like _ZERO_COLSUM; taken once.
 _GRAD_MAXIMA = {}
 
 
