@@ -484,40 +484,53 @@ __device__ __forceinline__ unsigned wgs_absmax4(const float __attribute__((ext_v
                max(__float_as_uint(v[2]) & 0x7fffffffu, __float_as_uint(v[3]) & 0x7fffffffu));
 }
 
+// (the small shapes' kernel -- the 16-channel branches, the first levels' specs.  Round 6: EL = 8 consecutive lanes share one
+// (source point, tap, float4 column) and split its in-edges (or, for the centre columns, its P windows) between them: one thread
+// walking all in-edges of a hub was a chain of up to 60 dependent loads -- 55 us per launch for 23 MB at stage 4, 0.44 ms per
+// iteration on the issuing stream; the eight partial sums meet in three xor-shuffles, a fixed order)
+template <int EL>
 __global__ __launch_bounds__(WGS_THREADS) void wgs_bwd_csr_kernel(
     long long total, int n, int k, int ldy, int T, int P, int CV, int off, int offc,
     const float *__restrict__ dout, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ edges,
     float *__restrict__ dY, unsigned *__restrict__ max_out) {
     typedef float vec_t __attribute__((ext_vector_type(4)));
-    long long e = (long long)blockIdx.x * WGS_THREADS + threadIdx.x;
+    static_assert(64 % EL == 0, "the lanes of an item lie in one wave");
+    const long long g = (long long)blockIdx.x * WGS_THREADS + threadIdx.x;
+    const long long e = g / EL;
+    const int el = (int)(g % EL);
+    const bool valid = e < total;
     vec_t acc = {0.f, 0.f, 0.f, 0.f};
-    if (e < total) {
     const int TT = offc >= 0 ? T + 1 : T;
     const int cv = (int)(e % CV);
-    long long r = e / CV;
+    const long long r = e / CV;
     const int t = (int)(r % TT);
     const long long bj = r / TT;                              // b * n + j
     const long long b = bj / n;
     const int j = (int)(bj - b * n);
     const int C = CV * 4, c = cv * 4;
-    if (t == T) {                                             // centre columns
-        const float *src = dout + bj * P * C + c;
-        for (int p = 0; p < P; ++p) acc += *reinterpret_cast<const vec_t *>(src + (size_t)p * C);
-        *reinterpret_cast<vec_t *>(dY + bj * ldy + offc + c) = acc;
-    } else {
-        const int32_t *R = rowptr + b * (n + 1);
-        const int32_t *E = edges + b * (long long)n * k;
-        const int e1 = R[j + 1];
-        for (int q = R[j]; q < e1; ++q) {
-            const int rec = E[q];
-            const int p = (rec & 31) - t;
-            if (p >= 0 && p < P)
-                acc += *reinterpret_cast<const vec_t *>(dout + ((b * n + (rec >> 5)) * P + p) * C + c);
+    if (valid) {
+        if (t == T) {                                         // centre columns
+            const float *src = dout + bj * P * C + c;
+            for (int p = el; p < P; p += EL) acc += *reinterpret_cast<const vec_t *>(src + (size_t)p * C);
+        } else {
+            const int32_t *R = rowptr + b * (n + 1);
+            const int32_t *E = edges + b * (long long)n * k;
+            const int e1 = R[j + 1];
+            for (int q = R[j] + el; q < e1; q += EL) {
+                const int rec = E[q];
+                const int p = (rec & 31) - t;
+                if (p >= 0 && p < P)
+                    acc += *reinterpret_cast<const vec_t *>(dout + ((b * n + (rec >> 5)) * P + p) * C + c);
+            }
         }
-        *reinterpret_cast<vec_t *>(dY + bj * ldy + off + t * C + c) = acc;
     }
-    if (max_out) atomicMax(max_out + bj, wgs_absmax4(acc));       // (the small shapes' kernel: one atomic per 16 B written)
-    }
+#pragma unroll
+    for (int o = 1; o < EL; o <<= 1)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] += __shfl_xor(acc[i], o);
+    if (!valid || el != 0) return;
+    *reinterpret_cast<vec_t *>(dY + bj * ldy + (t == T ? offc : off + t * C) + c) = acc;
+    if (max_out) atomicMax(max_out + bj, wgs_absmax4(acc));       // (one atomic per 16 B written)
 }
 
 // The adjoint in the task mapping of wgs_fwd_xcd_kernel.  A WAVE owns one source point j of a (sample, 64-channel
@@ -665,7 +678,7 @@ extern "C" int pdgn_window_gather_sum_backward_csr(int b, int n, int k, int ldy,
     }
     const int TT = offc >= 0 ? T + 1 : T;
     const long long total = (long long)b * n * TT * (C / 4);
-    hipLaunchKernelGGL(wgs_bwd_csr_kernel, dim3(cdiv(total, WGS_THREADS)), dim3(WGS_THREADS), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(wgs_bwd_csr_kernel<8>, dim3(cdiv(total * 8, WGS_THREADS)), dim3(WGS_THREADS), 0, (hipStream_t)stream,
                        total, n, k, ldy, T, P, C / 4, off, offc, dout, rowptr, edges, dY, max_out);
     return pdgn_launch_status();
 }

@@ -40,3 +40,17 @@ dout2 = torch.randn(b, n, P2, C2, device="cuda"); dY2 = torch.empty(b, n, ldy2, 
 f2 = t(lambda: L.pdgn_window_gather_sum(b, n, k, ldy2, T2, P2, C2, 0, T2 * C2, ptr(Y2), ptr(idx), ptr(bias), C, ptr(out2), stream_of(Y)))
 g2 = t(lambda: L.pdgn_window_gather_sum_backward_csr(b, n, k, ldy2, T2, P2, C2, 0, T2 * C2, ptr(dout2), ptr(rowptr), ptr(edges), ptr(dY2), None, 0, stream_of(Y)))
 print("conv2 half (T=10, P=1, C=512): wgs_fwd %.1f us | wgs_bwd_csr %.1f us" % (f2, g2))
+# the 16-channel branches (conv_fea: T = 1, P = 10, C = 16; conv_xyz likewise): the small shapes' kernels, forward and adjoint
+for (bb, nn) in ((35, 1024), (35, 512), (35, 256)):
+    T3, P3, C3 = 1, 10, 16
+    ldy3 = 12832 if nn == 1024 else 6432 if nn == 512 else 3232
+    idx3 = torch.randint(0, nn, (bb, nn, k), device="cuda", dtype=torch.int32)
+    idx3[:, :, 0] = 3                                         # a hub: every point's first neighbour
+    Y3 = torch.randn(bb, nn, ldy3, device="cuda"); out3 = torch.empty(bb, nn, P3, C3, device="cuda")
+    dout3 = torch.randn(bb, nn, P3, C3, device="cuda"); dY3 = torch.empty(bb, nn, ldy3, device="cuda")
+    rp3 = torch.empty(bb, nn + 1, dtype=torch.int32, device="cuda"); ed3 = torch.empty(bb, nn * k, dtype=torch.int32, device="cuda")
+    sc3 = torch.empty(2 * bb * nn, dtype=torch.int32, device="cuda")
+    L.pdgn_knn_graph_transpose(bb, nn, k, ptr(idx3), ptr(rp3), ptr(ed3), ptr(sc3), stream_of(Y))
+    f3 = t(lambda: L.pdgn_window_gather_sum(bb, nn, k, ldy3, T3, P3, C3, ldy3 - 32, ldy3 - 16, ptr(Y3), ptr(idx3), None, 0, ptr(out3), stream_of(Y)))
+    g3 = t(lambda: L.pdgn_window_gather_sum_backward_csr(bb, nn, k, ldy3, T3, P3, C3, ldy3 - 32, ldy3 - 16, ptr(dout3), ptr(rp3), ptr(ed3), ptr(dY3), None, 0, stream_of(Y)))
+    print("16-channel branch (T=1, P=10, C=16) n=%d: wgs_fwd %.1f us | wgs_bwd_csr %.1f us" % (nn, f3, g3))
