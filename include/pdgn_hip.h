@@ -261,10 +261,14 @@ int pdgn_bn_softmax_slots_permute(long long m, int k, int c, int act, const floa
  * row); w may be NULL (not needed when no backward pass follows). */
 int pdgn_bn_softmax_slots_permute_mul(long long m, int k, int c, int act, const float *x, const float *stats,
                                       int act_u, const float *u, const float *stats_u, float *w, float *y,
-                                      unsigned *max_out, pdgn_stream_t stream);
+                                      unsigned *max_out, const float *gamma_u, const float *beta_u, float bound_scale,
+                                      unsigned *cmax_out, pdgn_stream_t stream);
 /* (max_out, may be NULL: uint32[m], the maximum of |y| (bit pattern) over each point's k c outputs = the row maxima of y as the
  * (m, k c) first operand of conv2's dense half -- what pdgn_absmax_rows_cols would compute by a pass over y; zero-filled by the
- * call, atomic max.) */
+ * call, atomic max.
+ * cmax_out, may be NULL: uint32[k c], an upper BOUND of that operand's column maxima (its weight gradient scales it column by column):
+ * |beta_u[j]| + |gamma_u[j]| * bound_scale for column (p, j) -- with bound_scale = sqrt(n - 1) for batch statistics over n = m k / 2
+ * samples, since |xhat| <= sqrt(n - 1) and the softmax weights are <= 1; gamma_u / beta_u: the 2c BatchNorm parameters of u.) */
 /* Adjoint of pdgn_bn_softmax_slots_permute_mul in two passes over (x, u, w, dy): BatchNorm_u backward, slot-softmax
  * backward and BatchNorm_x backward with dW / dh kept in registers.  scratch: pdgn_bilateral_scratch_floats(m,k,c)
  * floats; bsums_x (2c) = [sum dz_x | sum dz_x*xhat] (= dbeta, dgamma of BN_x), bsums_u (4c) likewise for BN_u;

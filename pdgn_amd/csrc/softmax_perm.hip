@@ -100,7 +100,8 @@ template <int KT>
 __global__ __launch_bounds__(SP_THREADS) void bn_softmax_perm_mul_fwd_kernel(
     long long total2, int k_rt, int C, int act, const float *__restrict__ x, const float *__restrict__ stats,
     int act_u, const float *__restrict__ u, const float *__restrict__ stats_u, float *__restrict__ w_out,
-    float *__restrict__ y, unsigned *__restrict__ max_out) {
+    float *__restrict__ y, unsigned *__restrict__ max_out, const float *__restrict__ gamma_u, const float *__restrict__ beta_u,
+    float bound_scale, unsigned *__restrict__ cmax_out) {
     const long long e = (long long)blockIdx.x * SP_THREADS + threadIdx.x;
     unsigned ymax = 0u;
     if (e < total2) {
@@ -114,6 +115,18 @@ __global__ __launch_bounds__(SP_THREADS) void bn_softmax_perm_mul_fwd_kernel(
     const float4 hu = *reinterpret_cast<const float4 *>(stats_u + 2 * C + 2 * c);
     const float *H = x + m * k * C + c;
     const size_t o = (size_t)m * k * C + 2 * c;                // row (m, p): 2C floats; [2c .. 2c+3]
+    if (cmax_out && m == 0) {
+        // an upper bound of the COLUMN maxima of y as the (M, k C) operand (its weight gradient's scales): softmax weights <= 1 and,
+        // under batch statistics over n samples, |xhat| <= sqrt(n - 1) = bound_scale, so |y[:, (p, j)]| <= |beta_j| + |gamma_j| bound_scale
+        // -- from the 2C parameters alone, written by the threads of point 0 (the same for every slot p)
+        const float4 g = *reinterpret_cast<const float4 *>(gamma_u + 2 * c), b = *reinterpret_cast<const float4 *>(beta_u + 2 * c);
+        uint4 bd;
+        bd.x = __float_as_uint(__fmaf_rn(fabsf(g.x), bound_scale, fabsf(b.x)));
+        bd.y = __float_as_uint(__fmaf_rn(fabsf(g.y), bound_scale, fabsf(b.y)));
+        bd.z = __float_as_uint(__fmaf_rn(fabsf(g.z), bound_scale, fabsf(b.z)));
+        bd.w = __float_as_uint(__fmaf_rn(fabsf(g.w), bound_scale, fabsf(b.w)));
+        for (int p = 0; p < P; ++p) *reinterpret_cast<uint4 *>(cmax_out + (size_t)p * 2 * C + 2 * c) = bd;
+    }
     float2 v[KM];
     float4 uu[KM / 2];
 #pragma unroll
@@ -219,21 +232,23 @@ extern "C" int pdgn_bn_softmax_slots_permute(long long m, int k, int c, int act,
 
 extern "C" int pdgn_bn_softmax_slots_permute_mul(long long m, int k, int c, int act, const float *x, const float *stats,
                                                  int act_u, const float *u, const float *stats_u, float *w, float *y,
-                                                 unsigned *max_out, pdgn_stream_t stream) {
+                                                 unsigned *max_out, const float *gamma_u, const float *beta_u, float bound_scale,
+                                                 unsigned *cmax_out, pdgn_stream_t stream) {
     if (m < 1 || k < 2 || k > SP_MAXK || (k & 1) || c < 2 || (c & 1) || act < 0 || act > 2 || act_u < 0 || act_u > 2)
         return PDGN_ERR_INVALID;
+    if (cmax_out && (!gamma_u || !beta_u || !(bound_scale >= 0.f))) return PDGN_ERR_INVALID;
     const long long total2 = m * (c / 2);
     const dim3 grid(cdiv(total2, SP_THREADS)), block(SP_THREADS);
     hipStream_t s = (hipStream_t)stream;
     if (max_out && hipMemsetAsync(max_out, 0, (size_t)m * sizeof(unsigned), s) != hipSuccess) return pdgn_launch_status();
     if (k == 10)
-        hipLaunchKernelGGL(bn_softmax_perm_mul_fwd_kernel<10>, grid, block, 0, s, total2, k, c, act, x, stats, act_u, u, stats_u, w, y, max_out);
+        hipLaunchKernelGGL(bn_softmax_perm_mul_fwd_kernel<10>, grid, block, 0, s, total2, k, c, act, x, stats, act_u, u, stats_u, w, y, max_out, gamma_u, beta_u, bound_scale, cmax_out);
     else if (k == 20)
-        hipLaunchKernelGGL(bn_softmax_perm_mul_fwd_kernel<20>, grid, block, 0, s, total2, k, c, act, x, stats, act_u, u, stats_u, w, y, max_out);
+        hipLaunchKernelGGL(bn_softmax_perm_mul_fwd_kernel<20>, grid, block, 0, s, total2, k, c, act, x, stats, act_u, u, stats_u, w, y, max_out, gamma_u, beta_u, bound_scale, cmax_out);
     else if (k == 4)
-        hipLaunchKernelGGL(bn_softmax_perm_mul_fwd_kernel<4>, grid, block, 0, s, total2, k, c, act, x, stats, act_u, u, stats_u, w, y, max_out);
+        hipLaunchKernelGGL(bn_softmax_perm_mul_fwd_kernel<4>, grid, block, 0, s, total2, k, c, act, x, stats, act_u, u, stats_u, w, y, max_out, gamma_u, beta_u, bound_scale, cmax_out);
     else
-        hipLaunchKernelGGL(bn_softmax_perm_mul_fwd_kernel<0>, grid, block, 0, s, total2, k, c, act, x, stats, act_u, u, stats_u, w, y, max_out);
+        hipLaunchKernelGGL(bn_softmax_perm_mul_fwd_kernel<0>, grid, block, 0, s, total2, k, c, act, x, stats, act_u, u, stats_u, w, y, max_out, gamma_u, beta_u, bound_scale, cmax_out);
     return pdgn_launch_status();
 }
 

@@ -1042,12 +1042,16 @@ class BilateralWeighting(Function):
         # bits (here b ~ 6: sqrt(n) against the ~5 sigma a column really reaches); the product's error stays far below the fp32
         # accumulation's (gemm_x3.hip).  Measured against the alternatives: a scan of y is 176 us at stage 4, exact maxima from
         # this kernel (threads walking several points) made it 130 us slower per launch.
-        ycmax = None
+        # (the bound is written by the same launch: computed with tensor expressions it was four launches per block and pass on the
+        # issuing stream)
+        ycmax, g_u, b_u, bound = None, None, None, 0.0
         if want_max and training and any(ctx.needs_input_grad):
-            n_u = float(u.shape[0])
-            ycmax = torch.add(bu.detach().abs(), gu.detach().abs(), alpha=max(n_u - 1.0, 1.0) ** 0.5).repeat(k // 2).view(torch.int32)
+            ycmax = torch.empty((k // 2 * 2 * C,), dtype=torch.int32, device=x.device)
+            g_u, b_u = gu.detach().contiguous(), bu.detach().contiguous()
+            bound = max(float(u.shape[0]) - 1.0, 1.0) ** 0.5
         check(L.pdgn_bn_softmax_slots_permute_mul(ctypes.c_longlong(m), k, C, act, ptr(x), ptr(stats_x), act, ptr(u),
-                                                  ptr(stats_u), ptr(w), ptr(y), ptr(ymax), stream_of(x)),
+                                                  ptr(stats_u), ptr(w), ptr(y), ptr(ymax), ptr(g_u), ptr(b_u), ctypes.c_float(bound),
+                                                  ptr(ycmax), stream_of(x)),
               "pdgn_bn_softmax_slots_permute_mul")
         ctx.save_for_backward(x, u, w, stats_x, stats_u)
         ctx.cfg = (rows, C, act, bool(training), k, pbx is not None, pbu is not None)
