@@ -272,9 +272,20 @@ class BNActCL(Function):
 # ~100 launches per iteration; increments are collected here and applied by flush_bn_counters() with
 # one multi-tensor add (the network-level forward()s and the trainer call it).
 _PENDING_COUNTS = {}
+_HOLD_COUNTS = [False]
+
+
+def hold_bn_counters(on):
+    """While held, flush_bn_counters() collects only: a caller that brackets a whole training iteration (PDGNTrainer's
+    overlapped step) applies the iteration's increments with ONE launch at its end instead of one per network-level forward
+    (~30 per iteration, on whatever stream the forward ran).  Nothing on the device reads the counters.  Returns the old state."""
+    old, _HOLD_COUNTS[0] = _HOLD_COUNTS[0], bool(on)
+    return old
 
 
 def flush_bn_counters():
+    if _HOLD_COUNTS[0]:
+        return
     if _PENDING_COUNTS:
         tensors = list(_PENDING_COUNTS.keys())
         torch._foreach_add_(tensors, [int(v) for v in _PENDING_COUNTS.values()])

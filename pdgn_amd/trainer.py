@@ -13,7 +13,7 @@ import torch.distributed as dist
 import torch.nn as nn
 
 from . import streams as _streams
-from .fused import clear_zero_colsum, flush_bn_counters, release_zero_arena, reset_zero_arena
+from .fused import clear_zero_colsum, flush_bn_counters, hold_bn_counters, release_zero_arena, reset_zero_arena
 from .generator import PointDiscriminator, PointGenerator
 from . import losses
 from .losses import LocalPairLoss
@@ -328,7 +328,9 @@ class PDGNTrainer:
         base can resume from the other's files."""
         os.makedirs(checkpoint_dir, exist_ok=True)
         stem = os.path.join(checkpoint_dir, "%s_%s" % (index_epoch, category))
+        held = hold_bn_counters(False)
         flush_bn_counters()
+        hold_bn_counters(held)
         torch.save({"G_model": self._ref_model_state(self.G), "G_optimizer": self._ref_optim_state(self.optG),
                     "G_epoch": index_epoch}, stem + "_G.pth")
         dfile = {"D_epoch": index_epoch}
@@ -508,6 +510,15 @@ class PDGNTrainer:
         way D_k(G(z2)_k) (behind D_k's update, on D_k's stream) and the loss pairs that end at level k start from
         G(z2)'s stage hook; the default stream joins all of them before the backward.  Results are those of the
         sequential order (the reference's D updates do not read each other)."""
+        # num_batches_tracked: the iteration's increments in one launch at its end (fused.hold_bn_counters)
+        held_counts = hold_bn_counters(True)
+        try:
+            return self._step_overlapped_body(reals, z1, z2, st)
+        finally:
+            hold_bn_counters(held_counts)
+            flush_bn_counters()
+
+    def _step_overlapped_body(self, reals, z1, z2, st=None):
         st = st if st is not None else self._state(reals, z1, z2)
         main = torch.cuda.current_stream(self.device)
         pl = _streams.plan(self.device)                     # streams by measured hardware queue (streams.py)
