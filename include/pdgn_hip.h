@@ -408,10 +408,13 @@ int pdgn_gemm_two_part_planes(long long m, int n, int k, long long scan_bytes);
 /* Round 6: a product on two-part planes with a short reduction (k = 32, 64, 128), n >= 128, m >= 4096, m n >= 1.6e7 and neither
  * bias, addend nor epilogue extras runs on the ROW-PANEL kernel (csrc/gemm_rp.hip: a workgroup keeps 256 rows of A in registers as
  * matrix-instruction fragments and streams the weight's column tiles; same arithmetic as the tile kernel, bit for bit; no tail, no
- * workspace).  Its BatchNorm partials (stat_part) cover 32 rows each: pdgn_gemm_nt_ps_stat_rows / _stat_block_rows answer for the
+ * workspace).  Its BatchNorm partials (stat_part) cover a 256-row panel each (the eight waves of a workgroup join their 32-row sums): pdgn_gemm_nt_ps_stat_rows / _stat_block_rows answer for the
  * call that will actually run (plain != 0: no bias / addend / extras). */
 long long pdgn_gemm_nt_ps_stat_rows(long long m, int n, int k, int parts, int plain);
 int pdgn_gemm_nt_ps_stat_block_rows(long long m, int n, int k, int parts, int plain);
+/* 1 when that call runs on the row-panel kernel (the rule above under the switches in force), else 0: a caller skips the scan of
+ * A's row maxima then -- the kernel takes them itself. */
+int pdgn_gemm_nt_ps_row_panel(long long m, int n, int k, int parts, int plain);
 long long pdgn_gemm_nt_ps_workspace_floats(long long m, int n, int k, int parts, int with_stats);
 int pdgn_split_f16x2(int rows, int cols, const float *src, int ld_src, unsigned short *planes, int ld_planes,
                      long long plane_stride, unsigned short *planes_t, int ld_planes_t, long long plane_stride_t,

@@ -358,7 +358,7 @@ static inline int fb_slices(int c, long long nparts) {           // 0: the one-l
     if (c % 64 == 0) {                                              // the 64-channel form: ~16 partial rows per part lane, at most 128 slices
         // (tools/finalize_bench.py, round 6: 11200 x 512: 87 -> 36 us, 5600 x 256: 44 -> 17, 2800 x 512: 25 -> 12, 5600 x 64: 33 -> 16;
         //  below ~1400 rows one launch is as fast: 560 x 512 5.5 vs 10 us)
-        if (nparts < 1400) return 0;
+        if (nparts <= 1400) return 0;                               // (1400: a 358400-row layer on the row-panel kernel, one partial row per 256-row panel)
         long long s64 = nparts / 64;
         return (int)(s64 < 2 ? 2 : (s64 > 128 ? 128 : s64));
     }

@@ -35,7 +35,7 @@ struct RpArgs {
     int panels, ctiles;               // row panels of 256, column tiles of 64
     int rgroups, cslabs;              // rgroups * cslabs == 8: XCD x = (row group x / cslabs, column slab x % cslabs)
     int wg_per_xcd;
-    float *stat_part;                 // STATS: ceil(M / 32) rows of [3 N] floats, per-column sum (x - pv) | sum (x - pv)^2 | pv of every 32-row block
+    float *stat_part;                 // STATS: ceil(M / 256) rows of [3 N] floats, per-column sum (x - pv) | sum (x - pv)^2 | pv of every 256-row panel
                                       // of C (pv: the block's first row), the layout pdgn_bn_stats_from_gemm_partials reads
 };
 
@@ -56,8 +56,11 @@ __global__ __launch_bounds__(512, 1) void gemm_rp_kernel(const RpArgs p) {
     constexpr int PLANE = KC * BN * 64;                             // one part of a weight tile: [chunk][64 rows][64 B]
     constexpr int WTILE = 2 * PLANE;                                // h | l
     // LDS: two weight tiles, two tables of the tile's column exponents, eight staging blocks
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * WTILE + 2 * BN * 4 + 8 * 4096];
+    // STATS: two tables of the eight waves' partial sums of a tile (64 columns x [sum | squares | pivot]) and their row counts
+    constexpr int STL = STATS ? 2 * (8 * 3 * BN + 8) * 4 : 0;
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * WTILE + 2 * BN * 4 + 8 * 4096 + STL];
     int *const colexp = reinterpret_cast<int *>(smem + 2 * WTILE);
+    float *const stl = reinterpret_cast<float *>(smem + 2 * WTILE + 2 * BN * 4 + 8 * 4096);      // [2][8][3][BN] floats, then [2][8] ints
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     unsigned char *const stg = smem + 2 * WTILE + 2 * BN * 4 + wave * 4096;
@@ -112,13 +115,11 @@ __global__ __launch_bounds__(512, 1) void gemm_rp_kernel(const RpArgs p) {
     u32x4 afh[KS], afl[KS];
     int ua_e[4];                                                   // un-scale exponents -e_A of the rows this lane STORES: rows 8 j + (lane >> 3) of the staged read-back
     int cur_mrows = 0;                                             // rows of this wave's block of the current panel inside the matrix
-    long long cur_prow = 0;
     __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc((void *)p.C, 0, 0, 0x00020000);
     auto load_a = [&](int panel) {
         const long long m0 = (long long)panel * BM + 32 * wave;
         const int mrows = (int)max(0LL, min(32LL, p.M - m0));
         cur_mrows = mrows;
-        cur_prow = (long long)panel * 8 + wave;
         const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void *)(p.A + m0 * p.lda), 0,
                                                                             mrows > 0 ? (int)(((long long)(mrows - 1) * p.lda + K) * 4) : 0, 0x00020000);
         f32x4 raw[2 * KS];
@@ -183,7 +184,7 @@ __global__ __launch_bounds__(512, 1) void gemm_rp_kernel(const RpArgs p) {
         int ua[4];
         int n0;
         int mrows;                                                 // rows of this wave's block inside the matrix (0 .. 32)
-        long long prow;                                            // STATS: the block's partial row
+        int sbuf;                                                  // STATS: which of the two tables takes the tile's partial sums
         __amdgpu_buffer_rsrc_t rsC;
     };
     auto out_part = [&](const Done &d, int part) {
@@ -229,22 +230,60 @@ __global__ __launch_bounds__(512, 1) void gemm_rp_kernel(const RpArgs p) {
                     cs[r] += __shfl_xor(cs[r], o);
                     cq[r] += __shfl_xor(cq[r], o);
                 }
-            if (lane < 8 && nl < p.N && d.mrows > 0) {
-                float *P = p.stat_part + d.prow * 3 * p.N + nl;
-                *reinterpret_cast<float4 *>(P) = make_float4(cs[0], cs[1], cs[2], cs[3]);
-                *reinterpret_cast<float4 *>(P + p.N) = make_float4(cq[0], cq[1], cq[2], cq[3]);
-                *reinterpret_cast<float4 *>(P + 2 * p.N) = make_float4(pv[0], pv[1], pv[2], pv[3]);
+            // the wave's sums go to the tile's table in LDS: stat_combine joins the eight waves' blocks into ONE partial row per 256-row
+            // panel (a partial row per 32 rows made the finalisation of a 358400-row layer walk 11200 rows of [3 N] floats: 69 MB
+            // written and read back, two launches of 25-55 us in the step)
+            if (lane < 8) {
+                float *T = stl + (d.sbuf * 8 + wave) * 3 * BN + 32 * b + 4 * lane;
+                *reinterpret_cast<float4 *>(T) = make_float4(cs[0], cs[1], cs[2], cs[3]);
+                *reinterpret_cast<float4 *>(T + BN) = make_float4(cq[0], cq[1], cq[2], cq[3]);
+                *reinterpret_cast<float4 *>(T + 2 * BN) = make_float4(pv[0], pv[1], pv[2], pv[3]);
+                if (b == 0 && lane == 0) reinterpret_cast<int *>(stl + 2 * 8 * 3 * BN)[d.sbuf * 8 + wave] = d.mrows;
             }
         }
+    };
+    // STATS: the partial row of panel `pan`, columns n0 .. n0 + 63, from table `sb` (complete: a barrier lies between its last write and
+    // this call).  Re-based on wave 0's pivot pv0 (the panel's first row): with d = pv_w - pv0,
+    //   sum (x - pv0) = S_w + n_w d,   sum (x - pv0)^2 = Q_w + 2 d S_w + n_w d^2      (exact algebra; |d| ~ the column's spread)
+    auto stat_combine = [&](int pan, int n0, int sb) {
+        if (!STATS || wave != 0 || n0 + lane >= p.N) return;       // (wave 0: BN = 64 columns, one per lane)
+        const float *T = stl + sb * 8 * 3 * BN + lane;
+        const int *NW = reinterpret_cast<const int *>(stl + 2 * 8 * 3 * BN) + sb * 8;
+        const float pv0 = T[2 * BN];
+        float S = T[0], Q = T[BN];
+#pragma unroll 1                                                   // (one wave's entry at a time: the K = 128 instance has no registers to spare)
+        for (int w = 1; w < 8; ++w) {
+            const int nw = NW[w];
+            if (nw > 0) {
+                const float *Tw = T + w * 3 * BN;
+                const float sw = Tw[0], qw = Tw[BN], d = Tw[2 * BN] - pv0, fn = (float)nw;
+                S += sw + fn * d;
+                Q += qw + d * (2.f * sw + fn * d);
+            }
+        }
+        float *P = p.stat_part + (long long)pan * 3 * p.N + n0 + lane;
+        P[0] = S;
+        P[p.N] = Q;
+        P[2 * p.N] = pv0;
     };
     Done prev;
     bool have_prev = false;
     prev.n0 = 0;
     prev.mrows = 0;
-    prev.prow = 0;
+    prev.sbuf = 0;
     prev.rsC = rsC;
+    int prev_panel = 0;
+    // STATS: the tile whose sums the waves wrote during the LAST step (complete since that step's barrier): joined during this one
+    bool comb = false;
+    int comb_panel = 0, comb_n0 = 0, comb_sb = 0;
     int buf = 0;
     for (; t < t1; ++t) {
+        if (STATS && comb) stat_combine(comb_panel, comb_n0, comb_sb);
+        // (the tile that leaves during this step -- prev, when there is one -- is joined during the next)
+        comb = STATS && have_prev;
+        comb_panel = prev_panel;
+        comb_n0 = prev.n0;
+        comb_sb = prev.sbuf;
         const unsigned char *Wt = smem + buf * WTILE;
         rp_f32x16 acc[2];
 #pragma unroll
@@ -292,7 +331,8 @@ __global__ __launch_bounds__(512, 1) void gemm_rp_kernel(const RpArgs p) {
         for (int j = 0; j < 4; ++j) prev.ua[j] = ua_e[j];
         prev.n0 = (c0 + ct) * BN;
         prev.mrows = cur_mrows;
-        prev.prow = cur_prow;
+        prev.sbuf = (int)(t & 1);
+        prev_panel = panel;
         prev.rsC = rsC;
         have_prev = true;
         if (!PIPE) {
@@ -317,9 +357,16 @@ __global__ __launch_bounds__(512, 1) void gemm_rp_kernel(const RpArgs p) {
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     }
+    if (STATS && comb) stat_combine(comb_panel, comb_n0, comb_sb);
     if (PIPE && have_prev) {
 #pragma unroll
         for (int part = 0; part < 4; ++part) out_part(prev, part);
+    }
+    if (STATS && have_prev) {                                       // the last tile's sums: written just now
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        stat_combine(prev_panel, prev.n0, prev.sbuf);
     }
 }
 

@@ -1785,7 +1785,7 @@ extern "C" int pdgn_gemm_nt_ps(long long m, int n, int k, const float *A, int ld
         // a short reduction and a wide result: the row-panel kernel (gemm_rp.hip: A resident in registers, the weight tiles streamed,
         // the same two-part arithmetic bit for bit)
         // (A's row maxima: taken inside the kernel -- handed-in ones are not needed and not read)
-        return rp_launch(m, n, k, A, lda, Wplanes, ldw, wplane, C, ldc, stat_part, (hipStream_t)stream);      // (stat_part: one partial row per 32 rows, pdgn_gemm_nt_ps_stat_rows)
+        return rp_launch(m, n, k, A, lda, Wplanes, ldw, wplane, C, ldc, stat_part, (hipStream_t)stream);      // (stat_part: one partial row per 256-row panel, pdgn_gemm_nt_ps_stat_rows)
     }
     NtEpi e;
     e.row_bias = row_bias; e.ld_rb = ld_rb; e.rows_per_group = rows_per_group > 0 ? rows_per_group : 1; e.act = act; e.gate = gate;
@@ -1884,13 +1884,16 @@ extern "C" long long pdgn_gemm_tn_big_workspace_floats(long long m, int n, int k
 }
 
 // The same two questions for pdgn_gemm_nt_ps with `parts`-part planes, bias / addend / epilogue extras absent (`plain` != 0): a
-// short-reduction product on two-part planes runs on the row-panel kernel (gemm_rp.hip), whose partial rows cover 32 rows each.
+// short-reduction product on two-part planes runs on the row-panel kernel (gemm_rp.hip), whose partial rows cover a 256-row panel each.
+extern "C" int pdgn_gemm_nt_ps_row_panel(long long m, int n, int k, int parts, int plain) {
+    return (x3_mode() == 2 && parts == 2 && plain && m >= 1 && rp_takes(m, n, k)) ? 1 : 0;
+}
 extern "C" long long pdgn_gemm_nt_ps_stat_rows(long long m, int n, int k, int parts, int plain) {
-    if (x3_mode() == 2 && parts == 2 && plain && m >= 1 && rp_takes(m, n, k)) return (m + 31) / 32;
+    if (x3_mode() == 2 && parts == 2 && plain && m >= 1 && rp_takes(m, n, k)) return (m + 255) / 256;
     return pdgn_gemm_nt_stat_rows(m, n, k);
 }
 extern "C" int pdgn_gemm_nt_ps_stat_block_rows(long long m, int n, int k, int parts, int plain) {
-    if (x3_mode() == 2 && parts == 2 && plain && m >= 1 && rp_takes(m, n, k)) return 32;
+    if (x3_mode() == 2 && parts == 2 && plain && m >= 1 && rp_takes(m, n, k)) return 256;
     return pdgn_gemm_nt_stat_block_rows(m, n, k);
 }
 

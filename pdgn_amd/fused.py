@@ -470,9 +470,8 @@ def _tail_workspace(L, m, n, k, with_stats, device, parts=None):
 
 def _rp_takes(m, n, k, parts, plain):
     """Whether pdgn_gemm_nt_ps(m, n, k) on `parts`-part planes runs on the row-panel kernel (csrc/gemm_rp.hip: short reductions on
-    two-part planes, no bias / addend): its BatchNorm partials cover 32 rows each."""
-    return parts == 2 and plain and _lib.lib().pdgn_gemm_nt_ps_stat_block_rows(ctypes.c_longlong(m), n, k, 2, 1) == 32 \
-        and _lib.lib().pdgn_gemm_nt_stat_block_rows(ctypes.c_longlong(m), n, k) != 32
+    two-part planes, no bias / addend): its BatchNorm partials cover a 256-row panel each."""
+    return parts == 2 and plain and _lib.lib().pdgn_gemm_nt_ps_row_panel(ctypes.c_longlong(m), n, k, 2, 1) == 1
 
 
 def planes_fit(P, m, n, k, with_stats=False, plain=False):

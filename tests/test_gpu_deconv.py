@@ -1895,7 +1895,8 @@ def test_row_panel_kernel_of_the_short_reductions(M, N, K):
 @pytest.mark.parametrize("M,N,K", [(40960, 512, 64), (40999, 516, 64), (179200, 256, 64), (20000, 1024, 128)])
 def test_row_panel_kernel_emits_batchnorm_partials(M, N, K, ratio):
     """The row-panel kernel with stat_part (the edge-level layer in front of the bilateral weighting, conv_all.3: 358400 x 512 x 64
-    at stage 4): one partial row per 32 rows of the result -- sum (x - pv), sum (x - pv)^2, pv with pv the block's first row --
+    at stage 4): one partial row per 256-row panel of the result (the workgroup's eight waves join their 32-row sums on the panel's
+    first row as the pivot) -- sum (x - pv), sum (x - pv)^2, pv --
     through linear_cl(want_stats=True, planes=two-part planes) -> bn_act(partials=...) against fp64: normalised output at 1e-4, also
     with |mean| >> std (ratio: the weight rows get a common offset direction), ragged row / column counts, the result itself equal
     to the call without partials, running statistics."""
@@ -1909,7 +1910,15 @@ def test_row_panel_kernel_emits_batchnorm_partials(M, N, K, ratio):
     assert pl.parts_p == 2
     y0 = fused.linear_cl(x, w, planes=pl)
     y, part = fused.linear_cl(x, w, None, None, True, planes=pl)
-    assert part is not None and part[1] == 32 and part[0].shape == ((M + 31) // 32, 3 * N)
+    assert part is not None and part[1] == 256 and part[0].shape == ((M + 255) // 256, 3 * N)
+    # the partial rows themselves: sums of (y - pv) and its square over each panel's rows, pv = the panel's first row
+    p0 = part[0].double().view(-1, 3, N)
+    yp = torch.nn.functional.pad(y.double(), (0, 0, 0, p0.shape[0] * 256 - M)).view(-1, 256, N)
+    live = (torch.arange(p0.shape[0] * 256, device="cuda").view(-1, 256, 1) < M).double()
+    d = (yp - yp[:, :1]) * live
+    assert torch.equal(part[0].view(-1, 3, N)[:, 2], y[::256])
+    scale = d.abs().sum(1).max().item()
+    assert (p0[:, 0] - d.sum(1)).abs().max().item() < 2e-5 * scale and (p0[:, 1] - (d * d).sum(1)).abs().max().item() < 2e-5 * (d * d).sum(1).max().item()
     assert torch.equal(y, y0)
     bn = nn.BatchNorm1d(N).cuda().train()
     out = fused.bn_act(y, bn, True, act="none", partials=part)

@@ -8,4 +8,4 @@ python3 tools/x3_launches.py gpurun_out/kt_$TAG 6 20 > gpurun_out/${TAG}_x3_laun
 python3 tools/scan_launches.py gpurun_out/kt_$TAG 6 > gpurun_out/${TAG}_scan_launches.txt 2>&1
 python3 tools/main_chain.py gpurun_out/kt_$TAG 6 > gpurun_out/${TAG}_main_chain.txt 2>&1
 python3 tools/conv2_in_step.py gpurun_out/kt_$TAG > gpurun_out/${TAG}_conv2_in_step.txt 2>&1
-rm -rf gpurun_out/kt_$TAG
+[ -n "$KEEP_TRACE" ] || rm -rf gpurun_out/kt_$TAG
