@@ -38,8 +38,7 @@ _KNN_OVERLAP = __import__("os").environ.get("PDGN_KNN_OVERLAP", "1") == "1"
 
 def _knn_stream(device):
     """The kNN side stream of the issuing stream (one per (device, issuing stream): concurrent generator passes must
-    not share one), on a hardware queue other than the issuing stream's -- see streams.py.  (The trainer's pass #1, issued on D4's
-    stream concurrently with pass #2, switches _KNN_OVERLAP off for its duration and builds its graphs inline.)"""
+    not share one), on a hardware queue other than the issuing stream's -- see streams.py."""
     return _streams.plan(device).knn
 
 

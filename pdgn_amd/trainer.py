@@ -267,12 +267,6 @@ class PDGNTrainer:
         self._early_tail = os.environ.get("PDGN_EARLY_TAIL", "1") == "1"
         self._split_d = os.environ.get("PDGN_SPLIT_D", "1") == "1"
         self._defer_d = os.environ.get("PDGN_DEFER_D", "1") == "1"
-        # generator pass #1 (no graph, feeds only the discriminator updates) on D4's stream, CONCURRENT with pass #2 on the issuing
-        # stream: levels 1-3 of a pass are chains of ~110 small launches that leave the chip idle (round 6; _step_overlapped)
-        # (measured, DESIGN.md section 10b: the forward phase shrinks from 13.6 to ~9 ms but the 17 ms of discriminator / loss kernels
-        # that used to run underneath it then hold up the join: 24.7 vs 24.0 ms.  Off by default; kept as the A/B arm and for what it
-        # documents about capturing a schedule whose side streams depend on each other)
-        self._pass1_side = os.environ.get("PDGN_PASS1_SIDE", "0") == "1"
         self.sync_replicas()
 
     def sync_replicas(self, src=0):
@@ -577,24 +571,15 @@ class PDGNTrainer:
         if pre_ok:
             with torch.enable_grad():
                 self.G.preassemble(deepest_without_graph=self.distributed and self._buckets)
-        # Pass #1 on D4's stream (its own hardware queue, streams.py), CONCURRENT with pass #2 on the issuing stream (round 6): it
-        # needs no autograd graph and feeds only the discriminator updates.  Levels 1-3 of a generator pass are chains of ~110 small
-        # launches each that leave the chip idle; two such chains side by side cost little more than one.  The capture of the
-        # iteration constrains HOW: hipStreamEndCapture (ROCm 7.2) recurses without bound -- a segmentation fault inside
-        # hip::Stream::EndCapture -- as soon as one captured side stream waits for an event recorded on ANOTHER side stream.  So every
-        # dependency goes through the issuing stream: pass #1 builds its kNN graphs inline (no kNN stream), D4's whole update follows it
-        # on the same stream, and D1-D3's updates start behind ONE event of the issuing stream, recorded when pass #2 has finished its
-        # level 3 and the issuing stream has waited there for pass #1's levels 1-3 (it reaches that point at about the same time;
-        # D1-D3 have slack until the join in front of the backward).  D4's chain -- pass #1, D4's update, D4(G(z2)) -- is what the
-        # backward waits for: D4's REAL half, which needs nothing of the generator, runs on the issuing stream in front of pass #2
-        # (below), its fake half behind pass #1 and the same event of the issuing stream.
-        p1 = self._pass1_side and split and self._early_tail and hasattr(self.G, "preassemble")
+        # (Rule for anything added to this schedule: a side stream may wait for events of the ISSUING stream only.  hipStreamEndCapture
+        # (ROCm 7.2) recurses without bound -- a segmentation fault inside hip::Stream::EndCapture -- as soon as one captured side stream
+        # waits for an event recorded on ANOTHER side stream; round 6 ran pass #1 on D4's stream beside pass #2 that way and routed
+        # every dependency through the issuing stream.  It measured slower -- the iteration is bound by the sum of its kernels -- and
+        # is in git at 5c84567 (trainer.py, PDGN_PASS1_SIDE))
         if split:
             st["d_half"] = [None] * 4
             for level, side in enumerate(self._side):
                 side.wait_stream(main)                      # (the real batch / targets may have been produced on `main`)
-                if p1 and level == 3:
-                    continue
                 with torch.cuda.stream(side), torch.enable_grad():
                     self._seg_d_real(st, level)
 
@@ -602,32 +587,9 @@ class PDGNTrainer:
             d_mark(level, cloud)
             d_update(*levels.pop())
 
-        hook1 = d_mark if (self._defer_d or p1) else d_now
-        pend = []                                           # p1: D1-D3's updates, issued from pass #2's stage hook
-        if p1:
-            from . import deconv as _deconv
-            shadows = self._bn_shadows()                    # pass #1 updates COPIES of the generator's running statistics (below)
-            d3 = self._side[3]
-            d3.wait_stream(main)                            # (those copies, the pre-assembled operands, the noise)
-            # D4's real half on the ISSUING stream, in front of pass #2: on D1-D3's queue it starved behind two generator passes (the
-            # issuing stream then waited 6 ms for it), on D4's stream it holds up pass #1 -- and D4's chain, not pass #2, is what
-            # the backward waits for
-            with torch.enable_grad():
-                self._seg_d_real(st, 3)
-            knn_overlap, _deconv._KNN_OVERLAP = _deconv._KNN_OVERLAP, False
-            try:
-                with torch.cuda.stream(d3), torch.no_grad():
-                    self._swap_bn(shadows, True)
-                    try:
-                        self.G(self._z(st, "z1"), stage_hook=hook1)
-                    finally:
-                        self._swap_bn(shadows, False)
-            finally:
-                _deconv._KNN_OVERLAP = knn_overlap
-            pend, levels = [lv for lv in levels if lv[0] < 3], []   # (D4's fake half: behind pass #1 in stream order, issued with D1-D3's)
-        else:
-            with torch.no_grad():
-                self.G(self._z(st, "z1"), stage_hook=hook1)
+        hook1 = d_mark if self._defer_d else d_now
+        with torch.no_grad():
+            self.G(self._z(st, "z1"), stage_hook=hook1)
         for level, ev in levels:
             d_update(level, ev)
         mark("G(z1) level 4")
@@ -642,8 +604,6 @@ class PDGNTrainer:
         terms, own, g_loss, gen_so_far = {}, {}, [None] * 4, []
         early = self._early_tail
 
-        held = []
-
         def d_gen(level, cloud):                            # D_k(G(z2)_k) behind D_k's update, on D_k's stream
             side = self._side[level]
             side.wait_stream(main)
@@ -656,24 +616,7 @@ class PDGNTrainer:
                 self._side_lp.wait_stream(main)
                 with torch.cuda.stream(self._side_lp):
                     terms.update(self.similar_terms(gen_so_far, [(a, level) for a in range(level)], own))
-            if not (p1 and level < 3):
-                d_gen(level, cloud)
-                return
-            held.append((level, cloud))
-            if level == 2:
-                # pass #2 has finished its level 3: wait here for pass #1's levels 1-3 (events recorded on D4's stream), then let
-                # D1-D3 go -- update first (their parameters want gradients for it), D_k(G(z2)_k) behind it
-                for _, ev in pend:
-                    main.wait_event(ev)
-                go = torch.cuda.Event()
-                go.record(main)
-                self._freeze_D(False)
-                d_update(3, go)                             # (D4 first: its chain is the one the backward waits for)
-                for lv, _ in pend:
-                    d_update(lv, go)
-                self._freeze_D(True)
-                for lv, c in held:
-                    d_gen(lv, c)
+            d_gen(level, cloud)
 
         gen = self.G(self._z(st, "z2"), stage_hook=tail if early else None)
         mark("G(z2) forward")
@@ -701,43 +644,11 @@ class PDGNTrainer:
         st["out"]["g_loss"], st["out"]["similar_loss"] = lossG.detach(), similar.detach()
         self._comm(4)
         self._stepG.step()
-        if p1:
-            self._merge_bn(shadows)
         if pre_ok:
             self.G.drop_preassembled()
         release_zero_arena()                                # no later backward may receive slices of this step's arena
         mark("all-reduce + Adam G")
         return st["out"]
-
-    # ---------------------------------------------------------------- concurrent generator passes: running statistics
-    # Both passes run the generator in training mode and both update every BatchNorm's running statistics in place
-    # (models/PDGNet_v2.py:179, 229: r <- (1 - m) r + m s1, then r <- (1 - m) r + m s2).  Issued concurrently the two read-modify-
-    # writes of one buffer would race.  Pass #1 therefore updates a COPY (sh <- (1 - m) r0 + m s1, r0 = the buffer at the start
-    # of the iteration, kept as b0), pass #2 the buffer itself (r <- (1 - m) r0 + m s2), and after both
-    #     r <- r + (1 - m) (sh - b0)  =  (1 - m)^2 r0 + (1 - m) m s1 + m s2
-    # -- the sequential result (to rounding: the tests compare buffers to 1e-4).  Static copies (a launch list addresses them),
-    # three multi-tensor launches per iteration.
-    def _bn_shadows(self):
-        sh = getattr(self, "_bn_sh", None)
-        if sh is None:
-            mods = [m for m in self.G.modules() if isinstance(m, torch.nn.modules.batchnorm._BatchNorm) and m.track_running_stats]
-            bufs = [b for m in mods for b in (m.running_mean, m.running_var)]
-            keep = [1.0 - (m.momentum if m.momentum is not None else 0.1) for m in mods for _ in (0, 1)]
-            sh = self._bn_sh = {"mods": mods, "bufs": bufs, "keep": keep, "b0": [torch.empty_like(b) for b in bufs],
-                                "sh": [torch.empty_like(b) for b in bufs]}
-        torch._foreach_copy_(sh["b0"], sh["bufs"])
-        torch._foreach_copy_(sh["sh"], sh["bufs"])
-        return sh
-
-    def _swap_bn(self, sh, to_shadow):
-        src = sh["sh"] if to_shadow else sh["bufs"]
-        for i, m in enumerate(sh["mods"]):
-            m._buffers["running_mean"], m._buffers["running_var"] = src[2 * i], src[2 * i + 1]
-
-    def _merge_bn(self, sh):
-        d = torch._foreach_sub(sh["sh"], sh["b0"])
-        torch._foreach_mul_(d, sh["keep"])
-        torch._foreach_add_(sh["bufs"], d)
 
     # ---------------------------------------------------------------- hipGraph replay
     def capture(self, reals, z1=None, z2=None, warmup=3):
