@@ -11,7 +11,13 @@ path = max(glob.glob(f"{root}/**/*kernel_trace.csv", recursive=True), key=os.pat
 rows = list(csv.DictReader(open(path)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 marks = [i for i, r in enumerate(rows) if "small_mlp_fwd" in r["Kernel_Name"] and int(r["Grid_Size_X"]) >= 4096 * 64]
-lo, hi = marks[-5], marks[-3]                              # one iteration: two generator passes
+# an iteration = two generator passes; it begins at the mark that follows the optimizer's multi-tensor launch of the previous one
+def _starts_iteration(j):                                  # marks[j]: is the generator's optimizer launch between marks[j - 1] and it, on its queue?
+    q = rows[marks[j]]["Queue_Id"]
+    return any(r["Queue_Id"] == q and "multi_tensor_apply" in r["Kernel_Name"] and "FusedOptimizer" in r["Kernel_Name"]
+               for r in rows[marks[j - 1]:marks[j]])
+first = next(j for j in range(len(marks) - 5, 0, -1) if _starts_iteration(j))
+lo, hi = marks[first], marks[first + 2]                              # one iteration: two generator passes
 sel = rows[lo:hi]
 byq = defaultdict(list)
 for r in sel:
