@@ -35,6 +35,7 @@ from .fused import _STATS_MAX as STATS_MAX  # noqa: F401
 
 F32, I32 = torch.float32, torch.int32
 _KNN_OVERLAP = __import__("os").environ.get("PDGN_KNN_OVERLAP", "1") == "1"
+_KNN_CONST = __import__("os").environ.get("PDGN_KNN_CONST", "0") == "1"     # 1: the per-sample constant channels take part in the feature-kNN Gram
 
 def _knn_stream(device):
     """The kNN side stream of the issuing stream (one per (device, issuing stream): concurrent generator passes must
@@ -72,11 +73,17 @@ def start_feature_knn(xt, const, k, x_cf=None):
     together with the transposed graph a backward pass will want.  Returns (idx, event to wait for | None)."""
     want_csr = torch.is_grad_enabled() and xt.requires_grad
 
-    def channel_major():                                       # (B, Fin, N): what pdgn_feature_knn reads
+    def channel_major():                                       # (B, F, N): what pdgn_feature_knn reads
         if x_cf is not None:
             return x_cf.detach().contiguous()
         x = xt.detach().transpose(1, 2)
-        if const is not None:
+        # The channels that are CONSTANT over a sample's points (the broadcast global vector, half of the block's input at levels
+        # 2-4) do not enter the graph: they add (g_f - g_f)^2 = 0 to every pairwise distance -- in the Gram form |q|^2 + |c|^2 - 2 q.c
+        # they add 2 |g|^2 - 2 |g|^2, i.e. nothing but cancellation noise, at half of the kernel's work (stage 4: 245 -> ~130 us, and the
+        # graph kernel holds every CU while it runs: DESIGN.md section 10b).  The reference builds the graph from the concatenated
+        # tensor (models/PDGNet_v2.py:447-458, :708): same neighbours wherever the distances are separated by more than its own
+        # rounding.  PDGN_KNN_CONST=1: with them (A/B arm).
+        if const is not None and _KNN_CONST:
             x = torch.cat((const.detach().unsqueeze(2).expand(-1, -1, xt.shape[1]), x), 1)
         return x.contiguous()
 

@@ -265,8 +265,9 @@ def window_gather_sum_stage4(B, base_points, device):
 
 
 def feature_knn_stage4(B, base_points, device):
-    """Feature-space kNN of the last stage: Gram flops = 2*N*N*F per sample on the fp32 MFMA."""
-    N, F, k = 8 * base_points, 256, 10
+    """Feature-space kNN of the last stage: Gram flops = 2*N*N*F per sample on the fp32 MFMA.  F = the 128 channels that VARY over a
+    sample's points: the 128 broadcast ones cancel in every pairwise distance and stay out of the graph (deconv.start_feature_knn)."""
+    N, F, k = 8 * base_points, 128, 10
     x = torch.randn(B, F, N, device=device)
     idx = torch.empty(B, N, k, device=device, dtype=torch.int32)
     sq = torch.empty(B, N, device=device)
@@ -275,7 +276,7 @@ def feature_knn_stage4(B, base_points, device):
     def run():
         check(L.pdgn_feature_knn(B, F, N, k, ptr(x), ptr(sq), ptr(idx), stream_of(x)), "pdgn_feature_knn")
     us = _time_us(run)
-    return _entry("feat_knn_pc_kernel<128> (stage-4 kNN graph)", "mfma", 2.0 * B * N * N * F, us)
+    return _entry("feat_knn_pc_kernel<64> (stage-4 kNN graph, 128 varying channels)", "mfma", 2.0 * B * N * N * F, us)
 
 
 def knn3_largest(B, base_points, device):

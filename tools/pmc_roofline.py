@@ -18,7 +18,7 @@ ENTRIES = {   # entry function -> (kernel-name substrings whose dispatches belon
     "weight_grad_stage4": (["gemm_x3_kernel", "gemm_tn_kernel"], 2.0, "gemm_x3_kernel<AT,WT> = pdgn_gemm_tn_big"),
     "bn_act_backward_stage4": (["cl_bwd_reduce_kernel", "cl_bwd_apply_kernel"], 2.0, "cl_bwd_reduce + cl_bwd_apply"),
     "window_gather_sum_stage4": (["wgs_fwd_xcd_kernel"], 2.0, "wgs_fwd_xcd_kernel"),
-    "feature_knn_stage4": (["feat_knn_pc_kernel"], 2.0, "feat_knn_pc_kernel<128>"),
+    "feature_knn_stage4": (["feat_knn_pc_kernel"], 2.0, "feat_knn_pc_kernel<64>"),
     "knn3_largest": (["knn3_wave4_kernel"], 1.0, "knn3_wave4_kernel"),
 }
 TIMED = 5        # launches per entry that count (roofline_entry.py: 2 warm-up + 5)
