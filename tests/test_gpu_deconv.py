@@ -46,6 +46,32 @@ def test_feature_knn(B, F, N, k):
     assert same.float().mean() > 0.99
 
 
+@pytest.mark.parametrize("B,Fc,Fv,N,k", [(3, 32, 32, 256, 10), (2, 64, 64, 512, 10), (2, 128, 128, 1024, 10), (2, 24, 40, 200, 6)])
+def test_feature_knn_ignores_channels_constant_over_the_points(B, Fc, Fv, N, k):
+    """A block's input is cat([g broadcast over the points, x]) (models/PDGNet_v2.py:708) and the reference builds the graph from that
+    tensor (:447-458).  The broadcast channels add (g_f - g_f)^2 = 0 to every pairwise distance, so the graph of the varying channels
+    alone -- what deconv.start_feature_knn builds since round 6 -- is the same graph: equal to the fp64 graph of the CONCATENATED
+    tensor on every row whose distances are separated by more than rounding, and to the HIP graph of the concatenated tensor on
+    >= 99 % of all rows (there the Gram form's cancellation noise 2|g|^2 - 2|g|^2 flips near-ties)."""
+    from pdgn_amd import deconv
+    from pdgn_amd.deconv import feature_knn, start_feature_knn
+    rng = np.random.default_rng(Fc + N)
+    xt = torch.from_numpy(rng.standard_normal((B, N, Fv)).astype(np.float32))
+    const = torch.from_numpy((3.0 * rng.standard_normal((B, Fc))).astype(np.float32))
+    full = torch.cat((const.unsqueeze(2).expand(-1, -1, N), xt.transpose(1, 2)), 1).contiguous()        # (B, Fc + Fv, N)
+    assert not deconv._KNN_CONST
+    idx, ready = start_feature_knn(dev(xt), dev(const), k)
+    if ready is not None:
+        ready.synchronize()
+    torch.cuda.synchronize()
+    assert torch.equal(idx, feature_knn(dev(xt.transpose(1, 2).contiguous()), k))
+    safe, same = knn_agreement(full, k, idx)                       # the oracle sees the concatenated tensor
+    assert safe.float().mean() > 0.9
+    assert same[safe].all(), "graph differs from the concatenated tensor's on %d well-separated rows" % int((~same[safe]).sum())
+    agree = (idx == feature_knn(dev(full), k)).all(dim=2).float().mean().item()
+    assert agree > 0.99, agree
+
+
 def test_feature_knn_golden(golden):
     from pdgn_amd.deconv import feature_knn
     g = golden("edge_features.npz")
