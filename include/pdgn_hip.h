@@ -638,6 +638,17 @@ int pdgn_replay_launch_timed(void *plan, double *us32); /* measurement: host mic
 int pdgn_replay_probe_chain(void *plan, int chain, int stride, float *ms_out, int *pos_out, int max_out); /* measurement: device-time progress of one chain */
 int pdgn_replay_destroy(void *plan);
 
+/* ------------------------------------------------------------------ optimiser
+ * One Adam step (lr, betas, eps; no weight decay / amsgrad / maximize -- the reference's five torch.optim.Adam, models/PDGNet_v2.py:
+ * 121-125, 186-226, 256) of a whole list of fp32 tensors: replaces torch._fused_adam_ (five launches of 64 K-element chunks, 230 us
+ * for the generator's 12.7 M parameters).  p, g, m, v: HOST arrays of ntensors device pointers (parameter, gradient, first and
+ * second moment; 4-byte aligned, 16-byte aligned ones take the vector path), n: their element counts; the pointers travel in the
+ * kernel arguments (72 tensors per launch, one workgroup per 4096 elements).  step (device): the count t >= 1 of THIS update as one
+ * float.  torch's arithmetic, bit for bit: m <- beta1 m + (1 - beta1) g; v <- beta2 v + (1 - beta2) g g; p <- p - lr / (1 - beta1^t) * m /
+ * (sqrt(v) / sqrt(1 - beta2^t) + eps), bias corrections and 1 - beta in fp64 (torch keeps lr and the betas as doubles). */
+int pdgn_adam_multi(int ntensors, void *const *p, const void *const *g, void *const *m, void *const *v, const long long *n, double lr,
+                    double beta1, double beta2, double eps, const float *step, pdgn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

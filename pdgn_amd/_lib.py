@@ -10,7 +10,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "libpdgn_hip.so")
-ABI_VERSION = 25
+ABI_VERSION = 26
 _lib = None
 
 

@@ -714,4 +714,4 @@ extern "C" int pdgn_matchcost_grad(int b, int n, int m, const float *xyz1, const
     return pdgn_launch_status();
 }
 
-extern "C" int pdgn_abi_version(void) { return 25; }
+extern "C" int pdgn_abi_version(void) { return 26; }

@@ -185,11 +185,39 @@ class LeanAdamStep:
     changed signature falls back to `optimizer.step()` for good."""
 
     def __init__(self, opt):
-        self.opt, self.lists = opt, None
+        self.opt, self.lists, self._table = opt, None, None
 
     def reset(self):
         """The optimizer's state tensors were replaced (load_state_dict): rebuild the lists after the next ordinary step."""
         self.lists = None
+        self._table = None
+
+    _OWN = os.environ.get("PDGN_OWN_ADAM", "1") == "1"           # A/B switch: 0 = torch._fused_adam_
+
+    def _own_adam(self, ps, grads, exp_avgs, exp_avg_sqs, steps, g):
+        """The whole list in ceil(n / 72) launches of csrc/adam.hip, one workgroup per 4096 elements (torch's fused kernel: 64 K-element
+        chunks, five launches and 230 us for the generator's 12.7 M parameters at the end of every iteration).  The pointers travel in
+        the kernel arguments: nothing to upload, and a recorded iteration re-issues them as they were.  False (torch's kernel runs)
+        for anything but contiguous fp32 CUDA tensors."""
+        if not self._OWN or not ps or not ps[0].is_cuda:
+            return False
+        from . import _lib
+        import ctypes
+        n = len(ps)
+        tab = self._table
+        if tab is None or tab[0] != n or tab[1][0] != ps[0].data_ptr() or tab[2][n - 1] != exp_avgs[n - 1].data_ptr():
+            if any(t.dtype != torch.float32 or not t.is_contiguous() for lst in (ps, exp_avgs, exp_avg_sqs) for t in lst) \
+                    or steps[0].dtype != torch.float32:
+                return False
+            vp = ctypes.c_void_p * n
+            tab = self._table = (n, vp(*[t.data_ptr() for t in ps]), vp(*[t.data_ptr() for t in exp_avgs]),
+                                 vp(*[t.data_ptr() for t in exp_avg_sqs]), (ctypes.c_longlong * n)(*[t.numel() for t in ps]), vp)
+        if any(t.dtype != torch.float32 or not t.is_contiguous() for t in grads):
+            return False
+        _lib.check(_lib.lib().pdgn_adam_multi(n, tab[1], tab[5](*[t.data_ptr() for t in grads]), tab[2], tab[3], tab[4],
+                                              ctypes.c_double(g["lr"]), ctypes.c_double(g["betas"][0]), ctypes.c_double(g["betas"][1]),
+                                              ctypes.c_double(g["eps"]), _lib.ptr(steps[0]), _lib.stream_of(ps[0])), "pdgn_adam_multi")
+        return True
 
     def step(self):
         opt = self.opt
@@ -224,6 +252,8 @@ class LeanAdamStep:
         try:
             with torch.no_grad():
                 torch._foreach_add_(steps, 1)
+                if self._own_adam(ps, grads, exp_avgs, exp_avg_sqs, steps, g):
+                    return
                 torch._fused_adam_(ps, grads, exp_avgs, exp_avg_sqs, [], steps, amsgrad=False, lr=g["lr"], beta1=g["betas"][0],
                                    beta2=g["betas"][1], weight_decay=0.0, eps=g["eps"], maximize=False, grad_scale=None,
                                    found_inf=None)

@@ -299,3 +299,36 @@ def test_in_step_timing_of_the_dominant_contraction():
     out = tr.step_list(None, z1, z2)
     torch.cuda.synchronize()
     assert all(torch.isfinite(v).item() for v in out.values())
+
+
+@pytest.mark.gpu
+def test_own_adam_kernel_equals_torch_fused_adam():
+    """csrc/adam.hip (pdgn_adam_multi through trainer.LeanAdamStep) against torch.optim.Adam(fused, capturable) on a list with
+    ragged sizes (one element, sizes that are no multiple of four or of the 4096-element chunk, more than the 72 tensors one launch
+    carries, a 3 M-element tensor): parameters and both moments after five steps, to fp32 rounding of the update."""
+    from pdgn_amd.trainer import LeanAdamStep
+    g = torch.Generator(device="cuda").manual_seed(11)
+    sizes = [1, 3, 4, 5, 4095, 4096, 4097, 12288, 100003, 3 * 1024 * 1024 + 7] + [17 + 13 * i for i in range(80)]
+    def make():
+        ps = [torch.nn.Parameter(torch.randn(n, device="cuda", generator=torch.Generator(device="cuda").manual_seed(n))) for n in sizes]
+        return ps, torch.optim.Adam(ps, lr=1e-4, betas=(0.5, 0.999), fused=True, capturable=True)
+    pa, oa = make()
+    pb, ob = make()
+    lean = LeanAdamStep(ob)
+    assert lean._OWN
+    used = []
+    orig = lean._own_adam
+    lean._own_adam = lambda *a: used.append(orig(*a)) or used[-1]
+    for it in range(5):
+        grads = [torch.randn(n, device="cuda", generator=g) * (10.0 ** ((i % 7) - 4)) for i, n in enumerate(sizes)]
+        for p, q, gr in zip(pa, pb, grads):
+            p.grad, q.grad = gr.clone(), gr.clone()
+        oa.step()
+        lean.step()
+    assert used and all(used), used                       # steps 2..5 ran on the own kernel (the first is the optimizer's own)
+    for i, (p, q) in enumerate(zip(pa, pb)):
+        assert torch.allclose(p, q, rtol=3e-7, atol=1e-9), (i, (p - q).abs().max().item())      # an ulp of the parameter: five updates of <= lr each
+        for key in ("exp_avg", "exp_avg_sq"):
+            a, b = oa.state[p][key], ob.state[q][key]
+            assert (a - b).abs().max().item() <= 2e-6 * a.abs().max().item(), (i, key, (a - b).abs().max().item(), a.abs().max().item())
+        assert float(oa.state[p]["step"]) == float(ob.state[q]["step"]) == 5.0
