@@ -36,7 +36,10 @@ class FlatGrads:
         early = {id(p) for p in (first or [])}
         self.params = [p for p in ps if id(p) in early] + [p for p in ps if id(p) not in early]
         self.n_early = sum(1 for p in ps if id(p) in early)
-        total = sum(p.numel() for p in self.params)
+        # every gradient starts on a 16-byte boundary of the buffer (zero padding between them: the optimizer kernels' float4 path
+        # -- csrc/adam.hip, torch's fused Adam alike -- needs it once .grad are these views)
+        slot = lambda p: (p.numel() + 3) // 4 * 4
+        total = sum(slot(p) for p in self.params)
         ref = self.params[0]
         self.buf = torch.zeros(total, dtype=ref.dtype, device=ref.device)
         self.views, off = [], 0
@@ -44,7 +47,7 @@ class FlatGrads:
             if i == self.n_early:
                 self.early_numel = off
             self.views.append(self.buf[off:off + p.numel()].view_as(p))
-            off += p.numel()
+            off += slot(p)
         if self.n_early == len(self.params):
             self.early_numel = off
         self._early_work, self._early_done = None, False

@@ -167,7 +167,9 @@ def test_flat_grads_views_and_zero():
     for p, g in zip(m.parameters(), fresh):
         assert p.grad.data_ptr() == fg.buf[off:].data_ptr()               # .grad is now a view of the buffer
         assert torch.equal(p.grad, g)
-        off += p.numel()
+        assert p.grad.data_ptr() % 16 == fg.buf.data_ptr() % 16           # every slot starts on a 16-byte boundary of the buffer ...
+        off += (p.numel() + 3) // 4 * 4
+    assert off == fg.buf.numel() and int((fg.buf != 0).sum()) == sum(int((g != 0).sum()) for g in fresh)      # ... and the padding holds zeros
     fg.all_reduce_mean()                                                   # no process group: no-op
 
 
