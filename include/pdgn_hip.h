@@ -648,6 +648,10 @@ int pdgn_replay_destroy(void *plan);
  * (sqrt(v) / sqrt(1 - beta2^t) + eps), bias corrections and 1 - beta in fp64 (torch keeps lr and the betas as doubles). */
 int pdgn_adam_multi(int ntensors, void *const *p, const void *const *g, void *const *m, void *const *v, const long long *n, double lr,
                     double beta1, double beta2, double eps, const float *step, pdgn_stream_t stream);
+/* dst[i] (n[i] floats) <- src[i] for a list of fp32 tensors, the same way (128 tensors per launch): the pack of a network's fresh
+ * gradients into the flat buffer of its one all-reduce (the gradient reduction of nn.DataParallel, models/PDGNet_v2.py:101-105);
+ * replaces torch._foreach_copy_. */
+int pdgn_copy_multi(int ntensors, void *const *dst, const void *const *src, const long long *n, pdgn_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -119,3 +119,66 @@ extern "C" int pdgn_adam_multi(int ntensors, void *const *p, const void *const *
     }
     return pdgn_launch_status();
 }
+
+// ---- the same walk for a plain copy: dst[i] <- src[i] for a list of fp32 tensors (the pack of a network's fresh gradients into the
+// flat all-reduce buffer, trainer.FlatGrads: torch._foreach_copy_ takes 82 us for the generator's 160 tensors / 50.8 MB)
+#define COPY_MAXT 128               // tensors per launch (28 bytes of arguments each)
+struct CopyArgs {
+    float *d[COPY_MAXT];
+    const float *s[COPY_MAXT];
+    long long n[COPY_MAXT];
+    int chunk0[COPY_MAXT];
+    int ntensors;
+};
+
+__global__ __launch_bounds__(ADAM_THREADS) void copy_multi_kernel(const CopyArgs a) {
+    int lo = 0, hi = a.ntensors - 1;
+    const int c = blockIdx.x;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (a.chunk0[mid] <= c) lo = mid; else hi = mid - 1;
+    }
+    float *const D = a.d[lo];
+    const float *const S = a.s[lo];
+    const long long n = a.n[lo], i0 = (long long)(c - a.chunk0[lo]) * ADAM_CHUNK;
+    if (((((uintptr_t)D | (uintptr_t)S) & 15) == 0)) {
+        constexpr int NU = ADAM_CHUNK / (4 * ADAM_THREADS);
+        float4 v[NU];
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const long long i = i0 + 4LL * (threadIdx.x + u * ADAM_THREADS);
+            if (i + 3 < n) v[u] = *reinterpret_cast<const float4 *>(S + i);
+        }
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const long long i = i0 + 4LL * (threadIdx.x + u * ADAM_THREADS);
+            if (i + 3 < n) *reinterpret_cast<float4 *>(D + i) = v[u];
+            else for (long long j = i; j < n && j < i + 4; ++j) D[j] = S[j];
+        }
+    } else {
+        for (long long i = i0 + threadIdx.x; i < n && i < i0 + ADAM_CHUNK; i += ADAM_THREADS) D[i] = S[i];
+    }
+}
+
+// dst[i] (n[i] floats) <- src[i] for ntensors fp32 tensors (HOST arrays of device pointers, 4-byte aligned; 16-byte aligned pairs
+// take the vector path), in ceil(ntensors / 128) launches.  Replaces torch._foreach_copy_ where a network's gradients are packed
+// into one buffer for the all-reduce (the DataParallel gradient reduction of models/PDGNet_v2.py:101-105).
+extern "C" int pdgn_copy_multi(int ntensors, void *const *dst, const void *const *src, const long long *n, pdgn_stream_t stream) {
+    if (ntensors < 1 || !dst || !src || !n) return PDGN_ERR_INVALID;
+    for (int i = 0; i < ntensors; ++i)
+        if (!dst[i] || !src[i] || n[i] < 1 || (((uintptr_t)dst[i] | (uintptr_t)src[i]) & 3)) return PDGN_ERR_INVALID;
+    for (int t0 = 0; t0 < ntensors; t0 += COPY_MAXT) {
+        CopyArgs a;
+        a.ntensors = ntensors - t0 < COPY_MAXT ? ntensors - t0 : COPY_MAXT;
+        long long chunks = 0;
+        for (int i = 0; i < a.ntensors; ++i) {
+            a.d[i] = (float *)dst[t0 + i]; a.s[i] = (const float *)src[t0 + i]; a.n[i] = n[t0 + i];
+            a.chunk0[i] = (int)chunks;
+            chunks += (n[t0 + i] + ADAM_CHUNK - 1) / ADAM_CHUNK;
+            if (chunks > 0x3fffffffLL) return PDGN_ERR_INVALID;
+        }
+        for (int i = a.ntensors; i < COPY_MAXT; ++i) { a.d[i] = nullptr; a.s[i] = nullptr; a.n[i] = 0; a.chunk0[i] = 0x7fffffff; }
+        hipLaunchKernelGGL(copy_multi_kernel, dim3((unsigned)chunks), dim3(ADAM_THREADS), 0, (hipStream_t)stream, a);
+    }
+    return pdgn_launch_status();
+}

@@ -332,3 +332,26 @@ def test_own_adam_kernel_equals_torch_fused_adam():
             a, b = oa.state[p][key], ob.state[q][key]
             assert (a - b).abs().max().item() <= 2e-6 * a.abs().max().item(), (i, key, (a - b).abs().max().item(), a.abs().max().item())
         assert float(oa.state[p]["step"]) == float(ob.state[q]["step"]) == 5.0
+
+
+@pytest.mark.gpu
+def test_own_multi_tensor_copy_packs_gradients():
+    """pdgn_copy_multi through FlatGrads.pack: more tensors than one launch carries, ragged sizes, unaligned sources -- the flat
+    buffer's views hold the fresh gradients bit for bit, the padding between them stays zero."""
+    from pdgn_amd.trainer import FlatGrads
+    sizes = [1, 2, 3, 5, 4095, 4096, 4097, 70001] + [7 + 3 * i for i in range(150)]
+    ps = [torch.nn.Parameter(torch.zeros(n, device="cuda")) for n in sizes]
+    fg = FlatGrads(ps)
+    fg.begin()
+    g = torch.Generator(device="cuda").manual_seed(3)
+    big = torch.randn(sum(sizes) + len(sizes), device="cuda", generator=g)
+    off, fresh = 0, []
+    for p in ps:                                           # sources at odd offsets of one buffer: 4-byte alignment only
+        p.grad = big[off + 1:off + 1 + p.numel()]
+        fresh.append(p.grad.clone())
+        off += p.numel() + 1
+    fg.pack()
+    torch.cuda.synchronize()
+    for p, f in zip(ps, fresh):
+        assert p.grad.data_ptr() != f.data_ptr() and torch.equal(p.grad, f)
+    assert int((fg.buf != 0).sum()) == sum(int((f != 0).sum()) for f in fresh)
